@@ -1,0 +1,182 @@
+"""CPU oracle for the affinity U-Net, chunked predict and one training step.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``; never by anything under ``iterseg_amd/``.
+
+A *functional* fp32 restatement (torch CPU; the reference itself is torch.nn, so the
+same ATen arithmetic is the natural oracle for this floating-point path) of
+
+* ``UNet.forward``            -- reference src/iterseg/unet.py:284-364
+* ``ConvModule.forward``      -- unet.py:91-106 (train-mode BatchNorm3d)
+* ``make_chunks`` / ``process_chunks`` / ``predict_chunk_feature_map``
+                              -- src/iterseg/predict.py:38-126
+* ``_train_step`` + the second ``optimiser.step()`` -- src/iterseg/train.py:344-353, :310
+* losses                      -- train.py:197-217, custom_loss.py:24-185
+
+driven directly by a ``{key: ndarray}`` state dict (iterseg_amd.weights schema) instead
+of nn.Module objects.  Pinned against tests/golden/{unet_taps,predict_*,train_step}*.npz
+(captured from the reference's own modules) by tests/test_oracle_unet.py.
+"""
+from __future__ import annotations
+
+import itertools
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5        # nn.BatchNorm3d default (unet.py:80-81)
+BN_MOMENTUM = 0.1
+
+
+# --------------------------------------------------------------------------- chunker
+def make_chunks(arr_shape, chunk_shape, margin):
+    """predict.py:38-61, restated with numpy like the reference."""
+    ndim = len(arr_shape)
+    if isinstance(margin, int):
+        margin = [margin] * ndim
+    starts, crops = [], []
+    for arr, chk, mrg in zip(arr_shape, chunk_shape, margin):
+        start = np.arange(0, arr - 2 * mrg, chk - 2 * mrg)
+        start[-1] = arr - chk
+        if len(start) > 1 and start[-1] == start[-2]:
+            start = start[:-1]
+        crop = np.array([(mrg, chk - mrg)] * len(start))
+        crop[0, 0] = 0
+        crop[-1, 0] = chk - (arr - np.sum(crop[:-1, 1] - crop[:-1, 0]))
+        crop[-1, 1] = chk
+        starts.append(start)
+        crops.append(crop)
+    return list(itertools.product(*starts)), list(itertools.product(*crops))
+
+
+# --------------------------------------------------------------------------- forward
+def _as_params(sd, requires_grad=False):
+    p = OrderedDict()
+    for k, v in sd.items():
+        t = torch.from_numpy(np.ascontiguousarray(v)).clone() if isinstance(v, np.ndarray) else v
+        if requires_grad and t.dtype.is_floating_point and "running" not in k:
+            t.requires_grad_(True)
+        p[k] = t
+    return p
+
+
+def conv_module(p, name, x, final="relu", taps=None):
+    for j in (0, 1):
+        x = F.conv3d(x, p[f"{name}.conv{j}.weight"], p[f"{name}.conv{j}.bias"], padding=1)
+        if taps is not None:
+            taps[f"{name}.conv{j}"] = x
+        # train-mode BN: batch statistics, biased variance; running stats updated in place
+        x = F.batch_norm(x, p[f"{name}.batch{j}.running_mean"], p[f"{name}.batch{j}.running_var"],
+                         p[f"{name}.batch{j}.weight"], p[f"{name}.batch{j}.bias"],
+                         training=True, momentum=BN_MOMENTUM, eps=BN_EPS)
+        if f"{name}.batch{j}.num_batches_tracked" in p:
+            p[f"{name}.batch{j}.num_batches_tracked"] += 1
+        if taps is not None:
+            taps[f"{name}.batch{j}"] = x
+        if j == 0 or final == "relu":
+            x = F.relu(x)
+        elif final == "sigmoid":
+            x = torch.sigmoid(x)
+        elif final == "tanh":
+            x = torch.tanh(x)
+    if taps is not None:
+        taps[name] = x
+    return x
+
+
+def unet_forward(p, x, taps=None, final="sigmoid"):
+    """x: (1,1,D,H,W) float32 tensor -> (1,5,D,H,W).  Single (non-forked) decoder."""
+    c0 = conv_module(p, "c0", x, taps=taps)
+    x = F.max_pool3d(c0, (1, 2, 2), (1, 2, 2), padding=(0, 1, 1))
+    if taps is not None:
+        taps["d0"] = x
+    c1 = conv_module(p, "c1", x, taps=taps)
+    x = F.max_pool3d(c1, (1, 2, 2), (1, 2, 2), padding=(0, 1, 1))
+    c2 = conv_module(p, "c2", x, taps=taps)
+    x = F.max_pool3d(c2, (1, 2, 2), (1, 2, 2), padding=(0, 1, 1))
+    c3 = conv_module(p, "c3", x, taps=taps)
+    x = F.max_pool3d(c3, (2, 2, 2), (2, 2, 2), padding=(0, 1, 1))
+    if taps is not None:
+        taps["d3"] = x
+    x = conv_module(p, "c4", x, taps=taps)
+    x = F.conv_transpose3d(x, p["up0.weight"], p["up0.bias"], stride=(2, 2, 2), groups=256)
+    if taps is not None:
+        taps["up0"] = x
+    x = torch.cat([x[:, :, :, :-1, :-1], c3], 1)
+    if taps is not None:
+        taps["c5_0.in"] = x
+    x = conv_module(p, "c5_0", x, taps=taps)
+    x = F.conv_transpose3d(x, p["up1.weight"], p["up1.bias"], stride=(1, 2, 2), groups=128)
+    x = torch.cat([x[:, :, :, :-1, :-1], c2], 1)
+    x = conv_module(p, "c6_0", x, taps=taps)
+    x = F.conv_transpose3d(x, p["up2.weight"], p["up2.bias"], stride=(1, 2, 2), groups=64)
+    x = torch.cat([x[:, :, :, :-1, :-1], c1], 1)
+    x = conv_module(p, "c7_0", x, taps=taps)
+    x = F.conv_transpose3d(x, p["up3.weight"], p["up3.bias"], stride=(1, 2, 2), groups=32)
+    if taps is not None:
+        taps["up3"] = x
+    x = torch.cat([x[:, :, :, 1:-1, 1:-1], c0], 1)
+    if taps is not None:
+        taps["c8_0.in"] = x
+    return conv_module(p, "c8_0", x, final=final, taps=taps)
+
+
+def predict_volume(sd, volume, chunk_size, margin, threads=None):
+    """process_chunks + predict_chunk_feature_map (predict.py:64-126): (Z,Y,X) -> (5,Z,Y,X)."""
+    if threads:
+        torch.set_num_threads(threads)
+    p = _as_params(sd)
+    out = np.zeros((5,) + tuple(volume.shape), np.float32)
+    starts, crops = make_chunks(volume.shape, chunk_size, margin)
+    with torch.no_grad():
+        for st, cr in zip(starts, crops):
+            sl = tuple(slice(int(s), int(s) + int(c)) for s, c in zip(st, chunk_size))
+            y = unet_forward(p, torch.from_numpy(np.ascontiguousarray(volume[sl]))[None, None]).numpy()
+            crs = tuple(slice(int(a), int(b)) for a, b in cr)
+            out[(slice(None),) + sl][(slice(None),) + crs] = y[0][(slice(None),) + crs]
+    return out
+
+
+# --------------------------------------------------------------------------- losses / training
+def flatten_channels(x, channel_dim=1):
+    order = [channel_dim] + [i for i in range(x.dim()) if i != channel_dim]
+    return torch.flatten(x.permute(*order), start_dim=1)
+
+
+def loss_fn(name, y_hat, y, chan_weights=None):
+    if name == "BCELoss":
+        return F.binary_cross_entropy(y_hat, y)
+    if name == "MSELoss":
+        return F.mse_loss(y_hat, y)
+    if name == "DiceLoss":                                   # custom_loss.py:24-53, smooth=1
+        a, b = flatten_channels(y_hat), flatten_channels(y)
+        inter = (a * b).sum(-1)
+        dice = (2. * inter + 1) / (a.sum(-1) + b.sum(-1) + 1)
+        return (1 - dice).mean()
+    if name == "WeightedBCE":                                # custom_loss.py:161-185
+        a, b = flatten_channels(y_hat), flatten_channels(y)
+        per = F.binary_cross_entropy(a, b, reduction="none").mean(-1)
+        return (per * torch.as_tensor(chan_weights, dtype=per.dtype)).mean()
+    raise ValueError(name)
+
+
+def train_step(sd, x, y, lr=0.01, loss="BCELoss", double_step=True, chan_weights=None):
+    """One ``_train_step`` (+ the duplicated ``optimiser.step()`` of train.py:310).
+
+    Returns ``(loss, y_hat, grads, new_params)`` with numpy payloads.
+    """
+    p = _as_params(sd, requires_grad=True)
+    leaves = [t for t in p.values() if t.requires_grad]
+    opt = torch.optim.Adam(leaves, lr=lr)
+    opt.zero_grad()
+    y_hat = unet_forward(p, torch.from_numpy(x)[None, None].float())
+    l = loss_fn(loss, y_hat, torch.from_numpy(y)[None].float(), chan_weights)
+    l.backward()
+    grads = {k: t.grad.detach().numpy().copy() for k, t in p.items() if t.requires_grad}
+    opt.step()
+    if double_step:
+        opt.step()
+    new = OrderedDict((k, t.detach().numpy().copy()) for k, t in p.items())
+    return float(l.item()), y_hat.detach().numpy(), grads, new
