@@ -1,0 +1,180 @@
+/*
+ * itersegx.h -- C ABI of libitersegx.so: the MI355X (gfx950) implementation of iterseg's
+ * affinity-U-Net -> watershed hot path.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference checkout, AbigailMcGovern/iterseg v0.3.0).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - All array arguments are C-contiguous.  Unless a function name ends in `_host`, data
+ *     pointers are DEVICE pointers (HBM) valid on the context's device, and work is
+ *     enqueued on the context's stream (isx_ctx_set_stream); scalar results that the
+ *     signature returns through a host pointer imply a stream synchronisation.
+ *   - Volumes are (Z, Y, X); "padded" means one zero voxel on every side: (Z+2, Y+2, X+2),
+ *     the layout segment_single_volume hands to the processing function
+ *     (src/iterseg/segmentation.py:885-900).
+ *   - Return value: ISX_OK (0) or a negative ISX_ERR_* code; isx_last_error() returns a
+ *     thread-local message.  There is no CPU fallback: without a usable HIP device
+ *     isx_ctx_create fails (ISX_ERR_NO_DEVICE) and nothing else can be called.
+ */
+#ifndef ITERSEGX_H
+#define ITERSEGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISX_VERSION 100
+
+#define ISX_OK 0
+#define ISX_ERR_NO_DEVICE (-1)   /* no HIP device / context creation failed            */
+#define ISX_ERR_HIP (-2)         /* a HIP runtime call or kernel launch failed          */
+#define ISX_ERR_ARG (-3)         /* invalid argument (shape, null pointer, geometry)    */
+#define ISX_ERR_NO_SEEDS (-4)    /* zero seeds survive: the reference raises here
+                                    (np.apply_along_axis in watershed.py:50)            */
+#define ISX_ERR_STATE (-5)       /* weights not loaded / workspace not prepared         */
+#define ISX_ERR_NOMEM (-6)       /* device allocation failed                            */
+
+typedef struct isx_ctx isx_ctx;
+
+/* ---------------------------------------------------------------------------------- *
+ * Context (no reference counterpart: the reference keeps its state in the `config`     *
+ * dict built by affinity_watershed_prep_config, segmentation.py:80-135; the context is *
+ * what that dict owns in this implementation).                                         *
+ * ---------------------------------------------------------------------------------- */
+int isx_version(void);
+const char *isx_last_error(void);
+int isx_device_count(void);
+isx_ctx *isx_ctx_create(int device);               /* NULL on failure                   */
+void isx_ctx_destroy(isx_ctx *ctx);
+int isx_ctx_set_stream(isx_ctx *ctx, void *hip_stream);   /* NULL = context-owned stream */
+int isx_ctx_synchronize(isx_ctx *ctx);
+int isx_ctx_device(const isx_ctx *ctx);
+/* Bytes currently held by the context's device workspace cache. */
+int64_t isx_ctx_workspace_bytes(const isx_ctx *ctx);
+void isx_ctx_release_workspace(isx_ctx *ctx);
+
+/* Kernel timing by class, measured with HIP events on the context's stream
+ * (bench.py's roofline numbers).  Classes: see ISX_PROF_*.  enable=0 stops and clears. */
+#define ISX_PROF_CONV_MFMA 0
+#define ISX_PROF_CONV_DIRECT 1
+#define ISX_PROF_ELEMENTWISE 2
+#define ISX_PROF_WS_FILTERS 3
+#define ISX_PROF_WS_CCL 4
+#define ISX_PROF_WS_FLOOD 5
+#define ISX_PROF_NCLASS 6
+int isx_prof_enable(isx_ctx *ctx, int enable);
+int isx_prof_get(isx_ctx *ctx, int cls, double *total_ms, int64_t *launches);
+
+/* ---------------------------------------------------------------------------------- *
+ * Chunk geometry -- replaces make_chunks (src/iterseg/predict.py:38-61).               *
+ * table: int32 [cap][9] rows (sz, sy, sx, lo_z, hi_z, lo_y, hi_y, lo_x, hi_x), host     *
+ * memory, z-major order like itertools.product.  Returns the number of chunks (may be  *
+ * > cap: call again with a larger table) or a negative error.                          *
+ * ---------------------------------------------------------------------------------- */
+int64_t isx_make_chunks(const int64_t shape[3], const int64_t chunk[3], const int64_t margin[3],
+                        int32_t *table, int64_t cap);
+
+/* ---------------------------------------------------------------------------------- *
+ * U-Net -- replaces load_unet (predict.py:25-35), UNet.forward (unet.py:284-364) and    *
+ * the chunk loop process_chunks / predict_chunk_feature_map (predict.py:64-126).        *
+ * ---------------------------------------------------------------------------------- */
+/* One state_dict entry (host pointer, float32, reference layout e.g. OIDHW for conv
+ * weights; keys as in unet.py: "c0.conv0.weight", "up1.bias", ...).  Buffers
+ * ("...running_mean", "...running_var") are accepted; "num_batches_tracked" is int64. */
+int isx_load_weight_host(isx_ctx *ctx, const char *key, const void *data, const int64_t *shape,
+                         int ndim);
+/* Call after the last isx_load_weight_host: checks the schema strictly (like
+ * load_state_dict(strict=True)) and repacks into kernel layouts on the device. */
+int isx_weights_commit(isx_ctx *ctx, int out_channels);
+/* Read back a state_dict entry (running statistics are updated by forward passes, U2). */
+int isx_get_weight_host(isx_ctx *ctx, const char *key, void *data, int64_t nbytes);
+
+/* Forward `n` chunks cut from a device volume (Z,Y,X) f32 at the given starts
+ * (int32 [n][3], host memory), each of size chunk[3]; train-mode BatchNorm per chunk
+ * (SURVEY.md F2).  out: device float32 [n][out_channels][cz][cy][cx] (NCDHW, like the
+ * tensor predict_chunk_feature_map returns, predict.py:123). */
+int isx_unet_forward_chunks(isx_ctx *ctx, const float *volume, const int64_t shape[3],
+                            const int32_t *starts, int64_t n, const int64_t chunk[3], float *out);
+/* P2-P4 in one call: every chunk of `table` (isx_make_chunks rows, host memory) is pushed
+ * through the U-Net and its centre crop written into feature_map (5, Z, Y, X) on the
+ * device (process_chunks' `output_volume`, segmentation.py:138-140).  Chunks
+ * [first, first+count) only: the multi-GPU shard of one volume. */
+int isx_predict_volume(isx_ctx *ctx, const float *volume, const int64_t shape[3],
+                       const int32_t *table, int64_t first, int64_t count,
+                       const int64_t chunk[3], float *feature_map);
+/* Tap a named intermediate of the most recent single-chunk forward (tests): copies the
+ * activation as NCDHW float32 to host.  Names: "c0.conv0", "c0", "d0", "c4", "up0", ... */
+int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_elems,
+                      int64_t shape_out[4]);
+/* Max chunks processed concurrently by one launch set (workspace sizing). */
+int isx_unet_set_batch(isx_ctx *ctx, int batch);
+
+/* ---------------------------------------------------------------------------------- *
+ * Watershed post-processor -- src/iterseg/watershed.py.                                 *
+ * ---------------------------------------------------------------------------------- */
+/* skimage.filters.gaussian as used at watershed.py:227 / :234: float32 in/out, per-axis
+ * sigma in {0,1,2}, border 'nearest', truncate 4, double accumulation per pass. */
+int isx_ws_gaussian(isx_ctx *ctx, const float *img, float *out, const int64_t shape[3],
+                    const int32_t sigma[3]);
+/* skimage.filters.threshold_otsu (256 bins) of a float32 array; *thresh is HOST memory. */
+int isx_ws_threshold_otsu(isx_ctx *ctx, const float *img, int64_t n, float *thresh);
+/* W1 _get_mask (watershed.py:226-229): mask = img > otsu(gaussian(img, 2)), uint8 (Z,Y,X).
+ * thresh (host, optional) receives the threshold. */
+int isx_ws_mask(isx_ctx *ctx, const float *img, const int64_t shape[3], uint8_t *mask,
+                float *thresh);
+/* W2 _get_centroids (watershed.py:232-236): gaussian(0,1,1) (if smooth != 0) +
+ * peak_local_max(threshold_abs).  coords: device int64 [cap][3] (z,y,x), ordered by
+ * descending intensity then ascending raveled index; *count is HOST memory (true count,
+ * may exceed cap). */
+int isx_ws_seeds(isx_ctx *ctx, const float *cent, const int64_t shape[3], int smooth,
+                 float threshold_abs, int64_t *coords, int64_t cap, int64_t *count);
+/* W3 _remove_unwanted_objects (watershed.py:239-251) on a padded mask: 6-connected
+ * components with min_area <= size < max_area survive; seeds (device int64 [n][3], padded
+ * coordinates) outside them are dropped, order preserved.  *n_out is HOST memory. */
+int isx_ws_filter(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], int64_t min_area,
+                  int64_t max_area, uint8_t *mask_out, const int64_t *seeds, int64_t n_seeds,
+                  int64_t *seeds_out, int64_t *n_out);
+/* W4 affinity_watershed / raveled_affinity_watershed (watershed.py:17-35, :95-159):
+ * aff (3, PZ, PY, PX) float32 zero-padded, seeds int64 [n][3] padded coordinates
+ * (label = row + 1), mask uint8 padded with a zero border, out uint32 padded labels
+ * (zero on entry except where the caller wants pre-labelled voxels kept).
+ * scale (host, optional, 3 floats): |scale[a]| multiplies affinity channel a (:23-24). */
+int isx_affinity_watershed(isx_ctx *ctx, const float *aff, const int64_t *seeds, int64_t n_seeds,
+                           const uint8_t *mask, uint32_t *out, const int64_t pshape[3],
+                           const float *scale);
+/* W0 segment_output_image (watershed.py:165-223), plugin-path arguments
+ * (segmentation.py:190-194): feature_map (5,Z,Y,X) with channels (z,y,x affinity, mask,
+ * centres); labels (Z+2,Y+2,X+2) uint32, written in place (border stays 0).
+ * Optional device outputs (may be NULL): seeds_out int64 [cap][3] unpadded coords,
+ * mask_out uint8 padded.  Optional host outputs: n_seeds, thresh.
+ * abs_thresh: NULL for Otsu, else the `absolute_thresh` value. */
+int isx_segment_output_image(isx_ctx *ctx, const float *feature_map, const int64_t shape[3],
+                             uint32_t *labels, int64_t min_area, int64_t max_area,
+                             const float *abs_thresh, int64_t *seeds_out, int64_t seeds_cap,
+                             int64_t *n_seeds, uint8_t *mask_out, float *thresh);
+
+/* ---------------------------------------------------------------------------------- *
+ * End to end -- replaces segment_single_volume + affinity_watershed_for_chunks          *
+ * (segmentation.py:885-900, :147-195).                                                  *
+ * ---------------------------------------------------------------------------------- */
+/* volume /= max(volume) on the device (segmentation.py:889). */
+int isx_normalise_volume(isx_ctx *ctx, float *volume, int64_t n);
+/* Device-resident frame: normalised volume (Z,Y,X) -> labels (Z+2,Y+2,X+2) uint32.
+ * feature_map: caller-provided (5,Z,Y,X) scratch (the config dict's `output_volume`);
+ * it is zeroed on return like the reference does (segmentation.py:195). */
+int isx_segment_volume(isx_ctx *ctx, const float *volume, const int64_t shape[3],
+                       const int64_t chunk[3], const int64_t margin[3], float *feature_map,
+                       uint32_t *labels);
+/* Host-buffer form a maintainer binds from affinity_watershed_for_chunks: input_volume
+ * float32 (Z,Y,X) already normalised, current_output uint32 (Z+2,Y+2,X+2) zeros. */
+int isx_segment_volume_host(isx_ctx *ctx, const float *input_volume, const int64_t shape[3],
+                            const int64_t chunk[3], const int64_t margin[3],
+                            uint32_t *current_output);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ITERSEGX_H */

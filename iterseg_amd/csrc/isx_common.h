@@ -1,0 +1,111 @@
+// isx_common.h -- context, error plumbing and the device workspace cache shared by all
+// translation units of libitersegx.so.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/itersegx.h"
+
+namespace isx {
+
+void set_error(const char *fmt, ...);
+
+#define ISX_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            isx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                   \
+            return ISX_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define ISX_CHECK_LAUNCH()                                                              \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            isx::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_),   \
+                           __FILE__, __LINE__);                                         \
+            return ISX_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define ISX_TRY(expr)                \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != ISX_OK) return rc_; \
+    } while (0)
+
+#define ISX_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            isx::set_error(__VA_ARGS__); \
+            return ISX_ERR_ARG;         \
+        }                               \
+    } while (0)
+
+struct UNetState;   // unet.hip
+
+}  // namespace isx
+
+// Size-bucketed cache of hipMalloc'd blocks: the hot path allocates its scratch once and
+// then reuses it for every chunk / frame (no hipMalloc inside steady-state steps).
+struct isx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::multimap<size_t, void *> free_blocks;
+    std::unordered_map<void *, size_t> live_blocks;
+    size_t cached_bytes = 0;
+    // profiling by kernel class
+    bool prof_on = false;
+    struct ProfSpan { int cls; hipEvent_t a, b; };
+    std::vector<ProfSpan> prof_spans;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[ISX_PROF_NCLASS] = {0};
+    int64_t prof_n[ISX_PROF_NCLASS] = {0};
+    isx::UNetState *unet = nullptr;
+
+    void *alloc(size_t bytes);
+    void release(void *p);
+    void trim();
+    void prof_begin(int cls);
+    void prof_end();
+    void prof_collect();
+};
+
+namespace isx {
+
+// RAII device scratch tied to a context.
+template <typename T>
+struct Scratch {
+    isx_ctx *ctx;
+    T *p;
+    size_t n;
+    Scratch(isx_ctx *c, size_t count) : ctx(c), p((T *)c->alloc(count * sizeof(T))), n(count) {}
+    ~Scratch() { if (p) ctx->release(p); }
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    operator T *() const { return p; }
+    bool ok() const { return p != nullptr; }
+};
+
+struct ProfScope {
+    isx_ctx *ctx;
+    ProfScope(isx_ctx *c, int cls) : ctx(c) { if (c->prof_on) c->prof_begin(cls); }
+    ~ProfScope() { if (ctx->prof_on) ctx->prof_end(); }
+};
+
+inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+void unet_destroy(UNetState *);
+
+}  // namespace isx

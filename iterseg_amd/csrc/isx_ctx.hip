@@ -1,0 +1,251 @@
+// isx_ctx.hip -- context lifetime, workspace cache, error string, profiling spans and the
+// chunk-geometry entry point of libitersegx.so.
+#include <cstdarg>
+#include <cstring>
+
+#include "isx_common.h"
+
+namespace isx {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+}  // namespace isx
+
+void *isx_ctx::alloc(size_t bytes)
+{
+    if (bytes == 0) bytes = 256;
+    // round to 1 MiB above 1 MiB, else to 4 KiB: few distinct sizes -> good reuse
+    size_t gran = bytes >= (1u << 20) ? (1u << 20) : 4096;
+    bytes = (bytes + gran - 1) / gran * gran;
+    auto it = free_blocks.lower_bound(bytes);
+    if (it != free_blocks.end() && it->first <= bytes + bytes / 4) {
+        void *p = it->second;
+        size_t sz = it->first;
+        free_blocks.erase(it);
+        live_blocks[p] = sz;
+        return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        trim();
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            isx::set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+    cached_bytes += bytes;
+    live_blocks[p] = bytes;
+    return p;
+}
+
+void isx_ctx::release(void *p)
+{
+    auto it = live_blocks.find(p);
+    if (it == live_blocks.end()) return;
+    free_blocks.emplace(it->second, p);
+    live_blocks.erase(it);
+}
+
+void isx_ctx::trim()
+{
+    for (auto &kv : free_blocks) {
+        (void)hipFree(kv.second);
+        cached_bytes -= kv.first;
+    }
+    free_blocks.clear();
+}
+
+void isx_ctx::prof_begin(int cls)
+{
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!prof_pool.empty()) { e = prof_pool.back(); prof_pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    ProfSpan s{cls, get(), get()};
+    (void)hipEventRecord(s.a, stream);
+    prof_spans.push_back(s);
+}
+
+void isx_ctx::prof_end()
+{
+    (void)hipEventRecord(prof_spans.back().b, stream);
+    if (prof_spans.size() >= 4096) prof_collect();
+}
+
+void isx_ctx::prof_collect()
+{
+    if (prof_spans.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (auto &s : prof_spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            prof_ms[s.cls] += ms;
+            prof_n[s.cls] += 1;
+        }
+        prof_pool.push_back(s.a);
+        prof_pool.push_back(s.b);
+    }
+    prof_spans.clear();
+}
+
+extern "C" {
+
+int isx_version(void) { return ISX_VERSION; }
+
+const char *isx_last_error(void) { return isx::g_err.c_str(); }
+
+int isx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+isx_ctx *isx_ctx_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        isx::set_error("no HIP device available (%s): libitersegx has no CPU path",
+                       e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        isx::set_error("device %d out of range (0..%d)", device, n - 1);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        isx::set_error("hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            isx::set_error("device %d is %s; libitersegx is built for gfx950 only", device,
+                           prop.gcnArchName);
+            return nullptr;
+        }
+    }
+    isx_ctx *c = new isx_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        isx::set_error("hipStreamCreate failed");
+        delete c;
+        return nullptr;
+    }
+    c->stream = c->own_stream;
+    return c;
+}
+
+void isx_ctx_destroy(isx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->unet) isx::unet_destroy(c->unet);
+    for (auto &kv : c->live_blocks) (void)hipFree(kv.first);
+    c->live_blocks.clear();
+    c->trim();
+    for (auto &s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : c->prof_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int isx_ctx_set_stream(isx_ctx *c, void *s)
+{
+    ISX_REQUIRE(c, "null context");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return ISX_OK;
+}
+
+int isx_ctx_synchronize(isx_ctx *c)
+{
+    ISX_REQUIRE(c, "null context");
+    ISX_HIP(hipStreamSynchronize(c->stream));
+    return ISX_OK;
+}
+
+int isx_ctx_device(const isx_ctx *c) { return c ? c->device : -1; }
+
+int64_t isx_ctx_workspace_bytes(const isx_ctx *c) { return c ? (int64_t)c->cached_bytes : 0; }
+
+void isx_ctx_release_workspace(isx_ctx *c)
+{
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    c->trim();
+}
+
+int isx_prof_enable(isx_ctx *c, int enable)
+{
+    ISX_REQUIRE(c, "null context");
+    c->prof_collect();
+    c->prof_on = enable != 0;
+    if (!enable) {
+        memset(c->prof_ms, 0, sizeof(c->prof_ms));
+        memset(c->prof_n, 0, sizeof(c->prof_n));
+    }
+    return ISX_OK;
+}
+
+int isx_prof_get(isx_ctx *c, int cls, double *total_ms, int64_t *launches)
+{
+    ISX_REQUIRE(c && cls >= 0 && cls < ISX_PROF_NCLASS, "bad profile class");
+    c->prof_collect();
+    if (total_ms) *total_ms = c->prof_ms[cls];
+    if (launches) *launches = c->prof_n[cls];
+    return ISX_OK;
+}
+
+// make_chunks, src/iterseg/predict.py:38-61 -- same per-axis arithmetic as
+// iterseg_amd/chunking.py (kept in C so non-Python hosts get the identical table).
+int64_t isx_make_chunks(const int64_t shape[3], const int64_t chunk[3], const int64_t margin[3],
+                        int32_t *table, int64_t cap)
+{
+    std::vector<int64_t> st[3];
+    std::vector<std::pair<int64_t, int64_t>> cr[3];
+    for (int d = 0; d < 3; ++d) {
+        int64_t arr = shape[d], chk = chunk[d], mrg = margin[d], step = chk - 2 * mrg;
+        if (arr < chk) { isx::set_error("axis %d: volume %ld smaller than chunk %ld", d, (long)arr, (long)chk); return ISX_ERR_ARG; }
+        if (step <= 0 || arr - 2 * mrg <= 0) { isx::set_error("axis %d: margin too large", d); return ISX_ERR_ARG; }
+        for (int64_t s = 0; s < arr - 2 * mrg; s += step) st[d].push_back(s);
+        st[d].back() = arr - chk;
+        if (st[d].size() > 1 && st[d][st[d].size() - 1] == st[d][st[d].size() - 2]) st[d].pop_back();
+        cr[d].assign(st[d].size(), {mrg, chk - mrg});
+        cr[d][0].first = 0;
+        int64_t taken = 0;
+        for (size_t i = 0; i + 1 < cr[d].size(); ++i) taken += cr[d][i].second - cr[d][i].first;
+        cr[d].back().first = chk - (arr - taken);
+        cr[d].back().second = chk;
+    }
+    int64_t n = (int64_t)(st[0].size() * st[1].size() * st[2].size());
+    int64_t k = 0;
+    for (size_t a = 0; a < st[0].size(); ++a)
+        for (size_t b = 0; b < st[1].size(); ++b)
+            for (size_t c = 0; c < st[2].size(); ++c, ++k) {
+                if (!table || k >= cap) continue;
+                int32_t *r = table + 9 * k;
+                r[0] = (int32_t)st[0][a]; r[1] = (int32_t)st[1][b]; r[2] = (int32_t)st[2][c];
+                r[3] = (int32_t)cr[0][a].first; r[4] = (int32_t)cr[0][a].second;
+                r[5] = (int32_t)cr[1][b].first; r[6] = (int32_t)cr[1][b].second;
+                r[7] = (int32_t)cr[2][c].first; r[8] = (int32_t)cr[2][c].second;
+            }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,967 @@
+// ws.hip -- watershed post-processor of libitersegx.so (gfx950).
+//
+// Replaces src/iterseg/watershed.py of the reference: segment_output_image (:165-223),
+// _get_mask (:226-229), _get_centroids (:232-236), _remove_unwanted_objects (:239-251),
+// _prep_data (:38-63) and raveled_affinity_watershed (:95-159).  Results are bit-exact
+// with the reference for the integer/boolean outputs and for the float32 intermediates,
+// so every floating-point expression below follows the rounding sequence of the code it
+// replaces (double accumulation per separable pass, float32 histogram index, double
+// Otsu statistics).  FP contraction is therefore disabled for this translation unit.
+//
+// All of it is HBM-bound byte/integer work: kernels are one thread per voxel with
+// x-contiguous (coalesced) accesses; reductions use wave64 shuffles + one atomic per wave.
+#pragma clang fp contract(off)
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "isx_common.h"
+#include "prims.h"
+
+namespace isx {
+
+static constexpr int TPB = 256;
+static constexpr uint32_t NO_PARENT = 0xFFFFFFFFu;
+
+// Gaussian taps: scipy.ndimage._gaussian_kernel1d(sigma, 0, int(4*sigma+0.5)) as produced
+// by the numpy 1.26.4 the golden vectors were captured with (np.exp is not bit-stable
+// across numpy releases, so these are data).  [0] = centre.
+__constant__ double GK_SIGMA2[9] = {
+    0x1.98862a07ae7b4p-3, 0x1.68856f9ab1982p-3, 0x1.ef9093fc46e5ap-4, 0x1.0941b71ceef37p-4,
+    0x1.ba4d4125ffd29p-6, 0x1.1f30504e20207p-7, 0x1.227362b5fc92ep-9, 0x1.c98b8c5d0dda5p-12,
+    0x1.18aad19e4159bp-14};
+__constant__ double GK_SIGMA1[5] = {
+    0x1.9884a307594fbp-2, 0x1.ef8eb9ad499bap-3, 0x1.ba4b99d1799a9p-5, 0x1.22724cb7eb26ap-8,
+    0x1.18a9c4fd536c6p-13};
+
+// Order-preserving float32 -> uint32 (total order of non-NaN floats).
+__device__ __forceinline__ uint32_t ford(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float funord(uint32_t u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+// ------------------------------------------------------------------------------------
+// W1/W2: separable Gaussian pass (scipy NI_Correlate1D symmetric branch, 'nearest').
+//   tmp = c*w0; for k = R..1: tmp += (in[-k] + in[+k]) * w[k];   all in double; store f32.
+// ------------------------------------------------------------------------------------
+template <int R>
+__global__ void gauss_pass_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                  int64_t Z, int64_t Y, int64_t X, int axis)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = Z * Y * X;
+    if (i >= n) return;
+    const double *w = (R == 8) ? GK_SIGMA2 : GK_SIGMA1;
+    int64_t x = i % X, y = (i / X) % Y, z = i / (X * Y);
+    int64_t len, pos, stride;
+    if (axis == 0) { len = Z; pos = z; stride = Y * X; }
+    else if (axis == 1) { len = Y; pos = y; stride = X; }
+    else { len = X; pos = x; stride = 1; }
+    const float *base = in + (i - pos * stride);
+    double tmp = (double)base[pos * stride] * w[0];
+#pragma unroll
+    for (int k = R; k >= 1; --k) {
+        int64_t lo = pos - k < 0 ? 0 : pos - k;
+        int64_t hi = pos + k > len - 1 ? len - 1 : pos + k;
+        double s = (double)base[lo * stride] + (double)base[hi * stride];
+        double p = s * w[k];
+        tmp = tmp + p;
+    }
+    out[i] = (float)tmp;
+}
+
+static int gaussian_impl(isx_ctx *ctx, const float *img, float *out, const int64_t shape[3],
+                         const int32_t sigma[3], float *tmpbuf)
+{
+    int64_t n = shape[0] * shape[1] * shape[2];
+    int npass = 0;
+    for (int a = 0; a < 3; ++a) {
+        ISX_REQUIRE(sigma[a] >= 0 && sigma[a] <= 2, "sigma must be 0, 1 or 2 (reference uses 2 and (0,1,1))");
+        npass += sigma[a] > 0;
+    }
+    if (npass == 0) {
+        ISX_HIP(hipMemcpyAsync(out, img, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        return ISX_OK;
+    }
+    // ping-pong so that the last pass lands in `out`
+    const float *src = img;
+    int done = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (sigma[a] == 0) continue;
+        int remaining = npass - done - 1;
+        float *dst = (remaining % 2 == 0) ? out : tmpbuf;
+        if (sigma[a] == 2)
+            gauss_pass_kernel<8><<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(src, dst, shape[0], shape[1], shape[2], a);
+        else
+            gauss_pass_kernel<4><<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(src, dst, shape[0], shape[1], shape[2], a);
+        ISX_CHECK_LAUNCH();
+        src = dst;
+        ++done;
+    }
+    return ISX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Otsu: min/max -> float32 edges (float64 linspace cast) -> 256-bin histogram with numpy's
+// index recipe -> double between-class variance.  skimage thresholding.py:326-350,
+// numpy/lib/histograms.py uniform-bin path.
+// ------------------------------------------------------------------------------------
+__global__ void minmax_kernel(const float *__restrict__ a, int64_t n, uint32_t *mm)
+{
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t u = ford(a[i]);
+        lo = u < lo ? u : lo;
+        hi = u > hi ? u : hi;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t l2 = __shfl_down(lo, o), h2 = __shfl_down(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+
+// strided channel max for W0 (3 channels at once): cm[c] = ordered max of fm[c*n ...]
+__global__ void chanmax_kernel(const float *__restrict__ fm, int64_t n, uint32_t *cm)
+{
+    int c = blockIdx.y;
+    const float *a = fm + (int64_t)c * n;
+    uint32_t hi = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t u = ford(a[i]);
+        hi = u > hi ? u : hi;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t h2 = __shfl_down(hi, o);
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&cm[c], hi);
+}
+
+__global__ void otsu_edges_kernel(const uint32_t *mm, float *edges)
+{
+    int i = threadIdx.x;
+    if (i > 256) return;
+    float mn = funord(mm[0]), mx = funord(mm[1]);
+    double start = (double)mn, stop = (double)mx;
+    double step = (stop - start) / 256.0;
+    double y = (double)i * step;
+    y = y + start;
+    edges[i] = (i == 256) ? mx : (float)y;
+}
+
+__global__ void hist_kernel(const float *__restrict__ a, int64_t n, const uint32_t *mm,
+                            const float *__restrict__ edges_g, unsigned long long *counts)
+{
+    __shared__ unsigned int h[256];
+    __shared__ float edges[257];
+    for (int i = threadIdx.x; i < 257; i += blockDim.x) edges[i] = edges_g[i];
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    float mn = funord(mm[0]), mx = funord(mm[1]);
+    if (mn != mx) {
+        float denom = mx - mn;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            float v = a[i];
+            float f = (v - mn) / denom;
+            f = f * 256.0f;
+            int idx = (int)f;
+            if (idx == 256) idx = 255;
+            if (v < edges[idx]) idx -= 1;
+            if (v >= edges[idx + 1] && idx != 255) idx += 1;
+            atomicAdd(&h[idx], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256 && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// One lane: 256-bin double statistics, sequential like np.cumsum.
+__global__ void otsu_final_kernel(const unsigned long long *counts, const float *edges,
+                                  const uint32_t *mm, const float *a, float *thresh)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float mn = funord(mm[0]), mx = funord(mm[1]);
+    if (mn == mx) { *thresh = a[0]; return; }
+    // suffix sums first (they are consumed at i+1 while walking forward)
+    double w2[256], t2[256];
+    double acc = 0.0, acc2 = 0.0;
+    for (int i = 255; i >= 0; --i) {
+        float s = edges[i] + edges[i + 1];
+        float c = s / 2.0f;
+        double cnt = (double)counts[i];
+        acc = acc + cnt;
+        acc2 = acc2 + cnt * (double)c;
+        w2[i] = acc;
+        t2[i] = acc2;
+    }
+    double w1 = 0.0, t1 = 0.0, bestv = 0.0;
+    int best = 0;
+    for (int i = 0; i < 255; ++i) {
+        float s = edges[i] + edges[i + 1];
+        float c = s / 2.0f;
+        double cnt = (double)counts[i];
+        w1 = w1 + cnt;
+        t1 = t1 + cnt * (double)c;
+        double m1 = t1 / w1;
+        double m2 = t2[i + 1] / w2[i + 1];
+        double d = m1 - m2;
+        double v = (w1 * w2[i + 1]) * (d * d);
+        if (i == 0 || v > bestv) { bestv = v; best = i; }
+    }
+    float s = edges[best] + edges[best + 1];
+    *thresh = s / 2.0f;
+}
+
+static int otsu_impl(isx_ctx *ctx, const float *img, int64_t n, float *thresh_dev)
+{
+    Scratch<uint32_t> mm(ctx, 2);
+    Scratch<float> edges(ctx, 257);
+    Scratch<unsigned long long> counts(ctx, 256);
+    if (!mm.ok() || !edges.ok() || !counts.ok()) return ISX_ERR_NOMEM;
+    const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+    ISX_HIP(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    ISX_HIP(hipMemsetAsync(counts.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
+    unsigned grid = cdiv(n, (int64_t)TPB * 8);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    minmax_kernel<<<grid, TPB, 0, ctx->stream>>>(img, n, mm.p);
+    ISX_CHECK_LAUNCH();
+    otsu_edges_kernel<<<1, 320, 0, ctx->stream>>>(mm.p, edges.p);
+    ISX_CHECK_LAUNCH();
+    hist_kernel<<<grid, TPB, 0, ctx->stream>>>(img, n, mm.p, edges.p, counts.p);
+    ISX_CHECK_LAUNCH();
+    otsu_final_kernel<<<1, 64, 0, ctx->stream>>>(counts.p, edges.p, mm.p, img, thresh_dev);
+    ISX_CHECK_LAUNCH();
+    return ISX_OK;
+}
+
+// mask (optionally zero-padded by `pad` voxels per side) = img > *thresh
+__global__ void mask_kernel(const float *__restrict__ img, const float *thresh, int64_t Z, int64_t Y,
+                            int64_t X, int pad, uint8_t *__restrict__ mask)
+{
+    int64_t PZ = Z + 2 * pad, PY = Y + 2 * pad, PX = X + 2 * pad;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= PZ * PY * PX) return;
+    int64_t x = i % PX - pad, y = (i / PX) % PY - pad, z = i / (PX * PY) - pad;
+    uint8_t m = 0;
+    if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) m = img[(z * Y + y) * X + x] > *thresh;
+    mask[i] = m;
+}
+
+// ------------------------------------------------------------------------------------
+// W2: peak_local_max (skimage 0.18.3 feature/peak.py): 3x3x3 maximum filter with zero
+// padding, equality test, all-equal ("trivial") image -> no peaks, > threshold, 1-voxel
+// border excluded.  Candidates are emitted as sortable keys:
+//   key = (~ford(intensity) << 32) | raveled index   (descending intensity, ascending index)
+// ------------------------------------------------------------------------------------
+__global__ void peak_kernel(const float *__restrict__ g, int64_t Z, int64_t Y, int64_t X, float thr,
+                            uint32_t *nonpeak_flag, unsigned long long *keys, uint32_t *count,
+                            uint32_t cap)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Z * Y * X) return;
+    int64_t x = i % X, y = (i / X) % Y, z = i / (X * Y);
+    float c = g[i];
+    float m = -INFINITY;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                int64_t zz = z + dz, yy = y + dy, xx = x + dx;
+                float v = 0.0f;
+                if (zz >= 0 && zz < Z && yy >= 0 && yy < Y && xx >= 0 && xx < X)
+                    v = g[(zz * Y + yy) * X + xx];
+                m = v > m ? v : m;
+            }
+    bool pk = (c == m);
+    if (!pk) { *nonpeak_flag = 1u; return; }
+    bool interior = z >= 1 && z < Z - 1 && y >= 1 && y < Y - 1 && x >= 1 && x < X - 1;
+    if (interior && c > thr) {
+        uint32_t slot = atomicAdd(count, 1u);
+        if (slot < cap) keys[slot] = ((unsigned long long)(~ford(c)) << 32) | (unsigned long long)i;
+    }
+}
+
+// keys (sorted) -> (z,y,x) coordinates (+pad) as int64, and/or raveled padded index
+__global__ void seeds_decode_kernel(const unsigned long long *keys, uint32_t n, int64_t Y, int64_t X,
+                                    int pad, int64_t *coords)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t idx = (int64_t)(keys[i] & 0xFFFFFFFFull);
+    coords[3 * i + 0] = idx / (Y * X) + pad;
+    coords[3 * i + 1] = (idx / X) % Y + pad;
+    coords[3 * i + 2] = idx % X + pad;
+}
+
+// ------------------------------------------------------------------------------------
+// W3: connected components (6-connectivity) by lock-free union-find over the padded mask
+// (root = smallest raveled index of the component), component sizes, size filter.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t a)
+{
+    uint32_t p = parent[a];
+    while (p != a) {
+        uint32_t gp = parent[p];
+        if (gp != p) parent[a] = gp;      // path halving (values only ever decrease)
+        a = p;
+        p = gp;
+    }
+    return a;
+}
+
+__device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { uint32_t t = a; a = b; b = t; }     // a > b: hang a under b
+        uint32_t old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ void ccl_init_kernel(const uint8_t *__restrict__ mask, uint32_t *parent, int64_t N)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) parent[i] = mask[i] ? (uint32_t)i : NO_PARENT;
+}
+
+__global__ void ccl_merge_kernel(const uint8_t *__restrict__ mask, uint32_t *parent, int64_t PZ,
+                                 int64_t PY, int64_t PX)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t N = PZ * PY * PX;
+    if (i >= N || !mask[i]) return;
+    int64_t x = i % PX, y = (i / PX) % PY, z = i / (PX * PY);
+    if (x > 0 && mask[i - 1]) uf_union(parent, (uint32_t)i, (uint32_t)(i - 1));
+    if (y > 0 && mask[i - PX]) uf_union(parent, (uint32_t)i, (uint32_t)(i - PX));
+    if (z > 0 && mask[i - PX * PY]) uf_union(parent, (uint32_t)i, (uint32_t)(i - PX * PY));
+}
+
+__global__ void ccl_flatten_kernel(uint32_t *parent, int64_t N)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (parent[i] == NO_PARENT) return;
+    parent[i] = uf_find(parent, (uint32_t)i);
+}
+
+// sizes[root] += 1 per mask voxel; lanes of a wave that share a root add once.
+__global__ void ccl_sizes_kernel(const uint32_t *__restrict__ parent, uint32_t *sizes, int64_t N)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = (i < N) ? parent[i] : NO_PARENT;
+    bool todo = r != NO_PARENT;
+    while (__any(todo)) {
+        unsigned long long act = __ballot(todo);
+        int leader = __ffsll((long long)act) - 1;
+        uint32_t lr = __shfl(r, leader);
+        bool same = todo && r == lr;
+        unsigned long long grp = __ballot(same);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&sizes[lr], (uint32_t)__popcll(grp));
+        if (same) todo = false;
+    }
+}
+
+__global__ void ccl_apply_kernel(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ sizes,
+                                 uint32_t min_area, uint32_t max_area, uint8_t *__restrict__ mask_out,
+                                 int64_t N)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    uint32_t r = parent[i];
+    uint8_t keep = 0;
+    if (r != NO_PARENT) {
+        uint32_t s = sizes[r];
+        keep = (s >= min_area && s < max_area);
+    }
+    mask_out[i] = keep;
+}
+
+static int ccl_impl(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], uint32_t *parent,
+                    uint32_t *sizes)
+{
+    int64_t N = pshape[0] * pshape[1] * pshape[2];
+    ISX_REQUIRE(N < (int64_t)0xFFFFFFF0ll, "volume too large for 32-bit voxel indices");
+    unsigned grid = cdiv(N, TPB);
+    ccl_init_kernel<<<grid, TPB, 0, ctx->stream>>>(mask, parent, N);
+    ISX_CHECK_LAUNCH();
+    ccl_merge_kernel<<<grid, TPB, 0, ctx->stream>>>(mask, parent, pshape[0], pshape[1], pshape[2]);
+    ISX_CHECK_LAUNCH();
+    ccl_flatten_kernel<<<grid, TPB, 0, ctx->stream>>>(parent, N);
+    ISX_CHECK_LAUNCH();
+    if (sizes) {
+        ISX_HIP(hipMemsetAsync(sizes, 0, N * sizeof(uint32_t), ctx->stream));
+        ccl_sizes_kernel<<<grid, TPB, 0, ctx->stream>>>(parent, sizes, N);
+        ISX_CHECK_LAUNCH();
+    }
+    return ISX_OK;
+}
+
+// seed bookkeeping ---------------------------------------------------------------
+__global__ void seed_ravel_kernel(const int64_t *coords, uint32_t n, int64_t PY, int64_t PX,
+                                  uint32_t *ridx)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ridx[i] = (uint32_t)((coords[3 * i] * PY + coords[3 * i + 1]) * PX + coords[3 * i + 2]);
+}
+
+// Standalone W4 entry: seeds must lie strictly inside the padded box (the flood reads all six
+// neighbours unchecked, like the reference); a seed on a non-mask voxel still spreads into the
+// mask voxels around it (the reference never tests mask[seed]), so it is added to the mask used
+// for component analysis -- it is pre-labelled, hence never entered, and the flood is unchanged.
+__global__ void seed_check_mark_kernel(const int64_t *coords, uint32_t n, int64_t PZ, int64_t PY, int64_t PX,
+                                       uint8_t *mask, uint32_t *bad)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t z = coords[3 * i], y = coords[3 * i + 1], x = coords[3 * i + 2];
+    if (z < 1 || z > PZ - 2 || y < 1 || y > PY - 2 || x < 1 || x > PX - 2) { *bad = 1u; return; }
+    mask[(z * PY + y) * PX + x] = 1;
+}
+
+__global__ void seed_flag_kernel(const uint32_t *ridx, uint32_t n, const uint8_t *mask, uint32_t *flag)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = mask[ridx[i]] ? 1u : 0u;
+}
+
+__global__ void seed_copy_kernel(const int64_t *coords, uint32_t n, int64_t *out, int sub)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[3 * i + 0] = coords[3 * i + 0] - sub;
+    out[3 * i + 1] = coords[3 * i + 1] - sub;
+    out[3 * i + 2] = coords[3 * i + 2] - sub;
+}
+
+__global__ void seed_compact_kernel(const int64_t *coords, const uint32_t *flag, const uint32_t *pos,
+                                    uint32_t n, int64_t *out, int sub)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    uint32_t o = pos[i];
+    out[3 * o + 0] = coords[3 * i + 0] - sub;
+    out[3 * o + 1] = coords[3 * i + 1] - sub;
+    out[3 * o + 2] = coords[3 * i + 2] - sub;
+}
+
+// ------------------------------------------------------------------------------------
+// W0: affinities / per-channel max, zero-padded by one voxel (watershed.py:194-201).
+// ------------------------------------------------------------------------------------
+__global__ void aff_pad_kernel(const float *__restrict__ fm, const uint32_t *cm, int64_t Z, int64_t Y,
+                               int64_t X, float *__restrict__ aff)
+{
+    int64_t PZ = Z + 2, PY = Y + 2, PX = X + 2, PN = PZ * PY * PX;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= PN) return;
+    int c = blockIdx.y;
+    int64_t x = i % PX - 1, y = (i / PX) % PY - 1, z = i / (PX * PY) - 1;
+    float v = 0.0f;
+    if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z)
+        v = fm[(int64_t)c * Z * Y * X + (z * Y + y) * X + x] / funord(cm[c]);
+    aff[(int64_t)c * PN + i] = v;
+}
+
+// ------------------------------------------------------------------------------------
+// W4: the flood.  Exactly the reference's sequential process per mask component
+// (SURVEY.md F3/F4): min-heap on (value, age, index); a voxel is labelled when first
+// discovered; neighbours visited in the order [-z, -y, -x, +x, +y, +z]; the edge value is
+// aff[axis][idx] for the negative directions and aff[axis][neighbour] for the positive.
+// Components are independent, so each one is flooded by its own lane with a private
+// binary heap in HBM; ages are per-component push counters (only their order matters).
+// Heap entry: 16 bytes {key = ford(value) << 32 | age, idx}.
+// ------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) HeapEnt {
+    unsigned long long key;
+    uint32_t idx;
+    uint32_t pad;
+};
+
+__device__ __forceinline__ bool ent_less(const HeapEnt &a, const HeapEnt &b)
+{
+    return a.key < b.key || (a.key == b.key && a.idx < b.idx);
+}
+
+__device__ __forceinline__ void heap_push(HeapEnt *h, uint32_t &n, HeapEnt e)
+{
+    uint32_t c = n++;
+    while (c > 0) {
+        uint32_t p = (c - 1) >> 1;
+        HeapEnt pe = h[p];
+        if (!ent_less(e, pe)) break;
+        h[c] = pe;
+        c = p;
+    }
+    h[c] = e;
+}
+
+__device__ __forceinline__ HeapEnt heap_pop(HeapEnt *h, uint32_t &n)
+{
+    HeapEnt top = h[0];
+    HeapEnt last = h[--n];
+    if (n > 0) {
+        uint32_t c = 0;
+        for (;;) {
+            uint32_t l = 2 * c + 1;
+            if (l >= n) break;
+            HeapEnt le = h[l];
+            uint32_t m = l;
+            if (l + 1 < n) {
+                HeapEnt re = h[l + 1];
+                if (ent_less(re, le)) { le = re; m = l + 1; }
+            }
+            if (!ent_less(le, last)) break;
+            h[c] = le;
+            c = m;
+        }
+        h[c] = last;
+    }
+    return top;
+}
+
+__global__ void seed_label_kernel(const uint32_t *ridx, uint32_t n, const uint32_t *parent,
+                                  uint32_t *out, unsigned long long *keys)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = ridx[i];
+    out[p] = i + 1;                                        // _prep_data, watershed.py:61-62
+    uint32_t root = parent[p];                             // NO_PARENT if the seed is off-mask
+    keys[i] = ((unsigned long long)root << 32) | p;
+}
+
+// after sorting by (root, idx): head flags of each component run
+__global__ void comp_head_kernel(const unsigned long long *keys, uint32_t n, uint32_t *head)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = (uint32_t)(keys[i] >> 32);
+    head[i] = (i == 0 || r != (uint32_t)(keys[i - 1] >> 32)) ? 1u : 0u;
+}
+
+// comp_first[c] = index of the first seed of component c; comp_cap[c] = heap capacity
+__global__ void comp_table_kernel(const unsigned long long *keys, const uint32_t *head,
+                                  const uint32_t *cid, uint32_t n, const uint32_t *sizes,
+                                  uint32_t *comp_first, unsigned long long *comp_cap)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    uint32_t c = cid[i];
+    uint32_t root = (uint32_t)(keys[i] >> 32);
+    comp_first[c] = i;
+    comp_cap[c] = (root == NO_PARENT) ? 1ull : (unsigned long long)sizes[root];
+}
+
+__global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__restrict__ mask,
+                             uint32_t *__restrict__ out, const unsigned long long *__restrict__ keys,
+                             uint32_t n_seeds, const uint32_t *__restrict__ comp_first,
+                             const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
+                             HeapEnt *__restrict__ heap_pool, int64_t PY, int64_t PX, int64_t PN,
+                             float s0, float s1, float s2)
+{
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_comp) return;
+    uint32_t first = comp_first[c];
+    uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
+    if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;   // seeds outside the mask never spread
+    HeapEnt *h = heap_pool + comp_off[c];
+    uint32_t hn = 0, age = 0;
+    const unsigned long long ZERO_KEY = (unsigned long long)0x80000000u << 32;   // ford(+0.0f), age 0
+    for (uint32_t s = first; s < end; ++s) {
+        HeapEnt e;
+        e.key = ZERO_KEY;
+        e.idx = (uint32_t)(keys[s] & 0xFFFFFFFFull);
+        e.pad = 0;
+        heap_push(h, hn, e);
+    }
+    const int64_t SZ = PY * PX, SY = PX;
+    const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
+    const int ax[6] = {0, 1, 2, 2, 1, 0};
+    const float sc[3] = {s0, s1, s2};
+    while (hn > 0) {
+        HeapEnt top = heap_pop(h, hn);
+        int64_t idx = top.idx;
+        uint32_t lab = out[idx];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            int64_t nb = idx + noff[k];
+            if (!mask[nb] || out[nb]) continue;
+            out[nb] = lab;
+            float v = aff[(int64_t)ax[k] * PN + (k < 3 ? idx : nb)];
+            v = v * sc[ax[k]];
+            v = v + 0.0f;                                   // -0.0 == +0.0 in the heap order
+            HeapEnt e;
+            e.key = ((unsigned long long)ford(v) << 32) | (unsigned long long)(++age);
+            e.idx = (uint32_t)nb;
+            e.pad = 0;
+            heap_push(h, hn, e);
+        }
+    }
+}
+
+// Flood given raveled seed indices (device u32) in list order (label = position + 1).
+// parent/sizes: CCL of `mask` if the caller already has it, else nullptr.
+static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint32_t n_seeds,
+                      const uint8_t *mask, uint32_t *out, const int64_t pshape[3],
+                      const uint32_t *parent_in, const uint32_t *sizes_in, const float *scale)
+{
+    if (n_seeds == 0) {
+        set_error("zero seeds: the reference raises here (np.apply_along_axis, watershed.py:50)");
+        return ISX_ERR_NO_SEEDS;
+    }
+    int64_t PN = pshape[0] * pshape[1] * pshape[2];
+    Scratch<uint32_t> parent_own(ctx, parent_in ? 1 : PN), sizes_own(ctx, sizes_in ? 1 : PN);
+    if (!parent_own.ok() || !sizes_own.ok()) return ISX_ERR_NOMEM;
+    const uint32_t *parent = parent_in, *sizes = sizes_in;
+    if (!parent_in) {
+        ProfScope ps(ctx, ISX_PROF_WS_CCL);
+        ISX_TRY(ccl_impl(ctx, mask, pshape, parent_own.p, sizes_own.p));
+        parent = parent_own.p;
+        sizes = sizes_own.p;
+    }
+    ProfScope ps(ctx, ISX_PROF_WS_FLOOD);
+    Scratch<unsigned long long> keys(ctx, n_seeds), keys_sorted(ctx, n_seeds), comp_cap(ctx, n_seeds + 1),
+        comp_off(ctx, n_seeds + 1);
+    Scratch<uint32_t> head(ctx, n_seeds), cid(ctx, n_seeds), comp_first(ctx, n_seeds);
+    if (!keys.ok() || !keys_sorted.ok() || !comp_cap.ok() || !comp_off.ok() || !head.ok() || !cid.ok() ||
+        !comp_first.ok())
+        return ISX_ERR_NOMEM;
+    unsigned sg = cdiv(n_seeds, TPB);
+    seed_label_kernel<<<sg, TPB, 0, ctx->stream>>>(ridx, n_seeds, parent, out, keys.p);
+    ISX_CHECK_LAUNCH();
+    ISX_TRY(sort_u64(ctx, (const uint64_t *)keys.p, (uint64_t *)keys_sorted.p, n_seeds));
+    comp_head_kernel<<<sg, TPB, 0, ctx->stream>>>(keys_sorted.p, n_seeds, head.p);
+    ISX_CHECK_LAUNCH();
+    ISX_TRY(exclusive_scan_u32(ctx, head.p, cid.p, n_seeds));
+    // number of components = cid[last] + head[last]
+    uint32_t last_cid = 0, last_head = 0;
+    ISX_HIP(hipMemcpyAsync(&last_cid, cid.p + (n_seeds - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISX_HIP(hipMemcpyAsync(&last_head, head.p + (n_seeds - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t n_comp = last_cid + last_head;
+    ISX_HIP(hipMemsetAsync(comp_cap.p, 0, (size_t)(n_comp + 1) * 8, ctx->stream));
+    comp_table_kernel<<<sg, TPB, 0, ctx->stream>>>(keys_sorted.p, head.p, cid.p, n_seeds, sizes,
+                                                     comp_first.p, comp_cap.p);
+    ISX_CHECK_LAUNCH();
+    ISX_TRY(exclusive_scan_u64(ctx, (const uint64_t *)comp_cap.p, (uint64_t *)comp_off.p, n_comp + 1));
+    unsigned long long total = 0;
+    ISX_HIP(hipMemcpyAsync(&total, comp_off.p + n_comp, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    Scratch<HeapEnt> pool(ctx, (size_t)total + 1);
+    if (!pool.ok()) return ISX_ERR_NOMEM;
+    float s[3] = {1.f, 1.f, 1.f};
+    if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
+    flood_kernel<<<cdiv(n_comp, 64), 64, 0, ctx->stream>>>(aff, mask, out, keys_sorted.p, n_seeds,
+                                                          comp_first.p, comp_off.p, n_comp, pool.p,
+                                                          pshape[1], pshape[2], PN, s[0], s[1], s[2]);
+    ISX_CHECK_LAUNCH();
+    return ISX_OK;
+}
+
+// W2 shared by the public entry and the fused path.  keys_sorted must hold `cap` entries.
+static int seeds_impl(isx_ctx *ctx, const float *cent, const int64_t shape[3], int smooth, float thr,
+                      unsigned long long *keys_sorted, uint32_t cap, uint32_t *count_host)
+{
+    int64_t n = shape[0] * shape[1] * shape[2];
+    ISX_REQUIRE(n < (int64_t)0xFFFFFFF0ll, "volume too large for 32-bit voxel indices");
+    Scratch<float> g(ctx, smooth ? n : 1), tmp(ctx, smooth ? n : 1);
+    Scratch<uint32_t> flags(ctx, 2);
+    Scratch<unsigned long long> keys(ctx, cap);
+    if (!g.ok() || !tmp.ok() || !flags.ok() || !keys.ok()) return ISX_ERR_NOMEM;
+    const float *src = cent;
+    if (smooth) {
+        const int32_t sig[3] = {0, 1, 1};
+        ISX_TRY(gaussian_impl(ctx, cent, g.p, shape, sig, tmp.p));
+        src = g.p;
+    }
+    ISX_HIP(hipMemsetAsync(flags.p, 0, 8, ctx->stream));
+    peak_kernel<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(src, shape[0], shape[1], shape[2], thr, flags.p,
+                                                     keys.p, flags.p + 1, cap);
+    ISX_CHECK_LAUNCH();
+    uint32_t fl[2];
+    ISX_HIP(hipMemcpyAsync(fl, flags.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t cnt = fl[0] ? fl[1] : 0u;          // all voxels "peaks" => trivial image => none
+    *count_host = cnt;
+    uint32_t m = cnt < cap ? cnt : cap;
+    ISX_TRY(sort_u64(ctx, (const uint64_t *)keys.p, (uint64_t *)keys_sorted, m));
+    return ISX_OK;
+}
+
+}  // namespace isx
+
+using namespace isx;
+
+extern "C" {
+
+int isx_ws_gaussian(isx_ctx *ctx, const float *img, float *out, const int64_t shape[3],
+                    const int32_t sigma[3])
+{
+    ISX_REQUIRE(ctx && img && out && shape && sigma, "null argument");
+    ISX_HIP(hipSetDevice(ctx->device));
+    ProfScope ps(ctx, ISX_PROF_WS_FILTERS);
+    int64_t n = shape[0] * shape[1] * shape[2];
+    Scratch<float> tmp(ctx, n);
+    if (!tmp.ok()) return ISX_ERR_NOMEM;
+    return gaussian_impl(ctx, img, out, shape, sigma, tmp.p);
+}
+
+int isx_ws_threshold_otsu(isx_ctx *ctx, const float *img, int64_t n, float *thresh)
+{
+    ISX_REQUIRE(ctx && img && thresh && n > 0, "bad argument");
+    ISX_HIP(hipSetDevice(ctx->device));
+    Scratch<float> t(ctx, 1);
+    if (!t.ok()) return ISX_ERR_NOMEM;
+    ISX_TRY(otsu_impl(ctx, img, n, t.p));
+    ISX_HIP(hipMemcpyAsync(thresh, t.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    return ISX_OK;
+}
+
+int isx_ws_mask(isx_ctx *ctx, const float *img, const int64_t shape[3], uint8_t *mask, float *thresh)
+{
+    ISX_REQUIRE(ctx && img && shape && mask, "null argument");
+    ISX_HIP(hipSetDevice(ctx->device));
+    ProfScope ps(ctx, ISX_PROF_WS_FILTERS);
+    int64_t n = shape[0] * shape[1] * shape[2];
+    Scratch<float> sm(ctx, n), tmp(ctx, n), t(ctx, 1);
+    if (!sm.ok() || !tmp.ok() || !t.ok()) return ISX_ERR_NOMEM;
+    const int32_t sig[3] = {2, 2, 2};
+    ISX_TRY(gaussian_impl(ctx, img, sm.p, shape, sig, tmp.p));
+    ISX_TRY(otsu_impl(ctx, sm.p, n, t.p));
+    mask_kernel<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(img, t.p, shape[0], shape[1], shape[2], 0, mask);
+    ISX_CHECK_LAUNCH();
+    if (thresh) {
+        ISX_HIP(hipMemcpyAsync(thresh, t.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ISX_OK;
+}
+
+int isx_ws_seeds(isx_ctx *ctx, const float *cent, const int64_t shape[3], int smooth,
+                 float threshold_abs, int64_t *coords, int64_t cap, int64_t *count)
+{
+    ISX_REQUIRE(ctx && cent && shape && count && cap >= 0 && (coords || cap == 0), "bad argument");
+    ISX_HIP(hipSetDevice(ctx->device));
+    ProfScope ps(ctx, ISX_PROF_WS_FILTERS);
+    uint32_t c32 = (uint32_t)(cap > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : cap);
+    Scratch<unsigned long long> ks(ctx, c32 ? c32 : 1);
+    if (!ks.ok()) return ISX_ERR_NOMEM;
+    uint32_t cnt = 0;
+    ISX_TRY(seeds_impl(ctx, cent, shape, smooth, threshold_abs, ks.p, c32, &cnt));
+    *count = cnt;
+    uint32_t m = cnt < c32 ? cnt : c32;
+    if (m) {
+        seeds_decode_kernel<<<cdiv(m, TPB), TPB, 0, ctx->stream>>>(ks.p, m, shape[1], shape[2], 0, coords);
+        ISX_CHECK_LAUNCH();
+    }
+    return ISX_OK;
+}
+
+int isx_ws_filter(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], int64_t min_area,
+                  int64_t max_area, uint8_t *mask_out, const int64_t *seeds, int64_t n_seeds,
+                  int64_t *seeds_out, int64_t *n_out)
+{
+    ISX_REQUIRE(ctx && mask && pshape && mask_out, "null argument");
+    ISX_REQUIRE(n_seeds == 0 || (seeds && seeds_out && n_out), "seed buffers missing");
+    ISX_HIP(hipSetDevice(ctx->device));
+    ProfScope ps(ctx, ISX_PROF_WS_CCL);
+    int64_t N = pshape[0] * pshape[1] * pshape[2];
+    Scratch<uint32_t> parent(ctx, N), sizes(ctx, N);
+    if (!parent.ok() || !sizes.ok()) return ISX_ERR_NOMEM;
+    ISX_TRY(ccl_impl(ctx, mask, pshape, parent.p, sizes.p));
+    uint32_t lo = (uint32_t)(min_area < 0 ? 0 : (min_area > 0xFFFFFFFFll ? 0xFFFFFFFFll : min_area));
+    uint32_t hi = (uint32_t)(max_area < 0 ? 0 : (max_area > 0xFFFFFFFFll ? 0xFFFFFFFFll : max_area));
+    ccl_apply_kernel<<<cdiv(N, TPB), TPB, 0, ctx->stream>>>(parent.p, sizes.p, lo, hi, mask_out, N);
+    ISX_CHECK_LAUNCH();
+    if (n_out) *n_out = 0;
+    if (n_seeds > 0) {
+        uint32_t n = (uint32_t)n_seeds;
+        Scratch<uint32_t> ridx(ctx, n), flag(ctx, n), pos(ctx, n);
+        if (!ridx.ok() || !flag.ok() || !pos.ok()) return ISX_ERR_NOMEM;
+        unsigned sg = cdiv(n, TPB);
+        seed_ravel_kernel<<<sg, TPB, 0, ctx->stream>>>(seeds, n, pshape[1], pshape[2], ridx.p);
+        seed_flag_kernel<<<sg, TPB, 0, ctx->stream>>>(ridx.p, n, mask_out, flag.p);
+        ISX_CHECK_LAUNCH();
+        ISX_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, n));
+        seed_compact_kernel<<<sg, TPB, 0, ctx->stream>>>(seeds, flag.p, pos.p, n, seeds_out, 0);
+        ISX_CHECK_LAUNCH();
+        uint32_t lp = 0, lf = 0;
+        ISX_HIP(hipMemcpyAsync(&lp, pos.p + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ISX_HIP(hipMemcpyAsync(&lf, flag.p + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        *n_out = (int64_t)lp + lf;
+    }
+    return ISX_OK;
+}
+
+int isx_affinity_watershed(isx_ctx *ctx, const float *aff, const int64_t *seeds, int64_t n_seeds,
+                           const uint8_t *mask, uint32_t *out, const int64_t pshape[3],
+                           const float *scale)
+{
+    ISX_REQUIRE(ctx && aff && mask && out && pshape, "null argument");
+    ISX_HIP(hipSetDevice(ctx->device));
+    if (n_seeds <= 0 || !seeds) {
+        set_error("zero seeds: the reference raises here (np.apply_along_axis, watershed.py:50)");
+        return ISX_ERR_NO_SEEDS;
+    }
+    uint32_t n = (uint32_t)n_seeds;
+    int64_t PN = pshape[0] * pshape[1] * pshape[2];
+    Scratch<uint32_t> ridx(ctx, n), bad(ctx, 1);
+    Scratch<uint8_t> mask2(ctx, PN);
+    if (!ridx.ok() || !bad.ok() || !mask2.ok()) return ISX_ERR_NOMEM;
+    ISX_HIP(hipMemcpyAsync(mask2.p, mask, PN, hipMemcpyDeviceToDevice, ctx->stream));
+    ISX_HIP(hipMemsetAsync(bad.p, 0, 4, ctx->stream));
+    seed_check_mark_kernel<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(seeds, n, pshape[0], pshape[1], pshape[2],
+                                                                 mask2.p, bad.p);
+    ISX_CHECK_LAUNCH();
+    uint32_t hbad = 0;
+    ISX_HIP(hipMemcpyAsync(&hbad, bad.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    ISX_REQUIRE(!hbad, "a seed lies on or outside the zero border of the padded volume");
+    seed_ravel_kernel<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(seeds, n, pshape[1], pshape[2], ridx.p);
+    ISX_CHECK_LAUNCH();
+    return flood_impl(ctx, aff, ridx.p, n, mask2.p, out, pshape, nullptr, nullptr, scale);
+}
+
+int isx_segment_output_image(isx_ctx *ctx, const float *fm, const int64_t shape[3], uint32_t *labels,
+                             int64_t min_area, int64_t max_area, const float *abs_thresh,
+                             int64_t *seeds_out, int64_t seeds_cap, int64_t *n_seeds_out,
+                             uint8_t *mask_out, float *thresh_out)
+{
+    ISX_REQUIRE(ctx && fm && shape && labels, "null argument");
+    ISX_HIP(hipSetDevice(ctx->device));
+    const int64_t Z = shape[0], Y = shape[1], X = shape[2], n = Z * Y * X;
+    const int64_t pshape[3] = {Z + 2, Y + 2, X + 2};
+    const int64_t PN = pshape[0] * pshape[1] * pshape[2];
+    ISX_REQUIRE(PN < (int64_t)0xFFFFFFF0ll, "volume too large for 32-bit voxel indices");
+    if (n_seeds_out) *n_seeds_out = 0;
+
+    // ---- W2 seeds (centre map = channel 4) ------------------------------------------
+    uint32_t cap = (uint32_t)(n < 0x7FFFFFF0ll ? n : 0x7FFFFFF0ll);
+    // local maxima of a 3x3x3 filter are at most every other voxel per axis in practice;
+    // start with n/8 and retry with the true count if it ever overflows
+    uint32_t try_cap = (uint32_t)(n / 8 + 1024 < cap ? n / 8 + 1024 : cap);
+    uint32_t n_raw = 0;
+    std::unique_ptr<Scratch<unsigned long long>> ks;
+    {
+        ProfScope ps(ctx, ISX_PROF_WS_FILTERS);
+        for (;;) {
+            ks.reset(new Scratch<unsigned long long>(ctx, try_cap ? try_cap : 1));
+            if (!ks->ok()) return ISX_ERR_NOMEM;
+            ISX_TRY(seeds_impl(ctx, fm + 4 * n, shape, 1, 0.04f, ks->p, try_cap, &n_raw));
+            if (n_raw <= try_cap) break;
+            try_cap = n_raw;
+        }
+    }
+
+    // ---- W1 mask (channel 3), written zero-padded ---------------------------------------
+    Scratch<uint8_t> mask_p(ctx, PN);
+    Scratch<float> thr(ctx, 1);
+    if (!mask_p.ok() || !thr.ok()) return ISX_ERR_NOMEM;
+    {
+        ProfScope ps(ctx, ISX_PROF_WS_FILTERS);
+        if (abs_thresh) {
+            ISX_HIP(hipMemcpyAsync(thr.p, abs_thresh, 4, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            Scratch<float> sm(ctx, n), tmp(ctx, n);
+            if (!sm.ok() || !tmp.ok()) return ISX_ERR_NOMEM;
+            const int32_t sig[3] = {2, 2, 2};
+            ISX_TRY(gaussian_impl(ctx, fm + 3 * n, sm.p, shape, sig, tmp.p));
+            ISX_TRY(otsu_impl(ctx, sm.p, n, thr.p));
+        }
+        mask_kernel<<<cdiv(PN, TPB), TPB, 0, ctx->stream>>>(fm + 3 * n, thr.p, Z, Y, X, 1, mask_p.p);
+        ISX_CHECK_LAUNCH();
+        if (thresh_out) ISX_HIP(hipMemcpyAsync(thresh_out, thr.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+
+    // ---- W3 components + size filter; seeds restricted to survivors ----------------------
+    Scratch<uint32_t> parent(ctx, PN), sizes(ctx, PN);
+    Scratch<uint8_t> mask_f_own(ctx, mask_out ? 1 : PN);
+    if (!parent.ok() || !sizes.ok() || !mask_f_own.ok()) return ISX_ERR_NOMEM;
+    uint8_t *mask_f = mask_out ? mask_out : mask_f_own.p;
+    uint32_t n_keep = 0;
+    Scratch<uint32_t> ridx_keep(ctx, n_raw ? n_raw : 1);
+    if (!ridx_keep.ok()) return ISX_ERR_NOMEM;
+    {
+        ProfScope ps(ctx, ISX_PROF_WS_CCL);
+        ISX_TRY(ccl_impl(ctx, mask_p.p, pshape, parent.p, sizes.p));
+        uint32_t lo = (uint32_t)(min_area < 0 ? 0 : (min_area > 0xFFFFFFFFll ? 0xFFFFFFFFll : min_area));
+        uint32_t hi = (uint32_t)(max_area < 0 ? 0 : (max_area > 0xFFFFFFFFll ? 0xFFFFFFFFll : max_area));
+        ccl_apply_kernel<<<cdiv(PN, TPB), TPB, 0, ctx->stream>>>(parent.p, sizes.p, lo, hi, mask_f, PN);
+        ISX_CHECK_LAUNCH();
+        if (n_raw > 0) {
+            Scratch<int64_t> coords(ctx, (size_t)n_raw * 3), coords_keep(ctx, (size_t)n_raw * 3);
+            Scratch<uint32_t> ridx(ctx, n_raw), flag(ctx, n_raw), pos(ctx, n_raw);
+            if (!coords.ok() || !coords_keep.ok() || !ridx.ok() || !flag.ok() || !pos.ok()) return ISX_ERR_NOMEM;
+            unsigned sg = cdiv(n_raw, TPB);
+            seeds_decode_kernel<<<sg, TPB, 0, ctx->stream>>>(ks->p, n_raw, Y, X, 1, coords.p);
+            seed_ravel_kernel<<<sg, TPB, 0, ctx->stream>>>(coords.p, n_raw, pshape[1], pshape[2], ridx.p);
+            seed_flag_kernel<<<sg, TPB, 0, ctx->stream>>>(ridx.p, n_raw, mask_f, flag.p);
+            ISX_CHECK_LAUNCH();
+            ISX_TRY(exclusive_scan_u32(ctx, flag.p, pos.p, n_raw));
+            seed_compact_kernel<<<sg, TPB, 0, ctx->stream>>>(coords.p, flag.p, pos.p, n_raw, coords_keep.p, 0);
+            ISX_CHECK_LAUNCH();
+            uint32_t lp = 0, lf = 0;
+            ISX_HIP(hipMemcpyAsync(&lp, pos.p + (n_raw - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+            ISX_HIP(hipMemcpyAsync(&lf, flag.p + (n_raw - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+            ISX_HIP(hipStreamSynchronize(ctx->stream));
+            n_keep = lp + lf;
+            if (n_keep) {
+                seed_ravel_kernel<<<cdiv(n_keep, TPB), TPB, 0, ctx->stream>>>(coords_keep.p, n_keep, pshape[1],
+                                                                            pshape[2], ridx_keep.p);
+                ISX_CHECK_LAUNCH();
+                if (seeds_out) {
+                    uint32_t m = n_keep < (uint32_t)seeds_cap ? n_keep : (uint32_t)seeds_cap;
+                    // unpadded coordinates, like the `seeds` the reference returns (watershed.py:222)
+                    seed_copy_kernel<<<cdiv(m, TPB), TPB, 0, ctx->stream>>>(coords_keep.p, m, seeds_out, 1);
+                    ISX_CHECK_LAUNCH();
+                    ISX_HIP(hipStreamSynchronize(ctx->stream));
+                }
+            }
+        }
+    }
+    if (n_seeds_out) *n_seeds_out = n_keep;
+    if (n_keep == 0) {
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        set_error("zero seeds survive: the reference raises here (np.apply_along_axis, watershed.py:50)");
+        return ISX_ERR_NO_SEEDS;
+    }
+
+    // ---- W0 affinities + W4 flood -----------------------------------------------------
+    Scratch<float> aff(ctx, (size_t)3 * PN);
+    Scratch<uint32_t> cm(ctx, 4);
+    if (!aff.ok() || !cm.ok()) return ISX_ERR_NOMEM;
+    {
+        ProfScope ps(ctx, ISX_PROF_WS_FILTERS);
+        ISX_HIP(hipMemsetAsync(cm.p, 0, 16, ctx->stream));
+        unsigned g = cdiv(n, (int64_t)TPB * 8);
+        if (g > 2048) g = 2048;
+        chanmax_kernel<<<dim3(g, 3), TPB, 0, ctx->stream>>>(fm, n, cm.p);
+        ISX_CHECK_LAUNCH();
+        aff_pad_kernel<<<dim3(cdiv(PN, TPB), 3), TPB, 0, ctx->stream>>>(fm, cm.p, Z, Y, X, aff.p);
+        ISX_CHECK_LAUNCH();
+    }
+    // the filtered mask's components are a subset of the raw mask's: reuse roots and sizes
+    ISX_TRY(flood_impl(ctx, aff.p, ridx_keep.p, n_keep, mask_f, labels, pshape, parent.p, sizes.p, nullptr));
+    return ISX_OK;
+}
+
+}  // extern "C"

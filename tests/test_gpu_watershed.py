@@ -1,0 +1,137 @@
+"""GPU parity of the HIP watershed stage (through the C ABI) against the golden vectors of the
+reference and against the CPU oracle on seeded inputs.  Bit-exact: labels, masks, seeds,
+float32 filter outputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FM_CASES = ["ws_fm_10x48x48", "ws_fm_9x40x56", "ws_stages_0", "ws_stages_2", "ws_stages_3"]
+KERNEL_CASES = ["ws_k_ties", "ws_k_giant", "ws_k_noseed_comp", "ws_k_scale_axis", "ws_k_scale_neg",
+                "ws_k_negvals"]
+
+
+@pytest.fixture(scope="module")
+def ws():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from iterseg_amd import watershed
+    return watershed
+
+
+def _fm(golden, name):
+    d = golden(name)
+    if "feature_map" in d.files:
+        return d, d["feature_map"]
+    return d, golden("predict_" + name.split("ws_fm_")[1])["feature_map"]
+
+
+def _seeds_equal_mod_ties(got, ref, g):
+    if got.shape != ref.shape:
+        return False
+    if np.array_equal(got, ref):
+        return True
+    return (np.array_equal(g[tuple(got.T)], g[tuple(ref.T)])
+            and set(map(tuple, got)) == set(map(tuple, ref)))
+
+
+@pytest.mark.parametrize("name", FM_CASES + ["ws_stages_1"])
+def test_filters_bit_exact(ws, golden, name):
+    d, fm = _fm(golden, name)
+    sm = ws.gaussian(fm[3], 2)
+    assert np.array_equal(sm, d["mask_smooth"])
+    assert ws.threshold_otsu(sm) == d["thresh"]
+    assert np.array_equal(ws._get_mask(fm[3]), d["mask_raw"])
+    assert np.array_equal(ws.gaussian(fm[4], (0, 1, 1)), d["cent_smooth"])
+    pk = ws._get_centroids(fm[4])
+    assert _seeds_equal_mod_ties(pk, d["seeds_raw"], d["cent_smooth"])
+    mp = np.pad(d["mask_raw"], 1, constant_values=0)
+    m2, c2 = ws._remove_unwanted_objects(mp, d["seeds_raw"] + 1, min_area=10, max_area=10000000)
+    assert np.array_equal(m2, d["mask_filtered_padded"])
+    assert np.array_equal(c2, d["seeds_filtered_padded"])
+
+
+@pytest.mark.parametrize("name", FM_CASES)
+def test_segment_output_image_plugin_path(ws, golden, name):
+    d, fm = _fm(golden, name)
+    pshape = tuple(s + 2 for s in fm.shape[1:])
+    cur = np.zeros(pshape, np.uint32)
+    seg, seeds, mask = ws.segment_output_image(fm, affinities_channels=(0, 1, 2), thresholding_channel=3,
+                                               centroids_channel=4, out=cur.ravel())
+    assert np.array_equal(mask, d["mask_filtered_padded"])
+    if np.array_equal(seeds + 1, d["seeds_filtered_padded"]):
+        assert np.array_equal(cur, d["labels_padded"])            # bit-exact instance labels
+    else:                                                         # equal-intensity seeds permuted upstream
+        assert np.array_equal(cur > 0, d["labels_padded"] > 0)
+    assert np.array_equal(seg, cur[1:-1, 1:-1, 1:-1])
+
+
+def test_zero_seeds_raises_like_reference(ws, golden):
+    d = golden("ws_stages_1")
+    with pytest.raises(ValueError):
+        ws.segment_output_image(d["feature_map"], (0, 1, 2), 4, 3)
+    with pytest.raises(ValueError):
+        ws.affinity_watershed(np.zeros((3, 4, 4, 4), np.float32), np.zeros((0, 3), np.int64),
+                              np.zeros((4, 4, 4), bool))
+
+
+@pytest.mark.parametrize("name", KERNEL_CASES)
+def test_affinity_watershed_kernel_boundary(ws, golden, name):
+    d = golden(name)
+    ref = d["labels_padded"]
+    scale = d["scale"] if "scale" in d.files else None
+    out = np.zeros(ref.size, ref.dtype)
+    lab = ws.affinity_watershed(d["aff_padded"], d["seeds_padded"], d["mask_padded"], scale=scale, out=out)
+    assert lab.dtype == ref.dtype and np.array_equal(lab, ref)
+
+
+def test_affinity_watershed_default_mask(ws, golden):
+    d = golden("ws_k_giant_nomask")
+    lab = ws.affinity_watershed(d["aff_padded"], d["seeds_padded"], None)
+    assert lab.dtype == np.int32 and np.array_equal(lab, d["labels_padded"])
+
+
+@pytest.mark.parametrize("name", ["ws_blobs40", "ws_blobs32"])
+def test_reference_synthetic_blobs(ws, golden, name):
+    d = golden(name)
+    vol = d["volume"]
+    assert np.array_equal(ws.gaussian(vol[3], (0, 1, 1)), d["cent_smooth"])
+    assert _seeds_equal_mod_ties(ws._get_centroids(vol[3]), d["seeds_raw"], d["cent_smooth"])
+    lab = ws.affinity_watershed(d["aff_padded"], d["seeds_padded"], d["mask_padded"])
+    assert np.array_equal(lab[1:-1, 1:-1, 1:-1], d["labels"])
+    # full pipeline with the absolute threshold the reference's self-check uses (watershed.py:266)
+    seg, seeds, mask = ws.segment_output_image(vol, (0, 1, 2), 3, 4, absolute_thresh=0.5)
+    assert np.array_equal(mask, d["mask_padded"])
+    if np.array_equal(seeds + 1, d["seeds_padded"]):
+        assert np.array_equal(seg, d["labels"])
+    else:
+        assert np.array_equal(seg > 0, d["labels"] > 0)
+
+
+def test_size_filter_and_plateaus(ws, golden):
+    d = golden("ws_sizefilter")
+    m2, c2 = ws._remove_unwanted_objects(d["mask_padded"], d["seeds_padded"], int(d["min_area"]),
+                                         int(d["max_area"]))
+    assert np.array_equal(m2, d["mask_out"]) and np.array_equal(c2, d["seeds_out"])
+    p = golden("ws_plateau")
+    pk = ws._get_centroids(p["image"], gaussian=False)
+    assert set(map(tuple, pk)) == set(map(tuple, p["peaks"])) and len(pk) == len(p["peaks"])
+    assert len(ws._get_centroids(p["const"], gaussian=False)) == 0
+    assert ws.threshold_otsu(p["const"]) == p["otsu_const"]
+
+
+@pytest.mark.parametrize("shape,seed", [((24, 96, 80), 0), ((7, 33, 129), 1), ((40, 64, 64), 2)])
+def test_against_oracle_on_seeded_fields(ws, shape, seed):
+    """Larger seeded inputs than the fixtures: HIP path == CPU oracle, bit for bit."""
+    from oracle import watershed as ows
+    from tests.synth import smooth_feature_map
+    fm = smooth_feature_map(shape, seed)
+    pshape = tuple(s + 2 for s in shape)
+    ref = np.zeros(pshape, np.uint32)
+    rseg, rseeds, rmask = ows.segment_output_image(fm, out=ref.ravel())
+    cur = np.zeros(pshape, np.uint32)
+    seg, seeds, mask = ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=cur.ravel())
+    assert np.array_equal(mask, rmask)
+    assert np.array_equal(seeds, rseeds)
+    assert np.array_equal(cur, ref)
+    assert (cur > 0).sum() > 100
