@@ -49,7 +49,9 @@ const char *isx_last_error(void);
 int isx_device_count(void);
 isx_ctx *isx_ctx_create(int device);               /* NULL on failure                   */
 void isx_ctx_destroy(isx_ctx *ctx);
-int isx_ctx_set_stream(isx_ctx *ctx, void *hip_stream);   /* NULL = context-owned stream */
+/* Work is enqueued on a context-owned non-blocking stream until a caller stream is bound;
+ * NULL binds the HIP null stream (what torch.cuda.current_stream().cuda_stream is by default). */
+int isx_ctx_set_stream(isx_ctx *ctx, void *hip_stream);
 int isx_ctx_synchronize(isx_ctx *ctx);
 int isx_ctx_device(const isx_ctx *ctx);
 /* Bytes currently held by the context's device workspace cache. */
@@ -137,6 +139,11 @@ int isx_ws_seeds(isx_ctx *ctx, const float *cent, const int64_t shape[3], int sm
 int isx_ws_filter(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], int64_t min_area,
                   int64_t max_area, uint8_t *mask_out, const int64_t *seeds, int64_t n_seeds,
                   int64_t *seeds_out, int64_t *n_out);
+/* ndi.label(mask) of watershed.py:240 (6-connectivity): roots uint32 padded, the smallest
+ * raveled index of each voxel's component (0xFFFFFFFF outside the mask); sizes (optional)
+ * uint32 padded, the voxel count stored at each root. */
+int isx_ws_components(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], uint32_t *roots,
+                      uint32_t *sizes);
 /* W4 affinity_watershed / raveled_affinity_watershed (watershed.py:17-35, :95-159):
  * aff (3, PZ, PY, PX) float32 zero-padded, seeds int64 [n][3] padded coordinates
  * (label = row + 1), mask uint8 padded with a zero border, out uint32 padded labels

@@ -51,6 +51,7 @@ SIGNATURES = {
     "isx_ws_mask": (C.c_int, [_vp, _vp, _i64p, _vp, _f32p]),
     "isx_ws_seeds": (C.c_int, [_vp, _vp, _i64p, C.c_int, _f32, _vp, _i64, _i64p]),
     "isx_ws_filter": (C.c_int, [_vp, _vp, _i64p, _i64, _i64, _vp, _vp, _i64, _vp, _i64p]),
+    "isx_ws_components": (C.c_int, [_vp, _vp, _i64p, _vp, _vp]),
     "isx_affinity_watershed": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64p, _f32p]),
     "isx_segment_output_image": (C.c_int, [_vp, _vp, _i64p, _vp, _i64, _i64, _f32p, _vp, _i64, _i64p, _vp, _f32p]),
     "isx_normalise_volume": (C.c_int, [_vp, _vp, _i64]),
@@ -124,7 +125,7 @@ class Context:
         return self._h
 
     def set_stream(self, stream):
-        check(self.lib.isx_ctx_set_stream(self._h, C.c_void_p(int(stream) if stream else 0)))
+        check(self.lib.isx_ctx_set_stream(self._h, C.c_void_p(int(stream))))
 
     def use_torch_stream(self):
         import torch

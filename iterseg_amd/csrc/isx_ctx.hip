@@ -169,7 +169,7 @@ void isx_ctx_destroy(isx_ctx *c)
 int isx_ctx_set_stream(isx_ctx *c, void *s)
 {
     ISX_REQUIRE(c, "null context");
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;      // NULL is the HIP null (legacy default) stream
     return ISX_OK;
 }
 

@@ -311,12 +311,21 @@ __global__ void seeds_decode_kernel(const unsigned long long *keys, uint32_t n, 
 // W3: connected components (6-connectivity) by lock-free union-find over the padded mask
 // (root = smallest raveled index of the component), component sizes, size filter.
 // ------------------------------------------------------------------------------------
+// Every access to the union-find array inside the merge/flatten kernels is an agent-scope
+// access (sc1 load / atomic): the per-XCD L2s are not coherent with each other within a launch,
+// and a plain load or a plain path-compression store next to another XCD's atomicMin loses
+// links (observed on MI355X: a component shed 1-10 voxel pieces, differently on every run).
+__device__ __forceinline__ uint32_t uf_ld(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t a)
 {
-    uint32_t p = parent[a];
+    uint32_t p = uf_ld(parent + a);
     while (p != a) {
-        uint32_t gp = parent[p];
-        if (gp != p) parent[a] = gp;      // path halving (values only ever decrease)
+        uint32_t gp = uf_ld(parent + p);
+        if (gp != p) atomicMin(&parent[a], gp);      // path halving; values only ever decrease
         a = p;
         p = gp;
     }
@@ -358,8 +367,9 @@ __global__ void ccl_flatten_kernel(uint32_t *parent, int64_t N)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    if (parent[i] == NO_PARENT) return;
-    parent[i] = uf_find(parent, (uint32_t)i);
+    if (uf_ld(parent + i) == NO_PARENT) return;
+    uint32_t r = uf_find(parent, (uint32_t)i);
+    atomicMin(&parent[i], r);
 }
 
 // sizes[root] += 1 per mask voxel; lanes of a wave that share a root add once.
@@ -810,6 +820,15 @@ int isx_ws_filter(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], in
         *n_out = (int64_t)lp + lf;
     }
     return ISX_OK;
+}
+
+int isx_ws_components(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], uint32_t *roots,
+                      uint32_t *sizes)
+{
+    ISX_REQUIRE(ctx && mask && pshape && roots, "null argument");
+    ISX_HIP(hipSetDevice(ctx->device));
+    ProfScope ps(ctx, ISX_PROF_WS_CCL);
+    return ccl_impl(ctx, mask, pshape, roots, sizes);
 }
 
 int isx_affinity_watershed(isx_ctx *ctx, const float *aff, const int64_t *seeds, int64_t n_seeds,

@@ -127,6 +127,20 @@ def _remove_unwanted_objects(mask, centroids, min_area=0, max_area=1000000):
     return mout.bool(), cout
 
 
+def connected_components(mask):
+    """``ndi.label`` stand-in (6-connectivity): ``(roots, sizes)`` -- the smallest raveled index
+    of each voxel's component (0xFFFFFFFF off-mask) and the voxel count stored at the roots."""
+    dev = _device_of(mask)
+    ctx = get_context(dev.index)
+    m, was_np = _dev(mask, torch.uint8, dev)
+    roots = torch.empty(m.shape, dtype=torch.int32, device=dev)
+    sizes = torch.empty(m.shape, dtype=torch.int32, device=dev)
+    _lib.check(ctx.lib.isx_ws_components(ctx.handle, _ptr(m), _lib._dims(m.shape), _ptr(roots), _ptr(sizes)))
+    if was_np:
+        return roots.cpu().numpy().view(np.uint32), sizes.cpu().numpy().view(np.uint32)
+    return roots, sizes
+
+
 def affinity_watershed(image, marker_coords, mask, scale=None, out=None, py_func=False):
     """Kernel-boundary entry (watershed.py:17-35).  ``image``: (3, Z, Y, X) zero-padded
     affinities, ``marker_coords``: (n, 3) padded coordinates, ``mask``: bool with a zero border
