@@ -1,0 +1,143 @@
+"""Host-side U-Net object: holds a reference-format state dict and runs it on the MI355X.
+
+Mirror of ``iterseg.unet.UNet`` (reference: src/iterseg/unet.py:126-364) for the inference
+path: same constructor arguments (single decoder), ``load_state_dict`` / ``state_dict`` with the
+reference's key names and OIDHW float32 layouts, and ``__call__`` on a ``(1, 1, D, H, W)``
+tensor/array returning ``(1, C, D, H, W)`` -- what ``predict_chunk_feature_map`` expects
+(predict.py:120-123).  The arithmetic happens in ``libitersegx.so`` (HIP); this class never
+computes on the host.  As in the reference's inference, BatchNorm runs in training mode: batch
+statistics per chunk, running statistics updated as a side effect.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib, weights as _weights
+
+
+class UNet:
+    def __init__(self, in_channels=1, out_channels=5, down_factors=(1, 2, 2), up='convolution',
+                 downsample_1_at_bottom=True, chan_final_activations=None, device=None, batch=4):
+        if isinstance(out_channels, tuple):
+            raise NotImplementedError("forked decoders (out_channels tuple) are not on the accelerated path")
+        if in_channels != 1 or tuple(down_factors) != (1, 2, 2) or up != 'convolution' or not downsample_1_at_bottom:
+            raise NotImplementedError("only the configuration iterseg ships (in=1, (1,2,2), transposed conv) is built")
+        if chan_final_activations not in (None, ['sigmoid'], ('sigmoid',)):
+            raise NotImplementedError("final activation other than sigmoid")
+        self.in_channels, self.out_channels = in_channels, int(out_channels)
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.ctx = _lib.Context(self.device)
+        self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch))
+        self._loaded = False
+        self._sd = None
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts torch tensors or numpy arrays keyed like the reference (predict.py:34)."""
+        sd = OrderedDict()
+        for k, v in state_dict.items():
+            sd[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        _weights.check_state_dict(sd, self.in_channels, self.out_channels)     # strict key/shape check
+        if self._loaded:                          # a committed context cannot be re-loaded: start a new one
+            self.ctx.close()
+            self.ctx = _lib.Context(self.device)
+        lib, h = self.ctx.lib, self.ctx.handle
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                a = np.ascontiguousarray(v, np.int64).reshape(())
+                _lib.check(lib.isx_load_weight_host(h, k.encode(), a.ctypes.data_as(C.c_void_p), None, 0))
+            else:
+                a = np.ascontiguousarray(v, np.float32)
+                shp = (C.c_int64 * a.ndim)(*a.shape)
+                _lib.check(lib.isx_load_weight_host(h, k.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim))
+        _lib.check(lib.isx_weights_commit(h, self.out_channels))
+        self._sd = sd
+        self._loaded = True
+        return self
+
+    def state_dict(self):
+        """Reference-format state dict (torch CPU tensors); running statistics are read back."""
+        out = OrderedDict()
+        for k, v in self._sd.items():
+            if ".running_" in k or k.endswith("num_batches_tracked"):
+                buf = np.empty(v.shape, v.dtype if not k.endswith("tracked") else np.int64)
+                _lib.check(self.ctx.lib.isx_get_weight_host(self.ctx.handle, k.encode(),
+                                                            buf.ctypes.data_as(C.c_void_p), max(buf.nbytes, 8)))
+                out[k] = torch.from_numpy(buf.copy())
+            else:
+                out[k] = torch.from_numpy(np.array(v, copy=True))
+        return out
+
+    def set_batch(self, batch):
+        _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch)))
+
+    # ------------------------------------------------------------------ forward
+    def _bind_stream(self):
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def forward_chunks(self, volume, starts, chunk):
+        """volume: CUDA float32 (Z,Y,X); starts: (n,3) ints -> CUDA (n, C, cz, cy, cx)."""
+        assert self._loaded, 'Please ensure a unet is loaded and supplied'
+        self._bind_stream()
+        starts = np.ascontiguousarray(starts, np.int32).reshape(-1, 3)
+        out = torch.empty((len(starts), self.out_channels) + tuple(int(c) for c in chunk), dtype=torch.float32,
+                          device=volume.device)
+        _lib.check(self.ctx.lib.isx_unet_forward_chunks(
+            self.ctx.handle, C.c_void_p(volume.data_ptr()), _lib._dims(volume.shape),
+            starts.ctypes.data_as(C.POINTER(C.c_int32)), len(starts), _lib._dims(chunk), C.c_void_p(out.data_ptr())))
+        return out
+
+    def __call__(self, x):
+        """(1,1,D,H,W) tensor or array -> (1,C,D,H,W) tensor on the same kind of device."""
+        was_np = not isinstance(x, torch.Tensor)
+        t = torch.as_tensor(x, dtype=torch.float32)
+        on_gpu = t.is_cuda
+        assert t.dim() == 5 and t.shape[0] == 1 and t.shape[1] == 1, "expects a (1,1,D,H,W) chunk"
+        vol = t[0, 0].contiguous().to(f"cuda:{self.device}")
+        y = self.forward_chunks(vol, [(0, 0, 0)], vol.shape)
+        if was_np:
+            return y.cpu().numpy()
+        return y if on_gpu else y.cpu()
+
+    forward = __call__
+
+    def predict_volume(self, volume, chunk_size, margin, feature_map=None, first=0, count=None):
+        """P2-P4 on device: CUDA (Z,Y,X) volume -> CUDA (C,Z,Y,X) feature map (crops stitched)."""
+        assert self._loaded, 'Please ensure a unet is loaded and supplied'
+        self._bind_stream()
+        tab = _lib.make_chunks_table(volume.shape, chunk_size, margin)
+        if feature_map is None:
+            feature_map = torch.zeros((self.out_channels,) + tuple(volume.shape), dtype=torch.float32,
+                                      device=volume.device)
+        count = len(tab) - first if count is None else count
+        _lib.check(self.ctx.lib.isx_predict_volume(
+            self.ctx.handle, C.c_void_p(volume.data_ptr()), _lib._dims(volume.shape),
+            tab.ctypes.data_as(C.POINTER(C.c_int32)), int(first), int(count), _lib._dims(chunk_size),
+            C.c_void_p(feature_map.data_ptr())))
+        return feature_map
+
+    def tap(self, name):
+        """Named intermediate of chunk 0 of the last forward, as a (C, D, H, W) numpy array."""
+        cap = 1 << 24
+        buf = np.empty(cap, np.float32)
+        shp = (C.c_int64 * 4)()
+        _lib.check(self.ctx.lib.isx_unet_tap_host(self.ctx.handle, name.encode(), buf.ctypes.data_as(C.c_void_p),
+                                                  cap, shp))
+        shape = tuple(shp)
+        return buf[:int(np.prod(shape))].reshape(shape).copy()
+
+    # torch.nn.Module look-alikes the reference's callers touch
+    def cuda(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def train(self, mode=True):
+        if not mode:
+            raise NotImplementedError("iterseg runs its U-Net with train-mode BatchNorm; eval mode is not built")
+        return self

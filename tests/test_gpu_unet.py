@@ -1,0 +1,125 @@
+"""GPU parity of the HIP U-Net (through the C ABI) against the golden vectors captured from the
+reference's own UNet / process_chunks, and against the CPU oracle on a full-size chunk.
+
+Stated tolerance (fp32 path: exact fp32 products on the matrix cores, fp32 accumulation in a
+different summation order than ATen, train-mode BatchNorm statistics in double):
+  * sigmoid feature maps:      |err| <= 1e-4 absolute  
+  * pre-activation taps:       |err| <= 1e-4 * max(1, max|ref|)
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ABS_TOL = 1e-4
+REL_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def net():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    u = UNet(1, 5, batch=4)
+    u.load_state_dict(weights.generate_state_dict(0))
+    return u
+
+
+def _close(got, ref, name, rel=REL_TOL):
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = np.abs(got - ref).max()
+    assert err <= rel * max(1.0, np.abs(ref).max()), (name, err, np.abs(ref).max())
+
+
+def test_forward_taps_match_reference(net, golden):
+    d = golden("unet_taps_4x32x32")
+    y = net(d["x"][None, None])
+    assert y.shape == (1, 5, 4, 32, 32)
+    for name in ["c0.conv0", "c0.batch0", "c0", "d0", "c1", "d3", "c4", "c5_0", "c8_0.conv1"]:
+        _close(net.tap(name), d[name][0], name)
+    _close(net.tap("up0.cropped"), d["up0"][0][:, :, :-1, :-1], "up0")
+    _close(net.tap("up3.cropped"), d["up3"][0][:, :, 1:-1, 1:-1], "up3")
+    assert np.abs(y[0] - d["c8_0"][0]).max() <= ABS_TOL
+    assert np.abs(net.tap("c8_0") - d["y"][0]).max() <= ABS_TOL
+
+
+def test_running_statistics_side_effect(golden):
+    """Train-mode BN updates running stats during inference."""
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    d = golden("unet_taps_4x32x32")
+    u = UNet(1, 5, batch=1)
+    u.load_state_dict(weights.generate_state_dict(0))
+    u(d["x"][None, None])
+    sd = u.state_dict()
+    for k in ("c0.batch0.running_mean", "c0.batch0.running_var", "c8_0.batch1.running_mean",
+              "c8_0.batch1.running_var"):
+        assert np.allclose(sd[k].numpy(), d["post." + k], rtol=1e-4, atol=1e-6), k
+    assert int(sd["c0.batch0.num_batches_tracked"]) == 1
+    assert list(sd.keys()) == list(weights.unet_schema().keys())
+
+
+@pytest.mark.parametrize("tag", ["10x48x48", "9x40x56"])
+def test_chunked_predict_matches_reference(net, golden, tag):
+    from iterseg_amd import predict
+    d = golden("predict_" + tag)
+    out = np.zeros_like(d["feature_map"])
+    predict.process_chunks(d["volume"], tuple(int(c) for c in d["chunk"]), out, tuple(int(m) for m in d["margin"]),
+                           predict.predict_chunk_feature_map, config={"unet": net, "output_volume": out})
+    assert np.abs(out - d["feature_map"]).max() <= ABS_TOL
+
+
+def test_generic_chunk_loop_equals_device_loop(net, golden):
+    """The reference-shaped per-chunk loop (host round trips) and the device chunk scheduler agree."""
+    from iterseg_amd import predict
+    d = golden("predict_10x48x48")
+    chunk, margin = tuple(int(c) for c in d["chunk"]), tuple(int(m) for m in d["margin"])
+    a = np.zeros_like(d["feature_map"])
+    predict.process_chunks(d["volume"], chunk, a, margin, predict.predict_chunk_feature_map,
+                           config={"unet": net, "output_volume": a})
+    b = np.zeros_like(d["feature_map"])
+    predict.process_chunks(d["volume"], chunk, b, margin,
+                           lambda v, sl, **kw: predict.predict_chunk_feature_map(v, sl, **kw),
+                           config={"unet": net, "output_volume": b})
+    assert np.array_equal(a, b)              # same kernels, same per-chunk statistics: bit-identical
+
+
+def test_full_size_chunk_against_oracle(net):
+    """One (10,256,256) chunk -- the BASELINE geometry, all tile mappings and odd sizes
+    (129/65/33/17) -- against the torch-CPU oracle."""
+    from iterseg_amd import weights
+    from oracle import unet_torch as ou
+    from tests.synth import positive_volume
+    torch.set_num_threads(8)
+    x = positive_volume((10, 256, 256), 5)
+    p = ou._as_params(weights.generate_state_dict(0))
+    with torch.no_grad():
+        ref = ou.unet_forward(p, torch.from_numpy(x)[None, None]).numpy()
+    y = net(x[None, None])
+    err = np.abs(y - ref).max()
+    assert err <= ABS_TOL, err
+
+
+def test_batched_chunks_are_independent(net):
+    """Chunks forwarded together in one launch set keep per-chunk BatchNorm statistics."""
+    from tests.synth import positive_volume
+    vol = torch.from_numpy(positive_volume((8, 64, 96), 6)).cuda()
+    starts = [(0, 0, 0), (4, 32, 64), (2, 16, 32), (4, 0, 0), (0, 32, 0)]
+    together = net.forward_chunks(vol, starts, (4, 32, 32)).cpu().numpy()
+    for i, s in enumerate(starts):
+        alone = net.forward_chunks(vol, [s], (4, 32, 32)).cpu().numpy()
+        assert np.array_equal(alone[0], together[i]), i
+
+
+def test_rejects_bad_geometry_and_missing_weights(net):
+    from iterseg_amd.unet import UNet
+    with pytest.raises(ValueError):
+        net(np.zeros((1, 1, 5, 32, 32), np.float32))
+    with pytest.raises(ValueError):
+        net(np.zeros((1, 1, 4, 40, 32), np.float32))
+    u = UNet(1, 5)
+    with pytest.raises(AssertionError):
+        u(np.zeros((1, 1, 4, 32, 32), np.float32))
+    with pytest.raises(RuntimeError):
+        u.load_state_dict({"c0.conv0.weight": np.zeros((32, 1, 3, 3, 3), np.float32)})
