@@ -81,6 +81,8 @@ struct UNetState {
     float *raw[18] = {nullptr};
     float *pool[4] = {nullptr};
     float *ups[4] = {nullptr};
+    float *ptail = nullptr;           // [B][M0][16] partial sums of the folded tail layer
+    float *wtail = nullptr, *zeros32 = nullptr;
     const int32_t *d_table = nullptr;   // device rows of the launch set in flight
     int last_n = 0;
 };
@@ -195,16 +197,21 @@ struct ConvArgs {
     int mode;              // 0: 2x8x8 voxel tiles; 1: 2 planes x 64 row-wrapped positions; 2: 1 plane x 128
     int tiles_per_chunk, nty, ntx, ntp;
     int slots_max;         // LDS halo slots reserved
+    int store_cols;        // columns of the N tile actually stored (Cout, or 16 for the folded tail layer)
+    int no_stats;          // 1: skip BN partial sums (folded tail layer: statistics come from the combine)
 };
 
 static constexpr int A_STRIDE = 6;     // floats per halo slot (4 channels + 2 pad: conflict-free ds_read_b64)
 
-template <int BN>
+// TX = 3: all 27 taps.  TX = 1: the 9 taps with dx = 0 only (the folded tail layer, where the three
+// x-taps live in the output columns instead).
+template <int BN, int TX>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = BN / 32;
-    constexpr int BFLOATS = 27 * 4 * BN;
+    constexpr int NTAPS = 9 * TX;
+    constexpr int BFLOATS = NTAPS * 4 * BN;
     constexpr int B4 = BFLOATS / 4;                       // float4 per weight slab
     constexpr int NB = (B4 + 255) / 256;
     float *Bs = smem;
@@ -269,27 +276,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
         }
     }
 
-    // ---- halo slots staged by this thread: global voxel index or -1 (zero padding) --------
-    int gv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int s = tid + 256 * i;
-        int g = -2;                                       // -2: slot does not exist
-        if (s < S) {
-            int z, y, x;
-            if (a.mode == 0) {
-                int hz = s / 100, hy = (s / 10) % 10, hx = s % 10;
-                z = z0 + hz - 1; y = y0 + hy - 1; x = x0 + hx - 1;
-            } else {
-                int hz = s / PS, qq = qlo + s % PS + WP;  // + WP keeps the division non-negative
-                z = z0 + hz - 1;
-                y = qq / WP - 1;
-                x = qq % WP - 1;
-            }
-            g = (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
+    // ---- halo slots staged by this thread: global voxel index, -1 (zero padding) or -2 (no slot).
+    // Named scalars, not arrays: hipcc leaves array forms of these and of the prefetch registers in
+    // scratch memory when they live across the K loop (CDNA guide rule 20).
+    auto slot_voxel = [&](int s) __attribute__((always_inline)) -> int {
+        if (s >= S) return -2;
+        int z, y, x;
+        if (a.mode == 0) {
+            int hz = s / 100, hy = (s / 10) % 10, hx = s % 10;
+            z = z0 + hz - 1; y = y0 + hy - 1; x = x0 + hx - 1;
+        } else {
+            int hz = s / PS, qq = qlo + s % PS + WP;      // + WP keeps the division non-negative
+            z = z0 + hz - 1;
+            y = qq / WP - 1;
+            x = qq % WP - 1;
         }
-        gv[i] = g;
-    }
+        return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
+    };
+    const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + 256), gv2 = slot_voxel(tid + 512),
+              gv3 = slot_voxel(tid + 768);
 
     const int nsteps = (a.CA + a.CB) >> 2;
     f32x16 acc[NT];
@@ -298,58 +303,59 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-    float4 ra[4], rb[NB];
-    auto load_stage = [&](int step) {
-        int c0 = step << 2;
-        const float *src, *sc, *sh;
-        int C, cc;
-        if (c0 < a.CA) { src = a.srcA; sc = a.scaleA; sh = a.shiftA; C = a.CA; cc = c0; }
-        else { src = a.srcB; sc = a.scaleB; sh = a.shiftB; C = a.CB; cc = c0 - a.CA; }
-        float4 vs = make_float4(1.f, 1.f, 1.f, 1.f), vh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sc) { vs = *(const float4 *)&sc[(int64_t)b * C + cc]; vh = *(const float4 *)&sh[(int64_t)b * C + cc]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gv[i] >= 0) {
-                v = *(const float4 *)&src[((int64_t)b * M + gv[i]) * C + cc];
-                if (sc) {
-                    v.x = fmaxf(fmaf(v.x, vs.x, vh.x), 0.f);
-                    v.y = fmaxf(fmaf(v.y, vs.y, vh.y), 0.f);
-                    v.z = fmaxf(fmaf(v.z, vs.z, vh.z), 0.f);
-                    v.w = fmaxf(fmaf(v.w, vs.w, vh.w), 0.f);
-                }
-            }
-            ra[i] = v;
-        }
-        const float4 *wsrc = (const float4 *)(a.w + ((int64_t)ntile * nsteps + step) * BFLOATS);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            int idx = tid + 256 * i;
-            rb[i] = (idx < B4) ? wsrc[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (gv[i] != -2) {
-                float *dst = As + (tid + 256 * i) * A_STRIDE;
-                *(float2 *)dst = make_float2(ra[i].x, ra[i].y);
-                *(float2 *)(dst + 2) = make_float2(ra[i].z, ra[i].w);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            int idx = tid + 256 * i;
-            if (idx < B4) ((float4 *)Bs)[idx] = rb[i];
-        }
-    };
+    // Register prefetch of the next stage.  Loads are unconditional (out-of-tile slots read a
+    // clamped address) and stay untouched in registers while the matrix cores run; the producer's
+    // BN scale/shift + ReLU and the zero padding are applied when the stage is written to LDS, so
+    // nothing between the loads and the MFMA phase waits on vmcnt.
+    static_assert(NB <= 7, "prefetch register plan covers at most 7 float4 of weights per thread");
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6, vs, vh;
+    bool has_affine = false;
+#define ISX_LOAD_A(k) ra##k = *(const float4 *)&src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];
+#define ISX_LOAD_B(k) if constexpr (NB > k) rb##k = wsrc[tid + 256 * k];
+#define ISX_LOAD_STAGE(step_)                                                                     \
+    {                                                                                             \
+        const int c0 = (step_) << 2;                                                              \
+        const float *src, *sc, *sh;                                                               \
+        int C, cc;                                                                                \
+        if (c0 < a.CA) { src = a.srcA; sc = a.scaleA; sh = a.shiftA; C = a.CA; cc = c0; }         \
+        else { src = a.srcB; sc = a.scaleB; sh = a.shiftB; C = a.CB; cc = c0 - a.CA; }            \
+        has_affine = sc != nullptr;                                                               \
+        const float *scp = has_affine ? sc : a.bias, *shp = has_affine ? sh : a.bias;             \
+        const int64_t so = has_affine ? (int64_t)b * C + cc : 0;                                  \
+        vs = *(const float4 *)&scp[so];                                                           \
+        vh = *(const float4 *)&shp[so];                                                           \
+        ISX_LOAD_A(0) ISX_LOAD_A(1) ISX_LOAD_A(2) ISX_LOAD_A(3)                                   \
+        const float4 *wsrc = (const float4 *)(a.w + ((int64_t)ntile * nsteps + (step_)) * BFLOATS); \
+        ISX_LOAD_B(0) ISX_LOAD_B(1) ISX_LOAD_B(2) ISX_LOAD_B(3) ISX_LOAD_B(4) ISX_LOAD_B(5) ISX_LOAD_B(6) \
+    }
+#define ISX_STORE_A(k)                                                                            \
+    if (gv##k != -2) {                                                                            \
+        float4 v = ra##k;                                                                         \
+        if (has_affine) {                                                                         \
+            v.x = fmaxf(fmaf(v.x, vs.x, vh.x), 0.f);                                              \
+            v.y = fmaxf(fmaf(v.y, vs.y, vh.y), 0.f);                                              \
+            v.z = fmaxf(fmaf(v.z, vs.z, vh.z), 0.f);                                              \
+            v.w = fmaxf(fmaf(v.w, vs.w, vh.w), 0.f);                                              \
+        }                                                                                         \
+        if (gv##k < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
+        float *dst = As + (tid + 256 * k) * A_STRIDE;                                             \
+        *(float2 *)dst = make_float2(v.x, v.y);                                                   \
+        *(float2 *)(dst + 2) = make_float2(v.z, v.w);                                             \
+    }
+#define ISX_STORE_B(k) if constexpr (NB > k) { if (tid + 256 * k < B4) ((float4 *)Bs)[tid + 256 * k] = rb##k; }
+#define ISX_STORE_STAGE()                                                                         \
+    {                                                                                             \
+        ISX_STORE_A(0) ISX_STORE_A(1) ISX_STORE_A(2) ISX_STORE_A(3)                               \
+        ISX_STORE_B(0) ISX_STORE_B(1) ISX_STORE_B(2) ISX_STORE_B(3) ISX_STORE_B(4) ISX_STORE_B(5) ISX_STORE_B(6) \
+    }
 
-    load_stage(0);
+    ISX_LOAD_STAGE(0)
     for (int step = 0; step < nsteps; ++step) {
         __syncthreads();                 // everyone is done reading the previous stage
-        store_stage();
+        ISX_STORE_STAGE()
         __syncthreads();
-        if (step + 1 < nsteps) load_stage(step + 1);      // in flight while the matrix cores run
+        if (step + 1 < nsteps) ISX_LOAD_STAGE(step + 1)   // in flight while the matrix cores run
+        __builtin_amdgcn_sched_barrier(0);
         const float *ap = As + aslot * A_STRIDE + 2 * hh;
         const float *bp = Bs + (2 * hh) * BN + nn;
 #pragma unroll
@@ -357,8 +363,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int tap = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
+                for (int dxi = 0; dxi < TX; ++dxi) {
+                    const int dx = (TX == 3) ? dxi - 1 : 0;
+                    const int tap = ((dz + 1) * 3 + (dy + 1)) * TX + dxi;
                     const int toff = dz * PS + dy * RS + dx;
                     const float2 av = *(const float2 *)(ap + toff * A_STRIDE);
 #pragma unroll
@@ -369,7 +376,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc[j], 0, 0, 0);
                     }
                 }
+        __builtin_amdgcn_sched_barrier(0);
     }
+#undef ISX_LOAD_A
+#undef ISX_LOAD_B
+#undef ISX_LOAD_STAGE
+#undef ISX_STORE_A
+#undef ISX_STORE_B
+#undef ISX_STORE_STAGE
 
     // ---- epilogue: + bias, store, per-tile BN partial sums (valid rows only) ----------------
     // C/D layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
             const int g = rowinfo[row];
             if (g >= 0) {
                 const float v = acc[j][i] + bsv;
-                a.out[((int64_t)b * M + g) * a.Cout + ch] = v;
+                if (ch < a.store_cols) a.out[((int64_t)b * M + g) * a.store_cols + ch] = v;
                 s += v;
                 q += v * v;
             }
@@ -394,7 +408,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
         if (hh == 0) { red[(wave * BN + 32 * j + nn) * 2] = s; red[(wave * BN + 32 * j + nn) * 2 + 1] = q; }
     }
     __syncthreads();
-    if (tid < BN) {
+    if (tid < BN && !a.no_stats) {
         float s = 0.f, q = 0.f;
         for (int wv = 0; wv < 4; ++wv) { s += red[(wv * BN + tid) * 2]; q += red[(wv * BN + tid) * 2 + 1]; }
         int64_t o = ((int64_t)b * a.tiles_per_chunk + tile) * a.Cout + ntile * BN + tid;
@@ -614,6 +628,50 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Kernel: second half of the folded tail layer (c8.conv0, Cin -> <= 5 channels).  The MFMA pass
+// (TX = 1) produced P[v][dx*nout + o] = sum over (dz, dy, c) of in[v + (dz,dy,0)][c] * w[o][c][dz][dy][dx];
+// here out[v][o] = bias[o] + sum over dx of P[v + dx*ex][dx*nout + o] (x-neighbours outside the chunk
+// contribute zero = the convolution's zero padding), plus the per-block BN partial sums.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tail_combine_kernel(const float *__restrict__ P, const float *__restrict__ bias,
+                                                           int W, int64_t M, int nout, float *__restrict__ out,
+                                                           float *__restrict__ psum, float *__restrict__ psq,
+                                                           int blocks_per_chunk)
+{
+    __shared__ float red[4 * 8 * 2];
+    const int b = blockIdx.x / blocks_per_chunk, blk = blockIdx.x % blocks_per_chunk;
+    const int64_t m = (int64_t)blk * 256 + threadIdx.x;
+    const bool live = m < M;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const int x = (int)(m % W);
+        const float *p = P + ((int64_t)b * M + m) * 16;
+        for (int o = 0; o < nout; ++o) {
+            float v = bias[o] + p[nout + o];
+            if (x > 0) v += p[-16 + o];
+            if (x < W - 1) v += p[16 + 2 * nout + o];
+            acc[o] = v;
+            out[((int64_t)b * M + m) * nout + o] = v;
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 0; o < 5; ++o) {
+        float sm = live ? acc[o] : 0.f, q = live ? acc[o] * acc[o] : 0.f;
+        for (int off = 32; off > 0; off >>= 1) { sm += __shfl_xor(sm, off); q += __shfl_xor(q, off); }
+        if (lane == 0) { red[(wave * 8 + o) * 2] = sm; red[(wave * 8 + o) * 2 + 1] = q; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nout) {
+        float sm = 0.f, q = 0.f;
+        for (int wv = 0; wv < 4; ++wv) { sm += red[(wv * 8 + threadIdx.x) * 2]; q += red[(wv * 8 + threadIdx.x) * 2 + 1]; }
+        int64_t o = ((int64_t)b * blocks_per_chunk + blk) * nout + threadIdx.x;
+        psum[o] = sm;
+        psq[o] = q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Kernel: final BatchNorm + sigmoid; writes the chunk output as NCDHW (optional) and/or its centre
 // crop into the (C, Z, Y, X) feature map (process_chunks, predict.py:82-95).
 // ------------------------------------------------------------------------------------------
@@ -709,6 +767,8 @@ static const HostTensor *need(UNetState *u, const std::string &key, std::vector<
 }
 
 static bool use_mfma(int cin, int cout) { return cin >= 32 && (cin % 4) == 0 && (cout % 32) == 0; }
+// thin layer with many inputs: x-taps folded into the MFMA N tile (3 * cout <= 16 columns)
+static bool use_fold(int cin, int cout) { return cin >= 32 && (cin % 4) == 0 && cout <= 5; }
 
 static int commit_weights(isx_ctx *ctx, int out_channels)
 {
@@ -748,6 +808,15 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
                             size_t dst = ((((size_t)(co / BN) * nsteps + ci / 4) * 27 + t) * 4 + ci % 4) * BN + co % BN;
                             pk[dst] = w->f[((size_t)co * ci_n + ci) * 27 + t];
                         }
+            } else if (use_fold(L.cin, cout)) {   // folded tail: [Cin/4][9 (dz,dy)][4][32], column = dx*cout + o
+                const int nsteps = ci_n / 4;
+                pk.assign((size_t)nsteps * 9 * 4 * 32 + 2048, 0.f);
+                for (int co = 0; co < cout; ++co)
+                    for (int ci = 0; ci < ci_n; ++ci)
+                        for (int t9 = 0; t9 < 9; ++t9)
+                            for (int dxi = 0; dxi < 3; ++dxi)
+                                pk[((((size_t)(ci / 4)) * 9 + t9) * 4 + ci % 4) * 32 + dxi * cout + co] =
+                                    w->f[((size_t)co * ci_n + ci) * 27 + t9 * 3 + dxi];
             } else if (L.cin == 1) {          // conv_first: [27][32]
                 pk.assign((size_t)27 * cout, 0.f);
                 for (int co = 0; co < cout; ++co)
@@ -770,6 +839,7 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
             ISX_TRY(dev_upload(u, rv->f, &L.rvar));
         }
     }
+    ISX_TRY(dev_upload(u, std::vector<float>(32, 0.f), &u->zeros32));
     for (int k = 0; k < 4; ++k) {
         UpConv &U = u->up[k];
         U.name = UPS[k];
@@ -827,7 +897,7 @@ static int layer_tiles(const UNetState *u, int li, const Level &l)
         return conv_tiles(l, conv_mode(l), &a, &b, &c, &d);
     }
     if (L.cin == 1) return (int)((l.M + 127) / 128);
-    return (int)((l.M + 255) / 256);
+    return (int)((l.M + 255) / 256);      // thin kernel blocks, or combine blocks of the folded layer
 }
 
 static int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
@@ -865,6 +935,7 @@ static int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
         ISX_TRY(dev_alloc(u, (size_t)B * L.cout, &L.bmean));
         ISX_TRY(dev_alloc(u, (size_t)B * L.cout, &L.bvar));
     }
+    ISX_TRY(dev_alloc(u, (size_t)B * lv[0].M * 16 + 64, &u->ptail));
     for (int k = 0; k < 4; ++k) {
         ISX_TRY(dev_alloc(u, (size_t)B * lv[k + 1].M * MOD_COUT[k], &u->pool[k]));       // pooled module k output
         ISX_TRY(dev_alloc(u, (size_t)B * lv[3 - k].M * UP_C[k], &u->ups[k]));            // up_k output at level 3-k
@@ -890,14 +961,41 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
         a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = L.cout;
         a.mode = conv_mode(l);
         a.tiles_per_chunk = conv_tiles(l, a.mode, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+        a.store_cols = L.cout;
+        a.no_stats = 0;
         ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
         ISX_REQUIRE(a.tiles_per_chunk == L.tiles, "internal: tile count mismatch");
         const int BN = (L.cout % 64 == 0) ? 64 : 32;
         size_t lds = (size_t)(27 * 4 * BN + a.slots_max * A_STRIDE + 128 + 4 * BN * 2) * sizeof(float);
         dim3 grid((unsigned)(B * a.tiles_per_chunk), (unsigned)(L.cout / BN));
-        if (BN == 64) conv_mfma_kernel<64><<<grid, 256, lds, ctx->stream>>>(a);
-        else conv_mfma_kernel<32><<<grid, 256, lds, ctx->stream>>>(a);
+        if (BN == 64) conv_mfma_kernel<64, 3><<<grid, 256, lds, ctx->stream>>>(a);
+        else conv_mfma_kernel<32, 3><<<grid, 256, lds, ctx->stream>>>(a);
         ISX_CHECK_LAUNCH();
+    } else if (use_fold(L.cin, L.cout)) {
+        // pass 1 on the matrix cores: 9 (dz,dy) taps, x-taps folded into 3*cout <= 16 output columns
+        {
+            ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
+            ConvArgs a;
+            a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
+            a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
+            a.w = L.w; a.bias = u->zeros32; a.out = u->ptail; a.psum = nullptr; a.psq = nullptr;
+            a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = 32;
+            a.mode = conv_mode(l);
+            a.tiles_per_chunk = conv_tiles(l, a.mode, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+            a.store_cols = 16;
+            a.no_stats = 1;
+            ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
+            size_t lds = (size_t)(9 * 4 * 32 + a.slots_max * A_STRIDE + 128 + 4 * 32 * 2) * sizeof(float);
+            conv_mfma_kernel<32, 1><<<dim3((unsigned)(B * a.tiles_per_chunk), 1), 256, lds, ctx->stream>>>(a);
+            ISX_CHECK_LAUNCH();
+        }
+        // pass 2: shifted combine + bias + BN partial sums
+        {
+            ProfScope ps(ctx, ISX_PROF_CONV_DIRECT);
+            tail_combine_kernel<<<(unsigned)(B * L.tiles), 256, 0, ctx->stream>>>(u->ptail, L.bias, l.W, l.M, L.cout,
+                                                                              u->raw[li], L.psum, L.psq, L.tiles);
+            ISX_CHECK_LAUNCH();
+        }
     } else if (L.cin == 1) {
         ProfScope ps(ctx, ISX_PROF_CONV_DIRECT);
         ISX_REQUIRE(L.cout == 32 && !sa.scale, "internal: conv_first shape");
