@@ -13,6 +13,7 @@
 #pragma clang fp contract(off)
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -268,27 +269,39 @@ __global__ void mask_kernel(const float *__restrict__ img, const float *thresh, 
 // border excluded.  Candidates are emitted as sortable keys:
 //   key = (~ford(intensity) << 32) | raveled index   (descending intensity, ascending index)
 // ------------------------------------------------------------------------------------
-__global__ void peak_kernel(const float *__restrict__ g, int64_t Z, int64_t Y, int64_t X, float thr,
+__global__ void peak_kernel(const float *__restrict__ g, int Z, int Y, int X, float thr,
                             uint32_t *nonpeak_flag, unsigned long long *keys, uint32_t *count,
                             uint32_t cap)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Z * Y * X) return;
-    int64_t x = i % X, y = (i / X) % Y, z = i / (X * Y);
-    float c = g[i];
+    const uint32_t n = (uint32_t)Z * Y * X;                    // < 2^32 (checked by the caller)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % (uint32_t)X), y = (int)((i / (uint32_t)X) % (uint32_t)Y), z = (int)(i / ((uint32_t)X * Y));
+    const float c = g[i];
+    const bool interior = z >= 1 && z < Z - 1 && y >= 1 && y < Y - 1 && x >= 1 && x < X - 1;
     float m = -INFINITY;
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                int64_t zz = z + dz, yy = y + dy, xx = x + dx;
-                float v = 0.0f;
-                if (zz >= 0 && zz < Z && yy >= 0 && yy < Y && xx >= 0 && xx < X)
-                    v = g[(zz * Y + yy) * X + xx];
-                m = v > m ? v : m;
+    if (interior) {                                             // no bounds checks, 9 rows of 3
+        const float *p = g + i;
+        const int sy = X, sz = X * Y;
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const float *r = p + dz * sz + dy * sy;
+                m = fmaxf(m, fmaxf(r[-1], fmaxf(r[0], r[1])));
             }
-    bool pk = (c == m);
-    if (!pk) { *nonpeak_flag = 1u; return; }
-    bool interior = z >= 1 && z < Z - 1 && y >= 1 && y < Y - 1 && x >= 1 && x < X - 1;
+    } else {
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int zz = z + dz, yy = y + dy, xx = x + dx;
+                    float v = 0.0f;                              // mode='constant', cval=0
+                    if (zz >= 0 && zz < Z && yy >= 0 && yy < Y && xx >= 0 && xx < X)
+                        v = g[((uint32_t)zz * Y + yy) * X + xx];
+                    m = v > m ? v : m;
+                }
+    }
+    if (!(c == m)) { *nonpeak_flag = 1u; return; }
     if (interior && c > thr) {
         uint32_t slot = atomicAdd(count, 1u);
         if (slot < cap) keys[slot] = ((unsigned long long)(~ford(c)) << 32) | (unsigned long long)i;
@@ -372,19 +385,33 @@ __global__ void ccl_flatten_kernel(uint32_t *parent, int64_t N)
     atomicMin(&parent[i], r);
 }
 
-// sizes[root] += 1 per mask voxel; lanes of a wave that share a root add once.
+// sizes[root] += voxel count.  Each lane walks RUN contiguous voxels keeping a (root, count) run --
+// neighbouring voxels almost always share their root -- and flushes with an atomic only when the
+// root changes; the last run of every lane is flushed once per distinct root of the wave.  A giant
+// component thus costs one atomic per wave instead of one per voxel (same-address atomics serialise).
+static constexpr int CCL_RUN = 32;
 __global__ void ccl_sizes_kernel(const uint32_t *__restrict__ parent, uint32_t *sizes, int64_t N)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t r = (i < N) ? parent[i] : NO_PARENT;
-    bool todo = r != NO_PARENT;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i0 = t * CCL_RUN;
+    uint32_t r = NO_PARENT, cnt = 0;
+    for (int k = 0; k < CCL_RUN; ++k) {
+        const int64_t i = i0 + k;
+        const uint32_t p = (i < N) ? parent[i] : NO_PARENT;
+        if (p == r) { cnt += (p != NO_PARENT); continue; }
+        if (r != NO_PARENT && cnt) atomicAdd(&sizes[r], cnt);
+        r = p;
+        cnt = (p != NO_PARENT);
+    }
+    bool todo = r != NO_PARENT && cnt > 0;
     while (__any(todo)) {
         unsigned long long act = __ballot(todo);
         int leader = __ffsll((long long)act) - 1;
         uint32_t lr = __shfl(r, leader);
         bool same = todo && r == lr;
-        unsigned long long grp = __ballot(same);
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&sizes[lr], (uint32_t)__popcll(grp));
+        uint32_t c = same ? cnt : 0u;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&sizes[lr], c);
         if (same) todo = false;
     }
 }
@@ -418,7 +445,7 @@ static int ccl_impl(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], 
     ISX_CHECK_LAUNCH();
     if (sizes) {
         ISX_HIP(hipMemsetAsync(sizes, 0, N * sizeof(uint32_t), ctx->stream));
-        ccl_sizes_kernel<<<grid, TPB, 0, ctx->stream>>>(parent, sizes, N);
+        ccl_sizes_kernel<<<cdiv(cdiv(N, CCL_RUN), TPB), TPB, 0, ctx->stream>>>(parent, sizes, N);
         ISX_CHECK_LAUNCH();
     }
     return ISX_OK;
@@ -579,28 +606,11 @@ __global__ void comp_table_kernel(const unsigned long long *keys, const uint32_t
     comp_cap[c] = (root == NO_PARENT) ? 1ull : (unsigned long long)sizes[root];
 }
 
-__global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__restrict__ mask,
-                             uint32_t *__restrict__ out, const unsigned long long *__restrict__ keys,
-                             uint32_t n_seeds, const uint32_t *__restrict__ comp_first,
-                             const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
-                             HeapEnt *__restrict__ heap_pool, int64_t PY, int64_t PX, int64_t PN,
-                             float s0, float s1, float s2)
+// The reference's loop on one lane: pop the minimum, label + push the unlabelled mask neighbours.
+__device__ __forceinline__ void serial_flood(HeapEnt *h, uint32_t hn, uint32_t age, const float *__restrict__ aff,
+                                             const uint8_t *__restrict__ mask, uint32_t *__restrict__ out,
+                                             int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2)
 {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_comp) return;
-    uint32_t first = comp_first[c];
-    uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
-    if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;   // seeds outside the mask never spread
-    HeapEnt *h = heap_pool + comp_off[c];
-    uint32_t hn = 0, age = 0;
-    const unsigned long long ZERO_KEY = (unsigned long long)0x80000000u << 32;   // ford(+0.0f), age 0
-    for (uint32_t s = first; s < end; ++s) {
-        HeapEnt e;
-        e.key = ZERO_KEY;
-        e.idx = (uint32_t)(keys[s] & 0xFFFFFFFFull);
-        e.pad = 0;
-        heap_push(h, hn, e);
-    }
     const int64_t SZ = PY * PX, SY = PX;
     const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
     const int ax[6] = {0, 1, 2, 2, 1, 0};
@@ -623,6 +633,281 @@ __global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__res
             e.pad = 0;
             heap_push(h, hn, e);
         }
+    }
+}
+
+// Small components: one lane per component (thousands of them run side by side).
+__global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__restrict__ mask,
+                             uint32_t *__restrict__ out, const unsigned long long *__restrict__ keys,
+                             uint32_t n_seeds, const uint32_t *__restrict__ comp_first,
+                             const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
+                             HeapEnt *__restrict__ heap_pool, int64_t PY, int64_t PX, int64_t PN,
+                             float s0, float s1, float s2, unsigned long long coop_min_size)
+{
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_comp) return;
+    uint32_t first = comp_first[c];
+    uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
+    if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;   // seeds outside the mask never spread
+    if (comp_off[c + 1] - comp_off[c] >= coop_min_size) return;   // flooded by flood_wave_kernel
+    HeapEnt *h = heap_pool + comp_off[c];
+    uint32_t hn = 0;
+    // seeds are sorted by index inside the component; age = rank keeps (value 0, age 0, index) order
+    for (uint32_t s = first; s < end; ++s) {
+        HeapEnt e;
+        e.key = ((unsigned long long)0x80000000u << 32) | (unsigned long long)(s - first);
+        e.idx = (uint32_t)(keys[s] & 0xFFFFFFFFull);
+        e.pad = 0;
+        heap_push(h, hn, e);
+    }
+    serial_flood(h, hn, end - first - 1, aff, mask, out, PY, PX, PN, s0, s1, s2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large components: one WAVE per component, exact speculative batches.
+//
+// The 64 smallest queued elements sit sorted across the lanes (lane r = rank r); a sorted run in LDS
+// holds what follows.  Per round every lane treats its element as popped: it loads its six
+// neighbours and edge values at once, competes for unlabelled neighbours through claim[] (atomicMax of
+// epoch*64 + 63-rank: the lowest rank of the newest round wins), and the round commits the longest
+// prefix of ranks for which no lower rank pushed a STRICTLY smaller value (an equal value is younger,
+// hence later) -- exactly the pops the sequential heap would have made next, in the same order.
+// Ages are handed out in (rank, direction) order, i.e. the reference's push order.  On smooth fields
+// the prefix is short (chains) but still saves the heap traffic; on tie-heavy maps it is the whole
+// wave.  If the LDS run overflows, the component continues on the exact serial heap.
+// ------------------------------------------------------------------------------------------------
+static constexpr int COOP_SCAP = 2048;                      // LDS run capacity (entries of 16 B)
+static constexpr unsigned long long COOP_MIN_SIZE = 512;    // components below this stay on flood_kernel
+
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src);
+    hi = __shfl(hi, src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void flood_wave_kernel(
+    const float *__restrict__ aff, const uint8_t *__restrict__ mask, uint32_t *__restrict__ out,
+    uint32_t *__restrict__ claim, const unsigned long long *__restrict__ keys, uint32_t n_seeds,
+    const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
+    HeapEnt *__restrict__ heap_pool, int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2,
+    unsigned long long coop_min_size)
+{
+    __shared__ HeapEnt srun[COOP_SCAP];          // .pad carries the element's label
+    const uint32_t c = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (c >= n_comp) return;
+    const uint32_t first = comp_first[c];
+    const uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
+    if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;
+    if (comp_off[c + 1] - comp_off[c] < coop_min_size) return;
+    HeapEnt *heap = heap_pool + comp_off[c];
+    const uint32_t ns = end - first;
+
+    const int64_t SZ = PY * PX, SY = PX;
+    const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
+    const int ax[6] = {0, 1, 2, 2, 1, 0};
+    const float sc[3] = {s0, s1, s2};
+    const unsigned long long ZKEY = (unsigned long long)0x80000000u << 32;
+    constexpr int SMASK = COOP_SCAP - 1;
+    constexpr int ROUND_MAX = 6 * 64;            // most elements one round can add
+
+    // queue: registers (rk key, ri voxel, rl label; lanes < rcount valid, ascending) then the LDS run
+    unsigned long long rk = ~0ull;
+    uint32_t ri = 0, rl = 0;
+    int rcount = 0, shead = 0, scount = 0;
+    uint32_t age = ns - 1;                       // seeds carry ages 0..ns-1 in index order; pushes continue
+    uint32_t epoch = 0;
+    bool serial = (ns > 64u) && (ns - 64u > (uint32_t)(COOP_SCAP - ROUND_MAX));
+
+    if (!serial) {
+        rcount = ns < 64u ? (int)ns : 64;
+        if (lane < rcount) {
+            rk = ZKEY | (unsigned long long)lane;
+            ri = (uint32_t)(keys[first + lane] & 0xFFFFFFFFull);
+            rl = out[ri];
+        }
+        for (uint32_t j = 64 + lane; j < ns; j += 64) {
+            HeapEnt e;
+            e.key = ZKEY | (unsigned long long)j;
+            e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull);
+            e.pad = out[e.idx];
+            srun[j - 64] = e;
+        }
+        scount = ns > 64u ? (int)(ns - 64u) : 0;
+    }
+
+    while (!serial && rcount > 0) {
+        if (scount > COOP_SCAP - ROUND_MAX) { serial = true; break; }   // keep every round atomic
+        ++epoch;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // last round's label stores are in L2
+        const bool act = lane < rcount;
+        const int64_t idx = act ? (int64_t)ri : 0;
+        // ---- every lane looks at its six neighbours as if it were popped now -------------------------
+        bool cand[6];
+        float val[6];
+        int64_t nbv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            nbv[k] = idx + noff[k];
+            cand[k] = false;
+            val[k] = 0.f;
+            if (act && mask[nbv[k]])
+                cand[k] = __hip_atomic_load(&out[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+        }
+        const uint32_t mytag = (epoch << 6) | (uint32_t)(63 - lane);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (cand[k]) {
+                atomicMax(&claim[nbv[k]], mytag);
+                float v = aff[(int64_t)ax[k] * PN + (k < 3 ? idx : nbv[k])];
+                v = v * sc[ax[k]];
+                val[k] = v + 0.0f;                                       // -0.0 == +0.0 in the order
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every lane's claims are performed
+        // ---- who won what; smallest value each lane would push ------------------------------------------
+        uint32_t wonmask = 0, mymin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (cand[k] && __hip_atomic_load(&claim[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mytag) {
+                wonmask |= 1u << k;
+                const uint32_t ov = ford(val[k]);
+                mymin = ov < mymin ? ov : mymin;
+            }
+        // exclusive prefix-min over ranks; the first rank whose own value exceeds it ends the batch
+        uint32_t pm = mymin;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(pm, o);
+            if (lane >= o) pm = t < pm ? t : pm;
+        }
+        uint32_t epm = __shfl_up(pm, 1);
+        if (lane == 0) epm = 0xFFFFFFFFu;
+        const unsigned long long vb = __ballot(act && epm < (uint32_t)(rk >> 32));
+        const int ncommit = vb ? (__ffsll((long long)vb) - 1) : rcount;   // >= 1: rank 0 never violates
+        const bool commit = lane < ncommit;
+        // ---- label + ages in (rank, direction) order: the reference's push order ------------------------
+        const uint32_t npush = commit ? (uint32_t)__popc(wonmask) : 0u;
+        uint32_t incl = npush;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        uint32_t myage = age + (incl - npush);
+        unsigned long long pkey[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            pkey[k] = 0;
+            if (commit && (wonmask & (1u << k))) {
+                out[nbv[k]] = rl;                                          // label at discovery (watershed.py:153)
+                pkey[k] = ((unsigned long long)ford(val[k]) << 32) | (unsigned long long)(++myage);
+            }
+        }
+        age += total;
+        const uint32_t wm_all = commit ? wonmask : 0u;
+        const uint32_t lab_all = rl;
+        // ---- drop the committed ranks from the front, refill from the LDS run ---------------------------
+        {
+            const int src = (lane + ncommit) & 63;
+            const unsigned long long k2 = shfl64(rk, src);
+            const uint32_t i2 = __shfl(ri, src), l2 = __shfl(rl, src);
+            rcount -= ncommit;
+            if (lane < rcount) { rk = k2; ri = i2; rl = l2; } else { rk = ~0ull; ri = 0; rl = 0; }
+            int take = 64 - rcount;
+            if (take > scount) take = scount;
+            if (lane >= rcount && lane < rcount + take) {
+                const HeapEnt e = srun[(shead + (lane - rcount)) & SMASK];
+                rk = e.key; ri = e.idx; rl = e.pad;
+            }
+            rcount += take;
+            shead = (shead + take) & SMASK;
+            scount -= take;
+        }
+        // ---- insert the new elements (wave-uniform loop over committed lanes x directions) ---------------
+        for (int l = 0; l < ncommit; ++l) {
+            const uint32_t wm = __shfl(wm_all, l);
+            if (!wm) continue;
+            const uint32_t el = __shfl(lab_all, l);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (!(wm & (1u << k))) continue;
+                const unsigned long long ek = shfl64(pkey[k], l);
+                const uint32_t ei = __shfl((uint32_t)nbv[k], l);
+                const unsigned long long last = shfl64(rk, 63);
+                if (rcount < 64 || ek < last) {
+                    if (rcount == 64) {                  // full: the maximum moves to the front of the run
+                        shead = (shead - 1) & SMASK;
+                        if (lane == 63) { HeapEnt e; e.key = rk; e.idx = ri; e.pad = rl; srun[shead] = e; }
+                        ++scount;
+                        --rcount;
+                    }
+                    const int pos = __popcll(__ballot(lane < rcount && rk < ek));
+                    const int up = (lane - 1) & 63;
+                    const unsigned long long upk = shfl64(rk, up);
+                    const uint32_t upi = __shfl(ri, up), upl = __shfl(rl, up);
+                    if (lane > pos && lane <= rcount) { rk = upk; ri = upi; rl = upl; }
+                    if (lane == pos) { rk = ek; ri = ei; rl = el; }
+                    ++rcount;
+                } else {
+                    // sorted insert into the LDS run (circular: shift the shorter side by one)
+                    int below = 0;
+                    for (int j = lane; j < scount; j += 64) below += srun[(shead + j) & SMASK].key < ek;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+                    const int pos = below;
+                    if (pos >= scount - pos) {
+                        for (int base = scount - 64; base > pos - 64; base -= 64) {
+                            const int j = base + lane;
+                            const bool mv = j >= pos && j >= 0 && j < scount;
+                            HeapEnt e;
+                            if (mv) e = srun[(shead + j) & SMASK];
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            if (mv) srun[(shead + j + 1) & SMASK] = e;
+                        }
+                    } else {
+                        for (int base = 0; base < pos; base += 64) {
+                            const int j = base + lane;
+                            const bool mv = j < pos;
+                            HeapEnt e;
+                            if (mv) e = srun[(shead + j) & SMASK];
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            if (mv) srun[(shead + j - 1) & SMASK] = e;
+                        }
+                        shead = (shead - 1) & SMASK;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const int at = (pos >= scount - pos) ? pos : pos;      // slot index relative to the new head
+                    if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; srun[(shead + at) & SMASK] = e; }
+                    ++scount;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        }
+    }
+
+    if (serial) {
+        // Exact continuation on one lane: move the whole queue into the component's binary heap.
+        uint32_t hn = 0;
+        if (ns > 64u && rcount == 0 && scount == 0 && epoch == 0) {
+            // never started (too many seeds for the run): seed the heap directly
+            if (lane == 0)
+                for (uint32_t j = 0; j < ns; ++j) {
+                    HeapEnt e; e.key = ZKEY | (unsigned long long)j; e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull); e.pad = 0;
+                    heap_push(heap, hn, e);
+                }
+        } else {
+            for (int l = 0; l < rcount; ++l) {
+                HeapEnt e; e.key = shfl64(rk, l); e.idx = __shfl(ri, l); e.pad = 0;
+                if (lane == 0) heap_push(heap, hn, e);
+            }
+            if (lane == 0)
+                for (int j = 0; j < scount; ++j) { HeapEnt e = srun[(shead + j) & SMASK]; e.pad = 0; heap_push(heap, hn, e); }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane == 0) serial_flood(heap, hn, age, aff, mask, out, PY, PX, PN, s0, s1, s2);
     }
 }
 
@@ -675,12 +960,22 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     ISX_HIP(hipMemcpyAsync(&total, comp_off.p + n_comp, 8, hipMemcpyDeviceToHost, ctx->stream));
     ISX_HIP(hipStreamSynchronize(ctx->stream));
     Scratch<HeapEnt> pool(ctx, (size_t)total + 1);
-    if (!pool.ok()) return ISX_ERR_NOMEM;
+    Scratch<uint32_t> claim(ctx, (size_t)PN);
+    if (!pool.ok() || !claim.ok()) return ISX_ERR_NOMEM;
     float s[3] = {1.f, 1.f, 1.f};
     if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
+    unsigned long long coop_min = COOP_MIN_SIZE;
+    if (const char *e = getenv("ISX_FLOOD_COOP_MIN")) coop_min = strtoull(e, nullptr, 10);   // tests: force a path
+    // small components: one lane each; large ones: one wave each (both launched over all components,
+    // each picks its own by size -- no host round trip to split the list)
     flood_kernel<<<cdiv(n_comp, 64), 64, 0, ctx->stream>>>(aff, mask, out, keys_sorted.p, n_seeds,
                                                           comp_first.p, comp_off.p, n_comp, pool.p,
-                                                          pshape[1], pshape[2], PN, s[0], s[1], s[2]);
+                                                          pshape[1], pshape[2], PN, s[0], s[1], s[2], coop_min);
+    ISX_CHECK_LAUNCH();
+    ISX_HIP(hipMemsetAsync(claim.p, 0, (size_t)PN * sizeof(uint32_t), ctx->stream));
+    flood_wave_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, claim.p, keys_sorted.p, n_seeds, comp_first.p,
+                                                      comp_off.p, n_comp, pool.p, pshape[1], pshape[2], PN, s[0], s[1],
+                                                      s[2], coop_min);
     ISX_CHECK_LAUNCH();
     return ISX_OK;
 }
@@ -702,7 +997,7 @@ static int seeds_impl(isx_ctx *ctx, const float *cent, const int64_t shape[3], i
         src = g.p;
     }
     ISX_HIP(hipMemsetAsync(flags.p, 0, 8, ctx->stream));
-    peak_kernel<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(src, shape[0], shape[1], shape[2], thr, flags.p,
+    peak_kernel<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(src, (int)shape[0], (int)shape[1], (int)shape[2], thr, flags.p,
                                                      keys.p, flags.p + 1, cap);
     ISX_CHECK_LAUNCH();
     uint32_t fl[2];

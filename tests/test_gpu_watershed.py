@@ -135,3 +135,38 @@ def test_against_oracle_on_seeded_fields(ws, shape, seed):
     assert np.array_equal(seeds, rseeds)
     assert np.array_equal(cur, ref)
     assert (cur > 0).sum() > 100
+
+
+@pytest.fixture(params=["1", "100000000"], ids=["coop-all", "serial-all"])
+def flood_path(request, monkeypatch):
+    """Force every component through the wave-cooperative flood, or through the one-lane heap."""
+    monkeypatch.setenv("ISX_FLOOD_COOP_MIN", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("name", KERNEL_CASES + ["ws_blobs40", "ws_blobs32"])
+def test_flood_paths_bit_exact_on_fixtures(ws, golden, name, flood_path):
+    d = golden(name)
+    ref = d["labels_padded"] if "labels_padded" in d.files else np.pad(d["labels"], 1)
+    scale = d["scale"] if "scale" in d.files else None
+    out = np.zeros(ref.size, ref.dtype)
+    lab = ws.affinity_watershed(d["aff_padded"], d["seeds_padded"], d["mask_padded"], scale=scale, out=out)
+    assert np.array_equal(lab, ref)
+
+
+@pytest.mark.parametrize("kind,shape,seed", [("smooth", (24, 96, 80), 0), ("smooth3", (32, 128, 128), 1),
+                                              ("blobs", (40, 128, 128), 2)])
+def test_flood_paths_against_oracle(ws, kind, shape, seed, flood_path):
+    """Chain-heavy (smooth) and tie-heavy (blobs) inputs with components of 10^4..10^5 voxels: both
+    flood paths must reproduce the oracle bit for bit (the LDS run overflows on the big ones, which
+    exercises the hand-over to the serial heap too)."""
+    from oracle import watershed as ows
+    from tests.synth import blob_feature_map, smooth_feature_map
+    fm = blob_feature_map(shape, seed) if kind == "blobs" else smooth_feature_map(shape, seed, 3.0 if kind == "smooth3" else 1.5)
+    pshape = tuple(s + 2 for s in shape)
+    ref = np.zeros(pshape, np.uint32)
+    ows.segment_output_image(fm, out=ref.ravel())
+    cur = np.zeros(pshape, np.uint32)
+    ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=cur.ravel())
+    assert np.array_equal(cur, ref)
+    assert (cur > 0).sum() > 1000
