@@ -29,6 +29,15 @@
 namespace isx {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// streaming (non-temporal) 16-byte load.  Tried for the activation tiles of the MFMA conv (r01b): it
+// RAISED L2-miss traffic 93 -> 131 GB per launch set and cost 20 % -- halo overlap needs the L2.
+__device__ __forceinline__ float4 ld_stream(const float *p)
+{
+    f32x4 v = __builtin_nontemporal_load((const f32x4 *)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 static constexpr float BN_EPS = 1e-5f;
 static constexpr float BN_MOMENTUM = 0.1f;
