@@ -115,6 +115,35 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
 int isx_unet_set_batch(isx_ctx *ctx, int batch);
 
 /* ---------------------------------------------------------------------------------- *
+ * Training -- replaces _train_step + the duplicated optimiser.step() (src/iterseg/train.py:344-353,
+ * :310), nn.BCELoss / nn.MSELoss / WeightedBCELoss (train.py:197-217, custom_loss.py:56-84) and
+ * torch.optim.Adam (train.py:145) for one (1,1,D,H,W) patch per step (the reference's batch size).
+ * Parameters, gradients and Adam moments are four flat float32 DEVICE buffers owned by the caller,
+ * holding the trainable state-dict entries in state-dict order (per module: conv0.weight, conv0.bias,
+ * conv1.weight, conv1.bias, batch0.weight, batch0.bias, batch1.weight, batch1.bias; then up0..3
+ * weight, bias) in their reference layouts -- so a data-parallel gradient all-reduce is one RCCL call
+ * on the gradient buffer.
+ * ---------------------------------------------------------------------------------- */
+int64_t isx_train_param_count(isx_ctx *ctx);
+/* Binds the buffers (n = isx_train_param_count), copies the committed weights into `params`, allocates
+ * the backward workspace for patches of `chunk` voxels. */
+int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *grads, float *adam_m,
+                   float *adam_v, int64_t n);
+#define ISX_LOSS_BCE 0
+#define ISX_LOSS_MSE 1
+#define ISX_LOSS_WEIGHTED_BCE 2
+/* One step on a device patch x (D,H,W) with targets y (C,D,H,W): forward (train-mode BN), loss,
+ * and if do_backward: gradients into the bound buffer followed by n_adam Adam updates with the same
+ * gradients (the reference applies two, train.py:353 + :310).  loss_out (host, 1 + C floats): the loss
+ * and the per-channel means logged by channel_losses_to_dict (custom_loss.py:8-17). */
+int isx_train_step(isx_ctx *ctx, const float *x, const float *y, int loss_kind, const float *chan_weights,
+                   float lr, int n_adam, int do_backward, float *loss_out);
+/* n_steps Adam updates from the bound gradient buffer (after an external all-reduce), then repack. */
+int isx_adam_step(isx_ctx *ctx, float lr, int n_steps);
+/* Re-derive the kernel-layout weights after the caller changed the bound parameter buffer. */
+int isx_train_refresh_weights(isx_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------- *
  * Watershed post-processor -- src/iterseg/watershed.py.                                 *
  * ---------------------------------------------------------------------------------- */
 /* skimage.filters.gaussian as used at watershed.py:227 / :234: float32 in/out, per-axis

@@ -1,0 +1,902 @@
+// train.hip -- backward pass, losses and Adam for the affinity U-Net on gfx950 (MI355X).
+//
+// Replaces, for one (1,1,D,H,W) patch per step (the reference trains with batch size 1),
+// _train_step / the duplicated optimiser.step() of src/iterseg/train.py:344-353 and :310, nn.BCELoss /
+// nn.MSELoss / WeightedBCELoss (train.py:197-217, custom_loss.py:56-84,161-185) and torch.optim.Adam
+// (train.py:145).  torch.autograd is not used: the forward of unet.hip keeps every raw convolution
+// output of the patch, and this file walks the graph backwards with hand-written kernels:
+//
+//   * BatchNorm(train) + ReLU/sigmoid backward: two passes per layer (deterministic block partial sums of
+//     dz and dz*xhat, then d(raw) = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))); the second pass
+//     also emits the bias gradient partials;
+//   * dgrad: the forward implicit-GEMM MFMA kernel run on d(raw) with channel-transposed, tap-flipped
+//     weights (a 3x3x3 correlation backwards is the same correlation with mirrored taps);
+//   * wgrad: an MFMA GEMM with the voxels as the K dimension -- dW[tap] (Cout x Cin) = dY^T . X_shifted --
+//     64x64 tiles, one tap and one voxel slab per work-group, split-K partials reduced in a fixed order;
+//     the operand X gets the producer's BN+ReLU and the decoder concat on load, like the forward;
+//   * max-pool / depthwise transposed-conv backward, loss + d(loss), Adam on flat buffers.
+//
+// Parameters, gradients and Adam moments live in four flat float buffers OWNED BY THE CALLER (PyTorch
+// tensors), in state-dict order of the trainable keys, so the data-parallel gradient all-reduce is one
+// RCCL call on the gradient buffer.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "unet_state.h"
+
+namespace isx {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct TrainState {
+    int cz = 0, cy = 0, cx = 0;
+    float *P = nullptr, *G = nullptr, *Mo = nullptr, *Vo = nullptr;
+    int64_t nparam = 0, adam_t = 0;
+    int64_t off_w[18], off_b[18], off_gamma[18], off_beta[18], off_upw[4], off_upb[4];
+    std::vector<void *> blocks;
+    float *draw[18] = {nullptr}, *gact[18] = {nullptr}, *w_dgrad[18] = {nullptr};
+    float *dcat[4] = {nullptr}, *dpool[4] = {nullptr};
+    float *part = nullptr, *coef = nullptr, *wpart = nullptr, *lossbuf = nullptr, *zeros = nullptr;
+    size_t part_floats = 0, wpart_floats = 0;
+};
+
+void train_destroy(TrainState *t)
+{
+    if (!t) return;
+    for (void *p : t->blocks) (void)hipFree(p);
+    delete t;
+}
+
+static int talloc(TrainState *t, size_t floats, float **out)
+{
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (floats ? floats : 1) * sizeof(float));
+    if (e != hipSuccess) { set_error("hipMalloc(%zu floats) failed: %s", floats, hipGetErrorString(e)); return ISX_ERR_NOMEM; }
+    t->blocks.push_back(p);
+    *out = (float *)p;
+    return ISX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight repacking on the device (after every optimiser step): reference layouts in P -> kernel layouts
+// ------------------------------------------------------------------------------------------------
+// forward MFMA layout [Cout/BN][Cin/4][27][4][BN]; transpose = 1 builds the dgrad weights: the roles of the
+// channel axes are swapped and the taps mirrored (t -> 26 - t), i.e. w'[ci][co][t] = w[co][ci][26 - t].
+__global__ void repack_mfma_kernel(const float *__restrict__ wref, int cout, int cin, int transpose, float *__restrict__ pk)
+{
+    const int CO = transpose ? cin : cout, CI = transpose ? cout : cin;     // shapes of the conv being packed
+    const int BN = (CO % 64 == 0) ? 64 : 32;
+    const int nsteps = CI / 4;
+    const int64_t n = (int64_t)CO * CI * 27;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int t = (int)(i % 27);
+        int ci = (int)((i / 27) % CI), co = (int)(i / (27 * (int64_t)CI));
+        float v = transpose ? wref[((int64_t)ci * cin + co) * 27 + (26 - t)] : wref[((int64_t)co * cin + ci) * 27 + t];
+        int64_t dst = ((((int64_t)(co / BN) * nsteps + ci / 4) * 27 + t) * 4 + ci % 4) * BN + co % BN;
+        pk[dst] = v;
+    }
+}
+
+__global__ void repack_fold_kernel(const float *__restrict__ wref, int cout, int cin, float *__restrict__ pk)
+{
+    const int64_t n = (int64_t)cout * cin * 27;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int t = (int)(i % 27), ci = (int)((i / 27) % cin), co = (int)(i / (27 * (int64_t)cin));
+        int t9 = t / 3, dxi = t % 3;
+        pk[((((int64_t)(ci / 4)) * 9 + t9) * 4 + ci % 4) * 32 + dxi * cout + co] = wref[i];
+    }
+}
+
+// conv_first [27][32] (cin == 1) and conv_thin [27][Cin][8]
+__global__ void repack_direct_kernel(const float *__restrict__ wref, int cout, int cin, int first, float *__restrict__ pk)
+{
+    const int64_t n = (int64_t)cout * cin * 27;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int t = (int)(i % 27), ci = (int)((i / 27) % cin), co = (int)(i / (27 * (int64_t)cin));
+        if (first) pk[(int64_t)t * cout + co] = wref[i];
+        else pk[((int64_t)t * cin + ci) * 8 + co] = wref[i];
+    }
+}
+
+__global__ void repack_up_kernel(const float *__restrict__ wref, int C, int kt, float *__restrict__ pk)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * kt) return;
+    int t = i % kt, c = i / kt;
+    pk[(int64_t)t * C + c] = wref[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss + d(loss)/d(y_hat).  kind 0: BCE (mean over all elements, logs clamped at -100 like torch);
+// 1: MSE; 2: weighted BCE (per-channel mean * weight, mean over channels, custom_loss.py:161-185).
+// y_hat is recomputed from raw17 (sigmoid(BN(raw))); target is (C, D, H, W) planar.
+// lossbuf partials: [blocks][C] ; gout: [M][C] channels-last.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_kernel(const float *__restrict__ raw, const float *__restrict__ scale,
+                                                   const float *__restrict__ shift, const float *__restrict__ target,
+                                                   int C, int64_t M, int kind, const float *__restrict__ cw,
+                                                   float *__restrict__ gout, float *__restrict__ part)
+{
+    __shared__ float red[4][8];
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float l[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) l[c] = 0.f;
+    if (m < M)
+        for (int c = 0; c < C; ++c) {
+            float z = fmaf(raw[m * C + c], scale[c], shift[c]);
+            float yh = 1.f / (1.f + expf(-z));
+            float y = target[(int64_t)c * M + m];
+            float g;
+            if (kind == 1) {
+                float d = yh - y;
+                l[c] = d * d;
+                g = 2.f * d / (float)(M * C);
+            } else {
+                float lg = fmaxf(logf(yh), -100.f), lg1 = fmaxf(logf(1.f - yh), -100.f);
+                l[c] = -(y * lg + (1.f - y) * lg1);
+                float denom = fmaxf((1.f - yh) * yh, 1e-12f);
+                float wgt = (kind == 2) ? cw[c] / (float)M / (float)C : 1.f / (float)(M * C);
+                g = wgt * (yh - y) / denom;
+            }
+            gout[m * C + c] = g;
+        }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = 0; c < C; ++c) {
+        float v = l[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][c] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C) part[(int64_t)blockIdx.x * C + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// sums the [blocks][C] partials in double, fixed order: out[c] = per-channel sum
+__global__ void colsum_kernel(const float *__restrict__ part, int blocks, int C, float *__restrict__ out)
+{
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 256) s += (double)part[(int64_t)b * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (float)red[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN(train) + activation backward.  act: 0 relu, 1 sigmoid.  g may be strided (a channel slice of a wider
+// tensor): element (m, c) at g[m * gstride + c].
+// pass 1: partials of sum(dz), sum(dz * xhat) per channel -> part[blocks][2C]
+// pass 2: draw = gamma*invstd*(dz - c1 - xhat*c2); partials of sum(draw) -> part[blocks][C]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float g, float z, int act)
+{
+    if (act == 0) return z > 0.f ? g : 0.f;
+    float s = 1.f / (1.f + expf(-z));
+    return g * (1.f - s) * s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restrict__ g, int gstride,
+                                                            const float *__restrict__ raw, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd, int C, int64_t M, int act,
+                                                            int rows_per_block, float *__restrict__ part)
+{
+    // thread layout: channel = threadIdx.x % C4 groups... generic: each thread walks rows for a fixed channel
+    extern __shared__ double smd[];                     // [256][2]; double like ATen's CPU accumulation
+    const int nth = 256;
+    const int c = threadIdx.x % C;                      // requires C <= 256; threads >= (256/C)*C idle
+    const int lanes_per_row = C;
+    const int rslot = threadIdx.x / lanes_per_row, nslot = nth / lanes_per_row;
+    double s1 = 0.0, s2 = 0.0;
+    if (rslot < nslot) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t r1 = r0 + rows_per_block;
+        if (r1 > M) r1 = M;
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        for (int64_t m = r0 + rslot; m < r1; m += nslot) {
+            float x = raw[m * C + c];
+            float z = fmaf(x, sc, sh);
+            float dz = act_grad(g[m * gstride + c], z, act);
+            s1 += (double)dz;
+            s2 += (double)dz * (double)((x - mu) * is);
+        }
+    }
+    smd[threadIdx.x * 2] = s1;
+    smd[threadIdx.x * 2 + 1] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nslot; ++k) { a += smd[(k * lanes_per_row + threadIdx.x) * 2]; b += smd[(k * lanes_per_row + threadIdx.x) * 2 + 1]; }
+        part[((int64_t)blockIdx.x * C + threadIdx.x) * 2] = (float)a;
+        part[((int64_t)blockIdx.x * C + threadIdx.x) * 2 + 1] = (float)b;
+    }
+}
+
+// reduce [blocks][C][2] -> dgamma (sum dz*xhat), dbeta (sum dz), coef[c] = {mean(dz), mean(dz*xhat)}
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int blocks, int C, double count,
+                                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef)
+{
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < blocks; k += 256) { a += (double)part[((int64_t)k * C + c) * 2]; b += (double)part[((int64_t)k * C + c) * 2 + 1]; }
+    r1[threadIdx.x] = a;
+    r2[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        dbeta[c] = (float)r1[0];
+        dgamma[c] = (float)r2[0];
+        coef[2 * c] = (float)(r1[0] / count);
+        coef[2 * c + 1] = (float)(r2[0] / count);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ g, int gstride,
+                                                           const float *__restrict__ raw, const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd, const float *__restrict__ coef,
+                                                           int C, int64_t M, int act, int rows_per_block,
+                                                           float *__restrict__ draw, float *__restrict__ part)
+{
+    extern __shared__ float sm[];
+    const int c = threadIdx.x % C;
+    const int rslot = threadIdx.x / C, nslot = 256 / C;
+    float s1 = 0.f;
+    if (rslot < nslot) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t r1 = r0 + rows_per_block;
+        if (r1 > M) r1 = M;
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c], c1 = coef[2 * c], c2 = coef[2 * c + 1];
+        for (int64_t m = r0 + rslot; m < r1; m += nslot) {
+            float x = raw[m * C + c];
+            float z = fmaf(x, sc, sh);
+            float dz = act_grad(g[m * gstride + c], z, act);
+            float xh = (x - mu) * is;
+            float d = sc * (dz - c1 - xh * c2);          // sc = gamma * invstd
+            draw[m * C + c] = d;
+            s1 += d;
+        }
+    }
+    sm[threadIdx.x] = s1;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float a = 0.f;
+        for (int k = 0; k < nslot; ++k) a += sm[k * C + threadIdx.x];
+        part[(int64_t)blockIdx.x * C + threadIdx.x] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad on the fp32 matrix cores.  grid = (co_tiles * ci_tiles, 27 taps, splits); block = 4 waves in a
+// 2x2 arrangement over a 64(co) x 64(ci) tile.  K = voxels, staged 64 at a time in LDS:
+//   dY tile [64 vox][64 co], X tile [64 vox][64 ci] (X = concat of two sources, BN+ReLU on load,
+//   shifted by the tap, zero outside the patch).  D[co][ci] += sum_v dY[v][co] * X[v + tap][ci].
+// partial [split][27][CoP][CiP] (CoP/CiP = channel counts padded to 64).
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float *dy;                       // [M][Cout]
+    const float *srcA, *scaleA, *shiftA;   // conv input, channels [0, CA)
+    const float *srcB, *scaleB, *shiftB;   // channels [CA, CA+CB)
+    int CA, CB, Cout;
+    int D, H, W;
+    int co_tiles, ci_tiles, splits;
+    int64_t vox_per_split;                 // multiple of 64
+    float *partial;
+};
+
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
+{
+    __shared__ float Ys[64 * 64];
+    __shared__ float Xs[64 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
+    const int co_t = blockIdx.x / a.ci_tiles, ci_t = blockIdx.x % a.ci_tiles;
+    const int tap = blockIdx.y, split = blockIdx.z;
+    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    const int D = a.D, H = a.H, W = a.W, Cin = a.CA + a.CB;
+    const int64_t M = (int64_t)D * H * W;
+    const int64_t v_begin = (int64_t)split * a.vox_per_split;
+    int64_t v_end = v_begin + a.vox_per_split;
+    if (v_end > M) v_end = M;
+    const int wr = wave >> 1, wc = wave & 1;              // this wave's 32x32 sub-tile
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // staging role: 16 lanes cover the 64 channels of one voxel (float4 each), 16 voxels per pass, 4 passes
+    const int q = tid & 15, vs = tid >> 4;
+    const int co0 = co_t * 64, ci0 = ci_t * 64;
+    for (int64_t v0 = v_begin; v0 < v_end; v0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int vl = vs + 16 * p;
+            const int64_t v = v0 + vl;
+            float4 yv = make_float4(0.f, 0.f, 0.f, 0.f), xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < v_end) {
+                const int co = co0 + 4 * q;
+                if (co + 3 < a.Cout) yv = *(const float4 *)&a.dy[v * a.Cout + co];
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (co + j < a.Cout) (&yv.x)[j] = a.dy[v * a.Cout + co + j];
+                const int x = (int)(v % W) + dx, y = (int)((v / W) % H) + dy, z = (int)(v / ((int64_t)W * H)) + dz;
+                const int ci = ci0 + 4 * q;
+                if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W && ci < Cin) {
+                    const int64_t g = ((int64_t)z * H + y) * W + x;
+                    const bool fromB = ci >= a.CA;
+                    const float *src = fromB ? a.srcB : a.srcA, *sc = fromB ? a.scaleB : a.scaleA, *sh = fromB ? a.shiftB : a.shiftA;
+                    const int C = fromB ? a.CB : a.CA, cc = fromB ? ci - a.CA : ci;
+                    for (int j = 0; j < 4; ++j)
+                        if (cc + j < C) {
+                            float t = src[g * C + cc + j];
+                            if (sc) t = fmaxf(fmaf(t, sc[cc + j], sh[cc + j]), 0.f);
+                            (&xv.x)[j] = t;
+                        }
+                }
+            }
+            *(float4 *)&Ys[vl * 64 + 4 * q] = yv;
+            *(float4 *)&Xs[vl * 64 + 4 * q] = xv;
+        }
+        __syncthreads();
+        const float *yp = Ys + hh * 64 + wr * 32 + nn;
+        const float *xp = Xs + hh * 64 + wc * 32 + nn;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[k * 128], xp[k * 128], acc, 0, 0, 0);
+    }
+    // D layout: column (ci) = lane & 31, row (co) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+    const int CoP = a.co_tiles * 64, CiP = a.ci_tiles * 64;
+    float *dst = a.partial + (((int64_t)split * 27 + tap) * CoP) * CiP;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int co = co0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const int ci = ci0 + wc * 32 + nn;
+        dst[(int64_t)co * CiP + ci] = acc[i];
+    }
+}
+
+// dW[co][ci][tap] = sum over splits (fixed order)
+__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int splits, int Cout, int Cin, int CoP, int CiP,
+                                    float *__restrict__ dw)
+{
+    const int64_t n = (int64_t)Cout * Cin * 27;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int t = (int)(i % 27), ci = (int)((i / 27) % Cin), co = (int)(i / (27 * (int64_t)Cin));
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(((int64_t)k * 27 + t) * CoP + co) * CiP + ci];
+        dw[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small dgrad (few gradient channels in, up to 64 out): dX[v][ci] = sum_tap sum_co dY[v - tap][co] w[co][ci][tap]
+// thread = (voxel, 4 output channels); weights read straight from the reference layout in P (L1-resident)
+// ------------------------------------------------------------------------------------------------
+__global__ void dgrad_small_kernel(const float *__restrict__ dy, const float *__restrict__ wref, int Cout, int Cin,
+                                   int D, int H, int W, float *__restrict__ dx, int64_t total)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int C4 = (Cin + 3) / 4;
+    const int c4 = (int)(i % C4);
+    const int64_t v = i / C4;
+    const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((int64_t)W * H));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 27; ++t) {
+        const int zz = z - (t / 9 - 1), yy = y - ((t / 3) % 3 - 1), xx = x - (t % 3 - 1);
+        if (zz < 0 || zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const float *gy = dy + (((int64_t)zz * H + yy) * W + xx) * Cout;
+        for (int co = 0; co < Cout; ++co) {
+            const float gv = gy[co];
+            for (int j = 0; j < 4; ++j) {
+                const int ci = 4 * c4 + j;
+                if (ci < Cin) acc[j] = fmaf(gv, wref[((int64_t)co * Cin + ci) * 27 + t], acc[j]);
+            }
+        }
+    }
+    for (int j = 0; j < 4; ++j)
+        if (4 * c4 + j < Cin) dx[v * Cin + 4 * c4 + j] = acc[j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// max-pool backward (windows do not overlap): thread = (pooled voxel, 4 channels) recomputes the arg-max of
+// its window over act = relu(BN(raw)) (first maximum, like ATen), writes dpool there and zero elsewhere,
+// then adds the decoder's skip gradient (channels [skip_off, skip_off+C) of dcat, if any).
+// ------------------------------------------------------------------------------------------------
+__global__ void pool_bwd_kernel(const float *__restrict__ raw, const float *__restrict__ scale, const float *__restrict__ shift,
+                                int C, int D, int H, int W, int kz, int Do, int Ho, int Wo, const float *__restrict__ dpool,
+                                const float *__restrict__ dcat, int cat_stride, int skip_off, float *__restrict__ gact,
+                                int64_t total)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int C4 = C >> 2;
+    const int c4 = (int)(i % C4);
+    const int64_t mo = i / C4;
+    const int x = (int)(mo % Wo), y = (int)((mo / Wo) % Ho), z = (int)(mo / ((int64_t)Wo * Ho));
+    const float4 vs = *(const float4 *)&scale[4 * c4], vh = *(const float4 *)&shift[4 * c4];
+    const float4 gp = *(const float4 *)&dpool[mo * C + 4 * c4];
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {-1, -1, -1, -1};
+    for (int i0 = 0; i0 < kz; ++i0)
+        for (int j = 0; j < 2; ++j)
+            for (int k = 0; k < 2; ++k) {
+                const int zz = z * kz + i0, yy = 2 * y - 1 + j, xx = 2 * x - 1 + k;
+                if (zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const float4 t = *(const float4 *)&raw[(((int64_t)zz * H + yy) * W + xx) * C + 4 * c4];
+                const float a4[4] = {fmaxf(fmaf(t.x, vs.x, vh.x), 0.f), fmaxf(fmaf(t.y, vs.y, vh.y), 0.f),
+                                     fmaxf(fmaf(t.z, vs.z, vh.z), 0.f), fmaxf(fmaf(t.w, vs.w, vh.w), 0.f)};
+                const int code = (i0 * 2 + j) * 2 + k;
+                for (int e = 0; e < 4; ++e)
+                    if (a4[e] > best[e]) { best[e] = a4[e]; arg[e] = code; }
+            }
+    for (int i0 = 0; i0 < kz; ++i0)
+        for (int j = 0; j < 2; ++j)
+            for (int k = 0; k < 2; ++k) {
+                const int zz = z * kz + i0, yy = 2 * y - 1 + j, xx = 2 * x - 1 + k;
+                if (zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const int code = (i0 * 2 + j) * 2 + k;
+                const int64_t g = ((int64_t)zz * H + yy) * W + xx;
+                float4 o = make_float4(arg[0] == code ? gp.x : 0.f, arg[1] == code ? gp.y : 0.f,
+                                       arg[2] == code ? gp.z : 0.f, arg[3] == code ? gp.w : 0.f);
+                if (dcat) {
+                    const float4 s = *(const float4 *)&dcat[g * cat_stride + skip_off + 4 * c4];
+                    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+                }
+                *(float4 *)&gact[g * C + 4 * c4] = o;
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise transposed conv backward.  Forward: u[zo,yo,xo,c] = act[zs,ys,xs,c] * w[kidx][c] + b[c] on the
+// cropped box.  thread = (source voxel, 4 channels): gathers its <= kz*4 outputs:
+//   g_act[src][c] = sum dU * w ;  partial sums of dU * act (per kidx) and dU (bias) per block.
+// part layout [blocks][kt + 1][C]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ raw, const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, int C, int D, int H, int W,
+                                                           int kz, int off, const float *__restrict__ w,
+                                                           const float *__restrict__ dcat, int cat_stride, int Do, int Ho,
+                                                           int Wo, float *__restrict__ gact, float *__restrict__ part,
+                                                           int vox_per_block)
+{
+    extern __shared__ float sm[];                      // [(kt+1)][C] accumulators of this block
+    const int kt = kz * 4;
+    for (int i = threadIdx.x; i < (kt + 1) * C; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    const int C4 = C >> 2;
+    const int64_t M = (int64_t)D * H * W;
+    const int64_t i0 = (int64_t)blockIdx.x * vox_per_block * C4;
+    int64_t i1 = i0 + (int64_t)vox_per_block * C4;
+    if (i1 > M * C4) i1 = M * C4;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int c4 = (int)(i % C4);
+        const int64_t v = i / C4;
+        const int xs = (int)(v % W), ys = (int)((v / W) % H), zs = (int)(v / ((int64_t)W * H));
+        const float4 t = *(const float4 *)&raw[v * C + 4 * c4];
+        const float4 vsx = *(const float4 *)&scale[4 * c4], vhx = *(const float4 *)&shift[4 * c4];
+        const float a4[4] = {fmaxf(fmaf(t.x, vsx.x, vhx.x), 0.f), fmaxf(fmaf(t.y, vsx.y, vhx.y), 0.f),
+                             fmaxf(fmaf(t.z, vsx.z, vhx.z), 0.f), fmaxf(fmaf(t.w, vsx.w, vhx.w), 0.f)};
+        float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < kz; ++a)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    const int zo = zs * kz + a, yo = 2 * ys + j - off, xo = 2 * xs + k - off;
+                    if (zo >= Do || yo < 0 || yo >= Ho || xo < 0 || xo >= Wo) continue;
+                    const int kidx = (a * 2 + j) * 2 + k;
+                    const float4 du = *(const float4 *)&dcat[(((int64_t)zo * Ho + yo) * Wo + xo) * cat_stride + 4 * c4];
+                    const float4 wv = *(const float4 *)&w[(int64_t)kidx * C + 4 * c4];
+                    const float d4[4] = {du.x, du.y, du.z, du.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
+                    for (int e = 0; e < 4; ++e) {
+                        gsum[e] = fmaf(d4[e], w4[e], gsum[e]);
+                        atomicAdd(&sm[kidx * C + 4 * c4 + e], d4[e] * a4[e]);      // LDS atomics: order-free only
+                        atomicAdd(&sm[kt * C + 4 * c4 + e], d4[e]);                // within this block's partial
+                    }
+                }
+        *(float4 *)&gact[v * C + 4 * c4] = make_float4(gsum[0], gsum[1], gsum[2], gsum[3]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (kt + 1) * C; i += 256) part[(int64_t)blockIdx.x * (kt + 1) * C + i] = sm[i];
+}
+
+// up-conv parameter gradients: reference layout dW[c][kidx], db[c]
+__global__ void up_grad_finalize_kernel(const float *__restrict__ part, int blocks, int C, int kt,
+                                        float *__restrict__ dw, float *__restrict__ db)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (kt + 1) * C) return;
+    const int r = i / C, c = i % C;
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += (double)part[(int64_t)b * (kt + 1) * C + i];
+    if (r < kt) dw[(int64_t)c * kt + r] = (float)s;
+    else db[c] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad)
+// ------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, int64_t n, float lr, float bc1, float bc2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = 0.9f * m[i] + 0.1f * gi;
+        const float vi = 0.999f * v[i] + 0.001f * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + 1e-8f;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+static int64_t param_layout(UNetState *u, TrainState *t)
+{
+    int64_t off = 0;
+    for (int mi = 0; mi < 9; ++mi) {
+        for (int j = 0; j < 2; ++j) {
+            const ConvBN &L = u->cv[2 * mi + j];
+            t->off_w[2 * mi + j] = off; off += (int64_t)L.cout * L.cin * 27;
+            t->off_b[2 * mi + j] = off; off += L.cout;
+        }
+        for (int j = 0; j < 2; ++j) {
+            const ConvBN &L = u->cv[2 * mi + j];
+            t->off_gamma[2 * mi + j] = off; off += L.cout;
+            t->off_beta[2 * mi + j] = off; off += L.cout;
+        }
+    }
+    for (int k = 0; k < 4; ++k) {
+        t->off_upw[k] = off; off += (int64_t)u->up[k].C * u->up[k].kz * 4;
+        t->off_upb[k] = off; off += u->up[k].C;
+    }
+    return off;
+}
+
+static int repack_all(isx_ctx *ctx)
+{
+    UNetState *u = ctx->unet;
+    TrainState *t = u->train;
+    for (int li = 0; li < 18; ++li) {
+        ConvBN &L = u->cv[li];
+        const float *wref = t->P + t->off_w[li];
+        const int64_t n = (int64_t)L.cout * L.cin * 27;
+        unsigned grid = cdiv(n, 256);
+        if (grid > 4096) grid = 4096;
+        if (use_mfma(L.cin, L.cout)) {
+            repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 0, L.w);
+            if (t->w_dgrad[li]) repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 1, t->w_dgrad[li]);
+        } else if (use_fold(L.cin, L.cout)) {
+            repack_fold_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, L.w);
+        } else {
+            repack_direct_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, L.cin == 1 ? 1 : 0, L.w);
+        }
+        ISX_CHECK_LAUNCH();
+        if (L.cout < 8)      // thin layers read an 8-padded private copy of the bias
+            ISX_HIP(hipMemcpyAsync(L.bias, t->P + t->off_b[li], L.cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    for (int k = 0; k < 4; ++k) {
+        UpConv &U = u->up[k];
+        repack_up_kernel<<<cdiv(U.C * U.kz * 4, 256), 256, 0, ctx->stream>>>(t->P + t->off_upw[k], U.C, U.kz * 4, U.w);
+        ISX_CHECK_LAUNCH();
+    }
+    return ISX_OK;
+}
+
+// gradient of the loss w.r.t. the post-activation output of layer li arrives in g (channel stride gstride);
+// produces draw[li] and the BN / bias gradients.
+static int bn_backward(isx_ctx *ctx, int li, const float *g, int gstride, int act)
+{
+    UNetState *u = ctx->unet;
+    TrainState *t = u->train;
+    const ConvBN &L = u->cv[li];
+    const Level &l = u->lv[MOD_LEVEL[li / 2]];
+    const int C = L.cout;
+    const int rows = 512;
+    const int blocks = (int)((l.M + rows - 1) / rows);
+    ISX_REQUIRE((size_t)blocks * C * 2 <= t->part_floats, "internal: partial buffer too small");
+    bn_bwd_reduce_kernel<<<blocks, 256, 256 * 2 * sizeof(double), ctx->stream>>>(g, gstride, u->raw[li], L.scale, L.shift, L.bmean,
+                                                                             L.invstd, C, l.M, act, rows, t->part);
+    ISX_CHECK_LAUNCH();
+    bn_bwd_finalize_kernel<<<C, 256, 0, ctx->stream>>>(t->part, blocks, C, (double)l.M, t->G + t->off_gamma[li],
+                                                     t->G + t->off_beta[li], t->coef);
+    ISX_CHECK_LAUNCH();
+    bn_bwd_apply_kernel<<<blocks, 256, 256 * sizeof(float), ctx->stream>>>(g, gstride, u->raw[li], L.scale, L.shift, L.bmean,
+                                                                        L.invstd, t->coef, C, l.M, act, rows, t->draw[li],
+                                                                        t->part);
+    ISX_CHECK_LAUNCH();
+    colsum_kernel<<<C, 256, 0, ctx->stream>>>(t->part, blocks, C, t->G + t->off_b[li]);      // conv bias gradient
+    ISX_CHECK_LAUNCH();
+    return ISX_OK;
+}
+
+static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
+{
+    UNetState *u = ctx->unet;
+    TrainState *t = u->train;
+    const ConvBN &L = u->cv[li];
+    const Level &l = u->lv[MOD_LEVEL[li / 2]];
+    WgradArgs a;
+    a.dy = t->draw[li];
+    a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
+    a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
+    a.Cout = L.cout;
+    a.D = l.D; a.H = l.H; a.W = l.W;
+    a.co_tiles = (L.cout + 63) / 64;
+    a.ci_tiles = (L.cin + 63) / 64;
+    const int64_t chunks = (l.M + 63) / 64;
+    int want = 2048 / (a.co_tiles * a.ci_tiles * 27) + 1;          // enough work-groups to fill the chip
+    if (want > chunks) want = (int)chunks;
+    if (want > 64) want = 64;
+    a.vox_per_split = ((chunks + want - 1) / want) * 64;
+    a.splits = (int)((l.M + a.vox_per_split - 1) / a.vox_per_split);
+    a.partial = t->wpart;
+    const size_t need = (size_t)a.splits * 27 * a.co_tiles * 64 * a.ci_tiles * 64;
+    ISX_REQUIRE(need <= t->wpart_floats, "internal: wgrad partial buffer too small (%zu > %zu)", need, t->wpart_floats);
+    wgrad_mfma_kernel<<<dim3(a.co_tiles * a.ci_tiles, 27, a.splits), 256, 0, ctx->stream>>>(a);
+    ISX_CHECK_LAUNCH();
+    const int64_t n = (int64_t)L.cout * L.cin * 27;
+    unsigned grid = cdiv(n, 256);
+    if (grid > 4096) grid = 4096;
+    wgrad_reduce_kernel<<<grid, 256, 0, ctx->stream>>>(t->wpart, a.splits, L.cout, L.cin, a.co_tiles * 64, a.ci_tiles * 64,
+                                                    t->G + t->off_w[li]);
+    ISX_CHECK_LAUNCH();
+    return ISX_OK;
+}
+
+// gradient w.r.t. the input of conv li (all Cin channels, stride Cin) into dst
+static int dgrad(isx_ctx *ctx, int li, float *dst)
+{
+    UNetState *u = ctx->unet;
+    TrainState *t = u->train;
+    const ConvBN &L = u->cv[li];
+    const Level &l = u->lv[MOD_LEVEL[li / 2]];
+    if (t->w_dgrad[li]) {
+        // the forward kernel with Cin <-> Cout: "input" = d(raw) (Cout channels), "output" = dX (Cin channels)
+        return launch_conv_mfma(ctx, l, 1, Src{t->draw[li], nullptr, nullptr, L.cout}, Src{nullptr, nullptr, nullptr, 0},
+                                t->w_dgrad[li], t->zeros, L.cin, dst, nullptr, nullptr, 1);
+    }
+    const int64_t total = l.M * ((L.cin + 3) / 4);
+    dgrad_small_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(t->draw[li], t->P + t->off_w[li], L.cout, L.cin, l.D, l.H, l.W,
+                                                              dst, total);
+    ISX_CHECK_LAUNCH();
+    return ISX_OK;
+}
+
+static int backward(isx_ctx *ctx)
+{
+    UNetState *u = ctx->unet;
+    TrainState *t = u->train;
+    const Level *lv = u->lv;
+    const Src none{nullptr, nullptr, nullptr, 0};
+    auto act = [&](int li) { const ConvBN &L = u->cv[li]; return Src{u->raw[li], L.scale, L.shift, L.cout}; };
+    // ---- decoder, last module first --------------------------------------------------------------
+    for (int k = 3; k >= 0; --k) {
+        const int mi = 5 + k, l1 = 2 * mi + 1, l0 = 2 * mi;
+        const int skip_li = 2 * (3 - k) + 1;
+        const UpConv &U = u->up[k];
+        const Level &lo = lv[3 - k];
+        // conv1 of the module: g arrives in gact[l1] (the loss wrote it for the last module)
+        ISX_TRY(bn_backward(ctx, l1, t->gact[l1], u->cv[l1].cout, mi == 8 ? 1 : 0));
+        ISX_TRY(wgrad(ctx, l1, act(l0), none));
+        ISX_TRY(dgrad(ctx, l1, t->gact[l0]));
+        // conv0 of the module: input = cat(up_k, act(skip))
+        ISX_TRY(bn_backward(ctx, l0, t->gact[l0], u->cv[l0].cout, 0));
+        ISX_TRY(wgrad(ctx, l0, Src{u->ups[k], nullptr, nullptr, U.C}, act(skip_li)));
+        ISX_TRY(dgrad(ctx, l0, t->dcat[k]));                       // [M][2C]: first C -> up_k, last C -> skip
+        // transposed conv backward -> gradient of the module that fed it (c4, c5, c6, c7 second conv)
+        const int mi_in = (k == 0) ? 4 : 4 + k, li_in = 2 * mi_in + 1;
+        const Level &ls = lv[MOD_LEVEL[mi_in]];
+        const ConvBN &Lin = u->cv[li_in];
+        const int kt = U.kz * 4;
+        const int vpb = 1024;
+        const int blocks = (int)((ls.M + vpb - 1) / vpb);
+        ISX_REQUIRE((size_t)blocks * (kt + 1) * U.C <= t->part_floats, "internal: partial buffer too small");
+        upsample_bwd_kernel<<<blocks, 256, (size_t)(kt + 1) * U.C * sizeof(float), ctx->stream>>>(
+            u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, t->dcat[k], 2 * U.C, lo.D, lo.H,
+            lo.W, t->gact[li_in], t->part, vpb);
+        ISX_CHECK_LAUNCH();
+        up_grad_finalize_kernel<<<cdiv((kt + 1) * U.C, 256), 256, 0, ctx->stream>>>(t->part, blocks, U.C, kt, t->G + t->off_upw[k],
+                                                                                 t->G + t->off_upb[k]);
+        ISX_CHECK_LAUNCH();
+    }
+    // ---- encoder, bottom first ---------------------------------------------------------------------
+    for (int mi = 4; mi >= 0; --mi) {
+        const int l1 = 2 * mi + 1, l0 = 2 * mi;
+        const Level &l = lv[mi];
+        ISX_TRY(bn_backward(ctx, l1, t->gact[l1], u->cv[l1].cout, 0));
+        ISX_TRY(wgrad(ctx, l1, act(l0), none));
+        ISX_TRY(dgrad(ctx, l1, t->gact[l0]));
+        ISX_TRY(bn_backward(ctx, l0, t->gact[l0], u->cv[l0].cout, 0));
+        if (mi == 0) {
+            ISX_TRY(wgrad(ctx, l0, Src{u->x0, nullptr, nullptr, 1}, none));
+            break;
+        }
+        ISX_TRY(wgrad(ctx, l0, Src{u->pool[mi - 1], nullptr, nullptr, MOD_COUT[mi - 1]}, none));
+        ISX_TRY(dgrad(ctx, l0, t->dpool[mi - 1]));
+        // pool backward into the previous module's output gradient, plus its share of the decoder concat
+        const int lp = 2 * (mi - 1) + 1;
+        const ConvBN &Lp = u->cv[lp];
+        const Level &lprev = lv[mi - 1];
+        const int kdec = 3 - (mi - 1);                              // decoder stage that consumed this skip
+        const int64_t total = l.M * (Lp.cout / 4);
+        pool_bwd_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[lp], Lp.scale, Lp.shift, Lp.cout, lprev.D, lprev.H, lprev.W,
+                                                                mi == 4 ? 2 : 1, l.D, l.H, l.W, t->dpool[mi - 1], t->dcat[kdec],
+                                                                2 * Lp.cout, Lp.cout, t->gact[lp], total);
+        ISX_CHECK_LAUNCH();
+    }
+    return ISX_OK;
+}
+
+}  // namespace isx
+
+using namespace isx;
+
+extern "C" {
+
+int64_t isx_train_param_count(isx_ctx *ctx)
+{
+    if (!ctx || !ctx->unet || !ctx->unet->committed) { set_error("weights not committed"); return ISX_ERR_STATE; }
+    TrainState tmp;
+    return param_layout(ctx->unet, &tmp);
+}
+
+int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *grads, float *adam_m, float *adam_v,
+                   int64_t n)
+{
+    ISX_REQUIRE(ctx && chunk && params && grads && adam_m && adam_v, "null argument");
+    if (!ctx->unet || !ctx->unet->committed) { set_error("weights not committed"); return ISX_ERR_STATE; }
+    ISX_HIP(hipSetDevice(ctx->device));
+    UNetState *u = ctx->unet;
+    ISX_REQUIRE(!u->train, "training state already bound to this context");
+    ISX_REQUIRE(u->out_channels <= 8, "out_channels");
+    TrainState *t = new TrainState();
+    const int64_t np = param_layout(u, t);
+    if (n != np) { delete t; set_error("parameter buffer has %ld floats, expected %ld", (long)n, (long)np); return ISX_ERR_ARG; }
+    t->P = params; t->G = grads; t->Mo = adam_m; t->Vo = adam_v; t->nparam = np;
+    t->cz = (int)chunk[0]; t->cy = (int)chunk[1]; t->cx = (int)chunk[2];
+    u->train = t;
+    u->batch = 1;
+    u->wz = 0;                                        // force a B = 1 workspace
+    ISX_TRY(prepare_workspace(ctx, t->cz, t->cy, t->cx, 1));
+    // current weights (host copies in reference layout) -> P; BN / bias pointers now alias P
+    for (int li = 0; li < 18; ++li) {
+        ConvBN &L = u->cv[li];
+        const HostTensor &w = u->host[L.conv + ".weight"], &b = u->host[L.conv + ".bias"];
+        const HostTensor &g = u->host[L.bn + ".weight"], &be = u->host[L.bn + ".bias"];
+        ISX_HIP(hipMemcpyAsync(t->P + t->off_w[li], w.f.data(), w.f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ISX_HIP(hipMemcpyAsync(t->P + t->off_b[li], b.f.data(), b.f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ISX_HIP(hipMemcpyAsync(t->P + t->off_gamma[li], g.f.data(), g.f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ISX_HIP(hipMemcpyAsync(t->P + t->off_beta[li], be.f.data(), be.f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (L.cout >= 8) L.bias = t->P + t->off_b[li];     // thin layers keep their 8-padded bias copy (refreshed below)
+        L.gamma = t->P + t->off_gamma[li];
+        L.beta = t->P + t->off_beta[li];
+    }
+    for (int k = 0; k < 4; ++k) {
+        UpConv &U = u->up[k];
+        const HostTensor &w = u->host[U.name + ".weight"], &b = u->host[U.name + ".bias"];
+        ISX_HIP(hipMemcpyAsync(t->P + t->off_upw[k], w.f.data(), w.f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ISX_HIP(hipMemcpyAsync(t->P + t->off_upb[k], b.f.data(), b.f.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        U.bias = t->P + t->off_upb[k];
+    }
+    // backward buffers
+    size_t max_rawc = 0;
+    for (int li = 0; li < 18; ++li) {
+        const ConvBN &L = u->cv[li];
+        const Level &l = u->lv[MOD_LEVEL[li / 2]];
+        ISX_TRY(talloc(t, (size_t)l.M * L.cout, &t->draw[li]));
+        ISX_TRY(talloc(t, (size_t)l.M * L.cout, &t->gact[li]));
+        if (li != 0 && use_mfma(L.cout, L.cin)) ISX_TRY(talloc(t, (size_t)L.cout * L.cin * 27 + 2048, &t->w_dgrad[li]));
+        max_rawc = std::max(max_rawc, (size_t)L.cout);
+    }
+    for (int k = 0; k < 4; ++k) {
+        ISX_TRY(talloc(t, (size_t)u->lv[3 - k].M * 2 * u->up[k].C, &t->dcat[k]));
+        ISX_TRY(talloc(t, (size_t)u->lv[k + 1].M * MOD_COUT[k], &t->dpool[k]));
+    }
+    t->part_floats = (size_t)4 << 20;
+    ISX_TRY(talloc(t, t->part_floats, &t->part));
+    ISX_TRY(talloc(t, 1024, &t->coef));
+    ISX_TRY(talloc(t, 4096, &t->lossbuf));
+    ISX_TRY(talloc(t, 1024, &t->zeros));
+    ISX_HIP(hipMemsetAsync(t->zeros, 0, 1024 * 4, ctx->stream));
+    size_t wp = 0;
+    for (int li = 0; li < 18; ++li) {
+        const ConvBN &L = u->cv[li];
+        size_t tiles = (size_t)((L.cout + 63) / 64) * ((L.cin + 63) / 64);
+        size_t splits = 2048 / (tiles * 27) + 1;
+        if (splits > 64) splits = 64;
+        wp = std::max(wp, (splits + 1) * 27 * tiles * 64 * 64);
+    }
+    t->wpart_floats = wp;
+    ISX_TRY(talloc(t, wp, &t->wpart));
+    ISX_TRY(repack_all(ctx));
+    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    return ISX_OK;
+}
+
+// forward of one patch + loss (+ backward + n_adam optimiser steps).  x: device (D,H,W); y: device (C,D,H,W).
+// loss_out (host): [0] = loss, [1..C] = per-channel mean of the elementwise loss term.
+int isx_train_step(isx_ctx *ctx, const float *x, const float *y, int loss_kind, const float *chan_weights, float lr,
+                   int n_adam, int do_backward, float *loss_out)
+{
+    ISX_REQUIRE(ctx && x && y && loss_out, "null argument");
+    if (!ctx->unet || !ctx->unet->train) { set_error("call isx_train_bind first"); return ISX_ERR_STATE; }
+    ISX_REQUIRE(loss_kind >= 0 && loss_kind <= 2 && (loss_kind != 2 || chan_weights), "loss kind");
+    ISX_HIP(hipSetDevice(ctx->device));
+    UNetState *u = ctx->unet;
+    TrainState *t = u->train;
+    const Level &l0 = u->lv[0];
+    const int C = u->out_channels;
+    // forward (train-mode BN, keeps every raw tensor)
+    ISX_HIP(hipMemcpyAsync(u->x0, x, (size_t)l0.M * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    Scratch<int32_t> tab(ctx, 9);
+    if (!tab.ok()) return ISX_ERR_NOMEM;
+    ISX_HIP(hipMemsetAsync(tab.p, 0, 36, ctx->stream));
+    u->d_table = tab.p;
+    ISX_TRY(forward_batch(ctx, 1, nullptr, nullptr, nullptr));
+    // loss and its gradient
+    const ConvBN &LL = u->cv[17];
+    const int blocks = (int)((l0.M + 255) / 256);
+    ISX_REQUIRE((size_t)blocks * C <= t->part_floats, "internal: partial buffer too small");
+    float *cw_dev = t->lossbuf + 64;
+    if (loss_kind == 2) ISX_HIP(hipMemcpyAsync(cw_dev, chan_weights, C * 4, hipMemcpyHostToDevice, ctx->stream));
+    loss_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[17], LL.scale, LL.shift, y, C, l0.M, loss_kind, cw_dev, t->gact[17], t->part);
+    ISX_CHECK_LAUNCH();
+    colsum_kernel<<<C, 256, 0, ctx->stream>>>(t->part, blocks, C, t->lossbuf);
+    ISX_CHECK_LAUNCH();
+    float hs[8];
+    ISX_HIP(hipMemcpyAsync(hs, t->lossbuf, C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (do_backward) {
+        ISX_TRY(backward(ctx));
+        for (int s = 0; s < n_adam; ++s) {
+            ++t->adam_t;
+            const float bc1 = 1.f - powf(0.9f, (float)t->adam_t), bc2 = 1.f - powf(0.999f, (float)t->adam_t);
+            adam_kernel<<<2048, 256, 0, ctx->stream>>>(t->P, t->G, t->Mo, t->Vo, t->nparam, lr, bc1, bc2);
+            ISX_CHECK_LAUNCH();
+        }
+        if (n_adam > 0) ISX_TRY(repack_all(ctx));
+    }
+    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (int c = 0; c < C; ++c) {
+        loss_out[1 + c] = hs[c] / (float)l0.M;
+        tot += (loss_kind == 2 ? (double)chan_weights[c] : 1.0) * hs[c] / (double)l0.M;
+    }
+    loss_out[0] = (float)(tot / C);
+    return ISX_OK;
+}
+
+// after an external update of the bound parameter buffer (e.g. an all-reduce + optimiser step done elsewhere)
+int isx_train_refresh_weights(isx_ctx *ctx)
+{
+    if (!ctx || !ctx->unet || !ctx->unet->train) { set_error("call isx_train_bind first"); return ISX_ERR_STATE; }
+    ISX_HIP(hipSetDevice(ctx->device));
+    return repack_all(ctx);
+}
+
+// one Adam step on the bound buffers (used when gradients were all-reduced between backward and update)
+int isx_adam_step(isx_ctx *ctx, float lr, int n_steps)
+{
+    if (!ctx || !ctx->unet || !ctx->unet->train) { set_error("call isx_train_bind first"); return ISX_ERR_STATE; }
+    ISX_HIP(hipSetDevice(ctx->device));
+    TrainState *t = ctx->unet->train;
+    for (int s = 0; s < n_steps; ++s) {
+        ++t->adam_t;
+        const float bc1 = 1.f - powf(0.9f, (float)t->adam_t), bc2 = 1.f - powf(0.999f, (float)t->adam_t);
+        adam_kernel<<<2048, 256, 0, ctx->stream>>>(t->P, t->G, t->Mo, t->Vo, t->nparam, lr, bc1, bc2);
+        ISX_CHECK_LAUNCH();
+    }
+    return repack_all(ctx);
+}
+
+}  // extern "C"

@@ -24,7 +24,7 @@
 #include <string>
 #include <vector>
 
-#include "isx_common.h"
+#include "unet_state.h"
 
 namespace isx {
 
@@ -39,78 +39,23 @@ __device__ __forceinline__ float4 ld_stream(const float *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-static constexpr float BN_EPS = 1e-5f;
-static constexpr float BN_MOMENTUM = 0.1f;
-
-// ------------------------------------------------------------------------------------------
-// State
-// ------------------------------------------------------------------------------------------
-struct HostTensor {
-    std::vector<float> f;
-    std::vector<int64_t> shape;
-    int64_t i64 = 0;
-    bool is_i64 = false;
-};
-
-struct ConvBN {                 // one Conv3d followed by its BatchNorm3d
-    std::string conv, bn;       // state-dict prefixes, e.g. "c0.conv0", "c0.batch0"
-    int cin = 0, cout = 0;
-    float *w = nullptr;         // packed weights (layout depends on the kernel that reads them)
-    float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *rmean = nullptr, *rvar = nullptr;
-    int64_t nbt = 0;
-    float *scale = nullptr, *shift = nullptr;       // [B][cout], valid after bn_finalize
-    float *bmean = nullptr, *bvar = nullptr;        // [B][cout] batch mean / unbiased var
-    float *psum = nullptr, *psq = nullptr;          // [B][tiles][cout] partial sums
-    int tiles = 0;
-};
-
-struct UpConv {
-    std::string name;
-    int C = 0, kz = 1;
-    float *w = nullptr;         // [kz*4][C]
-    float *bias = nullptr;
-};
-
-struct Level { int D = 0, H = 0, W = 0; int64_t M = 0; };
-
-struct UNetState {
-    std::map<std::string, HostTensor> host;
-    bool committed = false;
-    int out_channels = 5;
-    int batch = 4;
-    // layers: index 0..17 = c0.conv0, c0.conv1, c1.conv0, ... c4.conv1, c5.conv0 ... c8.conv1
-    ConvBN cv[18];
-    UpConv up[4];
-    // workspace for (cz, cy, cx) x batch
-    int wz = 0, wy = 0, wx = 0, wbatch = 0;
-    Level lv[5];
-    std::vector<void *> blocks;      // workspace (re-allocated when the chunk geometry changes)
-    std::vector<void *> wblocks;     // weights
-    float *x0 = nullptr;
-    float *raw[18] = {nullptr};
-    float *pool[4] = {nullptr};
-    float *ups[4] = {nullptr};
-    float *ptail = nullptr;           // [B][M0][16] partial sums of the folded tail layer
-    float *wtail = nullptr, *zeros32 = nullptr;
-    const int32_t *d_table = nullptr;   // device rows of the launch set in flight
-    int last_n = 0;
-};
 
 void unet_destroy(UNetState *u)
 {
     if (!u) return;
+    if (u->train) train_destroy(u->train);
     for (void *p : u->blocks) (void)hipFree(p);
     for (void *p : u->wblocks) (void)hipFree(p);
     delete u;
 }
 
-static const char *MODS[9] = {"c0", "c1", "c2", "c3", "c4", "c5_0", "c6_0", "c7_0", "c8_0"};
-static const int MOD_CIN[9] = {1, 32, 64, 128, 256, 512, 256, 128, 64};
-static const int MOD_COUT[9] = {32, 64, 128, 256, 256, 128, 64, 32, -1};
-static const int MOD_LEVEL[9] = {0, 1, 2, 3, 4, 3, 2, 1, 0};
-static const char *UPS[4] = {"up0", "up1", "up2", "up3"};
-static const int UP_C[4] = {256, 128, 64, 32};
-static const int UP_KZ[4] = {2, 1, 1, 1};
+const char *MODS[9] = {"c0", "c1", "c2", "c3", "c4", "c5_0", "c6_0", "c7_0", "c8_0"};
+const int MOD_CIN[9] = {1, 32, 64, 128, 256, 512, 256, 128, 64};
+const int MOD_COUT[9] = {32, 64, 128, 256, 256, 128, 64, 32, -1};
+const int MOD_LEVEL[9] = {0, 1, 2, 3, 4, 3, 2, 1, 0};
+const char *UPS[4] = {"up0", "up1", "up2", "up3"};
+const int UP_C[4] = {256, 128, 64, 32};
+const int UP_KZ[4] = {2, 1, 1, 1};
 
 // ------------------------------------------------------------------------------------------
 // Kernels: chunk gather
@@ -194,21 +139,6 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
 // ------------------------------------------------------------------------------------------
 // Kernel: implicit-GEMM 3x3x3 convolution on the fp32 matrix cores.
 // ------------------------------------------------------------------------------------------
-struct ConvArgs {
-    const float *srcA, *scaleA, *shiftA;   // channels [0, CA): tensor [B][M][CA] (+ optional BN+ReLU)
-    const float *srcB, *scaleB, *shiftB;   // channels [CA, CA+CB): the skip tensor of the decoder
-    int CA, CB;
-    const float *w;        // packed [Cout/BN][Cin/4][27][4][BN]
-    const float *bias;     // [Cout]
-    float *out;            // [B][M][Cout] raw conv output (+bias)
-    float *psum, *psq;     // [B][tiles][Cout]
-    int D, H, W, Cout;
-    int mode;              // 0: 2x8x8 voxel tiles; 1: 2 planes x 64 row-wrapped positions; 2: 1 plane x 128
-    int tiles_per_chunk, nty, ntx, ntp;
-    int slots_max;         // LDS halo slots reserved
-    int store_cols;        // columns of the N tile actually stored (Cout, or 16 for the folded tail layer)
-    int no_stats;          // 1: skip BN partial sums (folded tail layer: statistics come from the combine)
-};
 
 static constexpr int A_STRIDE = 6;     // floats per halo slot (4 channels + 2 pad: conflict-free ds_read_b64)
 
@@ -433,7 +363,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
                                                           int tiles, int C, double count, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float *__restrict__ scale,
                                                           float *__restrict__ shift, float *__restrict__ bmean,
-                                                          float *__restrict__ bvar)
+                                                          float *__restrict__ bvar, float *__restrict__ invstd_out)
 {
     __shared__ double rs[256], rq[256];
     const int c = blockIdx.x, b = blockIdx.y;
@@ -459,6 +389,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
         scale[b * C + c] = sc;
         shift[b * C + c] = beta[c] - (float)mean * sc;
         bmean[b * C + c] = (float)mean;
+        invstd_out[b * C + c] = invstd;
         bvar[b * C + c] = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
     }
 }
@@ -754,7 +685,7 @@ static int dev_upload(UNetState *u, const std::vector<float> &h, float **out)
     return ISX_OK;
 }
 
-static int dev_alloc(UNetState *u, size_t floats, float **out)
+int dev_alloc(UNetState *u, size_t floats, float **out)
 {
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, (floats ? floats : 1) * sizeof(float));
@@ -775,9 +706,9 @@ static const HostTensor *need(UNetState *u, const std::string &key, std::vector<
     return &it->second;
 }
 
-static bool use_mfma(int cin, int cout) { return cin >= 32 && (cin % 4) == 0 && (cout % 32) == 0; }
+bool use_mfma(int cin, int cout) { return cin >= 32 && (cin % 4) == 0 && (cout % 32) == 0; }
 // thin layer with many inputs: x-taps folded into the MFMA N tile (3 * cout <= 16 columns)
-static bool use_fold(int cin, int cout) { return cin >= 32 && (cin % 4) == 0 && cout <= 5; }
+bool use_fold(int cin, int cout) { return cin >= 32 && (cin % 4) == 0 && cout <= 5; }
 
 static int commit_weights(isx_ctx *ctx, int out_channels)
 {
@@ -875,13 +806,13 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
 // ------------------------------------------------------------------------------------------
 // Host side: workspace and the forward pass
 // ------------------------------------------------------------------------------------------
-static int conv_mode(const Level &l)
+int conv_mode(const Level &l)
 {
     if (l.W > 88 || (l.W % 8 == 0 && l.H % 8 == 0)) return 0;
     return (l.D % 2 == 0) ? 1 : 2;
 }
 
-static int conv_tiles(const Level &l, int mode, int *nty, int *ntx, int *ntp, int *slots)
+int conv_tiles(const Level &l, int mode, int *nty, int *ntx, int *ntp, int *slots)
 {
     if (mode == 0) {
         *nty = (l.H + 7) / 8;
@@ -909,7 +840,7 @@ static int layer_tiles(const UNetState *u, int li, const Level &l)
     return (int)((l.M + 255) / 256);      // thin kernel blocks, or combine blocks of the folded layer
 }
 
-static int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
+int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
 {
     UNetState *u = ctx->unet;
     if (u->wz == cz && u->wy == cy && u->wx == cx && u->wbatch >= batch) return ISX_OK;
@@ -943,6 +874,7 @@ static int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
         ISX_TRY(dev_alloc(u, (size_t)B * L.cout, &L.shift));
         ISX_TRY(dev_alloc(u, (size_t)B * L.cout, &L.bmean));
         ISX_TRY(dev_alloc(u, (size_t)B * L.cout, &L.bvar));
+        ISX_TRY(dev_alloc(u, (size_t)B * L.cout, &L.invstd));
     }
     ISX_TRY(dev_alloc(u, (size_t)B * lv[0].M * 16 + 64, &u->ptail));
     for (int k = 0; k < 4; ++k) {
@@ -953,7 +885,29 @@ static int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
     return ISX_OK;
 }
 
-struct Src { const float *p; const float *scale; const float *shift; int C; };
+
+int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const float *w_packed, const float *bias,
+                     int cout, float *out, float *psum, float *psq, int no_stats)
+{
+    ConvArgs a;
+    a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
+    a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
+    a.w = w_packed; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
+    a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = cout;
+    a.mode = conv_mode(l);
+    a.tiles_per_chunk = conv_tiles(l, a.mode, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+    a.store_cols = cout;
+    a.no_stats = no_stats;
+    ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
+    ISX_REQUIRE(cout % 32 == 0 && (sa.C + sb.C) % 4 == 0, "internal: MFMA conv needs Cout %% 32 == 0, Cin %% 4 == 0");
+    const int BN = (cout % 64 == 0) ? 64 : 32;
+    size_t lds = (size_t)(27 * 4 * BN + a.slots_max * A_STRIDE + 128 + 4 * BN * 2) * sizeof(float);
+    dim3 grid((unsigned)(B * a.tiles_per_chunk), (unsigned)(cout / BN));
+    if (BN == 64) conv_mfma_kernel<64, 3><<<grid, 256, lds, ctx->stream>>>(a);
+    else conv_mfma_kernel<32, 3><<<grid, 256, lds, ctx->stream>>>(a);
+    ISX_CHECK_LAUNCH();
+    return ISX_OK;
+}
 
 static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
 {
@@ -963,23 +917,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
     ISX_REQUIRE(cin == L.cin, "internal: layer %s fed %d channels, expects %d", L.conv.c_str(), cin, L.cin);
     if (use_mfma(L.cin, L.cout)) {
         ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
-        ConvArgs a;
-        a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
-        a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
-        a.w = L.w; a.bias = L.bias; a.out = u->raw[li]; a.psum = L.psum; a.psq = L.psq;
-        a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = L.cout;
-        a.mode = conv_mode(l);
-        a.tiles_per_chunk = conv_tiles(l, a.mode, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
-        a.store_cols = L.cout;
-        a.no_stats = 0;
-        ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
-        ISX_REQUIRE(a.tiles_per_chunk == L.tiles, "internal: tile count mismatch");
-        const int BN = (L.cout % 64 == 0) ? 64 : 32;
-        size_t lds = (size_t)(27 * 4 * BN + a.slots_max * A_STRIDE + 128 + 4 * BN * 2) * sizeof(float);
-        dim3 grid((unsigned)(B * a.tiles_per_chunk), (unsigned)(L.cout / BN));
-        if (BN == 64) conv_mfma_kernel<64, 3><<<grid, 256, lds, ctx->stream>>>(a);
-        else conv_mfma_kernel<32, 3><<<grid, 256, lds, ctx->stream>>>(a);
-        ISX_CHECK_LAUNCH();
+        ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
     } else if (use_fold(L.cin, L.cout)) {
         // pass 1 on the matrix cores: 9 (dz,dy) taps, x-taps folded into 3*cout <= 16 output columns
         {
@@ -1028,7 +966,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
     {
         ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
         bn_finalize_kernel<<<dim3((unsigned)L.cout, (unsigned)B), 256, 0, ctx->stream>>>(
-            L.psum, L.psq, L.tiles, L.cout, (double)l.M, L.gamma, L.beta, L.scale, L.shift, L.bmean, L.bvar);
+            L.psum, L.psq, L.tiles, L.cout, (double)l.M, L.gamma, L.beta, L.scale, L.shift, L.bmean, L.bvar, L.invstd);
         ISX_CHECK_LAUNCH();
         bn_running_kernel<<<cdiv(L.cout, 64), 64, 0, ctx->stream>>>(L.bmean, L.bvar, B, L.cout, L.rmean, L.rvar);
         ISX_CHECK_LAUNCH();
@@ -1038,7 +976,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
 }
 
 // Forward B chunks whose rows are already in u->d_table and whose voxels are in u->x0.
-static int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3])
+int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3])
 {
     UNetState *u = ctx->unet;
     const Level *lv = u->lv;

@@ -1,0 +1,106 @@
+// unet_state.h -- state shared by the U-Net forward (unet.hip) and the training path (train.hip).
+#pragma once
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "isx_common.h"
+
+namespace isx {
+
+static constexpr float BN_EPS = 1e-5f;
+static constexpr float BN_MOMENTUM = 0.1f;
+
+struct HostTensor {
+    std::vector<float> f;
+    std::vector<int64_t> shape;
+    int64_t i64 = 0;
+    bool is_i64 = false;
+};
+
+struct ConvBN {                 // one Conv3d followed by its BatchNorm3d
+    std::string conv, bn;       // state-dict prefixes, e.g. "c0.conv0", "c0.batch0"
+    int cin = 0, cout = 0;
+    float *w = nullptr;         // packed weights (layout depends on the kernel that reads them)
+    float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *rmean = nullptr, *rvar = nullptr;
+    int64_t nbt = 0;
+    float *scale = nullptr, *shift = nullptr;       // [B][cout], valid after bn_finalize
+    float *bmean = nullptr, *bvar = nullptr;        // [B][cout] batch mean / unbiased var
+    float *invstd = nullptr;                        // [B][cout] 1/sqrt(biased var + eps) (backward)
+    float *psum = nullptr, *psq = nullptr;          // [B][tiles][cout] partial sums
+    int tiles = 0;
+};
+
+struct UpConv {
+    std::string name;
+    int C = 0, kz = 1;
+    float *w = nullptr;         // [kz*4][C]
+    float *bias = nullptr;
+};
+
+struct Level { int D = 0, H = 0, W = 0; int64_t M = 0; };
+
+struct UNetState {
+    std::map<std::string, HostTensor> host;
+    bool committed = false;
+    int out_channels = 5;
+    int batch = 4;
+    // layers: index 0..17 = c0.conv0, c0.conv1, c1.conv0, ... c4.conv1, c5.conv0 ... c8.conv1
+    ConvBN cv[18];
+    UpConv up[4];
+    // workspace for (cz, cy, cx) x batch
+    int wz = 0, wy = 0, wx = 0, wbatch = 0;
+    Level lv[5];
+    std::vector<void *> blocks;      // workspace (re-allocated when the chunk geometry changes)
+    std::vector<void *> wblocks;     // weights
+    float *x0 = nullptr;
+    float *raw[18] = {nullptr};
+    float *pool[4] = {nullptr};
+    float *ups[4] = {nullptr};
+    float *ptail = nullptr;           // [B][M0][16] partial sums of the folded tail layer
+    float *wtail = nullptr, *zeros32 = nullptr;
+    const int32_t *d_table = nullptr;   // device rows of the launch set in flight
+    int last_n = 0;
+    struct TrainState *train = nullptr;
+};
+
+
+struct TrainState;
+
+struct Src { const float *p; const float *scale; const float *shift; int C; };
+
+// implicit-GEMM conv on the fp32 matrix cores (unet.hip); see ConvArgs there
+struct ConvArgs {
+    const float *srcA, *scaleA, *shiftA;   // channels [0, CA): tensor [B][M][CA] (+ optional BN+ReLU)
+    const float *srcB, *scaleB, *shiftB;   // channels [CA, CA+CB): the skip tensor of the decoder
+    int CA, CB;
+    const float *w;        // packed [Cout/BN][Cin/4][taps][4][BN]
+    const float *bias;     // [Cout]
+    float *out;            // [B][M][store_cols] raw conv output (+bias)
+    float *psum, *psq;     // [B][tiles][Cout]
+    int D, H, W, Cout;
+    int mode;              // 0: 2x8x8 voxel tiles; 1: 2 planes x 64 row-wrapped positions; 2: 1 plane x 128
+    int tiles_per_chunk, nty, ntx, ntp;
+    int slots_max;         // LDS halo slots reserved
+    int store_cols;        // columns of the N tile actually stored (Cout, or 16 for the folded tail layer)
+    int no_stats;          // 1: skip BN partial sums
+};
+
+extern const char *MODS[9];
+extern const int MOD_CIN[9], MOD_COUT[9], MOD_LEVEL[9], UP_C[4], UP_KZ[4];
+extern const char *UPS[4];
+
+bool use_mfma(int cin, int cout);
+bool use_fold(int cin, int cout);
+int conv_mode(const Level &l);
+int conv_tiles(const Level &l, int mode, int *nty, int *ntx, int *ntp, int *slots);
+// raw launch of the MFMA conv (no BN finalize): used by the forward and by dgrad
+int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const float *w_packed, const float *bias,
+                     int cout, float *out, float *psum, float *psq, int no_stats);
+int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch);
+int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3]);
+int dev_alloc(UNetState *u, size_t floats, float **out);
+void train_destroy(TrainState *t);
+
+}  // namespace isx

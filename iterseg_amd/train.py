@@ -1,0 +1,222 @@
+"""Mirror of ``iterseg.train`` (reference: src/iterseg/train.py) on the MI355X path.
+
+* :func:`train_unet`   -- train.py:25-183 (same signature and return value ``(unet, unet_path)``)
+* :class:`Trainer`     -- the device side of ``_train_step`` / ``_validate`` (train.py:344-389): forward,
+  loss, backward and Adam run in ``libitersegx.so`` (``isx_train_step``); there is no torch.autograd.
+
+Parameters, gradients and the Adam moments are four flat CUDA tensors owned here (PyTorch = memory
+container), bound to the library with ``isx_train_bind``.  With ``torch.distributed`` initialised the
+gradient buffer is averaged across ranks with ONE all-reduce per step (RCCL over xGMI) between backward
+and the optimiser update -- data parallel, batch 1 per rank, BatchNorm statistics per rank like the
+reference's single-GPU semantics.
+
+Reference quirk kept and switchable: ``_train_loop`` calls ``optimiser.step()`` a second time on the same
+gradients (train.py:310) -> ``double_step=True`` by default.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from collections import OrderedDict
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from . import _lib, weights as _weights
+from .unet import UNet
+
+LOSS_KINDS = {"BCELoss": 0, "MSELoss": 1, "WeightedBCE": 2, "EpochWeightedBCE": 2}
+
+
+def trainable_layout(out_channels=5):
+    """``[(key, shape, offset)]`` of the flat parameter buffer: trainable state-dict entries, grouped per
+    module as conv0.{weight,bias}, conv1.{weight,bias}, batch0.{weight,bias}, batch1.{weight,bias}, then the
+    transposed convolutions (the order ``isx_train_bind`` documents)."""
+    schema = _weights.unet_schema(1, out_channels)
+    mods = ["c0", "c1", "c2", "c3", "c4", "c5_0", "c6_0", "c7_0", "c8_0"]
+    keys = []
+    for m in mods:
+        keys += [f"{m}.conv0.weight", f"{m}.conv0.bias", f"{m}.conv1.weight", f"{m}.conv1.bias",
+                 f"{m}.batch0.weight", f"{m}.batch0.bias", f"{m}.batch1.weight", f"{m}.batch1.bias"]
+    for k in range(4):
+        keys += [f"up{k}.weight", f"up{k}.bias"]
+    out, off = [], 0
+    for k in keys:
+        shape = tuple(schema[k])
+        out.append((k, shape, off))
+        off += int(np.prod(shape))
+    return out, off
+
+
+class Trainer:
+    """One U-Net replica being trained on this rank's GPU."""
+
+    def __init__(self, state_dict=None, out_channels=5, patch=(10, 256, 256), device=None, seed=0):
+        self.unet = UNet(1, out_channels, device=device, batch=1)
+        if state_dict is None:
+            state_dict = _weights.generate_state_dict(seed, 1, out_channels)
+        self.unet.load_state_dict(state_dict)
+        self.out_channels = out_channels
+        self.patch = tuple(int(p) for p in patch)
+        dev = torch.device("cuda", self.unet.device)
+        lib, h = self.unet.ctx.lib, self.unet.ctx.handle
+        self.layout, n = trainable_layout(out_channels)
+        n_lib = lib.isx_train_param_count(h)
+        assert n_lib == n, (n_lib, n)
+        self.params = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros_like(self.params)
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.unet._bind_stream()
+        _lib.check(lib.isx_train_bind(h, _lib._dims(self.patch), C.c_void_p(self.params.data_ptr()),
+                                      C.c_void_p(self.grads.data_ptr()), C.c_void_p(self.adam_m.data_ptr()),
+                                      C.c_void_p(self.adam_v.data_ptr()), n))
+
+    # ------------------------------------------------------------------ steps
+    def _call(self, x, y, loss, chan_weights, lr, n_adam, backward):
+        dev = self.params.device
+        x = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.float32).to(dev).contiguous()
+        y = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y, dtype=torch.float32).to(dev).contiguous()
+        assert tuple(x.shape) == self.patch and tuple(y.shape) == (self.out_channels,) + self.patch, (x.shape, y.shape)
+        if loss not in LOSS_KINDS:
+            raise ValueError('Valid loss options are BCELoss, WeightedBCE, MSELoss (DiceLoss / Channelwise: not built yet)')
+        cw = None
+        if LOSS_KINDS[loss] == 2:
+            cw = (C.c_float * self.out_channels)(*[float(w) for w in chan_weights])
+        out = (C.c_float * (1 + self.out_channels))()
+        self.unet._bind_stream()
+        _lib.check(self.unet.ctx.lib.isx_train_step(self.unet.ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                    LOSS_KINDS[loss], cw, C.c_float(lr), int(n_adam), 1 if backward else 0, out))
+        return float(out[0]), [float(v) for v in out[1:]]
+
+    def train_step(self, x, y, lr=0.01, loss="BCELoss", chan_weights=None, double_step=True, group=None):
+        """zero_grad -> forward -> loss -> backward -> Adam (x2 if ``double_step``).  Returns
+        ``(loss, per_channel_losses)``."""
+        n_adam = 2 if double_step else 1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            l, cl = self._call(x, y, loss, chan_weights, lr, 0, True)
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)          # one flat bucket: 39.9 MB fp32
+            self.grads.div_(dist.get_world_size(group))
+            self.unet._bind_stream()
+            _lib.check(self.unet.ctx.lib.isx_adam_step(self.unet.ctx.handle, C.c_float(lr), n_adam))
+            return l, cl
+        return self._call(x, y, loss, chan_weights, lr, n_adam, True)
+
+    def evaluate(self, x, y, loss="BCELoss", chan_weights=None):
+        """Validation forward (train-mode BN, no gradient), train.py:366-389."""
+        return self._call(x, y, loss, chan_weights, 0.0, 0, False)
+
+    # ------------------------------------------------------------------ state
+    def grad(self, key):
+        for k, shape, off in self.layout:
+            if k == key:
+                return self.grads[off:off + int(np.prod(shape))].view(shape)
+        raise KeyError(key)
+
+    def param(self, key):
+        for k, shape, off in self.layout:
+            if k == key:
+                return self.params[off:off + int(np.prod(shape))].view(shape)
+        raise KeyError(key)
+
+    def state_dict(self):
+        """Reference-format state dict: current parameters + running statistics."""
+        sd = self.unet.state_dict()
+        for k, shape, off in self.layout:
+            sd[k] = self.params[off:off + int(np.prod(shape))].view(shape).detach().cpu().clone()
+        return sd
+
+
+# --------------------------------------------------------------------------------------------------
+# train_unet: same signature as the reference (train.py:25-52)
+# --------------------------------------------------------------------------------------------------
+def _load(i, xs):
+    return np.asarray(xs[i])               # load_tensor_from_zarr (train_io.py:437-440)
+
+
+def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', channels=None, validate=True,
+               log=True, epochs=3, lr=0.01, loss_function='BCELoss', chan_weights=None, weights=None,
+               update_every=20, losses=None, chan_losses=None, fork_channels=None, chan_final_activations=None,
+               double_step=True, **kwargs):
+    """Train the affinity U-Net on lists of patches ``x[i]`` (Z,Y,X) / ``y[i]`` (C,Z,Y,X).  Returns
+    ``(unet, unet_path)`` like the reference; ``unet_path`` is None when ``out_dir`` is None (the reference
+    leaves it unbound there, train.py:177-183)."""
+    import pandas as pd
+    if fork_channels is not None or losses is not None:
+        raise NotImplementedError("forked decoders / Channelwise loss are not on the accelerated path yet")
+    save_output = out_dir is not None
+    print('Output will be saved: ', save_output)
+    print('Save directory: ', out_dir)
+    if ids is None:
+        ids = [name + f'_{i}' for i in range(len(x))]
+    if vids is None:
+        vids = [name + f'_val_{i}' for i in range(len(vx))]
+    n_out = len(channels) if channels is not None else int(np.asarray(y[0]).shape[0])
+    channels = tuple(channels) if channels is not None else tuple('channel_' + str(i) for i in range(n_out))
+    patch = tuple(np.asarray(x[0]).shape)
+    sd = None
+    if weights is not None:
+        sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in weights.items()}
+    trainer = Trainer(sd, out_channels=n_out, patch=patch, seed=kwargs.get('seed', 0))
+    loss_dict = {'epoch': [], 'batch_num': [], 'loss': [], 'data_id': []}
+    for c in channels:
+        loss_dict[c] = []
+    validation_dict = {'epoch': [], 'validation_loss': [], 'data_id': [], 'batch_id': []}
+
+    def epoch_weights(e):
+        if loss_function == 'EpochWeightedBCE':
+            return chan_weights[e]
+        return chan_weights
+
+    def run_validation(e, batch_no):
+        total = 0.0
+        for i in range(len(vx)):
+            vl, _ = trainer.evaluate(_load(i, vx), _load(i, vy), loss_function, epoch_weights(e))
+            total += vl
+            validation_dict['epoch'].append(e)
+            validation_dict['validation_loss'].append(vl)
+            validation_dict['data_id'].append(vids[i])
+            validation_dict['batch_id'].append(batch_no)
+        if len(vx):
+            print(f'Epoch {e} - validation loss: {total / len(vx)}')
+
+    unet_path = None
+    for e in range(epochs):
+        if validate and e == 0:
+            run_validation(e, 0)
+        running_loss = 0.0
+        for i in range(len(x)):
+            l, cl = trainer.train_step(_load(i, x), _load(i, y), lr=lr, loss=loss_function,
+                                       chan_weights=epoch_weights(e), double_step=double_step)
+            loss_dict['epoch'].append(e)
+            loss_dict['batch_num'].append(i)
+            loss_dict['loss'].append(l)
+            loss_dict['data_id'].append(ids[i])
+            for c, v in zip(channels, cl):
+                loss_dict[c].append(v)
+            running_loss += l
+            if i % update_every == (update_every - 1):
+                print(f'Epoch {e} - running loss: {running_loss / update_every}')
+                running_loss = 0.0
+        if validate:
+            run_validation(e, (e + 1) * len(x))
+        if save_output:
+            _save_checkpoint(trainer.state_dict(), out_dir, f'{name}_epoch-{e}')
+    if save_output:
+        unet_path = _save_checkpoint(trainer.state_dict(), out_dir, name, r=True)
+        pd.DataFrame(loss_dict).to_csv(os.path.join(out_dir, 'loss_' + name + '.csv'))
+        if validate:
+            pd.DataFrame(validation_dict).to_csv(os.path.join(out_dir, 'validation-loss_' + name + '.csv'))
+    trainer.unet.trainer = trainer
+    return trainer.unet, unet_path
+
+
+def _save_checkpoint(checkpoint, out_dir, name, r=False):
+    d = datetime.now().strftime("%y%d%m_%H%M%S")        # day-month order, as upstream (train.py:416)
+    path = os.path.join(out_dir, d + '_unet_' + name + '.pt')
+    os.makedirs(out_dir, exist_ok=True)
+    torch.save(OrderedDict(checkpoint), path)
+    if r:
+        return path

@@ -52,10 +52,12 @@ def make_chunks(arr_shape, chunk_shape, margin):
 
 
 # --------------------------------------------------------------------------- forward
-def _as_params(sd, requires_grad=False):
+def _as_params(sd, requires_grad=False, dtype=None):
     p = OrderedDict()
     for k, v in sd.items():
         t = torch.from_numpy(np.ascontiguousarray(v)).clone() if isinstance(v, np.ndarray) else v
+        if dtype is not None and t.dtype.is_floating_point:
+            t = t.to(dtype)
         if requires_grad and t.dtype.is_floating_point and "running" not in k:
             t.requires_grad_(True)
         p[k] = t
@@ -162,17 +164,17 @@ def loss_fn(name, y_hat, y, chan_weights=None):
     raise ValueError(name)
 
 
-def train_step(sd, x, y, lr=0.01, loss="BCELoss", double_step=True, chan_weights=None):
+def train_step(sd, x, y, lr=0.01, loss="BCELoss", double_step=True, chan_weights=None, dtype=torch.float32):
     """One ``_train_step`` (+ the duplicated ``optimiser.step()`` of train.py:310).
 
     Returns ``(loss, y_hat, grads, new_params)`` with numpy payloads.
     """
-    p = _as_params(sd, requires_grad=True)
+    p = _as_params(sd, requires_grad=True, dtype=dtype)
     leaves = [t for t in p.values() if t.requires_grad]
     opt = torch.optim.Adam(leaves, lr=lr)
     opt.zero_grad()
-    y_hat = unet_forward(p, torch.from_numpy(x)[None, None].float())
-    l = loss_fn(loss, y_hat, torch.from_numpy(y)[None].float(), chan_weights)
+    y_hat = unet_forward(p, torch.from_numpy(x)[None, None].to(dtype))
+    l = loss_fn(loss, y_hat, torch.from_numpy(y)[None].to(dtype), chan_weights)
     l.backward()
     grads = {k: t.grad.detach().numpy().copy() for k, t in p.items() if t.requires_grad}
     opt.step()
