@@ -34,6 +34,7 @@ struct TrainState {
     float *P = nullptr, *G = nullptr, *Mo = nullptr, *Vo = nullptr;
     int64_t nparam = 0, adam_t = 0;
     int64_t off_w[18], off_b[18], off_gamma[18], off_beta[18], off_upw[4], off_upb[4];
+    int dstride[18];                 // channel stride of draw[li] (cout, or 8 for a thin layer whose dgrad runs on MFMA)
     std::vector<void *> blocks;
     float *draw[18] = {nullptr}, *gact[18] = {nullptr}, *w_dgrad[18] = {nullptr};
     float *dcat[4] = {nullptr}, *dpool[4] = {nullptr};
@@ -63,11 +64,13 @@ static int talloc(TrainState *t, size_t floats, float **out)
 // ------------------------------------------------------------------------------------------------
 // forward MFMA layout [Cout/BN][Cin/4][27][4][BN]; transpose = 1 builds the dgrad weights: the roles of the
 // channel axes are swapped and the taps mirrored (t -> 26 - t), i.e. w'[ci][co][t] = w[co][ci][26 - t].
-__global__ void repack_mfma_kernel(const float *__restrict__ wref, int cout, int cin, int transpose, float *__restrict__ pk)
+__global__ void repack_mfma_kernel(const float *__restrict__ wref, int cout, int cin, int transpose, float *__restrict__ pk,
+                                   int ci_pad)
 {
+    // ci_pad > 0: the packed conv has ci_pad input channels of which only the first CI are real (zero rows after)
     const int CO = transpose ? cin : cout, CI = transpose ? cout : cin;     // shapes of the conv being packed
     const int BN = (CO % 64 == 0) ? 64 : 32;
-    const int nsteps = CI / 4;
+    const int nsteps = (ci_pad > 0 ? ci_pad : CI) / 4;
     const int64_t n = (int64_t)CO * CI * 27;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int t = (int)(i % 27);
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
                                                            const float *__restrict__ shift, const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const float *__restrict__ coef,
                                                            int C, int64_t M, int act, int rows_per_block,
-                                                           float *__restrict__ draw, float *__restrict__ part)
+                                                           float *__restrict__ draw, int dstride, float *__restrict__ part)
 {
     extern __shared__ float sm[];
     const int c = threadIdx.x % C;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
             float dz = act_grad(g[m * gstride + c], z, act);
             float xh = (x - mu) * is;
             float d = sc * (dz - c1 - xh * c2);          // sc = gamma * invstd
-            draw[m * C + c] = d;
+            draw[m * dstride + c] = d;
             s1 += d;
         }
     }
@@ -285,7 +288,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
 // partial [split][27][CoP][CiP] (CoP/CiP = channel counts padded to 64).
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
-    const float *dy;                       // [M][Cout]
+    const float *dy;                       // [M][dy_stride], first Cout channels
+    int dy_stride;
     const float *srcA, *scaleA, *shiftA;   // conv input, channels [0, CA)
     const float *srcB, *scaleB, *shiftB;   // channels [CA, CA+CB)
     int CA, CB, Cout;
@@ -324,10 +328,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
             float4 yv = make_float4(0.f, 0.f, 0.f, 0.f), xv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (v < v_end) {
                 const int co = co0 + 4 * q;
-                if (co + 3 < a.Cout) yv = *(const float4 *)&a.dy[v * a.Cout + co];
+                if (co + 3 < a.Cout) yv = *(const float4 *)&a.dy[v * a.dy_stride + co];
                 else
                     for (int j = 0; j < 4; ++j)
-                        if (co + j < a.Cout) (&yv.x)[j] = a.dy[v * a.Cout + co + j];
+                        if (co + j < a.Cout) (&yv.x)[j] = a.dy[v * a.dy_stride + co + j];
                 const int x = (int)(v % W) + dx, y = (int)((v / W) % H) + dy, z = (int)(v / ((int64_t)W * H)) + dz;
                 const int ci = ci0 + 4 * q;
                 if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W && ci < Cin) {
@@ -381,7 +385,7 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int split
 // small dgrad (few gradient channels in, up to 64 out): dX[v][ci] = sum_tap sum_co dY[v - tap][co] w[co][ci][tap]
 // thread = (voxel, 4 output channels); weights read straight from the reference layout in P (L1-resident)
 // ------------------------------------------------------------------------------------------------
-__global__ void dgrad_small_kernel(const float *__restrict__ dy, const float *__restrict__ wref, int Cout, int Cin,
+__global__ void dgrad_small_kernel(const float *__restrict__ dy, int dstride, const float *__restrict__ wref, int Cout, int Cin,
                                    int D, int H, int W, float *__restrict__ dx, int64_t total)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,7 +398,7 @@ __global__ void dgrad_small_kernel(const float *__restrict__ dy, const float *__
     for (int t = 0; t < 27; ++t) {
         const int zz = z - (t / 9 - 1), yy = y - ((t / 3) % 3 - 1), xx = x - (t % 3 - 1);
         if (zz < 0 || zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        const float *gy = dy + (((int64_t)zz * H + yy) * W + xx) * Cout;
+        const float *gy = dy + (((int64_t)zz * H + yy) * W + xx) * dstride;
         for (int co = 0; co < Cout; ++co) {
             const float gv = gy[co];
             for (int j = 0; j < 4; ++j) {
@@ -469,43 +473,64 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
                                                            int Wo, float *__restrict__ gact, float *__restrict__ part,
                                                            int vox_per_block)
 {
-    extern __shared__ float sm[];                      // [(kt+1)][C] accumulators of this block
+    // A thread keeps ONE channel quad for the whole block (256 % C4 == 0), so the per-(kidx, channel)
+    // parameter-gradient sums stay in registers; threads sharing a quad are combined through LDS in a
+    // fixed order -> deterministic.
+    extern __shared__ float sm[];                      // [256 / C4][(kt+1) * 4] per quad ... laid out [slot][9*4][C4]
     const int kt = kz * 4;
-    for (int i = threadIdx.x; i < (kt + 1) * C; i += 256) sm[i] = 0.f;
-    __syncthreads();
     const int C4 = C >> 2;
+    const int c4 = threadIdx.x % C4, slot = threadIdx.x / C4, nslot = 256 / C4;
     const int64_t M = (int64_t)D * H * W;
-    const int64_t i0 = (int64_t)blockIdx.x * vox_per_block * C4;
-    int64_t i1 = i0 + (int64_t)vox_per_block * C4;
-    if (i1 > M * C4) i1 = M * C4;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const int c4 = (int)(i % C4);
-        const int64_t v = i / C4;
-        const int xs = (int)(v % W), ys = (int)((v / W) % H), zs = (int)(v / ((int64_t)W * H));
-        const float4 t = *(const float4 *)&raw[v * C + 4 * c4];
-        const float4 vsx = *(const float4 *)&scale[4 * c4], vhx = *(const float4 *)&shift[4 * c4];
-        const float a4[4] = {fmaxf(fmaf(t.x, vsx.x, vhx.x), 0.f), fmaxf(fmaf(t.y, vsx.y, vhx.y), 0.f),
-                             fmaxf(fmaf(t.z, vsx.z, vhx.z), 0.f), fmaxf(fmaf(t.w, vsx.w, vhx.w), 0.f)};
-        float gsum[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int a = 0; a < kz; ++a)
-            for (int j = 0; j < 2; ++j)
-                for (int k = 0; k < 2; ++k) {
-                    const int zo = zs * kz + a, yo = 2 * ys + j - off, xo = 2 * xs + k - off;
-                    if (zo >= Do || yo < 0 || yo >= Ho || xo < 0 || xo >= Wo) continue;
-                    const int kidx = (a * 2 + j) * 2 + k;
-                    const float4 du = *(const float4 *)&dcat[(((int64_t)zo * Ho + yo) * Wo + xo) * cat_stride + 4 * c4];
-                    const float4 wv = *(const float4 *)&w[(int64_t)kidx * C + 4 * c4];
-                    const float d4[4] = {du.x, du.y, du.z, du.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
-                    for (int e = 0; e < 4; ++e) {
-                        gsum[e] = fmaf(d4[e], w4[e], gsum[e]);
-                        atomicAdd(&sm[kidx * C + 4 * c4 + e], d4[e] * a4[e]);      // LDS atomics: order-free only
-                        atomicAdd(&sm[kt * C + 4 * c4 + e], d4[e]);                // within this block's partial
+    const int64_t v0 = (int64_t)blockIdx.x * vox_per_block;
+    int64_t v1 = v0 + vox_per_block;
+    if (v1 > M) v1 = M;
+    float aw[8][4], ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aw[r][e] = 0.f;
+    const float4 vsx = *(const float4 *)&scale[4 * c4], vhx = *(const float4 *)&shift[4 * c4];
+    if (slot < nslot)
+        for (int64_t v = v0 + slot; v < v1; v += nslot) {
+            const int xs = (int)(v % W), ys = (int)((v / W) % H), zs = (int)(v / ((int64_t)W * H));
+            const float4 t = *(const float4 *)&raw[v * C + 4 * c4];
+            const float a4[4] = {fmaxf(fmaf(t.x, vsx.x, vhx.x), 0.f), fmaxf(fmaf(t.y, vsx.y, vhx.y), 0.f),
+                                 fmaxf(fmaf(t.z, vsx.z, vhx.z), 0.f), fmaxf(fmaf(t.w, vsx.w, vhx.w), 0.f)};
+            float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        if (a >= kz) continue;
+                        const int zo = zs * kz + a, yo = 2 * ys + j - off, xo = 2 * xs + k - off;
+                        if (zo >= Do || yo < 0 || yo >= Ho || xo < 0 || xo >= Wo) continue;
+                        const int kidx = (a * 2 + j) * 2 + k;
+                        const float4 du = *(const float4 *)&dcat[(((int64_t)zo * Ho + yo) * Wo + xo) * cat_stride + 4 * c4];
+                        const float4 wv = *(const float4 *)&w[(int64_t)kidx * C + 4 * c4];
+                        const float d4[4] = {du.x, du.y, du.z, du.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            gsum[e] = fmaf(d4[e], w4[e], gsum[e]);
+                            aw[kidx][e] = fmaf(d4[e], a4[e], aw[kidx][e]);
+                            ab[e] += d4[e];
+                        }
                     }
-                }
-        *(float4 *)&gact[v * C + 4 * c4] = make_float4(gsum[0], gsum[1], gsum[2], gsum[3]);
+            *(float4 *)&gact[v * C + 4 * c4] = make_float4(gsum[0], gsum[1], gsum[2], gsum[3]);
+        }
+    // sm[slot][r][c4*4+e], r = 0..kt (kt = bias row)
+    if (slot < nslot) {
+        for (int r = 0; r < kt; ++r)
+            for (int e = 0; e < 4; ++e) sm[((size_t)slot * (kt + 1) + r) * C + 4 * c4 + e] = aw[r][e];
+        for (int e = 0; e < 4; ++e) sm[((size_t)slot * (kt + 1) + kt) * C + 4 * c4 + e] = ab[e];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (kt + 1) * C; i += 256) part[(int64_t)blockIdx.x * (kt + 1) * C + i] = sm[i];
+    for (int i = threadIdx.x; i < (kt + 1) * C; i += 256) {
+        float acc = 0.f;
+        for (int sl = 0; sl < nslot; ++sl) acc += sm[(size_t)sl * (kt + 1) * C + i];
+        part[(int64_t)blockIdx.x * (kt + 1) * C + i] = acc;
+    }
 }
 
 // up-conv parameter gradients: reference layout dW[c][kidx], db[c]
@@ -574,10 +599,11 @@ static int repack_all(isx_ctx *ctx)
         unsigned grid = cdiv(n, 256);
         if (grid > 4096) grid = 4096;
         if (use_mfma(L.cin, L.cout)) {
-            repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 0, L.w);
-            if (t->w_dgrad[li]) repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 1, t->w_dgrad[li]);
+            repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 0, L.w, 0);
+            if (t->w_dgrad[li]) repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 1, t->w_dgrad[li], 0);
         } else if (use_fold(L.cin, L.cout)) {
             repack_fold_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, L.w);
+            if (t->w_dgrad[li]) repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 1, t->w_dgrad[li], 8);
         } else {
             repack_direct_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, L.cin == 1 ? 1 : 0, L.w);
         }
@@ -613,7 +639,7 @@ static int bn_backward(isx_ctx *ctx, int li, const float *g, int gstride, int ac
     ISX_CHECK_LAUNCH();
     bn_bwd_apply_kernel<<<blocks, 256, 256 * sizeof(float), ctx->stream>>>(g, gstride, u->raw[li], L.scale, L.shift, L.bmean,
                                                                         L.invstd, t->coef, C, l.M, act, rows, t->draw[li],
-                                                                        t->part);
+                                                                        t->dstride[li], t->part);
     ISX_CHECK_LAUNCH();
     colsum_kernel<<<C, 256, 0, ctx->stream>>>(t->part, blocks, C, t->G + t->off_b[li]);      // conv bias gradient
     ISX_CHECK_LAUNCH();
@@ -628,6 +654,7 @@ static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
     const Level &l = u->lv[MOD_LEVEL[li / 2]];
     WgradArgs a;
     a.dy = t->draw[li];
+    a.dy_stride = t->dstride[li];
     a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
     a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
     a.Cout = L.cout;
@@ -663,12 +690,12 @@ static int dgrad(isx_ctx *ctx, int li, float *dst)
     const Level &l = u->lv[MOD_LEVEL[li / 2]];
     if (t->w_dgrad[li]) {
         // the forward kernel with Cin <-> Cout: "input" = d(raw) (Cout channels), "output" = dX (Cin channels)
-        return launch_conv_mfma(ctx, l, 1, Src{t->draw[li], nullptr, nullptr, L.cout}, Src{nullptr, nullptr, nullptr, 0},
+        return launch_conv_mfma(ctx, l, 1, Src{t->draw[li], nullptr, nullptr, t->dstride[li]}, Src{nullptr, nullptr, nullptr, 0},
                                 t->w_dgrad[li], t->zeros, L.cin, dst, nullptr, nullptr, 1);
     }
     const int64_t total = l.M * ((L.cin + 3) / 4);
-    dgrad_small_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(t->draw[li], t->P + t->off_w[li], L.cout, L.cin, l.D, l.H, l.W,
-                                                              dst, total);
+    dgrad_small_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(t->draw[li], t->dstride[li], t->P + t->off_w[li], L.cout, L.cin,
+                                                              l.D, l.H, l.W, dst, total);
     ISX_CHECK_LAUNCH();
     return ISX_OK;
 }
@@ -702,7 +729,7 @@ static int backward(isx_ctx *ctx)
         const int vpb = 1024;
         const int blocks = (int)((ls.M + vpb - 1) / vpb);
         ISX_REQUIRE((size_t)blocks * (kt + 1) * U.C <= t->part_floats, "internal: partial buffer too small");
-        upsample_bwd_kernel<<<blocks, 256, (size_t)(kt + 1) * U.C * sizeof(float), ctx->stream>>>(
+        upsample_bwd_kernel<<<blocks, 256, (size_t)(256 / (U.C / 4)) * (kt + 1) * U.C * sizeof(float), ctx->stream>>>(
             u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, t->dcat[k], 2 * U.C, lo.D, lo.H,
             lo.W, t->gact[li_in], t->part, vpb);
         ISX_CHECK_LAUNCH();
@@ -794,9 +821,20 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
     for (int li = 0; li < 18; ++li) {
         const ConvBN &L = u->cv[li];
         const Level &l = u->lv[MOD_LEVEL[li / 2]];
-        ISX_TRY(talloc(t, (size_t)l.M * L.cout, &t->draw[li]));
+        t->dstride[li] = L.cout;
+        if (use_fold(L.cin, L.cout) && L.cin % 32 == 0) {
+            // thin layer fed by a wide one: its d(raw) is stored 8 channels wide (zeros after cout) so that the
+            // dgrad into the wide input runs on the MFMA kernel (8 -> Cin) instead of a scalar loop
+            t->dstride[li] = 8;
+            ISX_TRY(talloc(t, (size_t)l.M * 8, &t->draw[li]));
+            ISX_HIP(hipMemsetAsync(t->draw[li], 0, (size_t)l.M * 8 * sizeof(float), ctx->stream));
+            ISX_TRY(talloc(t, (size_t)8 * L.cin * 27 + 2048, &t->w_dgrad[li]));
+            ISX_HIP(hipMemsetAsync(t->w_dgrad[li], 0, ((size_t)8 * L.cin * 27 + 2048) * sizeof(float), ctx->stream));
+        } else {
+            ISX_TRY(talloc(t, (size_t)l.M * L.cout, &t->draw[li]));
+            if (li != 0 && use_mfma(L.cout, L.cin)) ISX_TRY(talloc(t, (size_t)L.cout * L.cin * 27 + 2048, &t->w_dgrad[li]));
+        }
         ISX_TRY(talloc(t, (size_t)l.M * L.cout, &t->gact[li]));
-        if (li != 0 && use_mfma(L.cout, L.cin)) ISX_TRY(talloc(t, (size_t)L.cout * L.cin * 27 + 2048, &t->w_dgrad[li]));
         max_rawc = std::max(max_rawc, (size_t)L.cout);
     }
     for (int k = 0; k < 4; ++k) {

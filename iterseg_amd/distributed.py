@@ -78,3 +78,14 @@ def predict_volume_sharded(predict_chunks, n_chunks, feature_map, group=None):
     if world > 1:
         dist.all_reduce(feature_map, op=dist.ReduceOp.SUM, group=group)
     return feature_map
+
+
+def average_gradients(flat_grads, group=None):
+    """Data-parallel training (BASELINE config 4): ONE all-reduce of the flat gradient buffer
+    (9 972 673 floats = 39.9 MB) per step, then divide by the world size.  With RCCL on the fully
+    connected xGMI mesh this is a reduce-scatter + all-gather over all 7 links."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+        flat_grads.div_(world)
+    return flat_grads

@@ -97,8 +97,8 @@ class Trainer:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             l, cl = self._call(x, y, loss, chan_weights, lr, 0, True)
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)          # one flat bucket: 39.9 MB fp32
-            self.grads.div_(dist.get_world_size(group))
+            from .distributed import average_gradients
+            average_gradients(self.grads, group)                                     # one flat bucket: 39.9 MB fp32
             self.unet._bind_stream()
             _lib.check(self.unet.ctx.lib.isx_adam_step(self.unet.ctx.handle, C.c_float(lr), n_adam))
             return l, cl

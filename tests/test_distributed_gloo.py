@@ -52,6 +52,15 @@ def _worker(rank, world, port, q):
                 fm[:, r[0] + r[3]:r[0] + r[4], r[1] + r[5]:r[1] + r[6], r[2] + r[7]:r[2] + r[8]] = float(i + 1)
         fm = torch.empty((2,) + shape)
         predict_volume_sharded(predict_chunks, len(tab), fm)
+        # data-parallel gradient averaging on a flat buffer the size of the U-Net's parameters
+        from iterseg_amd.distributed import average_gradients
+        g = torch.full((9972673,), float(rank + 1))
+        g[rank::7] += 0.5
+        average_gradients(g)
+        expect = torch.full((9972673,), 1.5)
+        for r in range(world):
+            expect[r::7] += 0.25
+        assert torch.equal(g, expect)
         q.put((rank, out.numpy(), fm.numpy()))
         dist.barrier()
     finally:
