@@ -678,6 +678,17 @@ __global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__res
 // ------------------------------------------------------------------------------------------------
 static constexpr int COOP_SCAP = 2048;                      // LDS run capacity (entries of 16 B)
 static constexpr unsigned long long COOP_MIN_SIZE = 512;    // components below this stay on flood_kernel
+static constexpr unsigned long long COLD_MIN_SIZE = 32768;  // components from this size get a cold arena
+static constexpr int COLD_NBK = 65536;                      // buckets: top 16 bits of the order-preserving key
+static constexpr int COLD_DRAIN = 1024;                     // elements moved from a bucket to the LDS run at once
+static constexpr uint32_t COLD_NONE = 0xFFFFFFFFu;
+// arena layout in 16-byte units: bhead | btail | bcount (u32[NBK] each), bm0 (u64[NBK/64]), bm1 (u64[NBK/4096]), pool
+static constexpr uint32_t COLD_META_ENTS = (3u * COLD_NBK * 4u + COLD_NBK / 64 * 8u + COLD_NBK / 4096 * 8u) / 16u;
+
+__host__ __device__ inline unsigned long long cold_arena_entries(unsigned long long size)
+{
+    return size >= COLD_MIN_SIZE ? (unsigned long long)COLD_META_ENTS + 4ull * size + 5ull * COLD_NBK + 4096ull : 0ull;
+}
 
 __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src)
 {
@@ -687,21 +698,317 @@ __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int s
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Every read of the cold structures bypasses the (non-coherent, possibly stale) vector L1: they are rewritten
+// in place by this wave between reads.
+__device__ __forceinline__ uint32_t cld32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long cld64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ HeapEnt cld_ent(const HeapEnt *p)
+{
+    HeapEnt e;
+    e.key = cld64(&p->key);
+    const unsigned long long t = cld64((const unsigned long long *)&p->idx);
+    e.idx = (uint32_t)t;
+    e.pad = (uint32_t)(t >> 32);
+    return e;
+}
+
+struct Cold {
+    uint32_t *bhead, *btail, *bcount;
+    unsigned long long *bm0, *bm1;
+    HeapEnt *pool;             // a segment = header entry {key = next | n << 32, idx = cap} + cap entries
+    uint32_t pool_cap, bump, count;
+    uint32_t low;              // lowest non-empty bucket (COLD_NBK when empty): decides which new elements may stay hot
+    bool on, failed;
+};
+
+__device__ __forceinline__ uint32_t cold_bucket(unsigned long long key) { return (uint32_t)(key >> 48); }
+
+// Append up to one element per lane to the buckets.  Lanes with the same bucket form a group (leader = lowest
+// lane); leaders do the bookkeeping in parallel, members get their slot from the leader.
+__device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long long key, uint32_t idx, uint32_t lab, int lane)
+{
+    const uint32_t b = cold_bucket(key);
+    int gleader = 0, grank = 0, gsize = 0;
+    bool todo = has;
+    while (__any(todo)) {
+        const unsigned long long act = __ballot(todo);
+        const int ld = __ffsll((long long)act) - 1;
+        const uint32_t lb = __shfl(b, ld);
+        const bool same = todo && b == lb;
+        const unsigned long long grp = __ballot(same);
+        if (same) {
+            gleader = ld;
+            grank = __popcll(grp & ((1ull << lane) - 1ull));
+            gsize = __popcll(grp);
+            todo = false;
+        }
+    }
+    const bool leader = has && gleader == lane;
+    uint32_t tail = COLD_NONE, cnt = 0, tn = 0, tcap = 0, tnext = COLD_NONE;
+    if (leader) {
+        tail = cld32(&c.btail[b]);
+        cnt = cld32(&c.bcount[b]);
+        if (tail != COLD_NONE) {
+            const HeapEnt h = cld_ent(&c.pool[tail]);
+            tnext = (uint32_t)h.key;
+            tn = (uint32_t)(h.key >> 32);
+            tcap = h.idx;
+        }
+    }
+    const uint32_t free_tail = leader ? tcap - tn : 0u;
+    const uint32_t need_new = (leader && (uint32_t)gsize > free_tail) ? (uint32_t)gsize - free_tail : 0u;
+    uint32_t newcap = 0;
+    if (need_new) {
+        newcap = tcap ? tcap * 2u : 4u;
+        if (newcap > 65536u) newcap = 65536u;
+        while (newcap < need_new) newcap *= 2u;
+    }
+    const uint32_t alloc = need_new ? newcap + 1u : 0u;
+    uint32_t incl = alloc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    if ((unsigned long long)c.bump + total > c.pool_cap) { c.failed = true; return; }
+    const uint32_t my_off = c.bump + incl - alloc;
+    c.bump += total;
+    if (leader) {
+        if (need_new) {
+            HeapEnt h;
+            h.key = (unsigned long long)COLD_NONE | ((unsigned long long)need_new << 32);
+            h.idx = newcap;
+            h.pad = 0;
+            c.pool[my_off] = h;
+            if (tail != COLD_NONE) {
+                HeapEnt ht;
+                ht.key = (unsigned long long)my_off | ((unsigned long long)tcap << 32);    // old tail is now full
+                ht.idx = tcap;
+                ht.pad = 0;
+                c.pool[tail] = ht;
+            } else {
+                c.bhead[b] = my_off;
+            }
+            c.btail[b] = my_off;
+        } else {
+            HeapEnt ht;
+            ht.key = (unsigned long long)tnext | ((unsigned long long)(tn + (uint32_t)gsize) << 32);
+            ht.idx = tcap;
+            ht.pad = 0;
+            c.pool[tail] = ht;
+        }
+        c.bcount[b] = cnt + (uint32_t)gsize;
+        if (cnt == 0) {
+            atomicOr(&c.bm0[b >> 6], 1ull << (b & 63));
+            atomicOr(&c.bm1[b >> 12], 1ull << ((b >> 6) & 63));
+        }
+    }
+    const int gl = gleader & 63;
+    const uint32_t l_tail = __shfl(tail, gl), l_tn = __shfl(tn, gl), l_free = __shfl(free_tail, gl), l_new = __shfl(my_off, gl);
+    if (has) {
+        const uint32_t slot = ((uint32_t)grank < l_free) ? l_tail + 1u + l_tn + (uint32_t)grank : l_new + 1u + ((uint32_t)grank - l_free);
+        HeapEnt e;
+        e.key = key;
+        e.idx = idx;
+        e.pad = lab;
+        c.pool[slot] = e;
+    }
+    c.count += (uint32_t)__popcll(__ballot(has));
+    uint32_t bl = has ? b : (uint32_t)COLD_NBK;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(bl, o); bl = t < bl ? t : bl; }
+    c.low = bl < c.low ? bl : c.low;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// lowest non-empty bucket (c.count > 0)
+__device__ __forceinline__ uint32_t cold_lowest(const Cold &c, int lane)
+{
+    const unsigned long long w1 = lane < COLD_NBK / 4096 ? cld64(&c.bm1[lane]) : 0ull;
+    const unsigned long long nz = __ballot(w1 != 0ull);
+    const int wi = __ffsll((long long)nz) - 1;
+    const unsigned long long word1 = shfl64(w1, wi);
+    const int i0 = wi * 64 + (__ffsll((long long)word1) - 1);
+    const unsigned long long word0 = cld64(&c.bm0[i0]);
+    return (uint32_t)i0 * 64u + (uint32_t)(__ffsll((long long)word0) - 1);
+}
+
+__device__ __forceinline__ void cold_mark_empty(Cold &c, uint32_t b, int lane)
+{
+    if (lane == 0) {
+        c.bhead[b] = COLD_NONE;
+        c.btail[b] = COLD_NONE;
+        c.bcount[b] = 0;
+        const unsigned long long old = atomicAnd(&c.bm0[b >> 6], ~(1ull << (b & 63)));
+        if ((old & ~(1ull << (b & 63))) == 0ull) atomicAnd(&c.bm1[b >> 12], ~(1ull << ((b >> 6) & 63)));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// in-LDS bitonic sort of srun[0, n) by key (n <= COLD_DRAIN); one wave
+__device__ __forceinline__ void lds_sort(HeapEnt *srun, int n, int lane)
+{
+    int np = 64;
+    while (np < n) np <<= 1;
+    for (int j = n + lane; j < np; j += 64) { HeapEnt e; e.key = ~0ull; e.idx = 0; e.pad = 0; srun[j] = e; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int k = 2; k <= np; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < np / 2; t += 64) {
+                const int i = ((t / j) * 2 * j) + (t % j);        // lower index of the pair
+                const int p = i + j;
+                const bool up = ((i & k) == 0);
+                const HeapEnt a = srun[i], bb = srun[p];
+                if ((a.key > bb.key) == up) { srun[i] = bb; srun[p] = a; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+}
+
+// Move the <= COLD_DRAIN smallest elements of the lowest bucket into srun[0, taken), sorted.  srun must be empty.
+__device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int lane, int drain_n)
+{
+    const uint32_t b = cold_lowest(c, lane);
+    const uint32_t cnt = cld32(&c.bcount[b]);
+    const uint32_t head = cld32(&c.bhead[b]);
+    int taken = 0;
+    if (cnt <= (uint32_t)drain_n) {
+        uint32_t seg = head;
+        while (seg != COLD_NONE) {
+            const HeapEnt h = cld_ent(&c.pool[seg]);
+            const uint32_t n = (uint32_t)(h.key >> 32);
+            for (uint32_t j = lane; j < n; j += 64) srun[taken + j] = cld_ent(&c.pool[seg + 1u + j]);
+            taken += (int)n;
+            seg = (uint32_t)h.key;
+        }
+        cold_mark_empty(c, b, lane);
+    } else {
+        // ---- select by key: min / max, then 64-bin histograms until a non-empty prefix of <= COLD_DRAIN exists ----
+        unsigned long long lo = ~0ull, hi = 0ull;
+        for (uint32_t seg = head; seg != COLD_NONE;) {
+            const HeapEnt h = cld_ent(&c.pool[seg]);
+            const uint32_t n = (uint32_t)(h.key >> 32);
+            for (uint32_t j = lane; j < n; j += 64) {
+                const unsigned long long k = cld64(&c.pool[seg + 1u + j].key);
+                lo = k < lo ? k : lo;
+                hi = k > hi ? k : hi;
+            }
+            seg = (uint32_t)h.key;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long l2 = shfl64(lo, lane ^ o), h2 = shfl64(hi, lane ^ o);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        unsigned long long width = hi - lo + 1ull;      // < 2^48: all keys share their top 16 bits
+        int B = 0;
+        for (;;) {
+            hist[lane] = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (uint32_t seg = head; seg != COLD_NONE;) {
+                const HeapEnt h = cld_ent(&c.pool[seg]);
+                const uint32_t n = (uint32_t)(h.key >> 32);
+                for (uint32_t j = lane; j < n; j += 64) {
+                    const unsigned long long k = cld64(&c.pool[seg + 1u + j].key);
+                    if (k >= lo && k - lo < width) atomicAdd(&hist[(int)(((k - lo) * 64ull) / width)], 1);
+                }
+                seg = (uint32_t)h.key;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int mine = hist[lane], incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            // B = number of leading bins whose cumulative count stays <= drain_n
+            const unsigned long long fits = __ballot(incl <= drain_n);
+            B = (~fits) ? (__ffsll((long long)~fits) - 1) : 64;
+            const int cumB = B > 0 ? __shfl(incl, B - 1) : 0;
+            if (cumB > 0) break;
+            // the first non-empty bin is bin B and it alone is too large: zoom into it
+            const unsigned long long nlo = lo + (B * width + 63ull) / 64ull;
+            const unsigned long long nhi = lo + ((B + 1) * width + 63ull) / 64ull - 1ull;
+            lo = nlo;
+            width = nhi - nlo + 1ull;
+        }
+        // ---- extract bins < B into the run; compact the rest in place (write cursor trails the read cursor) ----
+        uint32_t wseg = head, wn = 0, wcap = cld_ent(&c.pool[head]).idx, kept = 0;
+        for (uint32_t seg = head; seg != COLD_NONE;) {
+            const HeapEnt h = cld_ent(&c.pool[seg]);
+            const uint32_t n = (uint32_t)(h.key >> 32), nxt = (uint32_t)h.key;
+            for (uint32_t base = 0; base < n; base += 64) {
+                const uint32_t j = base + lane;
+                HeapEnt e;
+                bool valid = j < n, take = false;
+                if (valid) {
+                    e = cld_ent(&c.pool[seg + 1u + j]);
+                    take = e.key >= lo && e.key - lo < width && (int)(((e.key - lo) * 64ull) / width) < B;
+                }
+                const unsigned long long tb = __ballot(valid && take), kb = __ballot(valid && !take);
+                if (valid && take) srun[taken + __popcll(tb & ((1ull << lane) - 1ull))] = e;
+                taken += __popcll(tb);
+                int krank = __popcll(kb & ((1ull << lane) - 1ull));
+                int remaining = __popcll(kb), done = 0;
+                while (remaining > 0) {
+                    const int room = (int)(wcap - wn);
+                    const int m = room < remaining ? room : remaining;
+                    if (valid && !take && krank >= done && krank < done + m) c.pool[wseg + 1u + wn + (uint32_t)(krank - done)] = e;
+                    wn += (uint32_t)m;
+                    done += m;
+                    remaining -= m;
+                    if (wn == wcap && remaining > 0) {
+                        const HeapEnt wh = cld_ent(&c.pool[wseg]);
+                        if (lane == 0) { HeapEnt t2 = wh; t2.key = (wh.key & 0xFFFFFFFFull) | ((unsigned long long)wcap << 32); c.pool[wseg] = t2; }
+                        wseg = (uint32_t)wh.key;
+                        wn = 0;
+                        wcap = cld_ent(&c.pool[wseg]).idx;
+                    }
+                }
+                kept += (uint32_t)__popcll(kb);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            seg = nxt;
+        }
+        if (lane == 0) {
+            HeapEnt t2;
+            t2.key = (unsigned long long)COLD_NONE | ((unsigned long long)wn << 32);     // truncate the list here
+            t2.idx = wcap;
+            t2.pad = 0;
+            c.pool[wseg] = t2;
+            c.btail[b] = wseg;
+            c.bcount[b] = kept;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    lds_sort(srun, taken, lane);
+    c.count -= (uint32_t)taken;
+    c.low = c.count > 0 ? cold_lowest(c, lane) : (uint32_t)COLD_NBK;
+    return taken;
+}
+
 __global__ __launch_bounds__(64) void flood_wave_kernel(
     const float *__restrict__ aff, const uint8_t *__restrict__ mask, uint32_t *__restrict__ out,
     uint32_t *__restrict__ claim, const unsigned long long *__restrict__ keys, uint32_t n_seeds,
     const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
-    HeapEnt *__restrict__ heap_pool, int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2,
-    unsigned long long coop_min_size)
+    HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
+    int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long coop_min_size, int run_limit,
+    int drain_n)
 {
     __shared__ HeapEnt srun[COOP_SCAP];          // .pad carries the element's label
+    __shared__ HeapEnt stage[6 * 64];            // elements of this round bound for the cold tier
+    __shared__ int hist[64];
     const uint32_t c = blockIdx.x;
     const int lane = threadIdx.x;
     if (c >= n_comp) return;
     const uint32_t first = comp_first[c];
     const uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
     if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;
-    if (comp_off[c + 1] - comp_off[c] < coop_min_size) return;
+    const unsigned long long csize = comp_off[c + 1] - comp_off[c];
+    if (csize < coop_min_size) return;
     HeapEnt *heap = heap_pool + comp_off[c];
     const uint32_t ns = end - first;
 
@@ -713,33 +1020,84 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     constexpr int SMASK = COOP_SCAP - 1;
     constexpr int ROUND_MAX = 6 * 64;            // most elements one round can add
 
-    // queue: registers (rk key, ri voxel, rl label; lanes < rcount valid, ascending) then the LDS run
+    // ---- cold tier (large components only): arena views + clean metadata ----------------------------------
+    Cold cold;
+    cold.on = arena_off && (arena_off[c + 1] > arena_off[c]);
+    cold.failed = false;
+    cold.bump = 0;
+    cold.count = 0;
+    cold.low = COLD_NBK;
+    cold.pool_cap = 0;
+    if (cold.on) {
+        HeapEnt *base = arena + arena_off[c];
+        cold.bhead = (uint32_t *)base;
+        cold.btail = cold.bhead + COLD_NBK;
+        cold.bcount = cold.btail + COLD_NBK;
+        cold.bm0 = (unsigned long long *)(cold.bcount + COLD_NBK);
+        cold.bm1 = cold.bm0 + COLD_NBK / 64;
+        cold.pool = base + COLD_META_ENTS;
+        cold.pool_cap = (uint32_t)(arena_off[c + 1] - arena_off[c] - COLD_META_ENTS);
+        for (int i = lane; i < COLD_NBK; i += 64) { cold.bhead[i] = COLD_NONE; cold.btail[i] = COLD_NONE; cold.bcount[i] = 0; }
+        for (int i = lane; i < COLD_NBK / 64; i += 64) cold.bm0[i] = 0ull;
+        if (lane < COLD_NBK / 4096) cold.bm1[lane] = 0ull;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // queue: registers (rk key, ri voxel, rl label; lanes < rcount valid, ascending) then the LDS run, then cold
     unsigned long long rk = ~0ull;
     uint32_t ri = 0, rl = 0;
     int rcount = 0, shead = 0, scount = 0;
     uint32_t age = ns - 1;                       // seeds carry ages 0..ns-1 in index order; pushes continue
     uint32_t epoch = 0;
-    bool serial = (ns > 64u) && (ns - 64u > (uint32_t)(COOP_SCAP - ROUND_MAX));
+    const uint32_t hot_cap = 64u + (uint32_t)run_limit;          // run_limit <= COOP_SCAP - ROUND_MAX (host-checked)
+    bool serial = (ns > hot_cap) && !cold.on;
+    bool started = false;
+    int stage_from = 0, stage_to = 0;       // staged elements that never reached a bucket (arena exhausted)
 
     if (!serial) {
+        started = true;
         rcount = ns < 64u ? (int)ns : 64;
         if (lane < rcount) {
             rk = ZKEY | (unsigned long long)lane;
             ri = (uint32_t)(keys[first + lane] & 0xFFFFFFFFull);
             rl = out[ri];
         }
-        for (uint32_t j = 64 + lane; j < ns; j += 64) {
+        const uint32_t in_run = ns > hot_cap ? hot_cap : ns;
+        for (uint32_t j = 64 + lane; j < in_run; j += 64) {
             HeapEnt e;
             e.key = ZKEY | (unsigned long long)j;
             e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull);
             e.pad = out[e.idx];
             srun[j - 64] = e;
         }
-        scount = ns > 64u ? (int)(ns - 64u) : 0;
+        scount = in_run > 64u ? (int)(in_run - 64u) : 0;
+        for (uint32_t j0 = in_run; j0 < ns && !cold.failed; j0 += 64) {       // seeds beyond the hot tiers start cold
+            const uint32_t j = j0 + lane;
+            const bool has = j < ns;
+            const uint32_t vi = has ? (uint32_t)(keys[first + j] & 0xFFFFFFFFull) : 0u;
+            cold_append(cold, has, ZKEY | (unsigned long long)j, vi, has ? out[vi] : 0u, lane);
+        }
+        if (cold.failed) { serial = true; started = false; }     // restart from the seeds on the serial heap
     }
 
     while (!serial && rcount > 0) {
-        if (scount > COOP_SCAP - ROUND_MAX) { serial = true; break; }   // keep every round atomic
+        if (scount > run_limit) {
+            // the run is full: evict its largest elements to their buckets (or leave the wave path)
+            if (!cold.on) { serial = true; break; }
+            int ev = scount - run_limit / 2;
+            while (ev > 0 && !cold.failed) {
+                const int m = ev < 64 ? ev : 64;
+                const bool has = lane < m;
+                HeapEnt e;
+                e.key = 0; e.idx = 0; e.pad = 0;
+                if (has) e = srun[(shead + scount - 1 - lane) & SMASK];
+                cold_append(cold, has, e.key, e.idx, e.pad, lane);
+                if (cold.failed) break;       // the batch is still in the run
+                scount -= m;
+                ev -= m;
+            }
+            if (cold.failed) { serial = true; break; }
+        }
         ++epoch;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // last round's label stores are in L2
         const bool act = lane < rcount;
@@ -809,13 +1167,17 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         age += total;
         const uint32_t wm_all = commit ? wonmask : 0u;
         const uint32_t lab_all = rl;
-        // ---- drop the committed ranks from the front, refill from the LDS run ---------------------------
+        // ---- drop the committed ranks from the front, refill from the LDS run (and the cold tier) ----------
         {
             const int src = (lane + ncommit) & 63;
             const unsigned long long k2 = shfl64(rk, src);
             const uint32_t i2 = __shfl(ri, src), l2 = __shfl(rl, src);
             rcount -= ncommit;
             if (lane < rcount) { rk = k2; ri = i2; rl = l2; } else { rk = ~0ull; ri = 0; rl = 0; }
+            if (scount == 0 && rcount < 64 && cold.on && cold.count > 0) {
+                scount = cold_drain(cold, srun, hist, lane, drain_n);     // sorted, all >= every register element
+                shead = 0;
+            }
             int take = 64 - rcount;
             if (take > scount) take = scount;
             if (lane >= rcount && lane < rcount + take) {
@@ -827,6 +1189,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             scount -= take;
         }
         // ---- insert the new elements (wave-uniform loop over committed lanes x directions) ---------------
+        int nstage = 0;
         for (int l = 0; l < ncommit; ++l) {
             const uint32_t wm = __shfl(wm_all, l);
             if (!wm) continue;
@@ -836,8 +1199,22 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                 if (!(wm & (1u << k))) continue;
                 const unsigned long long ek = shfl64(pkey[k], l);
                 const uint32_t ei = __shfl((uint32_t)nbv[k], l);
-                const unsigned long long last = shfl64(rk, 63);
-                if (rcount < 64 || ek < last) {
+                // Tier rule (keeps "every cold element sorts after every hot element"): an element stays hot if it sorts
+                // below the current hot maximum, or if nothing in the cold tier can precede it (cold empty, or its
+                // bucket lies below the lowest non-empty bucket); otherwise it goes to its bucket.
+                unsigned long long back = 0ull;
+                if (scount > 0) back = srun[(shead + scount - 1) & SMASK].key;
+                const unsigned long long reg_last = rcount > 0 ? shfl64(rk, rcount - 1) : 0ull;
+                const unsigned long long hot_max = scount > 0 ? back : reg_last;
+                const bool hot_nonempty = scount > 0 || rcount > 0;
+                const bool below_hot_max = hot_nonempty && ek < hot_max;
+                const bool cold_free = !cold.on || cold.count == 0 || cold_bucket(ek) < cold.low;
+                if (!below_hot_max && !cold_free) {
+                    if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; stage[nstage] = e; }
+                    ++nstage;
+                    continue;
+                }
+                if ((rcount < 64 && scount == 0) || (rcount > 0 && ek < reg_last)) {
                     if (rcount == 64) {                  // full: the maximum moves to the front of the run
                         shead = (shead - 1) & SMASK;
                         if (lane == 63) { HeapEnt e; e.key = rk; e.idx = ri; e.pad = rl; srun[shead] = e; }
@@ -851,48 +1228,61 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                     if (lane > pos && lane <= rcount) { rk = upk; ri = upi; rl = upl; }
                     if (lane == pos) { rk = ek; ri = ei; rl = el; }
                     ++rcount;
-                } else {
-                    // sorted insert into the LDS run (circular: shift the shorter side by one)
-                    int below = 0;
-                    for (int j = lane; j < scount; j += 64) below += srun[(shead + j) & SMASK].key < ek;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
-                    const int pos = below;
-                    if (pos >= scount - pos) {
-                        for (int base = scount - 64; base > pos - 64; base -= 64) {
-                            const int j = base + lane;
-                            const bool mv = j >= pos && j >= 0 && j < scount;
-                            HeapEnt e;
-                            if (mv) e = srun[(shead + j) & SMASK];
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if (mv) srun[(shead + j + 1) & SMASK] = e;
-                        }
-                    } else {
-                        for (int base = 0; base < pos; base += 64) {
-                            const int j = base + lane;
-                            const bool mv = j < pos;
-                            HeapEnt e;
-                            if (mv) e = srun[(shead + j) & SMASK];
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if (mv) srun[(shead + j - 1) & SMASK] = e;
-                        }
-                        shead = (shead - 1) & SMASK;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const int at = (pos >= scount - pos) ? pos : pos;      // slot index relative to the new head
-                    if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; srun[(shead + at) & SMASK] = e; }
-                    ++scount;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    continue;
                 }
+                // sorted insert into the LDS run (circular: shift the shorter side by one)
+                int below = 0;
+                for (int j = lane; j < scount; j += 64) below += srun[(shead + j) & SMASK].key < ek;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+                const int pos = below;
+                if (pos >= scount - pos) {
+                    for (int base = scount - 64; base > pos - 64; base -= 64) {
+                        const int j = base + lane;
+                        const bool mv = j >= pos && j >= 0 && j < scount;
+                        HeapEnt e;
+                        if (mv) e = srun[(shead + j) & SMASK];
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (mv) srun[(shead + j + 1) & SMASK] = e;
+                    }
+                } else {
+                    for (int base = 0; base < pos; base += 64) {
+                        const int j = base + lane;
+                        const bool mv = j < pos;
+                        HeapEnt e;
+                        if (mv) e = srun[(shead + j) & SMASK];
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (mv) srun[(shead + j - 1) & SMASK] = e;
+                    }
+                    shead = (shead - 1) & SMASK;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; srun[(shead + pos) & SMASK] = e; }
+                ++scount;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        // ---- this round's cold-bound elements, 64 at a time ------------------------------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int s0i = 0; s0i < nstage; s0i += 64) {
+            const bool has = s0i + lane < nstage;
+            HeapEnt e;
+            e.key = 0; e.idx = 0; e.pad = 0;
+            if (has) e = stage[s0i + lane];
+            cold_append(cold, has, e.key, e.idx, e.pad, lane);
+            if (cold.failed) {               // arena exhausted: nothing of this batch was written
+                stage_from = s0i;
+                stage_to = nstage;
+                serial = true;
+                break;
             }
         }
     }
 
     if (serial) {
-        // Exact continuation on one lane: move the whole queue into the component's binary heap.
+        // Exact continuation on one lane: move the whole queue (registers, run, staged, buckets) into the binary heap.
         uint32_t hn = 0;
-        if (ns > 64u && rcount == 0 && scount == 0 && epoch == 0) {
-            // never started (too many seeds for the run): seed the heap directly
+        if (!started) {
             if (lane == 0)
                 for (uint32_t j = 0; j < ns; ++j) {
                     HeapEnt e; e.key = ZKEY | (unsigned long long)j; e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull); e.pad = 0;
@@ -903,12 +1293,41 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                 HeapEnt e; e.key = shfl64(rk, l); e.idx = __shfl(ri, l); e.pad = 0;
                 if (lane == 0) heap_push(heap, hn, e);
             }
-            if (lane == 0)
+            if (lane == 0) {
                 for (int j = 0; j < scount; ++j) { HeapEnt e = srun[(shead + j) & SMASK]; e.pad = 0; heap_push(heap, hn, e); }
+                for (int j = stage_from; j < stage_to; ++j) { HeapEnt e = stage[j]; e.pad = 0; heap_push(heap, hn, e); }
+            }
+            if (cold.on) {
+                // gather the buckets
+                while (cold.count > 0) {
+                    const uint32_t b = cold_lowest(cold, lane);
+                    uint32_t seg = cld32(&cold.bhead[b]);
+                    uint32_t got = 0;
+                    while (seg != COLD_NONE) {
+                        const HeapEnt h = cld_ent(&cold.pool[seg]);
+                        const uint32_t n = (uint32_t)(h.key >> 32);
+                        if (lane == 0)
+                            for (uint32_t j = 0; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
+                        got += n;
+                        seg = (uint32_t)h.key;
+                    }
+                    cold_mark_empty(cold, b, lane);
+                    cold.count -= got;
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (lane == 0) serial_flood(heap, hn, age, aff, mask, out, PY, PX, PN, s0, s1, s2);
     }
+}
+
+__global__ void arena_need_kernel(const unsigned long long *comp_cap, uint32_t n_comp, unsigned long long coop_min,
+                                  unsigned long long cold_min, unsigned long long *need)
+{
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_comp) return;
+    unsigned long long sz = c < n_comp ? comp_cap[c] : 0ull;
+    need[c] = (sz >= coop_min && sz >= cold_min) ? (unsigned long long)COLD_META_ENTS + 4ull * sz + 5ull * COLD_NBK + 4096ull : 0ull;
 }
 
 // Flood given raveled seed indices (device u32) in list order (label = position + 1).
@@ -959,13 +1378,30 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     unsigned long long total = 0;
     ISX_HIP(hipMemcpyAsync(&total, comp_off.p + n_comp, 8, hipMemcpyDeviceToHost, ctx->stream));
     ISX_HIP(hipStreamSynchronize(ctx->stream));
-    Scratch<HeapEnt> pool(ctx, (size_t)total + 1);
-    Scratch<uint32_t> claim(ctx, (size_t)PN);
-    if (!pool.ok() || !claim.ok()) return ISX_ERR_NOMEM;
-    float s[3] = {1.f, 1.f, 1.f};
-    if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
+    // cold arenas for the components large enough to need one (sizes are the heap capacities)
+    Scratch<unsigned long long> arena_need(ctx, n_comp + 1), arena_off(ctx, n_comp + 1);
+    if (!arena_need.ok() || !arena_off.ok()) return ISX_ERR_NOMEM;
     unsigned long long coop_min = COOP_MIN_SIZE;
     if (const char *e = getenv("ISX_FLOOD_COOP_MIN")) coop_min = strtoull(e, nullptr, 10);   // tests: force a path
+    unsigned long long cold_min = COLD_MIN_SIZE;
+    if (const char *e = getenv("ISX_FLOOD_COLD_MIN")) cold_min = strtoull(e, nullptr, 10);
+    int run_limit = COOP_SCAP - 6 * 64, drain_n = COLD_DRAIN;             // tests shrink these to stress the cold tier
+    if (const char *e = getenv("ISX_FLOOD_RUN_LIMIT")) run_limit = atoi(e);
+    if (const char *e = getenv("ISX_FLOOD_DRAIN")) drain_n = atoi(e);
+    ISX_REQUIRE(run_limit >= 8 && run_limit <= COOP_SCAP - 6 * 64 && drain_n >= 4 && drain_n <= COLD_DRAIN && drain_n <= run_limit,
+                "ISX_FLOOD_RUN_LIMIT / ISX_FLOOD_DRAIN out of range");
+    arena_need_kernel<<<cdiv(n_comp + 1, TPB), TPB, 0, ctx->stream>>>(comp_cap.p, n_comp, coop_min, cold_min, arena_need.p);
+    ISX_CHECK_LAUNCH();
+    ISX_TRY(exclusive_scan_u64(ctx, (const uint64_t *)arena_need.p, (uint64_t *)arena_off.p, n_comp + 1));
+    unsigned long long arena_total = 0;
+    ISX_HIP(hipMemcpyAsync(&arena_total, arena_off.p + n_comp, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    Scratch<HeapEnt> pool(ctx, (size_t)total + 1);
+    Scratch<HeapEnt> arena(ctx, (size_t)arena_total + 1);
+    Scratch<uint32_t> claim(ctx, (size_t)PN);
+    if (!pool.ok() || !claim.ok() || !arena.ok()) return ISX_ERR_NOMEM;
+    float s[3] = {1.f, 1.f, 1.f};
+    if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
     // small components: one lane each; large ones: one wave each (both launched over all components,
     // each picks its own by size -- no host round trip to split the list)
     flood_kernel<<<cdiv(n_comp, 64), 64, 0, ctx->stream>>>(aff, mask, out, keys_sorted.p, n_seeds,
@@ -974,8 +1410,8 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     ISX_CHECK_LAUNCH();
     ISX_HIP(hipMemsetAsync(claim.p, 0, (size_t)PN * sizeof(uint32_t), ctx->stream));
     flood_wave_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, claim.p, keys_sorted.p, n_seeds, comp_first.p,
-                                                      comp_off.p, n_comp, pool.p, pshape[1], pshape[2], PN, s[0], s[1],
-                                                      s[2], coop_min);
+                                                      comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
+                                                      pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n);
     ISX_CHECK_LAUNCH();
     return ISX_OK;
 }

@@ -137,10 +137,17 @@ def test_against_oracle_on_seeded_fields(ws, shape, seed):
     assert (cur > 0).sum() > 100
 
 
-@pytest.fixture(params=["1", "100000000"], ids=["coop-all", "serial-all"])
+@pytest.fixture(params=["coop-all", "serial-all", "cold-stress", "cold-tiny"])
 def flood_path(request, monkeypatch):
-    """Force every component through the wave-cooperative flood, or through the one-lane heap."""
-    monkeypatch.setenv("ISX_FLOOD_COOP_MIN", request.param)
+    """Force every component through the wave-cooperative flood (LDS run only), through the one-lane heap, or
+    through the cooperative flood with a cold arena and a deliberately tiny hot tier so that the bucket
+    append / select-drain / eviction / compaction paths carry most of the queue even on small inputs."""
+    env = {"coop-all": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000"},
+           "serial-all": {"ISX_FLOOD_COOP_MIN": "100000000"},
+           "cold-stress": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "96", "ISX_FLOOD_DRAIN": "48"},
+           "cold-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "8", "ISX_FLOOD_DRAIN": "4"}}[request.param]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     return request.param
 
 
