@@ -996,7 +996,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
     HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
     int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long coop_min_size, int run_limit,
-    int drain_n)
+    int drain_n, unsigned long long *stats)
 {
     __shared__ HeapEnt srun[COOP_SCAP];          // .pad carries the element's label
     __shared__ HeapEnt stage[6 * 64];            // elements of this round bound for the cold tier
@@ -1053,6 +1053,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     bool serial = (ns > hot_cap) && !cold.on;
     bool started = false;
     int stage_from = 0, stage_to = 0;       // staged elements that never reached a bucket (arena exhausted)
+    unsigned long long st_rounds = 0, st_pops = 0, st_reg = 0, st_run = 0, st_cold = 0, st_drain = 0, st_evict = 0, st_shift = 0;
 
     if (!serial) {
         started = true;
@@ -1085,6 +1086,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             // the run is full: evict its largest elements to their buckets (or leave the wave path)
             if (!cold.on) { serial = true; break; }
             int ev = scount - run_limit / 2;
+            st_evict += (unsigned long long)ev;
             while (ev > 0 && !cold.failed) {
                 const int m = ev < 64 ? ev : 64;
                 const bool has = lane < m;
@@ -1099,6 +1101,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             if (cold.failed) { serial = true; break; }
         }
         ++epoch;
+        ++st_rounds;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // last round's label stores are in L2
         const bool act = lane < rcount;
         const int64_t idx = act ? (int64_t)ri : 0;
@@ -1165,6 +1168,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             }
         }
         age += total;
+        st_pops += (unsigned long long)ncommit;
         const uint32_t wm_all = commit ? wonmask : 0u;
         const uint32_t lab_all = rl;
         // ---- drop the committed ranks from the front, refill from the LDS run (and the cold tier) ----------
@@ -1176,6 +1180,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             if (lane < rcount) { rk = k2; ri = i2; rl = l2; } else { rk = ~0ull; ri = 0; rl = 0; }
             if (scount == 0 && rcount < 64 && cold.on && cold.count > 0) {
                 scount = cold_drain(cold, srun, hist, lane, drain_n);     // sorted, all >= every register element
+                ++st_drain;
                 shead = 0;
             }
             int take = 64 - rcount;
@@ -1212,6 +1217,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                 if (!below_hot_max && !cold_free) {
                     if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; stage[nstage] = e; }
                     ++nstage;
+                    ++st_cold;
                     continue;
                 }
                 if ((rcount < 64 && scount == 0) || (rcount > 0 && ek < reg_last)) {
@@ -1228,14 +1234,17 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                     if (lane > pos && lane <= rcount) { rk = upk; ri = upi; rl = upl; }
                     if (lane == pos) { rk = ek; ri = ei; rl = el; }
                     ++rcount;
+                    ++st_reg;
                     continue;
                 }
+                ++st_run;
                 // sorted insert into the LDS run (circular: shift the shorter side by one)
                 int below = 0;
                 for (int j = lane; j < scount; j += 64) below += srun[(shead + j) & SMASK].key < ek;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
                 const int pos = below;
+                st_shift += (unsigned long long)(pos >= scount - pos ? scount - pos : pos);
                 if (pos >= scount - pos) {
                     for (int base = scount - 64; base > pos - 64; base -= 64) {
                         const int j = base + lane;
@@ -1279,6 +1288,11 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         }
     }
 
+    if (stats && lane == 0) {
+        atomicAdd(&stats[0], st_rounds); atomicAdd(&stats[1], st_pops); atomicAdd(&stats[2], st_reg); atomicAdd(&stats[3], st_run);
+        atomicAdd(&stats[4], st_cold); atomicAdd(&stats[5], st_drain); atomicAdd(&stats[6], st_evict); atomicAdd(&stats[7], st_shift);
+        if (serial) atomicAdd(&stats[8], 1ull);
+    }
     if (serial) {
         // Exact continuation on one lane: move the whole queue (registers, run, staged, buckets) into the binary heap.
         uint32_t hn = 0;
@@ -1399,7 +1413,9 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     Scratch<HeapEnt> pool(ctx, (size_t)total + 1);
     Scratch<HeapEnt> arena(ctx, (size_t)arena_total + 1);
     Scratch<uint32_t> claim(ctx, (size_t)PN);
-    if (!pool.ok() || !claim.ok() || !arena.ok()) return ISX_ERR_NOMEM;
+    Scratch<unsigned long long> stats(ctx, 16);
+    if (!pool.ok() || !claim.ok() || !arena.ok() || !stats.ok()) return ISX_ERR_NOMEM;
+    ISX_HIP(hipMemsetAsync(stats.p, 0, 16 * 8, ctx->stream));
     float s[3] = {1.f, 1.f, 1.f};
     if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
     // small components: one lane each; large ones: one wave each (both launched over all components,
@@ -1411,8 +1427,15 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     ISX_HIP(hipMemsetAsync(claim.p, 0, (size_t)PN * sizeof(uint32_t), ctx->stream));
     flood_wave_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, claim.p, keys_sorted.p, n_seeds, comp_first.p,
                                                       comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
-                                                      pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n);
+                                                      pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, stats.p);
     ISX_CHECK_LAUNCH();
+    if (getenv("ISX_FLOOD_STATS")) {
+        unsigned long long hs[16];
+        ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[isx flood] rounds %llu pops %llu (%.2f/round) reg_ins %llu run_ins %llu (avg shift %.1f) cold_app %llu drains %llu evicted %llu serial_handover %llu\n",
+                hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[3], hs[3] ? (double)hs[7] / hs[3] : 0.0, hs[4], hs[5], hs[6], hs[8]);
+    }
     return ISX_OK;
 }
 
