@@ -12,6 +12,7 @@
 // x-contiguous (coalesced) accesses; reductions use wave64 shuffles + one atomic per wave.
 #pragma clang fp contract(off)
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -273,39 +274,57 @@ __global__ void peak_kernel(const float *__restrict__ g, int Z, int Y, int X, fl
                             uint32_t *nonpeak_flag, unsigned long long *keys, uint32_t *count,
                             uint32_t cap)
 {
+    // Grid-stride: the "some voxel is not its own neighbourhood maximum" bit lives in a register and is
+    // written once per block.  (A shared flag word touched by every wave -- even test-before-set --
+    // serialises on its L2 line: 70 ms at 512^3.)
     const uint32_t n = (uint32_t)Z * Y * X;                    // < 2^32 (checked by the caller)
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x = (int)(i % (uint32_t)X), y = (int)((i / (uint32_t)X) % (uint32_t)Y), z = (int)(i / ((uint32_t)X * Y));
-    const float c = g[i];
-    const bool interior = z >= 1 && z < Z - 1 && y >= 1 && y < Y - 1 && x >= 1 && x < X - 1;
-    float m = -INFINITY;
-    if (interior) {                                             // no bounds checks, 9 rows of 3
-        const float *p = g + i;
-        const int sy = X, sz = X * Y;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const int sy = X, sz = X * Y;
+    bool nonpeak = false;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {       // block-uniform trip count
+        const uint32_t i = i0 + threadIdx.x;
+        bool emit = false;
+        float c = 0.0f;
+        if (i < n) {
+            const int x = (int)(i % (uint32_t)X), y = (int)((i / (uint32_t)X) % (uint32_t)Y), z = (int)(i / ((uint32_t)X * Y));
+            c = g[i];
+            const bool interior = z >= 1 && z < Z - 1 && y >= 1 && y < Y - 1 && x >= 1 && x < X - 1;
+            float m = -INFINITY;
+            if (interior) {                                         // no bounds checks, 9 rows of 3
+                const float *p = g + i;
 #pragma unroll
-        for (int dz = -1; dz <= 1; ++dz)
+                for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const float *r = p + dz * sz + dy * sy;
-                m = fmaxf(m, fmaxf(r[-1], fmaxf(r[0], r[1])));
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        const float *r = p + dz * sz + dy * sy;
+                        m = fmaxf(m, fmaxf(r[-1], fmaxf(r[0], r[1])));
+                    }
+            } else {
+                for (int dz = -1; dz <= 1; ++dz)
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            int zz = z + dz, yy = y + dy, xx = x + dx;
+                            float v = 0.0f;                          // mode='constant', cval=0
+                            if (zz >= 0 && zz < Z && yy >= 0 && yy < Y && xx >= 0 && xx < X)
+                                v = g[((uint32_t)zz * Y + yy) * X + xx];
+                            m = v > m ? v : m;
+                        }
             }
-    } else {
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    int zz = z + dz, yy = y + dy, xx = x + dx;
-                    float v = 0.0f;                              // mode='constant', cval=0
-                    if (zz >= 0 && zz < Z && yy >= 0 && yy < Y && xx >= 0 && xx < X)
-                        v = g[((uint32_t)zz * Y + yy) * X + xx];
-                    m = v > m ? v : m;
-                }
+            if (!(c == m)) nonpeak = true;
+            else emit = interior && c > thr;
+        }
+        const unsigned long long em = __ballot(emit);               // plateaus emit in bulk: one atomic per wave
+        if (em) {
+            const int first = __ffsll((long long)em) - 1;
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(count, (uint32_t)__popcll(em));
+            base = __shfl(base, first);
+            const uint32_t slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+            if (emit && slot < cap) keys[slot] = ((unsigned long long)(~ford(c)) << 32) | (unsigned long long)i;
+        }
     }
-    if (!(c == m)) { *nonpeak_flag = 1u; return; }
-    if (interior && c > thr) {
-        uint32_t slot = atomicAdd(count, 1u);
-        if (slot < cap) keys[slot] = ((unsigned long long)(~ford(c)) << 32) | (unsigned long long)i;
-    }
+    if (__syncthreads_or(nonpeak) && threadIdx.x == 0) *nonpeak_flag = 1u;
 }
 
 // keys (sorted) -> (z,y,x) coordinates (+pad) as int64, and/or raveled padded index
@@ -385,35 +404,43 @@ __global__ void ccl_flatten_kernel(uint32_t *parent, int64_t N)
     atomicMin(&parent[i], r);
 }
 
-// sizes[root] += voxel count.  Each lane walks RUN contiguous voxels keeping a (root, count) run --
-// neighbouring voxels almost always share their root -- and flushes with an atomic only when the
-// root changes; the last run of every lane is flushed once per distinct root of the wave.  A giant
-// component thus costs one atomic per wave instead of one per voxel (same-address atomics serialise).
+// sizes[root] += voxel count.  One wave walks CCL_RUN x 64 contiguous voxels with coalesced loads and
+// carries ONE wave-uniform (root, count) run across them: lanes whose root equals the run root are
+// counted with a ballot, holes (NO_PARENT) never break the run, and a different root either replaces
+// the run (when it is the bigger one so far) or is added directly.  A giant, porous component thus costs
+// about one same-address atomic per 2048 voxels (same-address atomics serialise in L2: the first version
+// flushed at every hole and spent 350 ms on a 512^3 frame).
 static constexpr int CCL_RUN = 32;
 __global__ void ccl_sizes_kernel(const uint32_t *__restrict__ parent, uint32_t *sizes, int64_t N)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i0 = t * CCL_RUN;
-    uint32_t r = NO_PARENT, cnt = 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t base = wave * (int64_t)(64 * CCL_RUN);
+    if (base >= N) return;
+    uint32_t run_root = NO_PARENT, run_cnt = 0;                  // wave-uniform
     for (int k = 0; k < CCL_RUN; ++k) {
-        const int64_t i = i0 + k;
+        const int64_t i = base + (int64_t)k * 64 + lane;
         const uint32_t p = (i < N) ? parent[i] : NO_PARENT;
-        if (p == r) { cnt += (p != NO_PARENT); continue; }
-        if (r != NO_PARENT && cnt) atomicAdd(&sizes[r], cnt);
-        r = p;
-        cnt = (p != NO_PARENT);
+        bool todo = p != NO_PARENT;
+        if (run_root != NO_PARENT) {
+            run_cnt += (uint32_t)__popcll(__ballot(todo && p == run_root));
+            todo = todo && p != run_root;
+        }
+        while (__any(todo)) {
+            const int leader = __ffsll((long long)__ballot(todo)) - 1;
+            const uint32_t lr = __shfl(p, leader);
+            const uint32_t c = (uint32_t)__popcll(__ballot(todo && p == lr));
+            if (c > run_cnt) {                                   // adopt the new root, flush the old run
+                if (lane == 0 && run_root != NO_PARENT && run_cnt) atomicAdd(&sizes[run_root], run_cnt);
+                run_root = lr;
+                run_cnt = c;
+            } else if (lane == 0) {
+                atomicAdd(&sizes[lr], c);
+            }
+            todo = todo && p != lr;
+        }
     }
-    bool todo = r != NO_PARENT && cnt > 0;
-    while (__any(todo)) {
-        unsigned long long act = __ballot(todo);
-        int leader = __ffsll((long long)act) - 1;
-        uint32_t lr = __shfl(r, leader);
-        bool same = todo && r == lr;
-        uint32_t c = same ? cnt : 0u;
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&sizes[lr], c);
-        if (same) todo = false;
-    }
+    if (lane == 0 && run_root != NO_PARENT && run_cnt) atomicAdd(&sizes[run_root], run_cnt);
 }
 
 __global__ void ccl_apply_kernel(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ sizes,
@@ -445,7 +472,7 @@ static int ccl_impl(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], 
     ISX_CHECK_LAUNCH();
     if (sizes) {
         ISX_HIP(hipMemsetAsync(sizes, 0, N * sizeof(uint32_t), ctx->stream));
-        ccl_sizes_kernel<<<cdiv(cdiv(N, CCL_RUN), TPB), TPB, 0, ctx->stream>>>(parent, sizes, N);
+        ccl_sizes_kernel<<<cdiv(cdiv(N, (int64_t)64 * CCL_RUN) * 64, TPB), TPB, 0, ctx->stream>>>(parent, sizes, N);
         ISX_CHECK_LAUNCH();
     }
     return ISX_OK;
@@ -1456,7 +1483,7 @@ static int seeds_impl(isx_ctx *ctx, const float *cent, const int64_t shape[3], i
         src = g.p;
     }
     ISX_HIP(hipMemsetAsync(flags.p, 0, 8, ctx->stream));
-    peak_kernel<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(src, (int)shape[0], (int)shape[1], (int)shape[2], thr, flags.p,
+    peak_kernel<<<std::min(cdiv(n, TPB), 8192u), TPB, 0, ctx->stream>>>(src, (int)shape[0], (int)shape[1], (int)shape[2], thr, flags.p,
                                                      keys.p, flags.p + 1, cap);
     ISX_CHECK_LAUNCH();
     uint32_t fl[2];
