@@ -144,7 +144,11 @@ static constexpr int A_STRIDE = 6;     // floats per halo slot (4 channels + 2 p
 
 // TX = 3: all 27 taps.  TX = 1: the 9 taps with dx = 0 only (the folded tail layer, where the three
 // x-taps live in the output columns instead).
-template <int BN, int TX>
+//
+// MT = 32-row GEMM tiles per wave: a workgroup covers 128 * MT output voxels.  With MT = 2 one weight
+// slab in LDS (the larger half of every stage) feeds twice the voxels, and each B fragment read from
+// LDS is used by two MFMAs.
+template <int BN, int TX, int MT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -155,8 +159,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
     constexpr int NB = (B4 + 255) / 256;
     float *Bs = smem;
     float *As = smem + BFLOATS;
+    constexpr int ROWS = 128 * MT;
+    constexpr int TXW = 8 * MT;                          // mode 0 tile: 2 x 8 x TXW voxels
     int *rowinfo = (int *)(As + a.slots_max * A_STRIDE);
-    float *red = (float *)(rowinfo + 128);
+    float *red = (float *)(rowinfo + ROWS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
     const int b = blockIdx.x / a.tiles_per_chunk, tile = blockIdx.x % a.tiles_per_chunk;
@@ -170,11 +176,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
     const int WP = W + 2;
     if (a.mode == 0) {
         int xt = tile % a.ntx, yt = (tile / a.ntx) % a.nty, zt = tile / (a.ntx * a.nty);
-        z0 = zt * 2; y0 = yt * 8; x0 = xt * 8; TZ = 2;
-        RS = 10; PS = 100; S = 400;
+        z0 = zt * 2; y0 = yt * 8; x0 = xt * TXW; TZ = 2;
+        RS = TXW + 2; PS = 10 * RS; S = 4 * PS;
     } else {
         TZ = (a.mode == 1) ? 2 : 1;
-        TP = 128 / TZ;
+        TP = ROWS / TZ;
         int pt = tile % a.ntp, zt = tile / a.ntp;
         z0 = zt * TZ; p0 = pt * TP;
         int plast = p0 + TP - 1;
@@ -187,11 +193,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
         S = (TZ + 2) * PS;
     }
 
-    // ---- per-row table (output voxel of each of the 128 GEMM rows) and this lane's A row ---
-    if (tid < 128) {
+    // ---- per-row table (output voxel of each GEMM row) and this lane's A rows ---------------
+    if (tid < ROWS) {
         int r = tid, g = -1;
         if (a.mode == 0) {
-            int zz = r >> 6, yy = (r >> 3) & 7, xx = r & 7;
+            int zz = r / (8 * TXW), yy = (r / TXW) & 7, xx = r % TXW;
             int z = z0 + zz, y = y0 + yy, x = x0 + xx;
             if (z < D && y < H && x < W) g = (z * H + y) * W + x;
         } else {
@@ -201,19 +207,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
         }
         rowinfo[r] = g;
     }
-    int aslot;
-    {
-        int r = wave * 32 + nn;
+    auto row_slot = [&](int r) __attribute__((always_inline)) -> int {
         if (a.mode == 0) {
-            int zz = r >> 6, yy = (r >> 3) & 7, xx = r & 7;
-            aslot = (zz + 1) * 100 + (yy + 1) * 10 + (xx + 1);
-        } else {
-            int zz = r / TP, p = p0 + r % TP;
-            if (p > H * W - 1) p = H * W - 1;            // invalid rows read some in-tile slot
-            int q = (p / W) * WP + (p % W) + 1;
-            aslot = (zz + 1) * PS + (q - qlo);
+            int zz = r / (8 * TXW), yy = (r / TXW) & 7, xx = r % TXW;
+            return (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
         }
-    }
+        int zz = r / TP, p = p0 + r % TP;
+        if (p > H * W - 1) p = H * W - 1;                // invalid rows read some in-tile slot
+        int q = (p / W) * WP + (p % W) + 1;
+        return (zz + 1) * PS + (q - qlo);
+    };
+    const int aslot0 = row_slot((wave * MT) * 32 + nn);
+    const int aslot1 = (MT > 1) ? row_slot((wave * MT + 1) * 32 + nn) : 0;
 
     // ---- halo slots staged by this thread: global voxel index, -1 (zero padding) or -2 (no slot).
     // Named scalars, not arrays: hipcc leaves array forms of these and of the prefetch registers in
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
         if (s >= S) return -2;
         int z, y, x;
         if (a.mode == 0) {
-            int hz = s / 100, hy = (s / 10) % 10, hx = s % 10;
+            int hz = s / PS, hy = (s / RS) % 10, hx = s % RS;
             z = z0 + hz - 1; y = y0 + hy - 1; x = x0 + hx - 1;
         } else {
             int hz = s / PS, qq = qlo + s % PS + WP;      // + WP keeps the division non-negative
@@ -233,23 +238,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
         return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
     };
     const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + 256), gv2 = slot_voxel(tid + 512),
-              gv3 = slot_voxel(tid + 768);
+              gv3 = slot_voxel(tid + 768), gv4 = (MT > 1) ? slot_voxel(tid + 1024) : -2;
 
     const int nsteps = (a.CA + a.CB) >> 2;
-    f32x16 acc[NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
 
     // Register prefetch of the next stage.  Loads are unconditional (out-of-tile slots read a
     // clamped address) and stay untouched in registers while the matrix cores run; the producer's
     // BN scale/shift + ReLU and the zero padding are applied when the stage is written to LDS, so
     // nothing between the loads and the MFMA phase waits on vmcnt.
     static_assert(NB <= 7, "prefetch register plan covers at most 7 float4 of weights per thread");
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6, vs, vh;
+    float4 ra0, ra1, ra2, ra3, ra4, rb0, rb1, rb2, rb3, rb4, rb5, rb6, vs, vh;
     bool has_affine = false;
-#define ISX_LOAD_A(k) ra##k = *(const float4 *)&src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];
+#define ISX_LOAD_A(k) if constexpr (k < 4 || MT > 1) ra##k = *(const float4 *)&src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];
 #define ISX_LOAD_B(k) if constexpr (NB > k) rb##k = wsrc[tid + 256 * k];
 #define ISX_LOAD_STAGE(step_)                                                                     \
     {                                                                                             \
@@ -263,12 +270,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
         const int64_t so = has_affine ? (int64_t)b * C + cc : 0;                                  \
         vs = *(const float4 *)&scp[so];                                                           \
         vh = *(const float4 *)&shp[so];                                                           \
-        ISX_LOAD_A(0) ISX_LOAD_A(1) ISX_LOAD_A(2) ISX_LOAD_A(3)                                   \
+        ISX_LOAD_A(0) ISX_LOAD_A(1) ISX_LOAD_A(2) ISX_LOAD_A(3) ISX_LOAD_A(4)                     \
         const float4 *wsrc = (const float4 *)(a.w + ((int64_t)ntile * nsteps + (step_)) * BFLOATS); \
         ISX_LOAD_B(0) ISX_LOAD_B(1) ISX_LOAD_B(2) ISX_LOAD_B(3) ISX_LOAD_B(4) ISX_LOAD_B(5) ISX_LOAD_B(6) \
     }
 #define ISX_STORE_A(k)                                                                            \
-    if (gv##k != -2) {                                                                            \
+    if ((k < 4 || MT > 1) && gv##k != -2) {                                                       \
         float4 v = ra##k;                                                                         \
         if (has_affine) {                                                                         \
             v.x = fmaxf(fmaf(v.x, vs.x, vh.x), 0.f);                                              \
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 #define ISX_STORE_B(k) if constexpr (NB > k) { if (tid + 256 * k < B4) ((float4 *)Bs)[tid + 256 * k] = rb##k; }
 #define ISX_STORE_STAGE()                                                                         \
     {                                                                                             \
-        ISX_STORE_A(0) ISX_STORE_A(1) ISX_STORE_A(2) ISX_STORE_A(3)                               \
+        ISX_STORE_A(0) ISX_STORE_A(1) ISX_STORE_A(2) ISX_STORE_A(3) ISX_STORE_A(4)                \
         ISX_STORE_B(0) ISX_STORE_B(1) ISX_STORE_B(2) ISX_STORE_B(3) ISX_STORE_B(4) ISX_STORE_B(5) ISX_STORE_B(6) \
     }
 
@@ -295,7 +302,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
         __syncthreads();
         if (step + 1 < nsteps) ISX_LOAD_STAGE(step + 1)   // in flight while the matrix cores run
         __builtin_amdgcn_sched_barrier(0);
-        const float *ap = As + aslot * A_STRIDE + 2 * hh;
+        const float *ap0 = As + aslot0 * A_STRIDE + 2 * hh;
+        const float *ap1 = As + aslot1 * A_STRIDE + 2 * hh;
         const float *bp = Bs + (2 * hh) * BN + nn;
 #pragma unroll
         for (int dz = -1; dz <= 1; ++dz)
@@ -306,13 +314,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
                     const int dx = (TX == 3) ? dxi - 1 : 0;
                     const int tap = ((dz + 1) * 3 + (dy + 1)) * TX + dxi;
                     const int toff = dz * PS + dy * RS + dx;
-                    const float2 av = *(const float2 *)(ap + toff * A_STRIDE);
+                    const float2 av0 = *(const float2 *)(ap0 + toff * A_STRIDE);
+                    float2 av1 = av0;
+                    if constexpr (MT > 1) av1 = *(const float2 *)(ap1 + toff * A_STRIDE);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const float b0 = bp[(tap * 4) * BN + 32 * j];
                         const float b1 = bp[(tap * 4 + 1) * BN + 32 * j];
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc[j], 0, 0, 0);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, b0, acc[0][j], 0, 0, 0);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, b1, acc[0][j], 0, 0, 0);
+                        if constexpr (MT > 1) {
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, b0, acc[1][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, b1, acc[1][j], 0, 0, 0);
+                        }
                     }
                 }
         __builtin_amdgcn_sched_barrier(0);
@@ -332,16 +346,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
         const float bsv = a.bias[ch];
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int g = rowinfo[row];
-            if (g >= 0) {
-                const float v = acc[j][i] + bsv;
-                if (ch < a.store_cols) a.out[((int64_t)b * M + g) * a.store_cols + ch] = v;
-                s += v;
-                q += v * v;
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (wave * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const int g = rowinfo[row];
+                if (g >= 0) {
+                    const float v = acc[m][j][i] + bsv;
+                    if (ch < a.store_cols) a.out[((int64_t)b * M + g) * a.store_cols + ch] = v;
+                    s += v;
+                    q += v * v;
+                }
             }
-        }
         s += __shfl_xor(s, 32);
         q += __shfl_xor(q, 32);
         if (hh == 0) { red[(wave * BN + 32 * j + nn) * 2] = s; red[(wave * BN + 32 * j + nn) * 2 + 1] = q; }
@@ -812,16 +828,27 @@ int conv_mode(const Level &l)
     return (l.D % 2 == 0) ? 1 : 2;
 }
 
-int conv_tiles(const Level &l, int mode, int *nty, int *ntx, int *ntp, int *slots)
+// Two GEMM row tiles per wave (256 voxels per workgroup): halves the weight-slab staging per voxel but
+// runs at 2 waves/SIMD instead of 4; measured 3 % SLOWER end to end on MI355X (profiles/README.md), so
+// it is off unless ISX_CONV_MT2_MIN_VOX lowers the threshold.  Decided from the workspace batch so
+// that the partial-sum layout of a layer never changes.
+int conv_mt(const Level &l, int batch)
+{
+    static const long min_vox = getenv("ISX_CONV_MT2_MIN_VOX") ? atol(getenv("ISX_CONV_MT2_MIN_VOX")) : (1L << 60);
+    return ((int64_t)batch * l.M >= min_vox) ? 2 : 1;
+}
+
+int conv_tiles(const Level &l, int mode, int mt, int *nty, int *ntx, int *ntp, int *slots)
 {
     if (mode == 0) {
+        const int txw = 8 * mt;
         *nty = (l.H + 7) / 8;
-        *ntx = (l.W + 7) / 8;
+        *ntx = (l.W + txw - 1) / txw;
         *ntp = 0;
-        *slots = 400;
+        *slots = 4 * 10 * (txw + 2);
         return ((l.D + 1) / 2) * *nty * *ntx;
     }
-    int TZ = mode == 1 ? 2 : 1, TP = 128 / TZ;
+    int TZ = mode == 1 ? 2 : 1, TP = 128 * mt / TZ;
     *nty = *ntx = 0;
     *ntp = (l.H * l.W + TP - 1) / TP;
     int Lh = TP + 2 * ((TP + l.W - 1) / l.W + 1) + 2 * (l.W + 2) + 2;
@@ -829,12 +856,12 @@ int conv_tiles(const Level &l, int mode, int *nty, int *ntx, int *ntp, int *slot
     return ((l.D + TZ - 1) / TZ) * *ntp;
 }
 
-static int layer_tiles(const UNetState *u, int li, const Level &l)
+static int layer_tiles(const UNetState *u, int li, const Level &l, int batch)
 {
     const ConvBN &L = u->cv[li];
     if (use_mfma(L.cin, L.cout)) {
         int a, b, c, d;
-        return conv_tiles(l, conv_mode(l), &a, &b, &c, &d);
+        return conv_tiles(l, conv_mode(l), conv_mt(l, batch), &a, &b, &c, &d);
     }
     if (L.cin == 1) return (int)((l.M + 127) / 128);
     return (int)((l.M + 255) / 256);      // thin kernel blocks, or combine blocks of the folded layer
@@ -867,7 +894,7 @@ int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
         ConvBN &L = u->cv[li];
         const Level &l = lv[MOD_LEVEL[li / 2]];
         ISX_TRY(dev_alloc(u, (size_t)B * l.M * L.cout, &u->raw[li]));
-        L.tiles = layer_tiles(u, li, l);
+        L.tiles = layer_tiles(u, li, l, B);
         ISX_TRY(dev_alloc(u, (size_t)B * L.tiles * L.cout, &L.psum));
         ISX_TRY(dev_alloc(u, (size_t)B * L.tiles * L.cout, &L.psq));
         ISX_TRY(dev_alloc(u, (size_t)B * L.cout, &L.scale));
@@ -895,16 +922,19 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     a.w = w_packed; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
     a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = cout;
     a.mode = conv_mode(l);
-    a.tiles_per_chunk = conv_tiles(l, a.mode, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+    const int mt = conv_mt(l, ctx->unet->wbatch);
+    a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
     a.store_cols = cout;
     a.no_stats = no_stats;
-    ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
+    ISX_REQUIRE(a.slots_max <= (mt > 1 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     ISX_REQUIRE(cout % 32 == 0 && (sa.C + sb.C) % 4 == 0, "internal: MFMA conv needs Cout %% 32 == 0, Cin %% 4 == 0");
     const int BN = (cout % 64 == 0) ? 64 : 32;
-    size_t lds = (size_t)(27 * 4 * BN + a.slots_max * A_STRIDE + 128 + 4 * BN * 2) * sizeof(float);
+    size_t lds = (size_t)(27 * 4 * BN + a.slots_max * A_STRIDE + 128 * mt + 4 * BN * 2) * sizeof(float);
     dim3 grid((unsigned)(B * a.tiles_per_chunk), (unsigned)(cout / BN));
-    if (BN == 64) conv_mfma_kernel<64, 3><<<grid, 256, lds, ctx->stream>>>(a);
-    else conv_mfma_kernel<32, 3><<<grid, 256, lds, ctx->stream>>>(a);
+    if (BN == 64 && mt == 2) conv_mfma_kernel<64, 3, 2><<<grid, 256, lds, ctx->stream>>>(a);
+    else if (BN == 64) conv_mfma_kernel<64, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
+    else if (mt == 2) conv_mfma_kernel<32, 3, 2><<<grid, 256, lds, ctx->stream>>>(a);
+    else conv_mfma_kernel<32, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
     ISX_CHECK_LAUNCH();
     return ISX_OK;
 }
@@ -928,12 +958,15 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
             a.w = L.w; a.bias = u->zeros32; a.out = u->ptail; a.psum = nullptr; a.psq = nullptr;
             a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = 32;
             a.mode = conv_mode(l);
-            a.tiles_per_chunk = conv_tiles(l, a.mode, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+            const int mt = conv_mt(l, u->wbatch);
+            a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
             a.store_cols = 16;
             a.no_stats = 1;
-            ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
-            size_t lds = (size_t)(9 * 4 * 32 + a.slots_max * A_STRIDE + 128 + 4 * 32 * 2) * sizeof(float);
-            conv_mfma_kernel<32, 1><<<dim3((unsigned)(B * a.tiles_per_chunk), 1), 256, lds, ctx->stream>>>(a);
+            ISX_REQUIRE(a.slots_max <= (mt > 1 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
+            size_t lds = (size_t)(9 * 4 * 32 + a.slots_max * A_STRIDE + 128 * mt + 4 * 32 * 2) * sizeof(float);
+            const dim3 grid((unsigned)(B * a.tiles_per_chunk), 1);
+            if (mt == 2) conv_mfma_kernel<32, 1, 2><<<grid, 256, lds, ctx->stream>>>(a);
+            else conv_mfma_kernel<32, 1, 1><<<grid, 256, lds, ctx->stream>>>(a);
             ISX_CHECK_LAUNCH();
         }
         // pass 2: shifted combine + bias + BN partial sums

@@ -80,7 +80,7 @@ struct ConvArgs {
     float *out;            // [B][M][store_cols] raw conv output (+bias)
     float *psum, *psq;     // [B][tiles][Cout]
     int D, H, W, Cout;
-    int mode;              // 0: 2x8x8 voxel tiles; 1: 2 planes x 64 row-wrapped positions; 2: 1 plane x 128
+    int mode;              // 0: 2x8x(8 MT) voxel tiles; 1: 2 planes x 64 MT row-wrapped positions; 2: 1 plane x 128 MT
     int tiles_per_chunk, nty, ntx, ntp;
     int slots_max;         // LDS halo slots reserved
     int store_cols;        // columns of the N tile actually stored (Cout, or 16 for the folded tail layer)
@@ -94,7 +94,8 @@ extern const char *UPS[4];
 bool use_mfma(int cin, int cout);
 bool use_fold(int cin, int cout);
 int conv_mode(const Level &l);
-int conv_tiles(const Level &l, int mode, int *nty, int *ntx, int *ntp, int *slots);
+int conv_mt(const Level &l, int batch);
+int conv_tiles(const Level &l, int mode, int mt, int *nty, int *ntx, int *ntp, int *slots);
 // raw launch of the MFMA conv (no BN finalize): used by the forward and by dgrad
 int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const float *w_packed, const float *bias,
                      int cout, float *out, float *psum, float *psq, int no_stats);
