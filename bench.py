@@ -83,13 +83,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # Rehearsal knobs (never set by the driver): ISX_BENCH_BACKEND=gloo with ISX_BENCH_ONE_DEVICE=1 runs
+    # the N > 1 control flow with every rank on cuda:0 of a one-GPU box (RCCL refuses two ranks per device).
+    backend = os.environ.get("ISX_BENCH_BACKEND", "nccl")
+    if os.environ.get("ISX_BENCH_ONE_DEVICE"):
+        local_rank = 0
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from iterseg_amd import segmentation, weights
     from iterseg_amd.unet import UNet
@@ -131,7 +139,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -178,6 +186,10 @@ def main():
                                    "bytes_per_voxel": 24},
             "t_unet_ms": t_unet, "t_ws_ms": t_ws,
         }
+        # combined fraction t_ideal / t_measured, t_ideal = FLOPs / peak_MFMA + 24 B * ZYX / peak_HBM
+        t_ideal = ((mfma_flops + direct_flops) * n_chunks / (PEAK_MFMA_F32 * 1e12) + 24.0 * nvox / (PEAK_HBM * 1e9)) * 1e3
+        out["combined_roofline_frac"] = t_ideal / (1e3 * elapsed / args.steps)
+        out["t_ideal_ms"] = t_ideal
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, chunk, margin)
         print(json.dumps(out))

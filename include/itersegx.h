@@ -132,12 +132,19 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
 #define ISX_LOSS_BCE 0
 #define ISX_LOSS_MSE 1
 #define ISX_LOSS_WEIGHTED_BCE 2
+#define ISX_LOSS_DICE 3         /* custom_loss.py:24-53 (smooth = 1, mean over channels) */
 /* One step on a device patch x (D,H,W) with targets y (C,D,H,W): forward (train-mode BN), loss,
  * and if do_backward: gradients into the bound buffer followed by n_adam Adam updates with the same
  * gradients (the reference applies two, train.py:353 + :310).  loss_out (host, 1 + C floats): the loss
  * and the per-channel means logged by channel_losses_to_dict (custom_loss.py:8-17). */
 int isx_train_step(isx_ctx *ctx, const float *x, const float *y, int loss_kind, const float *chan_weights,
                    float lr, int n_adam, int do_backward, float *loss_out);
+/* ChannelwiseLoss (custom_loss.py:131-159) and any other per-channel mix:
+ *   loss = sum_c chan_weight[c] * mean_m elem_loss(chan_kind[c])(y_hat[c, m], y[c, m]),
+ * chan_kind[c] in {ISX_LOSS_BCE, ISX_LOSS_MSE}.  For the reference's `losses` / `chan_losses` lists with L
+ * entries, a channel of entry i covering n_i channels gets weight 1 / (L * n_i).  Otherwise as isx_train_step. */
+int isx_train_step_channelwise(isx_ctx *ctx, const float *x, const float *y, const int32_t *chan_kind,
+                               const float *chan_weight, float lr, int n_adam, int do_backward, float *loss_out);
 /* n_steps Adam updates from the bound gradient buffer (after an external all-reduce), then repack. */
 int isx_adam_step(isx_ctx *ctx, float lr, int n_steps);
 /* Re-derive the kernel-layout weights after the caller changed the bound parameter buffer. */

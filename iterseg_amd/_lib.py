@@ -49,6 +49,7 @@ SIGNATURES = {
     "isx_train_param_count": (_i64, [_vp]),
     "isx_train_bind": (C.c_int, [_vp, _i64p, _vp, _vp, _vp, _vp, _i64]),
     "isx_train_step": (C.c_int, [_vp, _vp, _vp, C.c_int, _f32p, _f32, C.c_int, C.c_int, _f32p]),
+    "isx_train_step_channelwise": (C.c_int, [_vp, _vp, _vp, _i32p, _f32p, _f32, C.c_int, C.c_int, _f32p]),
     "isx_adam_step": (C.c_int, [_vp, _f32, C.c_int]),
     "isx_train_refresh_weights": (C.c_int, [_vp]),
     "isx_ws_gaussian": (C.c_int, [_vp, _vp, _vp, _i64p, _i32p]),

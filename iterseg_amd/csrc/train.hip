@@ -116,9 +116,14 @@ __global__ void repack_up_kernel(const float *__restrict__ wref, int C, int kt, 
 // y_hat is recomputed from raw17 (sigmoid(BN(raw))); target is (C, D, H, W) planar.
 // lossbuf partials: [blocks][C] ; gout: [M][C] channels-last.
 // ------------------------------------------------------------------------------------------------
+struct LossSpec {          // loss = sum_c w[c] * sum_m elem_loss_kind[c](yh[m,c], y[c,m])
+    int kind[8];           // 0 BCE (log clamped at -100 like torch), 1 squared error
+    float w[8];            // includes every mean: e.g. 1/(M*C) for nn.BCELoss
+};
+
 __global__ __launch_bounds__(256) void loss_kernel(const float *__restrict__ raw, const float *__restrict__ scale,
                                                    const float *__restrict__ shift, const float *__restrict__ target,
-                                                   int C, int64_t M, int kind, const float *__restrict__ cw,
+                                                   int C, int64_t M, const LossSpec spec,
                                                    float *__restrict__ gout, float *__restrict__ part)
 {
     __shared__ float red[4][8];
@@ -132,16 +137,15 @@ __global__ __launch_bounds__(256) void loss_kernel(const float *__restrict__ raw
             float yh = 1.f / (1.f + expf(-z));
             float y = target[(int64_t)c * M + m];
             float g;
-            if (kind == 1) {
+            if (spec.kind[c] == 1) {
                 float d = yh - y;
                 l[c] = d * d;
-                g = 2.f * d / (float)(M * C);
+                g = 2.f * d * spec.w[c];
             } else {
                 float lg = fmaxf(logf(yh), -100.f), lg1 = fmaxf(logf(1.f - yh), -100.f);
                 l[c] = -(y * lg + (1.f - y) * lg1);
                 float denom = fmaxf((1.f - yh) * yh, 1e-12f);
-                float wgt = (kind == 2) ? cw[c] / (float)M / (float)C : 1.f / (float)(M * C);
-                g = wgt * (yh - y) / denom;
+                g = spec.w[c] * (yh - y) / denom;
             }
             gout[m * C + c] = g;
         }
@@ -154,6 +158,58 @@ __global__ __launch_bounds__(256) void loss_kernel(const float *__restrict__ raw
     __syncthreads();
     if ((int)threadIdx.x < C) part[(int64_t)blockIdx.x * C + threadIdx.x] =
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// DiceLoss (custom_loss.py:24-53), pass 1: per-block partials of (sum yh*y, sum yh, sum y) per channel ->
+// part[blocks][3C].  H*W is a multiple of 256 (chunk y, x are multiples of 16), so a block never straddles
+// two z planes and the per-plane sums the reference's per-channel log needs fall out of the same partials.
+__global__ __launch_bounds__(256) void dice_sums_kernel(const float *__restrict__ raw, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, const float *__restrict__ target,
+                                                        int C, int64_t M, float *__restrict__ part)
+{
+    __shared__ float red[4][24];
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = 0; c < C; ++c) {
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (m < M) {
+            float z = fmaf(raw[m * C + c], scale[c], shift[c]);
+            float yh = 1.f / (1.f + expf(-z));
+            float y = target[(int64_t)c * M + m];
+            v0 = yh * y; v1 = yh; v2 = y;
+        }
+        for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); v2 += __shfl_xor(v2, o); }
+        if (lane == 0) { red[wave][3 * c] = v0; red[wave][3 * c + 1] = v1; red[wave][3 * c + 2] = v2; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 3 * C) part[(int64_t)blockIdx.x * 3 * C + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// part[blocks][K] -> out[group][K]: fixed-order double sums over `per` consecutive blocks per group
+__global__ void colsum_group_kernel(const float *__restrict__ part, int per, int K, float *__restrict__ out)
+{
+    __shared__ double red[256];
+    const int k = blockIdx.x, grp = blockIdx.y;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < per; b += 256) s += (double)part[((int64_t)grp * per + b) * K + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(int64_t)grp * K + k] = (float)red[0];
+}
+
+struct DiceCoef { float ka[8], kb[8]; };
+// DiceLoss, pass 2: d loss / d yh[m, c] = y * ka[c] + kb[c]
+__global__ void dice_grad_kernel(const float *__restrict__ target, int C, int64_t M, const DiceCoef k,
+                                 float *__restrict__ gout)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    for (int c = 0; c < C; ++c) gout[m * C + c] = fmaf(target[(int64_t)c * M + m], k.ka[c], k.kb[c]);
 }
 
 // sums the [blocks][C] partials in double, fixed order: out[c] = per-channel sum
@@ -864,17 +920,16 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
 
 // forward of one patch + loss (+ backward + n_adam optimiser steps).  x: device (D,H,W); y: device (C,D,H,W).
 // loss_out (host): [0] = loss, [1..C] = per-channel mean of the elementwise loss term.
-int isx_train_step(isx_ctx *ctx, const float *x, const float *y, int loss_kind, const float *chan_weights, float lr,
-                   int n_adam, int do_backward, float *loss_out)
+// shared body: loss_kind < 0 -> the per-channel (kind, weight) spec in `spec`; 3 -> DiceLoss
+static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dice, LossSpec spec, float lr,
+                           int n_adam, int do_backward, float *loss_out)
 {
-    ISX_REQUIRE(ctx && x && y && loss_out, "null argument");
-    if (!ctx->unet || !ctx->unet->train) { set_error("call isx_train_bind first"); return ISX_ERR_STATE; }
-    ISX_REQUIRE(loss_kind >= 0 && loss_kind <= 2 && (loss_kind != 2 || chan_weights), "loss kind");
     ISX_HIP(hipSetDevice(ctx->device));
     UNetState *u = ctx->unet;
     TrainState *t = u->train;
     const Level &l0 = u->lv[0];
     const int C = u->out_channels;
+    ISX_REQUIRE(C <= 8, "at most 8 output channels");
     // forward (train-mode BN, keeps every raw tensor)
     ISX_HIP(hipMemcpyAsync(u->x0, x, (size_t)l0.M * 4, hipMemcpyDeviceToDevice, ctx->stream));
     Scratch<int32_t> tab(ctx, 9);
@@ -882,18 +937,48 @@ int isx_train_step(isx_ctx *ctx, const float *x, const float *y, int loss_kind, 
     ISX_HIP(hipMemsetAsync(tab.p, 0, 36, ctx->stream));
     u->d_table = tab.p;
     ISX_TRY(forward_batch(ctx, 1, nullptr, nullptr, nullptr));
-    // loss and its gradient
+    // loss and its gradient with respect to the sigmoid output
     const ConvBN &LL = u->cv[17];
     const int blocks = (int)((l0.M + 255) / 256);
-    ISX_REQUIRE((size_t)blocks * C <= t->part_floats, "internal: partial buffer too small");
-    float *cw_dev = t->lossbuf + 64;
-    if (loss_kind == 2) ISX_HIP(hipMemcpyAsync(cw_dev, chan_weights, C * 4, hipMemcpyHostToDevice, ctx->stream));
-    loss_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[17], LL.scale, LL.shift, y, C, l0.M, loss_kind, cw_dev, t->gact[17], t->part);
-    ISX_CHECK_LAUNCH();
-    colsum_kernel<<<C, 256, 0, ctx->stream>>>(t->part, blocks, C, t->lossbuf);
-    ISX_CHECK_LAUNCH();
-    float hs[8];
-    ISX_HIP(hipMemcpyAsync(hs, t->lossbuf, C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    float hs[8] = {0};
+    double total = 0.0;
+    if (!dice) {
+        ISX_REQUIRE((size_t)blocks * C <= t->part_floats, "internal: partial buffer too small");
+        loss_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[17], LL.scale, LL.shift, y, C, l0.M, spec, t->gact[17], t->part);
+        ISX_CHECK_LAUNCH();
+        colsum_kernel<<<C, 256, 0, ctx->stream>>>(t->part, blocks, C, t->lossbuf);
+        ISX_CHECK_LAUNCH();
+        ISX_HIP(hipMemcpyAsync(hs, t->lossbuf, C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        const int64_t plane = (int64_t)l0.H * l0.W;
+        ISX_REQUIRE(plane % 256 == 0 && l0.D * 3 * C <= 2048, "internal: DiceLoss needs H*W %% 256 == 0");
+        ISX_REQUIRE((size_t)blocks * C * 3 <= t->part_floats, "internal: partial buffer too small");
+        dice_sums_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[17], LL.scale, LL.shift, y, C, l0.M, t->part);
+        ISX_CHECK_LAUNCH();
+        colsum_group_kernel<<<dim3(3 * C, l0.D), 256, 0, ctx->stream>>>(t->part, (int)(plane / 256), 3 * C, t->lossbuf + 128);
+        ISX_CHECK_LAUNCH();
+        std::vector<float> sums((size_t)l0.D * 3 * C);
+        ISX_HIP(hipMemcpyAsync(sums.data(), t->lossbuf + 128, sums.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        DiceCoef k;
+        for (int c = 0; c < C; ++c) {
+            double I = 0, A = 0, Bq = 0, zlog = 0;
+            for (int z = 0; z < l0.D; ++z) {
+                const double i = sums[(size_t)z * 3 * C + 3 * c], a2 = sums[(size_t)z * 3 * C + 3 * c + 1],
+                             b2 = sums[(size_t)z * 3 * C + 3 * c + 2];
+                I += i; A += a2; Bq += b2;
+                zlog += 1.0 - (2.0 * i + 1.0) / (a2 + b2 + 1.0);
+            }
+            const double S = A + Bq + 1.0;
+            total += (1.0 - (2.0 * I + 1.0) / S) / C;
+            k.ka[c] = (float)(-2.0 / (C * S));
+            k.kb[c] = (float)((2.0 * I + 1.0) / (C * S * S));
+            // the reference's per-channel log applies DiceLoss to (1, Z, Y, X): the z planes act as channels
+            hs[c] = (float)(zlog / l0.D);
+        }
+        dice_grad_kernel<<<blocks, 256, 0, ctx->stream>>>(y, C, l0.M, k, t->gact[17]);
+        ISX_CHECK_LAUNCH();
+    }
     if (do_backward) {
         ISX_TRY(backward(ctx));
         for (int s = 0; s < n_adam; ++s) {
@@ -905,13 +990,52 @@ int isx_train_step(isx_ctx *ctx, const float *x, const float *y, int loss_kind, 
         if (n_adam > 0) ISX_TRY(repack_all(ctx));
     }
     ISX_HIP(hipStreamSynchronize(ctx->stream));
-    double tot = 0.0;
-    for (int c = 0; c < C; ++c) {
-        loss_out[1 + c] = hs[c] / (float)l0.M;
-        tot += (loss_kind == 2 ? (double)chan_weights[c] : 1.0) * hs[c] / (double)l0.M;
+    if (!dice) {
+        for (int c = 0; c < C; ++c) {
+            loss_out[1 + c] = hs[c] / (float)l0.M;
+            total += (double)spec.w[c] * (double)hs[c];
+        }
+    } else {
+        for (int c = 0; c < C; ++c) loss_out[1 + c] = hs[c];
     }
-    loss_out[0] = (float)(tot / C);
+    loss_out[0] = (float)total;
     return ISX_OK;
+}
+
+int isx_train_step(isx_ctx *ctx, const float *x, const float *y, int loss_kind, const float *chan_weights, float lr,
+                   int n_adam, int do_backward, float *loss_out)
+{
+    ISX_REQUIRE(ctx && x && y && loss_out, "null argument");
+    if (!ctx->unet || !ctx->unet->train) { set_error("call isx_train_bind first"); return ISX_ERR_STATE; }
+    ISX_REQUIRE(loss_kind >= 0 && loss_kind <= 3 && (loss_kind != 2 || chan_weights), "loss kind");
+    const int C = ctx->unet->out_channels;
+    const double MC = (double)ctx->unet->lv[0].M * C;
+    LossSpec spec;
+    for (int c = 0; c < 8; ++c) {
+        spec.kind[c] = loss_kind == 1 ? 1 : 0;
+        spec.w[c] = (float)((loss_kind == 2 && c < C ? (double)chan_weights[c] : 1.0) / MC);
+    }
+    return train_step_impl(ctx, x, y, loss_kind == 3, spec, lr, n_adam, do_backward, loss_out);
+}
+
+int isx_train_step_channelwise(isx_ctx *ctx, const float *x, const float *y, const int32_t *chan_kind,
+                               const float *chan_weight, float lr, int n_adam, int do_backward, float *loss_out)
+{
+    ISX_REQUIRE(ctx && x && y && loss_out && chan_kind && chan_weight, "null argument");
+    if (!ctx->unet || !ctx->unet->train) { set_error("call isx_train_bind first"); return ISX_ERR_STATE; }
+    const int C = ctx->unet->out_channels;
+    const double M = (double)ctx->unet->lv[0].M;
+    LossSpec spec;
+    for (int c = 0; c < 8; ++c) {
+        spec.kind[c] = 0;
+        spec.w[c] = 0.f;
+        if (c < C) {
+            ISX_REQUIRE(chan_kind[c] == ISX_LOSS_BCE || chan_kind[c] == ISX_LOSS_MSE, "channel %d: loss kind %d", c, chan_kind[c]);
+            spec.kind[c] = chan_kind[c];
+            spec.w[c] = (float)((double)chan_weight[c] / M);
+        }
+    }
+    return train_step_impl(ctx, x, y, 0, spec, lr, n_adam, do_backward, loss_out);
 }
 
 // after an external update of the bound parameter buffer (e.g. an all-reduce + optimiser step done elsewhere)

@@ -26,7 +26,31 @@ import torch
 from . import _lib, weights as _weights
 from .unet import UNet
 
-LOSS_KINDS = {"BCELoss": 0, "MSELoss": 1, "WeightedBCE": 2, "EpochWeightedBCE": 2}
+LOSS_KINDS = {"BCELoss": 0, "MSELoss": 1, "WeightedBCE": 2, "EpochWeightedBCE": 2, "DiceLoss": 3, "Channelwise": 4}
+
+
+def channelwise_spec(losses, chan_losses, out_channels):
+    """``ChannelwiseLoss(losses, chan_losses)`` (custom_loss.py:131-159) as per-channel (kind, weight):
+    entry i of ``losses`` (an ``nn.BCELoss`` / ``nn.MSELoss`` instance, class or name) is applied to
+    ``y_hat[:, chan_losses[i]]`` (an int or a slice), each is a mean over its elements and the result is the
+    mean over entries -> channel weight 1 / (L * n_i)."""
+    if losses is None or chan_losses is None or len(losses) != len(chan_losses) or not len(losses):
+        raise ValueError("Channelwise needs `losses` and `chan_losses` of equal, non-zero length")
+    kinds = [-1] * out_channels
+    wts = [0.0] * out_channels
+    L = len(losses)
+    for lf, sel in zip(losses, chan_losses):
+        name = lf if isinstance(lf, str) else (lf.__name__ if isinstance(lf, type) else type(lf).__name__)
+        if name not in ("BCELoss", "MSELoss"):
+            raise NotImplementedError(f"Channelwise: {name} per channel is not on the accelerated path")
+        idx = list(range(out_channels))[sel] if isinstance(sel, slice) else [int(sel)]
+        for c in idx:
+            if kinds[c] != -1:
+                raise ValueError(f"Channelwise: channel {c} appears in two entries")
+            kinds[c] = LOSS_KINDS[name]
+            wts[c] = 1.0 / (L * len(idx))
+    kinds = [k if k >= 0 else 0 for k in kinds]          # channels no entry covers: weight 0
+    return kinds, wts
 
 
 def trainable_layout(out_channels=5):
@@ -74,39 +98,50 @@ class Trainer:
                                       C.c_void_p(self.adam_v.data_ptr()), n))
 
     # ------------------------------------------------------------------ steps
-    def _call(self, x, y, loss, chan_weights, lr, n_adam, backward):
+    def _call(self, x, y, loss, chan_weights, lr, n_adam, backward, channelwise=None):
         dev = self.params.device
         x = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.float32).to(dev).contiguous()
         y = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y, dtype=torch.float32).to(dev).contiguous()
         assert tuple(x.shape) == self.patch and tuple(y.shape) == (self.out_channels,) + self.patch, (x.shape, y.shape)
         if loss not in LOSS_KINDS:
-            raise ValueError('Valid loss options are BCELoss, WeightedBCE, MSELoss (DiceLoss / Channelwise: not built yet)')
-        cw = None
-        if LOSS_KINDS[loss] == 2:
-            cw = (C.c_float * self.out_channels)(*[float(w) for w in chan_weights])
+            raise ValueError('Valid loss options are BCELoss, WeightedBCE, and DiceLoss')      # train.py:214-216
         out = (C.c_float * (1 + self.out_channels))()
         self.unet._bind_stream()
-        _lib.check(self.unet.ctx.lib.isx_train_step(self.unet.ctx.handle, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
-                                                    LOSS_KINDS[loss], cw, C.c_float(lr), int(n_adam), 1 if backward else 0, out))
+        lib, h = self.unet.ctx.lib, self.unet.ctx.handle
+        if LOSS_KINDS[loss] == 4:
+            kinds, wts = channelwise if channelwise is not None else (None, None)
+            if kinds is None:
+                raise ValueError("Channelwise needs `losses` and `chan_losses`")
+            ck = (C.c_int32 * self.out_channels)(*kinds)
+            cwt = (C.c_float * self.out_channels)(*wts)
+            _lib.check(lib.isx_train_step_channelwise(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), ck, cwt,
+                                                      C.c_float(lr), int(n_adam), 1 if backward else 0, out))
+        else:
+            cw = None
+            if LOSS_KINDS[loss] == 2:
+                cw = (C.c_float * self.out_channels)(*[float(w) for w in chan_weights])
+            _lib.check(lib.isx_train_step(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), LOSS_KINDS[loss], cw,
+                                          C.c_float(lr), int(n_adam), 1 if backward else 0, out))
         return float(out[0]), [float(v) for v in out[1:]]
 
-    def train_step(self, x, y, lr=0.01, loss="BCELoss", chan_weights=None, double_step=True, group=None):
+    def train_step(self, x, y, lr=0.01, loss="BCELoss", chan_weights=None, double_step=True, group=None,
+                   channelwise=None):
         """zero_grad -> forward -> loss -> backward -> Adam (x2 if ``double_step``).  Returns
         ``(loss, per_channel_losses)``."""
         n_adam = 2 if double_step else 1
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            l, cl = self._call(x, y, loss, chan_weights, lr, 0, True)
+            l, cl = self._call(x, y, loss, chan_weights, lr, 0, True, channelwise)
             from .distributed import average_gradients
             average_gradients(self.grads, group)                                     # one flat bucket: 39.9 MB fp32
             self.unet._bind_stream()
             _lib.check(self.unet.ctx.lib.isx_adam_step(self.unet.ctx.handle, C.c_float(lr), n_adam))
             return l, cl
-        return self._call(x, y, loss, chan_weights, lr, n_adam, True)
+        return self._call(x, y, loss, chan_weights, lr, n_adam, True, channelwise)
 
-    def evaluate(self, x, y, loss="BCELoss", chan_weights=None):
+    def evaluate(self, x, y, loss="BCELoss", chan_weights=None, channelwise=None):
         """Validation forward (train-mode BN, no gradient), train.py:366-389."""
-        return self._call(x, y, loss, chan_weights, 0.0, 0, False)
+        return self._call(x, y, loss, chan_weights, 0.0, 0, False, channelwise)
 
     # ------------------------------------------------------------------ state
     def grad(self, key):
@@ -144,8 +179,8 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
     ``(unet, unet_path)`` like the reference; ``unet_path`` is None when ``out_dir`` is None (the reference
     leaves it unbound there, train.py:177-183)."""
     import pandas as pd
-    if fork_channels is not None or losses is not None:
-        raise NotImplementedError("forked decoders / Channelwise loss are not on the accelerated path yet")
+    if fork_channels is not None:
+        raise NotImplementedError("forked decoders are not on the accelerated path yet")
     save_output = out_dir is not None
     print('Output will be saved: ', save_output)
     print('Save directory: ', out_dir)
@@ -160,6 +195,7 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
     if weights is not None:
         sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in weights.items()}
     trainer = Trainer(sd, out_channels=n_out, patch=patch, seed=kwargs.get('seed', 0))
+    cwise = channelwise_spec(losses, chan_losses, n_out) if loss_function == 'Channelwise' else None
     loss_dict = {'epoch': [], 'batch_num': [], 'loss': [], 'data_id': []}
     for c in channels:
         loss_dict[c] = []
@@ -173,7 +209,7 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
     def run_validation(e, batch_no):
         total = 0.0
         for i in range(len(vx)):
-            vl, _ = trainer.evaluate(_load(i, vx), _load(i, vy), loss_function, epoch_weights(e))
+            vl, _ = trainer.evaluate(_load(i, vx), _load(i, vy), loss_function, epoch_weights(e), cwise)
             total += vl
             validation_dict['epoch'].append(e)
             validation_dict['validation_loss'].append(vl)
@@ -189,7 +225,7 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
         running_loss = 0.0
         for i in range(len(x)):
             l, cl = trainer.train_step(_load(i, x), _load(i, y), lr=lr, loss=loss_function,
-                                       chan_weights=epoch_weights(e), double_step=double_step)
+                                       chan_weights=epoch_weights(e), double_step=double_step, channelwise=cwise)
             loss_dict['epoch'].append(e)
             loss_dict['batch_num'].append(i)
             loss_dict['loss'].append(l)

@@ -161,7 +161,17 @@ def loss_fn(name, y_hat, y, chan_weights=None):
         a, b = flatten_channels(y_hat), flatten_channels(y)
         per = F.binary_cross_entropy(a, b, reduction="none").mean(-1)
         return (per * torch.as_tensor(chan_weights, dtype=per.dtype)).mean()
+    if name == "Channelwise":                                # custom_loss.py:131-159, reduction='mean'
+        kinds, sels = chan_weights                           # e.g. (["BCELoss", "MSELoss"], [slice(0, 4), 4])
+        vals = [loss_fn(k, y_hat[:, s], y[:, s]) for k, s in zip(kinds, sels)]
+        return torch.stack(vals).mean()
     raise ValueError(name)
+
+
+def channel_log(name, y_hat, y, chan_weights=None):
+    """What channel_losses_to_dict (custom_loss.py:8-17) logs: the loss applied to y_hat[:, i] -- a
+    (N, Z, Y, X) tensor, so for DiceLoss the z planes take the place of the channels."""
+    return [float(loss_fn(name, y_hat[:, i].detach(), y[:, i].detach(), chan_weights)) for i in range(y_hat.shape[1])]
 
 
 def train_step(sd, x, y, lr=0.01, loss="BCELoss", double_step=True, chan_weights=None, dtype=torch.float32):

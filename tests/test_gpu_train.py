@@ -136,3 +136,44 @@ def test_full_size_patch_against_oracle():
         scale = np.abs(ref).max()
         # measured (scratch/dbg_train.py): both fp32 implementations sit at 0.001 % .. 7 % of max|grad| from float64
         assert mine <= max(10.0 * theirs, 3e-2 * scale) + 1e-9, (k, mine, theirs, scale)
+
+
+@pytest.mark.parametrize("tag,name,arg", [
+    ("dice", "DiceLoss", None),
+    ("channelwise", "Channelwise", (["BCELoss", "MSELoss"], [slice(0, 4), 4])),
+    ("channelwise3", "Channelwise", (["MSELoss", "BCELoss", "BCELoss"], [slice(0, 3), 3, 4])),
+])
+def test_dice_and_channelwise(golden, tag, name, arg):
+    """DiceLoss / ChannelwiseLoss: value against the reference's classes (fixture), every parameter gradient
+    against torch autograd through the oracle with the same loss."""
+    from oracle import unet_torch as ou
+    from iterseg_amd import weights
+    from iterseg_amd.train import channelwise_spec
+    d, g = golden("train_step_4x32x32"), golden("losses_4x32x32")
+    t = _trainer()
+    cw = channelwise_spec(*arg, 5) if arg else None
+    loss, chan = t._call(d["x"], d["y"], name, None, 0.01, 0, True, cw)
+    assert abs(loss - float(g[f"{tag}.loss"])) < 1e-5
+    if tag == "dice":
+        assert np.allclose(chan, g["dice.per_channel_log"], atol=1e-5)
+    _, _, grads, _ = ou.train_step(weights.generate_state_dict(0), d["x"], d["y"], loss=name, chan_weights=arg)
+    for k, shape, off in t.layout:
+        ref = grads[k]
+        got = t.grad(k).detach().cpu().numpy()
+        if k.endswith("conv0.bias") or k.endswith("conv1.bias"):
+            continue                                       # bias in front of BN: float noise on both sides
+        tol = 2e-3 * np.abs(ref).max() + 1e-7
+        assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_train_unet_accepts_dice_and_channelwise():
+    from iterseg_amd import train
+    from tests.synth import positive_volume
+    rng = np.random.default_rng(5)
+    xs = [positive_volume((4, 32, 32), s) for s in range(2)]
+    ys = [(rng.random((5, 4, 32, 32)) < 0.3).astype(np.float32) for _ in range(2)]
+    train.train_unet(xs, xs[:1], ys, ys[:1], epochs=1, loss_function="DiceLoss")
+    train.train_unet(xs, xs[:1], ys, ys[:1], epochs=1, loss_function="Channelwise",
+                     losses=[torch.nn.BCELoss(), torch.nn.MSELoss()], chan_losses=[slice(0, 4), 4])
+    with pytest.raises(ValueError):
+        train.train_unet(xs, xs[:1], ys, ys[:1], epochs=1, loss_function="NoSuchLoss")

@@ -134,3 +134,21 @@ def test_train_step_single_and_double(sd, golden):
     assert abs(float(ou.loss_fn("DiceLoss", yh, yy)) - float(d["loss_dice"])) < 1e-6
     assert abs(float(ou.loss_fn("WeightedBCE", yh, yy, (1., 2., 2., 1., .5))) - float(d["loss_wbce"])) < 1e-6
     assert abs(float(ou.loss_fn("MSELoss", yh, yy)) - float(d["loss_mse"])) < 1e-6
+
+
+def test_dice_and_channelwise_losses_match_reference_classes(golden):
+    """Value, autograd gradient and the per-channel log of DiceLoss / ChannelwiseLoss against the reference's
+    own classes (tests/golden/gen_stage1b_losses.py)."""
+    d, g = golden("train_step_4x32x32"), golden("losses_4x32x32")
+    yy = torch.from_numpy(d["y"])[None]
+    cases = {"dice": ("DiceLoss", None),
+             "channelwise": ("Channelwise", (["BCELoss", "MSELoss"], [slice(0, 4), 4])),
+             "channelwise3": ("Channelwise", (["MSELoss", "BCELoss", "BCELoss"], [slice(0, 3), 3, 4]))}
+    for tag, (name, arg) in cases.items():
+        yh = torch.from_numpy(d["y_hat"]).clone().requires_grad_(True)
+        l = ou.loss_fn(name, yh, yy, arg)
+        l.backward()
+        assert abs(float(l) - float(g[f"{tag}.loss"])) < 1e-6, tag
+        assert np.abs(yh.grad.numpy() - g[f"{tag}.grad"]).max() <= 1e-9 + 1e-5 * np.abs(g[f"{tag}.grad"]).max(), tag
+    log = ou.channel_log("DiceLoss", torch.from_numpy(d["y_hat"]), yy)
+    assert np.allclose(log, g["dice.per_channel_log"], atol=1e-6)
