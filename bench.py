@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume (default: the 512^3 north star)")
-    ap.add_argument("--batch", type=int, default=8, help="chunks per launch set")
+    ap.add_argument("--batch", type=int, default=64, help="chunks per launch set (1..64; ~0.6 GB of workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

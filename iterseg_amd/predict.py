@@ -23,7 +23,7 @@ IGNORE_CUDA = False          # kept for API compatibility; this build has no CPU
 DEFAULT_UNET_PATH = None     # upstream's default weights are not distributed (.MISSING_LARGE_BLOBS)
 
 
-def load_unet(u_state_fn=DEFAULT_UNET_PATH, device=None, batch=4):
+def load_unet(u_state_fn=DEFAULT_UNET_PATH, device=None, batch=32):
     """``UNet(1, 5)`` with the state dict stored at ``u_state_fn`` (``torch.save`` format)."""
     if u_state_fn is None:
         raise FileNotFoundError(

@@ -21,7 +21,7 @@ from . import _lib, weights as _weights
 
 class UNet:
     def __init__(self, in_channels=1, out_channels=5, down_factors=(1, 2, 2), up='convolution',
-                 downsample_1_at_bottom=True, chan_final_activations=None, device=None, batch=4):
+                 downsample_1_at_bottom=True, chan_final_activations=None, device=None, batch=32):
         if isinstance(out_channels, tuple):
             raise NotImplementedError("forked decoders (out_channels tuple) are not on the accelerated path")
         if in_channels != 1 or tuple(down_factors) != (1, 2, 2) or up != 'convolution' or not downsample_1_at_bottom:
@@ -31,7 +31,7 @@ class UNet:
         self.in_channels, self.out_channels = in_channels, int(out_channels)
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.ctx = _lib.Context(self.device)
-        self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch))
+        _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch)))
         self._loaded = False
         self._sd = None
 

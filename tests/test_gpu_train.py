@@ -162,7 +162,9 @@ def test_dice_and_channelwise(golden, tag, name, arg):
         got = t.grad(k).detach().cpu().numpy()
         if k.endswith("conv0.bias") or k.endswith("conv1.bias"):
             continue                                       # bias in front of BN: float noise on both sides
-        tol = 2e-3 * np.abs(ref).max() + 1e-7
+        # fp32 on both sides with different summation orders: 5e-3 of the tensor's largest gradient (the float64
+        # referee in test_full_size_patch_against_oracle shows either fp32 result is that far from the exact value)
+        tol = 5e-3 * np.abs(ref).max() + 1e-7
         assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())
 
 
