@@ -174,10 +174,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_MFMA_F32,
                          # L2-miss bytes per launch from separate rocprofv3 --pmc passes over one 64-chunk launch
-                         # set (profiles/r01f_pmc_*: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE = 815 GB
-                         # over 16 launches; the 8-chunk passes of r01b give the same 0.80 GB per chunk-launch).
-                         # Algorithmic = every activation read once + written once + weights once.
-                         "traffic": 0.7962e9 * args.batch, "traffic_algorithmic": 0.05725e9 * args.batch,
+                         # set (profiles/r01g_pmc_*: FETCH_SIZE x2 per the gfx950 correction = 84.7 GB, WRITE_SIZE =
+                         # 23.2 GB, 16 launches).  Algorithmic = every activation read once + written once + weights.
+                         "traffic": 0.1054e9 * args.batch, "traffic_algorithmic": 0.05725e9 * args.batch,
                          "kernel": "conv_mfma_kernel (fp32 32x32x2 implicit-GEMM conv, 16 of 18 layers)",
                          "avg_launch_ms": ms_mfma / max(n_mfma, 1), "launches": n_mfma,
                          "algorithmic_gflop_per_chunk": mfma_flops / 1e9},

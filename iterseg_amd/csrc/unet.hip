@@ -165,8 +165,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
     float *red = (float *)(rowinfo + ROWS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
-    const int b = blockIdx.x / a.tiles_per_chunk, tile = blockIdx.x % a.tiles_per_chunk;
-    const int ntile = blockIdx.y;
+    // XCD-aware order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own
+    // L2), so give XCD k the k-th contiguous eighth of the tile list -- the work-groups resident on one XCD
+    // are then spatial neighbours and share their halo lines in that XCD's L2.
+    int lin = blockIdx.x;
+    if (a.xcd_remap) {
+        const int per = gridDim.x >> 3, main = per << 3;
+        if (lin < main) lin = (lin & 7) * per + (lin >> 3);
+    }
+    // the N tiles of one voxel tile are adjacent in this order: they read the same halo lines
+    const int ntile = lin % a.ntiles;
+    lin /= a.ntiles;
+    const int b = lin / a.tiles_per_chunk, tile = lin % a.tiles_per_chunk;
     const int D = a.D, H = a.H, W = a.W;
     const int64_t M = (int64_t)D * H * W;
 
@@ -175,13 +185,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
     int z0, y0 = 0, x0 = 0, p0 = 0, qlo = 0, TZ, TP = 0;
     const int WP = W + 2;
     if (a.mode == 0) {
-        int xt = tile % a.ntx, yt = (tile / a.ntx) % a.nty, zt = tile / (a.ntx * a.nty);
+        // z fastest: the tiles in flight on one XCD then cover whole z columns (no z halo re-fetch)
+        const int nzt = (D + 1) >> 1;
+        int zt = tile % nzt, xt = (tile / nzt) % a.ntx, yt = tile / (nzt * a.ntx);
         z0 = zt * 2; y0 = yt * 8; x0 = xt * TXW; TZ = 2;
         RS = TXW + 2; PS = 10 * RS; S = 4 * PS;
     } else {
         TZ = (a.mode == 1) ? 2 : 1;
         TP = ROWS / TZ;
-        int pt = tile % a.ntp, zt = tile / a.ntp;
+        const int nzt = (D + TZ - 1) / TZ;
+        int zt = tile % nzt, pt = tile / nzt;
         z0 = zt * TZ; p0 = pt * TP;
         int plast = p0 + TP - 1;
         if (plast > H * W - 1) plast = H * W - 1;
@@ -838,6 +851,12 @@ int conv_mt(const Level &l, int batch)
     return ((int64_t)batch * l.M >= min_vox) ? 2 : 1;
 }
 
+static int conv_xcd_remap()
+{
+    static const int v = getenv("ISX_CONV_XCD_REMAP") ? atoi(getenv("ISX_CONV_XCD_REMAP")) : 1;
+    return v;
+}
+
 int conv_tiles(const Level &l, int mode, int mt, int *nty, int *ntx, int *ntp, int *slots)
 {
     if (mode == 0) {
@@ -926,11 +945,13 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
     a.store_cols = cout;
     a.no_stats = no_stats;
+    a.xcd_remap = conv_xcd_remap();
     ISX_REQUIRE(a.slots_max <= (mt > 1 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     ISX_REQUIRE(cout % 32 == 0 && (sa.C + sb.C) % 4 == 0, "internal: MFMA conv needs Cout %% 32 == 0, Cin %% 4 == 0");
     const int BN = (cout % 64 == 0) ? 64 : 32;
     size_t lds = (size_t)(27 * 4 * BN + a.slots_max * A_STRIDE + 128 * mt + 4 * BN * 2) * sizeof(float);
-    dim3 grid((unsigned)(B * a.tiles_per_chunk), (unsigned)(cout / BN));
+    a.ntiles = cout / BN;
+    const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
     if (BN == 64 && mt == 2) conv_mfma_kernel<64, 3, 2><<<grid, 256, lds, ctx->stream>>>(a);
     else if (BN == 64) conv_mfma_kernel<64, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
     else if (mt == 2) conv_mfma_kernel<32, 3, 2><<<grid, 256, lds, ctx->stream>>>(a);
@@ -962,9 +983,11 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
             a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
             a.store_cols = 16;
             a.no_stats = 1;
+            a.xcd_remap = conv_xcd_remap();
             ISX_REQUIRE(a.slots_max <= (mt > 1 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
             size_t lds = (size_t)(9 * 4 * 32 + a.slots_max * A_STRIDE + 128 * mt + 4 * 32 * 2) * sizeof(float);
-            const dim3 grid((unsigned)(B * a.tiles_per_chunk), 1);
+            a.ntiles = 1;
+            const unsigned grid = (unsigned)(B * a.tiles_per_chunk);
             if (mt == 2) conv_mfma_kernel<32, 1, 2><<<grid, 256, lds, ctx->stream>>>(a);
             else conv_mfma_kernel<32, 1, 1><<<grid, 256, lds, ctx->stream>>>(a);
             ISX_CHECK_LAUNCH();

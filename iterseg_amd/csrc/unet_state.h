@@ -85,6 +85,8 @@ struct ConvArgs {
     int slots_max;         // LDS halo slots reserved
     int store_cols;        // columns of the N tile actually stored (Cout, or 16 for the folded tail layer)
     int no_stats;          // 1: skip BN partial sums
+    int xcd_remap;         // 1: XCD-contiguous tile order (see the kernel)
+    int ntiles;            // Cout / BN (the grid is 1-D: [chunk][tile][ntile])
 };
 
 extern const char *MODS[9];
