@@ -754,6 +754,7 @@ __device__ __forceinline__ uint32_t cold_bucket(unsigned long long key) { return
 // lane); leaders do the bookkeeping in parallel, members get their slot from the leader.
 __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long long key, uint32_t idx, uint32_t lab, int lane)
 {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // earlier arena stores of this wave are visible
     const uint32_t b = cold_bucket(key);
     int gleader = 0, grank = 0, gsize = 0;
     bool todo = has;
@@ -846,12 +847,14 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(bl, o); bl = t < bl ? t : bl; }
     c.low = bl < c.low ? bl : c.low;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // no wait here: every reader of the arena (cold_append, cold_drain, cold_lowest, the hand-over) starts with
+    // s_waitcnt vmcnt(0), so these stores complete under the LDS work that follows
 }
 
 // lowest non-empty bucket (c.count > 0)
 __device__ __forceinline__ uint32_t cold_lowest(const Cold &c, int lane)
 {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long w1 = lane < COLD_NBK / 4096 ? cld64(&c.bm1[lane]) : 0ull;
     const unsigned long long nz = __ballot(w1 != 0ull);
     const int wi = __ffsll((long long)nz) - 1;
@@ -1080,7 +1083,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     bool serial = (ns > hot_cap) && !cold.on;
     bool started = false;
     int stage_from = 0, stage_to = 0;       // staged elements that never reached a bucket (arena exhausted)
-    unsigned long long st_rounds = 0, st_pops = 0, st_reg = 0, st_run = 0, st_cold = 0, st_drain = 0, st_evict = 0, st_shift = 0;
+    unsigned long long st_rounds = 0, st_pops = 0, st_reg = 0, st_run = 0, st_cold = 0, st_drain = 0, st_evict = 0, st_shift = 0, st_oob = 0;
 
     if (!serial) {
         started = true;
@@ -1131,28 +1134,33 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         ++st_rounds;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // last round's label stores are in L2
         const bool act = lane < rcount;
-        const int64_t idx = act ? (int64_t)ri : 0;
+        // idle lanes look at rank 0's voxel (an interior mask voxel): their loads below are unconditional and
+        // must stay inside the padded volume
+        const uint32_t ri0 = __shfl(ri, 0);            // outside the select: a shuffle in a ternary arm runs divergent
+        const int64_t idx = act ? (int64_t)ri : (int64_t)ri0;
         // ---- every lane looks at its six neighbours as if it were popped now -------------------------
+        // mask, label and edge value of all six neighbours are loaded unconditionally and together: one memory
+        // round trip instead of three dependent ones (the padded border keeps every address in bounds)
         bool cand[6];
         float val[6];
         int64_t nbv[6];
+        uint8_t mk[6];
+        uint32_t lb[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             nbv[k] = idx + noff[k];
-            cand[k] = false;
-            val[k] = 0.f;
-            if (act && mask[nbv[k]])
-                cand[k] = __hip_atomic_load(&out[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+            if (nbv[k] < 0 || nbv[k] >= PN) { nbv[k] = idx; ++st_oob; }    // cannot happen (padded border); never fault
+            mk[k] = mask[nbv[k]];
+            lb[k] = __hip_atomic_load(&out[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            val[k] = aff[(int64_t)ax[k] * PN + (k < 3 ? idx : nbv[k])];
         }
         const uint32_t mytag = (epoch << 6) | (uint32_t)(63 - lane);
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (cand[k]) {
-                atomicMax(&claim[nbv[k]], mytag);
-                float v = aff[(int64_t)ax[k] * PN + (k < 3 ? idx : nbv[k])];
-                v = v * sc[ax[k]];
-                val[k] = v + 0.0f;                                       // -0.0 == +0.0 in the order
-            }
+        for (int k = 0; k < 6; ++k) {
+            cand[k] = act && mk[k] && lb[k] == 0u;
+            if (cand[k]) atomicMax(&claim[nbv[k]], mytag);
+            val[k] = val[k] * sc[ax[k]] + 0.0f;                          // -0.0 == +0.0 in the order
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every lane's claims are performed
         // ---- who won what; smallest value each lane would push ------------------------------------------
         uint32_t wonmask = 0, mymin = 0xFFFFFFFFu;
@@ -1319,9 +1327,11 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         atomicAdd(&stats[0], st_rounds); atomicAdd(&stats[1], st_pops); atomicAdd(&stats[2], st_reg); atomicAdd(&stats[3], st_run);
         atomicAdd(&stats[4], st_cold); atomicAdd(&stats[5], st_drain); atomicAdd(&stats[6], st_evict); atomicAdd(&stats[7], st_shift);
         if (serial) atomicAdd(&stats[8], 1ull);
+        if (st_oob) atomicAdd(&stats[9], st_oob);
     }
     if (serial) {
         // Exact continuation on one lane: move the whole queue (registers, run, staged, buckets) into the binary heap.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t hn = 0;
         if (!started) {
             if (lane == 0)
@@ -1460,8 +1470,8 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         unsigned long long hs[16];
         ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         ISX_HIP(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[isx flood] rounds %llu pops %llu (%.2f/round) reg_ins %llu run_ins %llu (avg shift %.1f) cold_app %llu drains %llu evicted %llu serial_handover %llu\n",
-                hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[3], hs[3] ? (double)hs[7] / hs[3] : 0.0, hs[4], hs[5], hs[6], hs[8]);
+        fprintf(stderr, "[isx flood] rounds %llu pops %llu (%.2f/round) reg_ins %llu run_ins %llu (avg shift %.1f) cold_app %llu drains %llu evicted %llu serial_handover %llu oob %llu\n",
+                hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[3], hs[3] ? (double)hs[7] / hs[3] : 0.0, hs[4], hs[5], hs[6], hs[8], hs[9]);
     }
     return ISX_OK;
 }
