@@ -355,10 +355,17 @@ struct WgradArgs {
     float *partial;
 };
 
+// TCO x TCI output tile (32 or 64 each) = NSUB 32x32 sub-tiles; with fewer than 4 sub-tiles the waves also split the
+// 64 voxels of a K block between them (KG groups) and their accumulators are summed through LDS at the end, so a
+// 32-channel layer no longer computes a zero-padded 64x64 tile.  The next block is prefetched into registers
+// while the matrix cores work on the current one.
+template <int TCO, int TCI>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
 {
-    __shared__ float Ys[64 * 64];
-    __shared__ float Xs[64 * 64];
+    constexpr int NSUB = (TCO / 32) * (TCI / 32), KG = 4 / NSUB, KSTEPS = 32 / KG;
+    constexpr int NY = TCO / 16, NX = TCI / 16;             // float4 per thread per block (64 voxels x TC / 4 / 256)
+    __shared__ __attribute__((aligned(16))) float Ys[64 * TCO];
+    __shared__ __attribute__((aligned(16))) float Xs[64 * TCI];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
     const int co_t = blockIdx.x / a.ci_tiles, ci_t = blockIdx.x % a.ci_tiles;
     const int tap = blockIdx.y, split = blockIdx.z;
@@ -368,59 +375,104 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
     const int64_t v_begin = (int64_t)split * a.vox_per_split;
     int64_t v_end = v_begin + a.vox_per_split;
     if (v_end > M) v_end = M;
-    const int wr = wave >> 1, wc = wave & 1;              // this wave's 32x32 sub-tile
+    const int sub = wave % NSUB, kg = wave / NSUB;
+    const int wr = sub / (TCI / 32), wc = sub % (TCI / 32);
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // staging role: 16 lanes cover the 64 channels of one voxel (float4 each), 16 voxels per pass, 4 passes
-    const int q = tid & 15, vs = tid >> 4;
-    const int co0 = co_t * 64, ci0 = ci_t * 64;
-    for (int64_t v0 = v_begin; v0 < v_end; v0 += 64) {
-        __syncthreads();
+    const int co0 = co_t * TCO, ci0 = ci_t * TCI;
+    // staging roles: TCO/4 (TCI/4) lanes cover the channels of one voxel with a float4 each
+    constexpr int YQ = TCO / 4, XQ = TCI / 4, YV = 256 / YQ, XV = 256 / XQ;     // voxels per pass
+    const int yq = tid % YQ, yv = tid / YQ, xq = tid % XQ, xv = tid / XQ;
+    float4 ry[NY], rx[NX];
+
+    auto load_block = [&](int64_t v0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int vl = vs + 16 * p;
-            const int64_t v = v0 + vl;
-            float4 yv = make_float4(0.f, 0.f, 0.f, 0.f), xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < NY; ++p) {
+            const int64_t v = v0 + yv + YV * p;
+            float4 yvv = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int co = co0 + 4 * yq;
             if (v < v_end) {
-                const int co = co0 + 4 * q;
-                if (co + 3 < a.Cout) yv = *(const float4 *)&a.dy[v * a.dy_stride + co];
+                if (co + 3 < a.Cout) yvv = *(const float4 *)&a.dy[v * a.dy_stride + co];
                 else
                     for (int j = 0; j < 4; ++j)
-                        if (co + j < a.Cout) (&yv.x)[j] = a.dy[v * a.dy_stride + co + j];
+                        if (co + j < a.Cout) (&yvv.x)[j] = a.dy[v * a.dy_stride + co + j];
+            }
+            ry[p] = yvv;
+        }
+#pragma unroll
+        for (int p = 0; p < NX; ++p) {
+            const int64_t v = v0 + xv + XV * p;
+            float4 xvv = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ci = ci0 + 4 * xq;
+            if (v < v_end && ci < Cin) {
                 const int x = (int)(v % W) + dx, y = (int)((v / W) % H) + dy, z = (int)(v / ((int64_t)W * H)) + dz;
-                const int ci = ci0 + 4 * q;
-                if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W && ci < Cin) {
+                if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
                     const int64_t g = ((int64_t)z * H + y) * W + x;
                     const bool fromB = ci >= a.CA;
                     const float *src = fromB ? a.srcB : a.srcA, *sc = fromB ? a.scaleB : a.scaleA, *sh = fromB ? a.shiftB : a.shiftA;
                     const int C = fromB ? a.CB : a.CA, cc = fromB ? ci - a.CA : ci;
-                    for (int j = 0; j < 4; ++j)
-                        if (cc + j < C) {
-                            float t = src[g * C + cc + j];
-                            if (sc) t = fmaxf(fmaf(t, sc[cc + j], sh[cc + j]), 0.f);
-                            (&xv.x)[j] = t;
+                    if (cc + 3 < C) {
+                        xvv = *(const float4 *)&src[g * C + cc];
+                        if (sc) {
+                            const float4 s4 = *(const float4 *)&sc[cc], h4 = *(const float4 *)&sh[cc];
+                            xvv.x = fmaxf(fmaf(xvv.x, s4.x, h4.x), 0.f);
+                            xvv.y = fmaxf(fmaf(xvv.y, s4.y, h4.y), 0.f);
+                            xvv.z = fmaxf(fmaf(xvv.z, s4.z, h4.z), 0.f);
+                            xvv.w = fmaxf(fmaf(xvv.w, s4.w, h4.w), 0.f);
                         }
+                    } else {
+                        for (int j = 0; j < 4; ++j)
+                            if (cc + j < C) {
+                                float t = src[g * C + cc + j];
+                                if (sc) t = fmaxf(fmaf(t, sc[cc + j], sh[cc + j]), 0.f);
+                                (&xvv.x)[j] = t;
+                            }
+                    }
                 }
             }
-            *(float4 *)&Ys[vl * 64 + 4 * q] = yv;
-            *(float4 *)&Xs[vl * 64 + 4 * q] = xv;
+            rx[p] = xvv;
         }
+    };
+
+    if (v_begin < v_end) load_block(v_begin);
+    for (int64_t v0 = v_begin; v0 < v_end; v0 += 64) {
         __syncthreads();
-        const float *yp = Ys + hh * 64 + wr * 32 + nn;
-        const float *xp = Xs + hh * 64 + wc * 32 + nn;
 #pragma unroll
-        for (int k = 0; k < 32; ++k)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[k * 128], xp[k * 128], acc, 0, 0, 0);
+        for (int p = 0; p < NY; ++p) *(float4 *)&Ys[(yv + YV * p) * TCO + 4 * yq] = ry[p];
+#pragma unroll
+        for (int p = 0; p < NX; ++p) *(float4 *)&Xs[(xv + XV * p) * TCI + 4 * xq] = rx[p];
+        __syncthreads();
+        if (v0 + 64 < v_end) load_block(v0 + 64);          // in flight while the matrix cores run
+        const float *yp = Ys + (kg * 2 * KSTEPS + hh) * TCO + wr * 32 + nn;
+        const float *xp = Xs + (kg * 2 * KSTEPS + hh) * TCI + wc * 32 + nn;
+#pragma unroll
+        for (int k = 0; k < KSTEPS; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[k * 2 * TCO], xp[k * 2 * TCI], acc, 0, 0, 0);
     }
-    // D layout: column (ci) = lane & 31, row (co) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
-    const int CoP = a.co_tiles * 64, CiP = a.ci_tiles * 64;
-    float *dst = a.partial + (((int64_t)split * 27 + tap) * CoP) * CiP;
+    // sum the K groups (fixed order), then store.  D layout: column (ci) = lane & 31,
+    // row (co) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+    if (KG > 1) {
+        __shared__ float red[(KG > 1 ? (KG - 1) * NSUB : 1) * 1024];       // [KG-1][NSUB][16][64]
+        __syncthreads();
+        if (kg > 0)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int co = co0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const int ci = ci0 + wc * 32 + nn;
-        dst[(int64_t)co * CiP + ci] = acc[i];
+            for (int i = 0; i < 16; ++i) red[(((kg - 1) * NSUB + sub) * 16 + i) * 64 + lane] = acc[i];
+        __syncthreads();
+        if (kg == 0)
+            for (int g = 1; g < KG; ++g)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += red[(((g - 1) * NSUB + sub) * 16 + i) * 64 + lane];
+    }
+    if (kg == 0) {
+        const int CoP = a.co_tiles * TCO, CiP = a.ci_tiles * TCI;
+        float *dst = a.partial + (((int64_t)split * 27 + tap) * CoP) * CiP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = co0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int ci = ci0 + wc * 32 + nn;
+            dst[(int64_t)co * CiP + ci] = acc[i];
+        }
     }
 }
 
@@ -715,23 +767,28 @@ static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
     a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
     a.Cout = L.cout;
     a.D = l.D; a.H = l.H; a.W = l.W;
-    a.co_tiles = (L.cout + 63) / 64;
-    a.ci_tiles = (L.cin + 63) / 64;
+    const int tco = L.cout <= 32 ? 32 : 64, tci = L.cin <= 32 ? 32 : 64;
+    a.co_tiles = (L.cout + tco - 1) / tco;
+    a.ci_tiles = (L.cin + tci - 1) / tci;
     const int64_t chunks = (l.M + 63) / 64;
-    int want = 2048 / (a.co_tiles * a.ci_tiles * 27) + 1;          // enough work-groups to fill the chip
-    if (want > chunks) want = (int)chunks;
-    if (want > 64) want = 64;
+    int want = 4096 / (a.co_tiles * a.ci_tiles * 27) + 1;          // enough work-groups to fill the chip
+    if (want > chunks / 4) want = (int)std::max<int64_t>(1, chunks / 4);     // at least 4 K blocks per work-group
+    if (want > 256) want = 256;
     a.vox_per_split = ((chunks + want - 1) / want) * 64;
     a.splits = (int)((l.M + a.vox_per_split - 1) / a.vox_per_split);
     a.partial = t->wpart;
-    const size_t need = (size_t)a.splits * 27 * a.co_tiles * 64 * a.ci_tiles * 64;
+    const size_t need = (size_t)a.splits * 27 * a.co_tiles * tco * a.ci_tiles * tci;
     ISX_REQUIRE(need <= t->wpart_floats, "internal: wgrad partial buffer too small (%zu > %zu)", need, t->wpart_floats);
-    wgrad_mfma_kernel<<<dim3(a.co_tiles * a.ci_tiles, 27, a.splits), 256, 0, ctx->stream>>>(a);
+    const dim3 wgrid(a.co_tiles * a.ci_tiles, 27, a.splits);
+    if (tco == 64 && tci == 64) wgrad_mfma_kernel<64, 64><<<wgrid, 256, 0, ctx->stream>>>(a);
+    else if (tco == 32 && tci == 64) wgrad_mfma_kernel<32, 64><<<wgrid, 256, 0, ctx->stream>>>(a);
+    else if (tco == 64 && tci == 32) wgrad_mfma_kernel<64, 32><<<wgrid, 256, 0, ctx->stream>>>(a);
+    else wgrad_mfma_kernel<32, 32><<<wgrid, 256, 0, ctx->stream>>>(a);
     ISX_CHECK_LAUNCH();
     const int64_t n = (int64_t)L.cout * L.cin * 27;
     unsigned grid = cdiv(n, 256);
     if (grid > 4096) grid = 4096;
-    wgrad_reduce_kernel<<<grid, 256, 0, ctx->stream>>>(t->wpart, a.splits, L.cout, L.cin, a.co_tiles * 64, a.ci_tiles * 64,
+    wgrad_reduce_kernel<<<grid, 256, 0, ctx->stream>>>(t->wpart, a.splits, L.cout, L.cin, a.co_tiles * tco, a.ci_tiles * tci,
                                                     t->G + t->off_w[li]);
     ISX_CHECK_LAUNCH();
     return ISX_OK;
@@ -906,10 +963,11 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
     size_t wp = 0;
     for (int li = 0; li < 18; ++li) {
         const ConvBN &L = u->cv[li];
-        size_t tiles = (size_t)((L.cout + 63) / 64) * ((L.cin + 63) / 64);
-        size_t splits = 2048 / (tiles * 27) + 1;
-        if (splits > 64) splits = 64;
-        wp = std::max(wp, (splits + 1) * 27 * tiles * 64 * 64);
+        const size_t tco = L.cout <= 32 ? 32 : 64, tci = L.cin <= 32 ? 32 : 64;       // as in wgrad()
+        size_t tiles = ((L.cout + tco - 1) / tco) * ((L.cin + tci - 1) / tci);
+        size_t splits = 4096 / (tiles * 27) + 1;
+        if (splits > 256) splits = 256;
+        wp = std::max(wp, (splits + 1) * 27 * tiles * tco * tci);
     }
     t->wpart_floats = wp;
     ISX_TRY(talloc(t, wp, &t->wpart));
