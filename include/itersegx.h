@@ -153,6 +153,13 @@ int isx_train_refresh_weights(isx_ctx *ctx);
 /* ---------------------------------------------------------------------------------- *
  * Watershed post-processor -- src/iterseg/watershed.py.                                 *
  * ---------------------------------------------------------------------------------- */
+/* Multi-GPU flood: the flood decomposes exactly over 6-connected mask components (the heap order inside one
+ * component does not depend on the others: watershed.py:95-159), so with world > 1 this context
+ * floods only the components of its rank -- contiguous ranges of the root-ordered component list balanced by
+ * voxel count, the same on every rank -- and leaves the voxels of the others 0 (seed voxels are labelled on every
+ * rank).  The caller combines the label volumes with an element-wise max (RCCL all-reduce).  Applies to
+ * isx_affinity_watershed / isx_segment_output_image / isx_segment_volume*; (0, 1) restores the default. */
+int isx_ws_set_shard(isx_ctx *ctx, int rank, int world);
 /* skimage.filters.gaussian as used at watershed.py:227 / :234: float32 in/out, per-axis
  * sigma in {0,1,2}, border 'nearest', truncate 4, double accumulation per pass. */
 int isx_ws_gaussian(isx_ctx *ctx, const float *img, float *out, const int64_t shape[3],

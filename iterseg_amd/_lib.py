@@ -52,6 +52,7 @@ SIGNATURES = {
     "isx_train_step_channelwise": (C.c_int, [_vp, _vp, _vp, _i32p, _f32p, _f32, C.c_int, C.c_int, _f32p]),
     "isx_adam_step": (C.c_int, [_vp, _f32, C.c_int]),
     "isx_train_refresh_weights": (C.c_int, [_vp]),
+    "isx_ws_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
     "isx_ws_gaussian": (C.c_int, [_vp, _vp, _vp, _i64p, _i32p]),
     "isx_ws_threshold_otsu": (C.c_int, [_vp, _vp, _i64, _f32p]),
     "isx_ws_mask": (C.c_int, [_vp, _vp, _i64p, _vp, _f32p]),
@@ -145,6 +146,10 @@ class Context:
 
     def release_workspace(self):
         self.lib.isx_ctx_release_workspace(self._h)
+
+    def set_flood_shard(self, rank=0, world=1):
+        """Flood only the mask components of ``rank`` out of ``world`` (isx_ws_set_shard); (0, 1) = all."""
+        check(self.lib.isx_ws_set_shard(self._h, int(rank), int(world)))
 
     def prof_enable(self, on=True):
         check(self.lib.isx_prof_enable(self._h, 1 if on else 0))

@@ -73,6 +73,7 @@ struct isx_ctx {
     double prof_ms[ISX_PROF_NCLASS] = {0};
     int64_t prof_n[ISX_PROF_NCLASS] = {0};
     isx::UNetState *unet = nullptr;
+    int ws_shard_rank = 0, ws_shard_world = 1;     // W4 component sharding (isx_ws_set_shard)
 
     void *alloc(size_t bytes);
     void release(void *p);

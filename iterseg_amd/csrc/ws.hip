@@ -664,15 +664,27 @@ __device__ __forceinline__ void serial_flood(HeapEnt *h, uint32_t hn, uint32_t a
 }
 
 // Small components: one lane per component (thousands of them run side by side).
+// Component -> rank for the multi-GPU flood (W4 shards exactly by mask component, F4): contiguous
+// ranges of the (root-sorted) component list balanced by voxel count; identical on every rank.
+__device__ __forceinline__ bool comp_owned(const unsigned long long *comp_off, uint32_t c, uint32_t n_comp, int rank, int world)
+{
+    if (world <= 1) return true;
+    const unsigned long long total = comp_off[n_comp];
+    const int owner = total ? (int)((comp_off[c] * (unsigned long long)world) / total) : 0;
+    return owner == rank;
+}
+
 __global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__restrict__ mask,
                              uint32_t *__restrict__ out, const unsigned long long *__restrict__ keys,
                              uint32_t n_seeds, const uint32_t *__restrict__ comp_first,
                              const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
                              HeapEnt *__restrict__ heap_pool, int64_t PY, int64_t PX, int64_t PN,
-                             float s0, float s1, float s2, unsigned long long coop_min_size)
+                             float s0, float s1, float s2, unsigned long long coop_min_size, int shard_rank,
+                             int shard_world)
 {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_comp) return;
+    if (!comp_owned(comp_off, c, n_comp, shard_rank, shard_world)) return;
     uint32_t first = comp_first[c];
     uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
     if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;   // seeds outside the mask never spread
@@ -1026,7 +1038,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
     HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
     int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long coop_min_size, int run_limit,
-    int drain_n, unsigned long long *stats)
+    int drain_n, unsigned long long *stats, int shard_rank, int shard_world)
 {
     __shared__ HeapEnt srun[COOP_SCAP];          // .pad carries the element's label
     __shared__ HeapEnt stage[6 * 64];            // elements of this round bound for the cold tier
@@ -1034,6 +1046,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     const uint32_t c = blockIdx.x;
     const int lane = threadIdx.x;
     if (c >= n_comp) return;
+    if (!comp_owned(comp_off, c, n_comp, shard_rank, shard_world)) return;
     const uint32_t first = comp_first[c];
     const uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
     if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;
@@ -1459,12 +1472,14 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     // each picks its own by size -- no host round trip to split the list)
     flood_kernel<<<cdiv(n_comp, 64), 64, 0, ctx->stream>>>(aff, mask, out, keys_sorted.p, n_seeds,
                                                           comp_first.p, comp_off.p, n_comp, pool.p,
-                                                          pshape[1], pshape[2], PN, s[0], s[1], s[2], coop_min);
+                                                          pshape[1], pshape[2], PN, s[0], s[1], s[2], coop_min,
+                                                          ctx->ws_shard_rank, ctx->ws_shard_world);
     ISX_CHECK_LAUNCH();
     ISX_HIP(hipMemsetAsync(claim.p, 0, (size_t)PN * sizeof(uint32_t), ctx->stream));
     flood_wave_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, claim.p, keys_sorted.p, n_seeds, comp_first.p,
                                                       comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
-                                                      pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, stats.p);
+                                                      pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, stats.p,
+                                                      ctx->ws_shard_rank, ctx->ws_shard_world);
     ISX_CHECK_LAUNCH();
     if (getenv("ISX_FLOOD_STATS")) {
         unsigned long long hs[16];
@@ -1511,6 +1526,14 @@ static int seeds_impl(isx_ctx *ctx, const float *cent, const int64_t shape[3], i
 using namespace isx;
 
 extern "C" {
+
+int isx_ws_set_shard(isx_ctx *ctx, int rank, int world)
+{
+    ISX_REQUIRE(ctx && world >= 1 && rank >= 0 && rank < world, "shard (%d of %d)", rank, world);
+    ctx->ws_shard_rank = rank;
+    ctx->ws_shard_world = world;
+    return ISX_OK;
+}
 
 int isx_ws_gaussian(isx_ctx *ctx, const float *img, float *out, const int64_t shape[3],
                     const int32_t sigma[3])

@@ -181,13 +181,14 @@ def affinity_watershed(image, marker_coords, mask, scale=None, out=None, py_func
 
 
 def segment_output_image(unet_output, affinities_channels, centroids_channel, thresholding_channel,
-                         scale=None, absolute_thresh=None, out=None, py_func=False):
+                         scale=None, absolute_thresh=None, out=None, py_func=False, ctx=None):
     """W0-W4 (watershed.py:165-223).  Returns ``(segmentation, seeds, mask)`` like the reference:
     unpadded labels, unpadded seed coordinates, padded boolean mask.  With ``out`` given
     (flat, padded size -- ``current_output.ravel()`` on the plugin path) labels are written in
     place.  Hard-coded like upstream: min_area=10, max_area=10_000_000, threshold_abs=0.04."""
     dev = _device_of(unet_output)
-    ctx = get_context(dev.index)
+    if ctx is None:                      # ``ctx``: run on a caller-owned context (e.g. one with a flood shard set)
+        ctx = get_context(dev.index)
     if isinstance(unet_output, torch.Tensor):
         fm, was_np = unet_output.squeeze().to(dev, torch.float32), False
     else:

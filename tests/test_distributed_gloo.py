@@ -30,6 +30,31 @@ def _frame_labels(frame):
     return lab[1:-1, 1:-1, 1:-1].astype(np.int32)
 
 
+def _component_sharded_labels(rank, world):
+    """(full labels, labels of the components ``rank`` owns) with the product's ownership rule restated on the
+    host: components in root order, owner = floor(voxel offset * world / total voxels)."""
+    from scipy import ndimage as ndi
+    from oracle import watershed as ows
+    from tests.synth import blob_feature_map
+    fm = blob_feature_map((16, 40, 40), 3, 0.25, 2.0)
+    pshape = tuple(s + 2 for s in fm.shape[1:])
+    full = np.zeros(pshape, np.uint32)
+    _, seeds, mask = ows.segment_output_image(fm, out=full.ravel())
+    aff = np.zeros((3,) + pshape, np.float32)
+    aff[:, 1:-1, 1:-1, 1:-1] = fm[:3] / fm[:3].reshape(3, -1).max(1)[:, None, None, None]
+    comp, n = ndi.label(mask)                       # label ids follow the smallest raveled index = root order
+    sizes = ndi.sum(mask, comp, index=np.arange(1, n + 1)).astype(np.int64)
+    seeded = [c for c in range(1, n + 1) if (comp[tuple((seeds + 1).T)] == c).any()]
+    off = np.concatenate([[0], np.cumsum([sizes[c - 1] for c in seeded])])
+    owned = np.zeros(pshape, np.uint32)
+    for k, (zz, yy, xx) in enumerate(seeds + 1):
+        owned[zz, yy, xx] = k + 1                   # seed voxels are labelled on every rank
+    for j, c in enumerate(seeded):
+        if int(off[j] * world // off[-1]) == rank:
+            owned[comp == c] = full[comp == c]
+    return full.astype(np.int32), owned.astype(np.int32)
+
+
 def _stack():
     rng = np.random.default_rng(5)
     return rng.random((5, 8, 24, 24), dtype=np.float32)          # 5 frames: uneven split over 2 ranks
@@ -61,6 +86,12 @@ def _worker(rank, world, port, q):
         for r in range(world):
             expect[r::7] += 0.25
         assert torch.equal(g, expect)
+        # component-sharded flood: each rank floods the components its range owns (oracle, one component at a
+        # time), the max all-reduce must rebuild the single-process labels
+        from iterseg_amd.distributed import combine_labels
+        full, owned = _component_sharded_labels(rank, world)
+        lab = combine_labels(torch.from_numpy(owned))
+        assert torch.equal(lab, torch.from_numpy(full))
         q.put((rank, out.numpy(), fm.numpy()))
         dist.barrier()
     finally:

@@ -177,3 +177,35 @@ def test_flood_paths_against_oracle(ws, kind, shape, seed, flood_path):
     ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=cur.ravel())
     assert np.array_equal(cur, ref)
     assert (cur > 0).sum() > 1000
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_component_sharded_flood_union_is_exact(ws, world):
+    """Multi-GPU flood (isx_ws_set_shard): every rank floods its own range of mask components; the element-wise
+    max of the rank outputs is the unsharded result, supports are disjoint apart from the seed voxels."""
+    import torch
+    from tests.synth import blob_feature_map
+    fm = torch.from_numpy(blob_feature_map((24, 64, 64), 5, 0.2, 2.5)).cuda()
+    ctx = ws.get_context()
+    pshape = tuple(s + 2 for s in fm.shape[1:])
+    full = torch.zeros(pshape, dtype=torch.int32, device="cuda")
+    _, seeds, _ = ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=full)
+    union = torch.zeros_like(full)
+    nonseed_hits = torch.zeros(pshape, dtype=torch.int32, device="cuda")
+    sz, sy, sx = (seeds + 1).T
+    try:
+        for r in range(world):
+            ctx.set_flood_shard(r, world)
+            part = torch.zeros_like(full)
+            ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=part, ctx=ctx)
+            assert torch.equal(part[sz, sy, sx], full[sz, sy, sx])        # seeds labelled on every rank
+            hit = (part > 0).to(torch.int32)
+            hit[sz, sy, sx] = 0
+            nonseed_hits += hit
+            union = torch.maximum(union, part)
+    finally:
+        ctx.set_flood_shard(0, 1)
+    assert torch.equal(union, full)
+    assert int(nonseed_hits.max()) == 1 and len(seeds) > world            # disjoint supports
+    with pytest.raises(ValueError):
+        ctx.set_flood_shard(2, 2)
