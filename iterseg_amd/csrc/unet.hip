@@ -841,13 +841,15 @@ int conv_mode(const Level &l)
     return (l.D % 2 == 0) ? 1 : 2;
 }
 
-// Two GEMM row tiles per wave (256 voxels per workgroup): halves the weight-slab staging per voxel but
-// runs at 2 waves/SIMD instead of 4; measured 3 % SLOWER end to end on MI355X (profiles/README.md), so
-// it is off unless ISX_CONV_MT2_MIN_VOX lowers the threshold.  Decided from the workspace batch so
-// that the partial-sum layout of a layer never changes.
-int conv_mt(const Level &l, int batch)
+// Two GEMM row tiles per wave (256 voxels per workgroup): halves the weight-slab staging per voxel and doubles the
+// MFMAs per LDS read, but runs at fewer waves per SIMD.  Measured on MI355X (scratch/layer_eff.py): 3 % slower for
+// the 64-column layers; for the 32-column layers +3 % at level 0 and -5 % at 129^2 (16-wide tiles pad more), a wash
+// end to end.  So it is off; ISX_CONV_MT2_MIN_VOX turns it on for launches above that many voxels.  Decided from
+// the workspace batch so that the partial-sum layout of a layer never changes.
+int conv_mt(const Level &l, int batch, int cout)
 {
     static const long min_vox = getenv("ISX_CONV_MT2_MIN_VOX") ? atol(getenv("ISX_CONV_MT2_MIN_VOX")) : (1L << 60);
+    (void)cout;
     return ((int64_t)batch * l.M >= min_vox) ? 2 : 1;
 }
 
@@ -880,7 +882,7 @@ static int layer_tiles(const UNetState *u, int li, const Level &l, int batch)
     const ConvBN &L = u->cv[li];
     if (use_mfma(L.cin, L.cout)) {
         int a, b, c, d;
-        return conv_tiles(l, conv_mode(l), conv_mt(l, batch), &a, &b, &c, &d);
+        return conv_tiles(l, conv_mode(l), conv_mt(l, batch, L.cout > 8 ? L.cout : 32), &a, &b, &c, &d);
     }
     if (L.cin == 1) return (int)((l.M + 127) / 128);
     return (int)((l.M + 255) / 256);      // thin kernel blocks, or combine blocks of the folded layer
@@ -941,7 +943,7 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     a.w = w_packed; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
     a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = cout;
     a.mode = conv_mode(l);
-    const int mt = conv_mt(l, ctx->unet->wbatch);
+    const int mt = conv_mt(l, ctx->unet->wbatch, cout);
     a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
     a.store_cols = cout;
     a.no_stats = no_stats;
@@ -979,7 +981,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
             a.w = L.w; a.bias = u->zeros32; a.out = u->ptail; a.psum = nullptr; a.psq = nullptr;
             a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = 32;
             a.mode = conv_mode(l);
-            const int mt = conv_mt(l, u->wbatch);
+            const int mt = conv_mt(l, u->wbatch, 32);
             a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
             a.store_cols = 16;
             a.no_stats = 1;
