@@ -46,6 +46,7 @@ SIGNATURES = {
     "isx_predict_volume": (C.c_int, [_vp, _vp, _i64p, _i32p, _i64, _i64, _i64p, _vp]),
     "isx_unet_tap_host": (C.c_int, [_vp, C.c_char_p, _vp, _i64, _i64p]),
     "isx_unet_set_batch": (C.c_int, [_vp, C.c_int]),
+    "isx_unet_set_precision": (C.c_int, [_vp, C.c_int]),
     "isx_train_param_count": (_i64, [_vp]),
     "isx_train_bind": (C.c_int, [_vp, _i64p, _vp, _vp, _vp, _vp, _i64]),
     "isx_train_step": (C.c_int, [_vp, _vp, _vp, C.c_int, _f32p, _f32, C.c_int, C.c_int, _f32p]),

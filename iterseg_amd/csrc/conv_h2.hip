@@ -1,0 +1,331 @@
+// conv_h2.hip -- 3x3x3 convolution on the fp16 matrix cores with fp32-class accuracy ("split" operands).
+//
+// Replaces the same reference operator as conv_mfma_kernel (nn.Conv3d inside ConvModule.forward,
+// src/iterseg/unet.py:63-79,91-106) for the wide layers when the context's precision is ISX_PRECISION_SPLIT_F16.
+//
+// Arithmetic.  Every fp32 operand x is split as  x = x_h + x_l / 2^11 (+ residual <= 2^-22 |x|):
+//     x_h = half(x)                     (0 if |x| < 2^-14, so no operand is subnormal)
+//     x_l = half((x - x_h) * 2^11)      (0 if that is below 2^-14: absolute error <= 3e-8)
+// and a product a*b is accumulated as  a_h*b_h  (accumulator HI)  +  (a_h*b_l + a_l*b_h)  (accumulator LO, carrying
+// the 2^11 scale), the a_l*b_l term (2^-22 relative) is dropped.  All three partial products are exact in fp32
+// (11 x 11 significant bits) and both accumulators are fp32, so the result differs from an fp32 convolution by
+// about 2^-21 per product -- below the rounding noise of the fp32 accumulation over K >= 864 terms.  The epilogue
+// returns HI + LO * 2^-11 + bias.  Operands are clamped to +-65504 (post-BatchNorm activations are nowhere near).
+//
+// Structure: as conv_mfma_kernel (128 voxels x BN columns per work-group, halo tile of the input in LDS reused by
+// all 27 taps, register prefetch of the next stage, BN+ReLU of the producer and zero padding applied at the LDS
+// store, XCD-aware 1-D grid), with a K stage of 8 input channels: v_mfma_f32_32x32x16_f16 takes k = 8*(lane/32)+j,
+// so lanes 0-31 feed tap 2p and lanes 32-63 tap 2p+1 (j = channel); 14 tap pairs, the 28th tap has zero weights.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "unet_state.h"
+
+namespace isx {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr float H2_SCALE = 2048.f, H2_MIN = 6.103515625e-05f, H2_MAX = 65504.f;
+
+__host__ __device__ inline void split_h2(float x, _Float16 &h, _Float16 &l)
+{
+    x = x < -H2_MAX ? -H2_MAX : (x > H2_MAX ? H2_MAX : x);
+    h = (x < H2_MIN && x > -H2_MIN) ? (_Float16)0.f : (_Float16)x;
+    const float r = (x - (float)h) * H2_SCALE;
+    l = (r < H2_MIN && r > -H2_MIN) ? (_Float16)0.f : (_Float16)r;
+}
+
+// 8 fp32 -> 8 halves (hi) + 8 halves (lo), each packed in a uint4
+__device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo)
+{
+    union { f16x8 v; uint4 u; } H, L;
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        _Float16 h, l;
+        split_h2(x[j], h, l);
+        H.v[j] = h;
+        L.v[j] = l;
+    }
+    hi = H.u;
+    lo = L.u;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+    constexpr int NT = BN / 32;
+    constexpr int BU = 28 * BN;                           // uint4 per half of the weight slab (hi | lo)
+    constexpr int NB = (2 * BU) / 256;                    // uint4 of weights per thread per stage: 14 (BN 64) / 7 (BN 32)
+    static_assert((2 * BU) % 256 == 0, "weight slab must split evenly over the block");
+    uint4 *Bs = smem4;                                    // [hi: 28][BN] | [lo: 28][BN]
+    uint4 *AsH = smem4 + 2 * BU;
+    uint4 *AsL = AsH + a.slots_max;
+    int *rowinfo = (int *)(AsL + a.slots_max);
+    float *red = (float *)(rowinfo + 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
+    int lin = blockIdx.x;
+    if (a.xcd_remap) {
+        const int per = gridDim.x >> 3, main = per << 3;
+        if (lin < main) lin = (lin & 7) * per + (lin >> 3);
+    }
+    const int ntile = lin % a.ntiles;
+    lin /= a.ntiles;
+    const int b = lin / a.tiles_per_chunk, tile = lin % a.tiles_per_chunk;
+    const int D = a.D, H = a.H, W = a.W;
+    const int64_t M = (int64_t)D * H * W;
+
+    // ---- tile geometry: identical to conv_mfma_kernel with one row tile per wave ---------------------------
+    int PS, RS, S;
+    int z0, y0 = 0, x0 = 0, p0 = 0, qlo = 0, TZ, TP = 0;
+    const int WP = W + 2;
+    if (a.mode == 0) {
+        const int nzt = (D + 1) >> 1;
+        int zt = tile % nzt, xt = (tile / nzt) % a.ntx, yt = tile / (nzt * a.ntx);
+        z0 = zt * 2; y0 = yt * 8; x0 = xt * 8; TZ = 2;
+        RS = 10; PS = 100; S = 400;
+    } else {
+        TZ = (a.mode == 1) ? 2 : 1;
+        TP = 128 / TZ;
+        const int nzt = (D + TZ - 1) / TZ;
+        int zt = tile % nzt, pt = tile / nzt;
+        z0 = zt * TZ; p0 = pt * TP;
+        int plast = p0 + TP - 1;
+        if (plast > H * W - 1) plast = H * W - 1;
+        int qfirst = (p0 / W) * WP + (p0 % W) + 1;
+        int qlast = (plast / W) * WP + (plast % W) + 1;
+        qlo = qfirst - WP - 1;
+        RS = WP;
+        PS = qlast + WP + 1 - qlo + 1;
+        S = (TZ + 2) * PS;
+    }
+    if (tid < 128) {
+        int r = tid, g = -1;
+        if (a.mode == 0) {
+            int zz = r >> 6, yy = (r >> 3) & 7, xx = r & 7;
+            int z = z0 + zz, y = y0 + yy, x = x0 + xx;
+            if (z < D && y < H && x < W) g = (z * H + y) * W + x;
+        } else {
+            int zz = r / TP, p = p0 + r % TP;
+            int z = z0 + zz;
+            if (z < D && p < H * W) g = z * H * W + p;
+        }
+        rowinfo[r] = g;
+    }
+    int aslot;
+    {
+        const int r = wave * 32 + nn;
+        if (a.mode == 0) {
+            int zz = r >> 6, yy = (r >> 3) & 7, xx = r & 7;
+            aslot = (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
+        } else {
+            int zz = r / TP, p = p0 + r % TP;
+            if (p > H * W - 1) p = H * W - 1;
+            int q = (p / W) * WP + (p % W) + 1;
+            aslot = (zz + 1) * PS + (q - qlo);
+        }
+    }
+    auto slot_voxel = [&](int s) __attribute__((always_inline)) -> int {
+        if (s >= S) return -2;
+        int z, y, x;
+        if (a.mode == 0) {
+            int hz = s / PS, hy = (s / RS) % 10, hx = s % RS;
+            z = z0 + hz - 1; y = y0 + hy - 1; x = x0 + hx - 1;
+        } else {
+            int hz = s / PS, qq = qlo + s % PS + WP;
+            z = z0 + hz - 1;
+            y = qq / WP - 1;
+            x = qq % WP - 1;
+        }
+        return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
+    };
+    const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + 256), gv2 = slot_voxel(tid + 512), gv3 = slot_voxel(tid + 768);
+
+    const int nsteps = (a.CA + a.CB) >> 3;
+    f32x16 acc_hi[NT], acc_lo[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc_hi[j][i] = 0.f; acc_lo[j][i] = 0.f; }
+
+    // named prefetch registers (arrays that live across the K loop end up in scratch)
+    float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, vs0, vs1, vh0, vh1;
+    uint4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rb8, rb9, rb10, rb11, rb12, rb13;
+    bool has_affine = false;
+#define H2_LOAD_A(k)                                                                              \
+    {                                                                                             \
+        const float *pp = &src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];            \
+        ra##k = *(const float4 *)pp;                                                              \
+        rc##k = *(const float4 *)(pp + 4);                                                        \
+    }
+#define H2_LOAD_B(k) if constexpr (NB > k) rb##k = wsrc[tid + 256 * k];
+#define H2_LOAD_STAGE(step_)                                                                      \
+    {                                                                                             \
+        const int c0 = (step_) << 3;                                                              \
+        const float *src, *sc, *sh;                                                               \
+        int C, cc;                                                                                \
+        if (c0 < a.CA) { src = a.srcA; sc = a.scaleA; sh = a.shiftA; C = a.CA; cc = c0; }         \
+        else { src = a.srcB; sc = a.scaleB; sh = a.shiftB; C = a.CB; cc = c0 - a.CA; }            \
+        has_affine = sc != nullptr;                                                               \
+        const float *scp = has_affine ? sc : a.bias, *shp = has_affine ? sh : a.bias;             \
+        const int64_t so = has_affine ? (int64_t)b * C + cc : 0;                                  \
+        vs0 = *(const float4 *)&scp[so]; vs1 = *(const float4 *)&scp[so + 4];                     \
+        vh0 = *(const float4 *)&shp[so]; vh1 = *(const float4 *)&shp[so + 4];                     \
+        H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3)                                       \
+        const uint4 *wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  \
+        H2_LOAD_B(0) H2_LOAD_B(1) H2_LOAD_B(2) H2_LOAD_B(3) H2_LOAD_B(4) H2_LOAD_B(5) H2_LOAD_B(6) \
+        H2_LOAD_B(7) H2_LOAD_B(8) H2_LOAD_B(9) H2_LOAD_B(10) H2_LOAD_B(11) H2_LOAD_B(12) H2_LOAD_B(13) \
+    }
+#define H2_AFF(v, s_, h_)                                                                         \
+    v.x = fmaxf(fmaf(v.x, s_.x, h_.x), 0.f); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), 0.f);             \
+    v.z = fmaxf(fmaf(v.z, s_.z, h_.z), 0.f); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), 0.f);
+#define H2_STORE_A(k)                                                                             \
+    if (gv##k != -2) {                                                                            \
+        float4 v = ra##k, w = rc##k;                                                              \
+        if (has_affine) { H2_AFF(v, vs0, vh0) H2_AFF(w, vs1, vh1) }                               \
+        if (gv##k < 0) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }                            \
+        uint4 hi, lo;                                                                             \
+        split8(v, w, hi, lo);                                                                     \
+        AsH[tid + 256 * k] = hi;                                                                  \
+        AsL[tid + 256 * k] = lo;                                                                  \
+    }
+#define H2_STORE_B(k) if constexpr (NB > k) Bs[tid + 256 * k] = rb##k;
+
+    // LDS offset of tap t relative to the output voxel's slot (tap 27 = padding pair of tap 26: zero weights)
+    auto tap_off = [&](int t) __attribute__((always_inline)) -> int {
+        if (t > 26) t = 26;
+        return (t / 9 - 1) * PS + ((t / 3) % 3 - 1) * RS + (t % 3 - 1);
+    };
+
+    H2_LOAD_STAGE(0)
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();
+        H2_STORE_A(0) H2_STORE_A(1) H2_STORE_A(2) H2_STORE_A(3)
+        H2_STORE_B(0) H2_STORE_B(1) H2_STORE_B(2) H2_STORE_B(3) H2_STORE_B(4) H2_STORE_B(5) H2_STORE_B(6)
+        H2_STORE_B(7) H2_STORE_B(8) H2_STORE_B(9) H2_STORE_B(10) H2_STORE_B(11) H2_STORE_B(12) H2_STORE_B(13)
+        __syncthreads();
+        if (step + 1 < nsteps) H2_LOAD_STAGE(step + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4 *bph = Bs + hh * BN + nn, *bpl = bph + BU;
+#pragma unroll
+        for (int p = 0; p < 14; ++p) {
+            const int to = hh ? tap_off(2 * p + 1) : tap_off(2 * p);
+            union { uint4 u; f16x8 v; } ah, al;
+            ah.u = AsH[aslot + to];
+            al.u = AsL[aslot + to];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                union { uint4 u; f16x8 v; } bh, bl;
+                bh.u = bph[(2 * p) * BN + 32 * j];
+                bl.u = bpl[(2 * p) * BN + 32 * j];
+                acc_hi[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, acc_hi[j], 0, 0, 0);
+                acc_lo[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl.v, acc_lo[j], 0, 0, 0);
+                acc_lo[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh.v, acc_lo[j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef H2_LOAD_A
+#undef H2_LOAD_B
+#undef H2_LOAD_STAGE
+#undef H2_AFF
+#undef H2_STORE_A
+#undef H2_STORE_B
+
+    // ---- epilogue: HI + LO / 2^11 + bias, store, per-tile BN partial sums (valid rows only) ------------------
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ch = ntile * BN + 32 * j + nn;
+        const float bsv = a.bias[ch];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int g = rowinfo[row];
+            if (g >= 0) {
+                const float v = fmaf(acc_lo[j][i], 1.f / H2_SCALE, acc_hi[j][i]) + bsv;
+                if (ch < a.store_cols) a.out[((int64_t)b * M + g) * a.store_cols + ch] = v;
+                s += v;
+                q += v * v;
+            }
+        }
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (hh == 0) { red[(wave * BN + 32 * j + nn) * 2] = s; red[(wave * BN + 32 * j + nn) * 2 + 1] = q; }
+    }
+    __syncthreads();
+    if (tid < BN && !a.no_stats) {
+        float s = 0.f, q = 0.f;
+        for (int wv = 0; wv < 4; ++wv) { s += red[(wv * BN + tid) * 2]; q += red[(wv * BN + tid) * 2 + 1]; }
+        int64_t o = ((int64_t)b * a.tiles_per_chunk + tile) * a.Cout + ntile * BN + tid;
+        a.psum[o] = s;
+        a.psq[o] = q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+int conv_h2_bn(int mode, int cout) { return (mode == 0 && cout % 64 == 0) ? 64 : 32; }
+
+// w: reference layout [Cout][Cin][27] fp32 -> [Cout/BN][Cin/8][hi|lo][28 taps][BN][8 channels] halves
+void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out)
+{
+    const int ntiles = cout / bn, nsteps = cin / 8;
+    const size_t half_slab = (size_t)28 * bn * 8;
+    out.assign((size_t)ntiles * nsteps * 2 * half_slab + 4096, 0);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 27; ++t) {
+                _Float16 h, l;
+                split_h2(w[((size_t)co * cin + ci) * 27 + t], h, l);
+                const size_t base = ((size_t)(co / bn) * nsteps + ci / 8) * 2 * half_slab;
+                const size_t e = ((size_t)t * bn + co % bn) * 8 + ci % 8;
+                uint16_t hb, lb;
+                memcpy(&hb, &h, 2);
+                memcpy(&lb, &l, 2);
+                out[base + e] = hb;
+                out[base + half_slab + e] = lb;
+            }
+}
+
+int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap)
+{
+    ConvArgs a;
+    a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
+    a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
+    a.w = (const float *)w_h2; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
+    a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = cout;
+    a.mode = conv_mode(l);
+    a.tiles_per_chunk = conv_tiles(l, a.mode, 1, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+    a.store_cols = cout;
+    a.no_stats = no_stats;
+    a.xcd_remap = xcd_remap;
+    ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
+    ISX_REQUIRE(cout % 32 == 0 && sa.C % 8 == 0 && sb.C % 8 == 0, "internal: split-f16 conv needs Cout %% 32 == 0, Cin %% 8 == 0");
+    const int BN = conv_h2_bn(a.mode, cout);
+    a.ntiles = cout / BN;
+    const size_t lds = (size_t)(2 * 28 * BN + 2 * a.slots_max) * 16 + (128 + 4 * BN * 2) * sizeof(float);
+    ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
+    const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
+    static bool attr_done = false;
+    if (!attr_done) {
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    if (BN == 64) conv_h2_kernel<64><<<grid, 256, lds, ctx->stream>>>(a);
+    else conv_h2_kernel<32><<<grid, 256, lds, ctx->stream>>>(a);
+    ISX_CHECK_LAUNCH();
+    return ISX_OK;
+}
+
+}  // namespace isx

@@ -799,6 +799,18 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
                             pk[((size_t)t * ci_n + ci) * 8 + co] = w->f[((size_t)co * ci_n + ci) * 27 + t];
             }
             ISX_TRY(dev_upload(u, pk, &L.w));
+            if (use_mfma(L.cin, cout) && L.cin % 8 == 0) {       // split-f16 packs (both tile widths: the tile
+                std::vector<uint16_t> hp;                       // geometry is only known once a chunk arrives)
+                for (int bn = 32; bn <= 64; bn += 32) {
+                    if (cout % bn) continue;
+                    pack_h2_weights(w->f.data(), cout, L.cin, bn, hp);
+                    void *d = nullptr;
+                    ISX_HIP(hipMalloc(&d, hp.size() * 2));
+                    u->wblocks.push_back(d);
+                    ISX_HIP(hipMemcpy(d, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+                    (bn == 64 ? L.w_h2_64 : L.w_h2_32) = d;
+                }
+            }
             std::vector<float> b8(std::max(cout, 8), 0.f);
             std::copy(bs->f.begin(), bs->f.end(), b8.begin());
             ISX_TRY(dev_upload(u, b8, &L.bias));
@@ -970,7 +982,11 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
     ISX_REQUIRE(cin == L.cin, "internal: layer %s fed %d channels, expects %d", L.conv.c_str(), cin, L.cin);
     if (use_mfma(L.cin, L.cout)) {
         ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
-        ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
+        const void *wh = conv_h2_bn(conv_mode(l), L.cout) == 64 ? L.w_h2_64 : L.w_h2_32;
+        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && wh && conv_mt(l, u->wbatch, L.cout) == 1)
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, conv_xcd_remap()));
+        else
+            ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
     } else if (use_fold(L.cin, L.cout)) {
         // pass 1 on the matrix cores: 9 (dz,dy) taps, x-taps folded into 3*cout <= 16 output columns
         {
@@ -1197,6 +1213,14 @@ int isx_get_weight_host(isx_ctx *ctx, const char *key, void *data, int64_t nbyte
     // parameters are not changed by inference: return the loaded values
     ISX_REQUIRE(!it->second.is_i64 && nbytes >= (int64_t)it->second.f.size() * 4, "buffer too small");
     memcpy(data, it->second.f.data(), it->second.f.size() * 4);
+    return ISX_OK;
+}
+
+int isx_unet_set_precision(isx_ctx *ctx, int mode)
+{
+    ISX_REQUIRE(ctx && (mode == ISX_PRECISION_FP32 || mode == ISX_PRECISION_SPLIT_F16), "precision mode %d", mode);
+    if (!ctx->unet) ctx->unet = new UNetState();
+    ctx->unet->precision = mode;
     return ISX_OK;
 }
 

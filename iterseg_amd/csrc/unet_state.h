@@ -23,6 +23,7 @@ struct ConvBN {                 // one Conv3d followed by its BatchNorm3d
     std::string conv, bn;       // state-dict prefixes, e.g. "c0.conv0", "c0.batch0"
     int cin = 0, cout = 0;
     float *w = nullptr;         // packed weights (layout depends on the kernel that reads them)
+    void *w_h2_64 = nullptr, *w_h2_32 = nullptr;   // split-f16 packs for 64- / 32-column tiles (conv_h2.hip)
     float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *rmean = nullptr, *rvar = nullptr;
     int64_t nbt = 0;
     float *scale = nullptr, *shift = nullptr;       // [B][cout], valid after bn_finalize
@@ -46,6 +47,7 @@ struct UNetState {
     bool committed = false;
     int out_channels = 5;
     int batch = 4;
+    int precision = 0;          // ISX_PRECISION_FP32 | ISX_PRECISION_SPLIT_F16 (inference convolutions)
     // layers: index 0..17 = c0.conv0, c0.conv1, c1.conv0, ... c4.conv1, c5.conv0 ... c8.conv1
     ConvBN cv[18];
     UpConv up[4];
@@ -101,6 +103,11 @@ int conv_tiles(const Level &l, int mode, int mt, int *nty, int *ntx, int *ntp, i
 // raw launch of the MFMA conv (no BN finalize): used by the forward and by dgrad
 int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const float *w_packed, const float *bias,
                      int cout, float *out, float *psum, float *psq, int no_stats);
+// split-f16 convolution (conv_h2.hip)
+int conv_h2_bn(int mode, int cout);
+void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out);
+int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap);
 int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch);
 int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3]);
 int dev_alloc(UNetState *u, size_t floats, float **out);

@@ -11,6 +11,7 @@ statistics per chunk, running statistics updated as a side effect (SURVEY.md F2/
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -21,7 +22,8 @@ from . import _lib, weights as _weights
 
 class UNet:
     def __init__(self, in_channels=1, out_channels=5, down_factors=(1, 2, 2), up='convolution',
-                 downsample_1_at_bottom=True, chan_final_activations=None, device=None, batch=32):
+                 downsample_1_at_bottom=True, chan_final_activations=None, device=None, batch=32,
+                 precision=None):
         if isinstance(out_channels, tuple):
             raise NotImplementedError("forked decoders (out_channels tuple) are not on the accelerated path")
         if in_channels != 1 or tuple(down_factors) != (1, 2, 2) or up != 'convolution' or not downsample_1_at_bottom:
@@ -32,8 +34,11 @@ class UNet:
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.ctx = _lib.Context(self.device)
         _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch)))
+        self._batch = int(batch)
         self._loaded = False
         self._sd = None
+        self.precision = "fp32"
+        self.set_precision(precision if precision is not None else os.environ.get("ISX_CONV_PRECISION", "fp32"))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict, strict=True):
@@ -45,6 +50,8 @@ class UNet:
         if self._loaded:                          # a committed context cannot be re-loaded: start a new one
             self.ctx.close()
             self.ctx = _lib.Context(self.device)
+            _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, self._batch))
+            self.set_precision(self.precision)
         lib, h = self.ctx.lib, self.ctx.handle
         for k, v in sd.items():
             if k.endswith("num_batches_tracked"):
@@ -72,8 +79,19 @@ class UNet:
                 out[k] = torch.from_numpy(np.array(v, copy=True))
         return out
 
+    def set_precision(self, precision):
+        """Arithmetic of the wide inference convolutions: ``"fp32"`` (exact fp32 products) or ``"split-f16"``
+        (fp32 operands split into two halves each, f16 matrix cores, fp32 accumulation: fp32-class results;
+        see include/itersegx.h).  Training always runs fp32."""
+        modes = {"fp32": 0, "split-f16": 1}
+        if precision not in modes:
+            raise ValueError(f"precision must be one of {sorted(modes)}")
+        _lib.check(self.ctx.lib.isx_unet_set_precision(self.ctx.handle, modes[precision]))
+        self.precision = precision
+
     def set_batch(self, batch):
         _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch)))
+        self._batch = int(batch)
 
     # ------------------------------------------------------------------ forward
     def _bind_stream(self):

@@ -123,3 +123,50 @@ def test_rejects_bad_geometry_and_missing_weights(net):
         u(np.zeros((1, 1, 4, 32, 32), np.float32))
     with pytest.raises(RuntimeError):
         u.load_state_dict({"c0.conv0.weight": np.zeros((32, 1, 3, 3, 3), np.float32)})
+
+
+# ---------------------------------------------------------------------------------------------------
+# split-f16 arithmetic (conv_h2.hip): same stated tolerances as the fp32 path, plus how close the two are
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def net_h2():
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    u = UNet(1, 5, batch=4, precision="split-f16")
+    u.load_state_dict(weights.generate_state_dict(0))
+    return u
+
+
+def test_split_f16_taps_match_reference(net_h2, golden):
+    d = golden("unet_taps_4x32x32")
+    y = net_h2(d["x"][None, None])
+    for name in ["c0.conv0", "c0.batch0", "c0", "d0", "c1", "d3", "c4", "c5_0", "c8_0.conv1"]:
+        _close(net_h2.tap(name), d[name][0], name)
+    assert np.abs(y[0] - d["c8_0"][0]).max() <= ABS_TOL
+
+
+@pytest.mark.parametrize("tag", ["10x48x48", "9x40x56"])
+def test_split_f16_chunked_predict_matches_reference(net_h2, golden, tag):
+    from iterseg_amd import predict
+    d = golden("predict_" + tag)
+    out = np.zeros_like(d["feature_map"])
+    predict.process_chunks(d["volume"], tuple(int(c) for c in d["chunk"]), out, tuple(int(m) for m in d["margin"]),
+                           predict.predict_chunk_feature_map, config={"unet": net_h2, "output_volume": out})
+    assert np.abs(out - d["feature_map"]).max() <= ABS_TOL
+
+
+def test_split_f16_full_size_chunk_vs_fp32_and_oracle(net, net_h2):
+    """(10,256,256): every tile mapping and both tile widths; error of each path against the float64 oracle."""
+    from oracle import unet_torch as ou
+    from iterseg_amd import weights
+    from tests.synth import positive_volume
+    x = positive_volume((10, 256, 256), 11)
+    a = net(x[None, None])[0]
+    b = net_h2(x[None, None])[0]
+    p = ou._as_params(weights.generate_state_dict(0), dtype=torch.float64)
+    with torch.no_grad():
+        ref = ou.unet_forward(p, torch.from_numpy(x)[None, None].double())[0].numpy()
+    e32, eh2 = np.abs(a - ref).max(), np.abs(b - ref).max()
+    print(f"max |err| vs float64 oracle: fp32 path {e32:.3e}, split-f16 path {eh2:.3e}; fp32 vs split {np.abs(a - b).max():.3e}")
+    assert e32 <= ABS_TOL and eh2 <= ABS_TOL
+    assert eh2 <= 4 * e32 + 2e-6                 # fp32-class: within a small factor of the fp32 kernel's own error
