@@ -40,30 +40,42 @@ __host__ __device__ inline void split_h2(float x, _Float16 &h, _Float16 &l)
     l = (r < H2_MIN && r > -H2_MIN) ? (_Float16)0.f : (_Float16)r;
 }
 
-// 8 fp32 -> 8 halves (hi) + 8 halves (lo), each packed in a uint4
-__device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo)
+// 8 fp32 -> 8 halves (hi) + 8 halves (lo), each packed in a uint4.  Device staging version of split_h2: the high
+// part is rounded toward zero (v_cvt_pkrtz_f16_f32, two values per instruction) -- any rounding works, the low part
+// absorbs the remainder -- and subnormal halves are kept (the f16 matrix cores honour them; checked on MI355X with
+// scratch/h2/mfma_layout.hip), so only the clamp remains of the host routine's special cases.
+__device__ __forceinline__ void split2(float x, float y, uint32_t &hi, uint32_t &lo)
 {
-    union { f16x8 v; uint4 u; } H, L;
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        _Float16 h, l;
-        split_h2(x[j], h, l);
-        H.v[j] = h;
-        L.v[j] = l;
-    }
+    typedef __fp16 h2v __attribute__((ext_vector_type(2)));
+    union { h2v v; uint32_t u; } H, L;
+    x = __builtin_amdgcn_fmed3f(x, -H2_MAX, H2_MAX);
+    y = __builtin_amdgcn_fmed3f(y, -H2_MAX, H2_MAX);
+    H.v = __builtin_amdgcn_cvt_pkrtz(x, y);
+    const float rx = (x - (float)H.v[0]) * H2_SCALE, ry = (y - (float)H.v[1]) * H2_SCALE;
+    L.v = __builtin_amdgcn_cvt_pkrtz(rx, ry);
     hi = H.u;
     lo = L.u;
 }
 
-template <int BN>
+__device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo)
+{
+    split2(a.x, a.y, hi.x, lo.x);
+    split2(a.z, a.w, hi.y, lo.y);
+    split2(b.x, b.y, hi.z, lo.z);
+    split2(b.z, b.w, hi.w, lo.w);
+}
+
+// TX = 3: all 27 taps (14 pairs).  TX = 1: the 9 taps with dx = 0 (5 pairs) -- the folded tail layer, whose three
+// x-taps live in the output columns (see conv_mfma_kernel / tail_combine_kernel).
+template <int BN, int TX>
 __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     constexpr int NT = BN / 32;
-    constexpr int BU = 28 * BN;                           // uint4 per half of the weight slab (hi | lo)
-    constexpr int NB = (2 * BU) / 256;                    // uint4 of weights per thread per stage: 14 (BN 64) / 7 (BN 32)
-    static_assert((2 * BU) % 256 == 0, "weight slab must split evenly over the block");
+    constexpr int NTAPS = 9 * TX, NPAIR = (NTAPS + 1) / 2;
+    constexpr int BU = 2 * NPAIR * BN;                    // uint4 per half of the weight slab (hi | lo)
+    constexpr int NB = (2 * BU + 255) / 256;              // uint4 of weights per thread per stage (14 / 7 / 3)
+    constexpr bool BEXACT = (2 * BU) % 256 == 0;
     uint4 *Bs = smem4;                                    // [hi: 28][BN] | [lo: 28][BN]
     uint4 *AsH = smem4 + 2 * BU;
     uint4 *AsL = AsH + a.slots_max;
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }
-#define H2_LOAD_B(k) if constexpr (NB > k) rb##k = wsrc[tid + 256 * k];
+#define H2_LOAD_B(k) if constexpr (NB > k) { if (BEXACT || tid + 256 * k < 2 * BU) rb##k = wsrc[tid + 256 * k]; }
 #define H2_LOAD_STAGE(step_)                                                                      \
     {                                                                                             \
         const int c0 = (step_) << 3;                                                              \
@@ -196,12 +208,13 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         AsH[tid + 256 * k] = hi;                                                                  \
         AsL[tid + 256 * k] = lo;                                                                  \
     }
-#define H2_STORE_B(k) if constexpr (NB > k) Bs[tid + 256 * k] = rb##k;
+#define H2_STORE_B(k) if constexpr (NB > k) { if (BEXACT || tid + 256 * k < 2 * BU) Bs[tid + 256 * k] = rb##k; }
 
     // LDS offset of tap t relative to the output voxel's slot (tap 27 = padding pair of tap 26: zero weights)
     auto tap_off = [&](int t) __attribute__((always_inline)) -> int {
-        if (t > 26) t = 26;
-        return (t / 9 - 1) * PS + ((t / 3) % 3 - 1) * RS + (t % 3 - 1);
+        if (t > NTAPS - 1) t = NTAPS - 1;
+        if (TX == 3) return (t / 9 - 1) * PS + ((t / 3) % 3 - 1) * RS + (t % 3 - 1);
+        return (t / 3 - 1) * PS + (t % 3 - 1) * RS;
     };
 
     H2_LOAD_STAGE(0)
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         __builtin_amdgcn_sched_barrier(0);
         const uint4 *bph = Bs + hh * BN + nn, *bpl = bph + BU;
 #pragma unroll
-        for (int p = 0; p < 14; ++p) {
+        for (int p = 0; p < NPAIR; ++p) {
             const int to = hh ? tap_off(2 * p + 1) : tap_off(2 * p);
             union { uint4 u; f16x8 v; } ah, al;
             ah.u = AsH[aslot + to];
@@ -273,7 +286,12 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-int conv_h2_bn(int mode, int cout) { return (mode == 0 && cout % 64 == 0) ? 64 : 32; }
+// 64-column tiles whenever two work-groups still fit into the 160 KB of LDS (weight slab 57 KB + 32 B per halo slot)
+int conv_h2_bn(int slots, int cout)
+{
+    const size_t lds64 = (size_t)(2 * 28 * 64 + 2 * slots) * 16 + (128 + 4 * 64 * 2) * sizeof(float);
+    return (cout % 64 == 0 && 2 * lds64 <= 160 * 1024) ? 64 : 32;
+}
 
 // w: reference layout [Cout][Cin][27] fp32 -> [Cout/BN][Cin/8][hi|lo][28 taps][BN][8 channels] halves
 void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out)
@@ -296,34 +314,60 @@ void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint
             }
 }
 
+// folded tail layer (cout <= 5): [Cin/8][hi|lo][10 (dz,dy) taps][32 columns = dx*cout + o][8 channels] halves
+void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out)
+{
+    const int nsteps = cin / 8;
+    const size_t half_slab = (size_t)10 * 32 * 8;
+    out.assign((size_t)nsteps * 2 * half_slab + 4096, 0);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 27; ++t) {
+                _Float16 h, l;
+                split_h2(w[((size_t)co * cin + ci) * 27 + t], h, l);
+                const int t9 = t / 3, dxi = t % 3;
+                const size_t base = (size_t)(ci / 8) * 2 * half_slab;
+                const size_t e = ((size_t)t9 * 32 + dxi * cout + co) * 8 + ci % 8;
+                uint16_t hb, lb;
+                memcpy(&hb, &h, 2);
+                memcpy(&lb, &l, 2);
+                out[base + e] = hb;
+                out[base + half_slab + e] = lb;
+            }
+}
+
+// fold != 0: the folded tail layer (TX = 1, 32 columns of which store_cols = 16 are stored, no statistics)
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap)
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold)
 {
     ConvArgs a;
     a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
     a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
     a.w = (const float *)w_h2; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
-    a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = cout;
+    a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = fold ? 32 : cout;
     a.mode = conv_mode(l);
     a.tiles_per_chunk = conv_tiles(l, a.mode, 1, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
-    a.store_cols = cout;
+    a.store_cols = fold ? 16 : cout;
     a.no_stats = no_stats;
     a.xcd_remap = xcd_remap;
     ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
-    ISX_REQUIRE(cout % 32 == 0 && sa.C % 8 == 0 && sb.C % 8 == 0, "internal: split-f16 conv needs Cout %% 32 == 0, Cin %% 8 == 0");
-    const int BN = conv_h2_bn(a.mode, cout);
-    a.ntiles = cout / BN;
-    const size_t lds = (size_t)(2 * 28 * BN + 2 * a.slots_max) * 16 + (128 + 4 * BN * 2) * sizeof(float);
+    ISX_REQUIRE((fold || cout % 32 == 0) && sa.C % 8 == 0 && sb.C % 8 == 0, "internal: split-f16 conv needs Cout %% 32 == 0, Cin %% 8 == 0");
+    const int BN = fold ? 32 : conv_h2_bn(a.slots_max, cout);
+    a.ntiles = fold ? 1 : cout / BN;
+    const int npair = fold ? 5 : 14;
+    const size_t lds = (size_t)(2 * 2 * npair * BN + 2 * a.slots_max) * 16 + (128 + 4 * BN * 2) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
     static bool attr_done = false;
     if (!attr_done) {
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    if (BN == 64) conv_h2_kernel<64><<<grid, 256, lds, ctx->stream>>>(a);
-    else conv_h2_kernel<32><<<grid, 256, lds, ctx->stream>>>(a);
+    if (fold) conv_h2_kernel<32, 1><<<grid, 256, lds, ctx->stream>>>(a);
+    else if (BN == 64) conv_h2_kernel<64, 3><<<grid, 256, lds, ctx->stream>>>(a);
+    else conv_h2_kernel<32, 3><<<grid, 256, lds, ctx->stream>>>(a);
     ISX_CHECK_LAUNCH();
     return ISX_OK;
 }

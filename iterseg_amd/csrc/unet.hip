@@ -799,6 +799,15 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
                             pk[((size_t)t * ci_n + ci) * 8 + co] = w->f[((size_t)co * ci_n + ci) * 27 + t];
             }
             ISX_TRY(dev_upload(u, pk, &L.w));
+            if (use_fold(L.cin, cout) && L.cin % 8 == 0) {
+                std::vector<uint16_t> hp;
+                pack_h2_fold_weights(w->f.data(), cout, L.cin, hp);
+                void *d = nullptr;
+                ISX_HIP(hipMalloc(&d, hp.size() * 2));
+                u->wblocks.push_back(d);
+                ISX_HIP(hipMemcpy(d, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+                L.w_h2_32 = d;
+            }
             if (use_mfma(L.cin, cout) && L.cin % 8 == 0) {       // split-f16 packs (both tile widths: the tile
                 std::vector<uint16_t> hp;                       // geometry is only known once a chunk arrives)
                 for (int bn = 32; bn <= 64; bn += 32) {
@@ -982,14 +991,20 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
     ISX_REQUIRE(cin == L.cin, "internal: layer %s fed %d channels, expects %d", L.conv.c_str(), cin, L.cin);
     if (use_mfma(L.cin, L.cout)) {
         ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
-        const void *wh = conv_h2_bn(conv_mode(l), L.cout) == 64 ? L.w_h2_64 : L.w_h2_32;
+        int t0, t1, t2, slots;
+        conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
+        const void *wh = conv_h2_bn(slots, L.cout) == 64 ? L.w_h2_64 : L.w_h2_32;
         if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && wh && conv_mt(l, u->wbatch, L.cout) == 1)
-            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, conv_xcd_remap()));
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, conv_xcd_remap(), 0));
         else
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
     } else if (use_fold(L.cin, L.cout)) {
         // pass 1 on the matrix cores: 9 (dz,dy) taps, x-taps folded into 3*cout <= 16 output columns
-        {
+        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && L.w_h2_32 && conv_mt(l, u->wbatch, 32) == 1) {
+            ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, L.w_h2_32, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
+                                   conv_xcd_remap(), 1));
+        } else {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ConvArgs a;
             a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
