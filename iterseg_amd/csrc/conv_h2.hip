@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 int conv_h2_bn(int slots, int cout)
 {
     const size_t lds64 = (size_t)(2 * 28 * 64 + 2 * slots) * 16 + (128 + 4 * 64 * 2) * sizeof(float);
-    return (cout % 64 == 0 && 2 * lds64 <= 160 * 1024) ? 64 : 32;
+    static const int force64 = getenv("ISX_H2_FORCE_BN64") ? atoi(getenv("ISX_H2_FORCE_BN64")) : 0;
+    return (cout % 64 == 0 && (force64 || 2 * lds64 <= 160 * 1024)) ? 64 : 32;
 }
 
 // w: reference layout [Cout][Cin][27] fp32 -> [Cout/BN][Cin/8][hi|lo][28 taps][BN][8 channels] halves
