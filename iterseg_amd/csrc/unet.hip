@@ -799,7 +799,10 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
                             pk[((size_t)t * ci_n + ci) * 8 + co] = w->f[((size_t)co * ci_n + ci) * 27 + t];
             }
             ISX_TRY(dev_upload(u, pk, &L.w));
-            if (use_fold(L.cin, cout) && L.cin % 8 == 0) {
+            float wabs = 0.f;
+            for (float v : w->f) wabs = std::max(wabs, fabsf(v));
+            const bool w_in_range = wabs < 6.0e4f;              // otherwise this layer stays on the fp32 kernel
+            if (use_fold(L.cin, cout) && L.cin % 8 == 0 && w_in_range) {
                 std::vector<uint16_t> hp;
                 pack_h2_fold_weights(w->f.data(), cout, L.cin, hp);
                 void *d = nullptr;
@@ -808,7 +811,7 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
                 ISX_HIP(hipMemcpy(d, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
                 L.w_h2_32 = d;
             }
-            if (use_mfma(L.cin, cout) && L.cin % 8 == 0) {       // split-f16 packs (both tile widths: the tile
+            if (use_mfma(L.cin, cout) && L.cin % 8 == 0 && w_in_range) {       // split-f16 packs (both tile widths: the tile
                 std::vector<uint16_t> hp;                       // geometry is only known once a chunk arrives)
                 for (int bn = 32; bn <= 64; bn += 32) {
                     if (cout % bn) continue;
@@ -825,6 +828,9 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
             ISX_TRY(dev_upload(u, b8, &L.bias));
             ISX_TRY(dev_upload(u, g->f, &L.gamma));
             ISX_TRY(dev_upload(u, be->f, &L.beta));
+            L.gmax = L.bmax = 0.f;
+            for (float v : g->f) L.gmax = std::max(L.gmax, fabsf(v));
+            for (float v : be->f) L.bmax = std::max(L.bmax, fabsf(v));
             ISX_TRY(dev_upload(u, rm->f, &L.rmean));
             ISX_TRY(dev_upload(u, rv->f, &L.rvar));
         }
@@ -844,6 +850,9 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
             for (int t = 0; t < U.kz * 4; ++t) pk[(size_t)t * U.C + c] = w->f[(size_t)c * U.kz * 4 + t];
         ISX_TRY(dev_upload(u, pk, &U.w));
         ISX_TRY(dev_upload(u, bs->f, &U.bias));
+        U.wmax = U.bmax = 0.f;
+        for (float v : w->f) U.wmax = std::max(U.wmax, fabsf(v));
+        for (float v : bs->f) U.bmax = std::max(U.bmax, fabsf(v));
     }
     if (u->host.size() != expected) {
         set_error("state_dict: %zu unexpected key(s)", u->host.size() - expected);
@@ -994,13 +1003,15 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
         int t0, t1, t2, slots;
         conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
         const void *wh = conv_h2_bn(slots, L.cout) == 64 ? L.w_h2_64 : L.w_h2_32;
-        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && wh && conv_mt(l, u->wbatch, L.cout) == 1)
+        const bool in_range = std::max(sa.bound, sb.bound) < 6.0e4f;          // else operands could leave the f16 range
+        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && wh && in_range && conv_mt(l, u->wbatch, L.cout) == 1)
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, conv_xcd_remap(), 0));
         else
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
     } else if (use_fold(L.cin, L.cout)) {
         // pass 1 on the matrix cores: 9 (dz,dy) taps, x-taps folded into 3*cout <= 16 output columns
-        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && L.w_h2_32 && conv_mt(l, u->wbatch, 32) == 1) {
+        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && L.w_h2_32 && std::max(sa.bound, sb.bound) < 6.0e4f &&
+            conv_mt(l, u->wbatch, 32) == 1) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, L.w_h2_32, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
                                    conv_xcd_remap(), 1));
@@ -1070,11 +1081,15 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
     UNetState *u = ctx->unet;
     const Level *lv = u->lv;
     const Src none{nullptr, nullptr, nullptr, 0};
-    auto act = [&](int li) { const ConvBN &L = u->cv[li]; return Src{u->raw[li], L.scale, L.shift, L.cout}; };
+    // |relu(BN(x))| <= |gamma| * sqrt(M - 1) + |beta| for batch statistics over M values: the range check of the
+    // split-f16 convolution (run_conv) uses these bounds, pooling keeps them, the up-convolution scales them
+    auto bn_bound = [&](int li) { const ConvBN &L = u->cv[li]; return L.gmax * sqrtf((float)lv[MOD_LEVEL[li / 2]].M) + L.bmax; };
+    auto act = [&](int li) { const ConvBN &L = u->cv[li]; return Src{u->raw[li], L.scale, L.shift, L.cout, bn_bound(li)}; };
     // ---- encoder ----------------------------------------------------------------------------
     for (int mi = 0; mi <= 4; ++mi) {
         const Level &l = lv[mi];
-        Src in = (mi == 0) ? Src{u->x0, nullptr, nullptr, 1} : Src{u->pool[mi - 1], nullptr, nullptr, MOD_COUT[mi - 1]};
+        Src in = (mi == 0) ? Src{u->x0, nullptr, nullptr, 1}
+                           : Src{u->pool[mi - 1], nullptr, nullptr, MOD_COUT[mi - 1], bn_bound(2 * (mi - 1) + 1)};
         ISX_TRY(run_conv(ctx, 2 * mi, l, B, in, none));
         ISX_TRY(run_conv(ctx, 2 * mi + 1, l, B, act(2 * mi), none));
         if (mi < 4) {
@@ -1106,7 +1121,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
         }
         const int mi = 5 + k;                                  // c5..c8
         const int skip_li = 2 * (3 - k) + 1;                   // c3, c2, c1, c0 second conv
-        ISX_TRY(run_conv(ctx, 2 * mi, lo, B, Src{u->ups[k], nullptr, nullptr, U.C}, act(skip_li)));
+        ISX_TRY(run_conv(ctx, 2 * mi, lo, B, Src{u->ups[k], nullptr, nullptr, U.C, bn_bound(li_in) * U.wmax + U.bmax}, act(skip_li)));
         ISX_TRY(run_conv(ctx, 2 * mi + 1, lo, B, act(2 * mi), none));
     }
     {

@@ -31,6 +31,7 @@ struct ConvBN {                 // one Conv3d followed by its BatchNorm3d
     float *invstd = nullptr;                        // [B][cout] 1/sqrt(biased var + eps) (backward)
     float *psum = nullptr, *psq = nullptr;          // [B][tiles][cout] partial sums
     int tiles = 0;
+    float gmax = 0.f, bmax = 0.f;                   // max |gamma|, max |beta|: |BN output| <= gmax * sqrt(M - 1) + bmax
 };
 
 struct UpConv {
@@ -38,6 +39,7 @@ struct UpConv {
     int C = 0, kz = 1;
     float *w = nullptr;         // [kz*4][C]
     float *bias = nullptr;
+    float wmax = 0.f, bmax = 0.f;
 };
 
 struct Level { int D = 0, H = 0, W = 0; int64_t M = 0; };
@@ -70,7 +72,7 @@ struct UNetState {
 
 struct TrainState;
 
-struct Src { const float *p; const float *scale; const float *shift; int C; };
+struct Src { const float *p; const float *scale; const float *shift; int C; float bound = 0.f; };   // bound: max |activation| (split-f16 range check)
 
 // implicit-GEMM conv on the fp32 matrix cores (unet.hip); see ConvArgs there
 struct ConvArgs {

@@ -170,3 +170,22 @@ def test_split_f16_full_size_chunk_vs_fp32_and_oracle(net, net_h2):
     print(f"max |err| vs float64 oracle: fp32 path {e32:.3e}, split-f16 path {eh2:.3e}; fp32 vs split {np.abs(a - b).max():.3e}")
     assert e32 <= ABS_TOL and eh2 <= ABS_TOL
     assert eh2 <= 4 * e32 + 2e-6                 # fp32-class: within a small factor of the fp32 kernel's own error
+
+
+def test_split_f16_falls_back_to_fp32_out_of_range():
+    """A BatchNorm scale so large that its activations could leave the f16 range (|gamma| * sqrt(M) + |beta| >= 6e4)
+    sends the consumers of that tensor to the fp32 kernel: results still match the oracle."""
+    from oracle import unet_torch as ou
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    from tests.synth import positive_volume
+    sd = weights.generate_state_dict(0)
+    sd["c0.batch1.weight"] = sd["c0.batch1.weight"] * 3000.0          # bound ~ 3000 * 64 at a (4,32,32) chunk
+    sd["c5_0.batch0.weight"] = sd["c5_0.batch0.weight"] * 1.0e4
+    x = positive_volume((4, 32, 32), 9)
+    u = UNet(1, 5, batch=1, precision="split-f16")
+    u.load_state_dict(sd)
+    y = u(x[None, None])
+    with torch.no_grad():
+        ref = ou.unet_forward(ou._as_params(sd), torch.from_numpy(x)[None, None]).numpy()
+    assert np.isfinite(y).all() and np.abs(y - ref).max() <= ABS_TOL
