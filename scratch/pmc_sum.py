@@ -5,7 +5,7 @@ for f in sys.argv[1:]:
         agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
         for r in csv.DictReader(open(path)):
             k = r['Kernel_Name'].split('(')[0].replace('void isx::', '')
-            if 'conv_mfma' not in k: continue
+            if 'conv_mfma' not in k and 'conv_h2' not in k: continue
             agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         for k, d in agg.items():
             print(k, {c: f"{v:.4g}" for c, v in d.items()})
