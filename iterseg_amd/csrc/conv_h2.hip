@@ -68,9 +68,12 @@ __device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &
 
 // TX = 3: all 27 taps (14 pairs).  TX = 1: the 9 taps with dx = 0 (5 pairs) -- the folded tail layer, whose three
 // x-taps live in the output columns (see conv_mfma_kernel / tail_combine_kernel).
-template <int BN, int TX>
+// MT = 32-row tiles per wave (1: 128 voxels per work-group, 2: 256).  With 32 columns, MT = 2 gives the wave a
+// 64 x 32 tile whose six fragment reads feed six MFMAs, like the 32 x 64 tile of the 64-column variant.
+template <int BN, int TX, int MT>
 __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 {
+    constexpr int ROWS = 128 * MT, TXW = 8 * MT;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     constexpr int NT = BN / 32;
     constexpr int NTAPS = 9 * TX, NPAIR = (NTAPS + 1) / 2;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     uint4 *AsH = smem4 + 2 * BU;
     uint4 *AsL = AsH + a.slots_max;
     int *rowinfo = (int *)(AsL + a.slots_max);
-    float *red = (float *)(rowinfo + 128);
+    float *red = (float *)(rowinfo + ROWS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
     int lin = blockIdx.x;
@@ -102,11 +105,11 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     if (a.mode == 0) {
         const int nzt = (D + 1) >> 1;
         int zt = tile % nzt, xt = (tile / nzt) % a.ntx, yt = tile / (nzt * a.ntx);
-        z0 = zt * 2; y0 = yt * 8; x0 = xt * 8; TZ = 2;
-        RS = 10; PS = 100; S = 400;
+        z0 = zt * 2; y0 = yt * 8; x0 = xt * TXW; TZ = 2;
+        RS = TXW + 2; PS = 10 * RS; S = 4 * PS;
     } else {
         TZ = (a.mode == 1) ? 2 : 1;
-        TP = 128 / TZ;
+        TP = ROWS / TZ;
         const int nzt = (D + TZ - 1) / TZ;
         int zt = tile % nzt, pt = tile / nzt;
         z0 = zt * TZ; p0 = pt * TP;
@@ -119,10 +122,10 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         PS = qlast + WP + 1 - qlo + 1;
         S = (TZ + 2) * PS;
     }
-    if (tid < 128) {
+    if (tid < ROWS) {
         int r = tid, g = -1;
         if (a.mode == 0) {
-            int zz = r >> 6, yy = (r >> 3) & 7, xx = r & 7;
+            int zz = r / (8 * TXW), yy = (r / TXW) & 7, xx = r % TXW;
             int z = z0 + zz, y = y0 + yy, x = x0 + xx;
             if (z < D && y < H && x < W) g = (z * H + y) * W + x;
         } else {
@@ -132,19 +135,18 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         }
         rowinfo[r] = g;
     }
-    int aslot;
-    {
-        const int r = wave * 32 + nn;
+    auto row_slot = [&](int r) __attribute__((always_inline)) -> int {
         if (a.mode == 0) {
-            int zz = r >> 6, yy = (r >> 3) & 7, xx = r & 7;
-            aslot = (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
-        } else {
-            int zz = r / TP, p = p0 + r % TP;
-            if (p > H * W - 1) p = H * W - 1;
-            int q = (p / W) * WP + (p % W) + 1;
-            aslot = (zz + 1) * PS + (q - qlo);
+            int zz = r / (8 * TXW), yy = (r / TXW) & 7, xx = r % TXW;
+            return (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
         }
-    }
+        int zz = r / TP, p = p0 + r % TP;
+        if (p > H * W - 1) p = H * W - 1;
+        int q = (p / W) * WP + (p % W) + 1;
+        return (zz + 1) * PS + (q - qlo);
+    };
+    const int aslot0 = row_slot((wave * MT) * 32 + nn);
+    const int aslot1 = MT > 1 ? row_slot((wave * MT + 1) * 32 + nn) : 0;
     auto slot_voxel = [&](int s) __attribute__((always_inline)) -> int {
         if (s >= S) return -2;
         int z, y, x;
@@ -159,21 +161,24 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         }
         return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
     };
-    const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + 256), gv2 = slot_voxel(tid + 512), gv3 = slot_voxel(tid + 768);
+    const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + 256), gv2 = slot_voxel(tid + 512), gv3 = slot_voxel(tid + 768),
+              gv4 = MT > 1 ? slot_voxel(tid + 1024) : -2;
 
     const int nsteps = (a.CA + a.CB) >> 3;
-    f32x16 acc_hi[NT], acc_lo[NT];
+    f32x16 acc_hi[MT][NT], acc_lo[MT][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc_hi[j][i] = 0.f; acc_lo[j][i] = 0.f; }
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc_hi[m][j][i] = 0.f; acc_lo[m][j][i] = 0.f; }
 
     // named prefetch registers (arrays that live across the K loop end up in scratch)
-    float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, vs0, vs1, vh0, vh1;
+    float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
     uint4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rb8, rb9, rb10, rb11, rb12, rb13;
     bool has_affine = false;
 #define H2_LOAD_A(k)                                                                              \
-    {                                                                                             \
+    if constexpr (k < 4 || MT > 1) {                                                              \
         const float *pp = &src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];            \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         const int64_t so = has_affine ? (int64_t)b * C + cc : 0;                                  \
         vs0 = *(const float4 *)&scp[so]; vs1 = *(const float4 *)&scp[so + 4];                     \
         vh0 = *(const float4 *)&shp[so]; vh1 = *(const float4 *)&shp[so + 4];                     \
-        H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3)                                       \
+        H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4)                          \
         const uint4 *wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  \
         H2_LOAD_B(0) H2_LOAD_B(1) H2_LOAD_B(2) H2_LOAD_B(3) H2_LOAD_B(4) H2_LOAD_B(5) H2_LOAD_B(6) \
         H2_LOAD_B(7) H2_LOAD_B(8) H2_LOAD_B(9) H2_LOAD_B(10) H2_LOAD_B(11) H2_LOAD_B(12) H2_LOAD_B(13) \
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     v.x = fmaxf(fmaf(v.x, s_.x, h_.x), 0.f); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), 0.f);             \
     v.z = fmaxf(fmaf(v.z, s_.z, h_.z), 0.f); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), 0.f);
 #define H2_STORE_A(k)                                                                             \
-    if (gv##k != -2) {                                                                            \
+    if ((k < 4 || MT > 1) && gv##k != -2) {                                                       \
         float4 v = ra##k, w = rc##k;                                                              \
         if (has_affine) { H2_AFF(v, vs0, vh0) H2_AFF(w, vs1, vh1) }                               \
         if (gv##k < 0) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }                            \
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     H2_LOAD_STAGE(0)
     for (int step = 0; step < nsteps; ++step) {
         __syncthreads();
-        H2_STORE_A(0) H2_STORE_A(1) H2_STORE_A(2) H2_STORE_A(3)
+        H2_STORE_A(0) H2_STORE_A(1) H2_STORE_A(2) H2_STORE_A(3) H2_STORE_A(4)
         H2_STORE_B(0) H2_STORE_B(1) H2_STORE_B(2) H2_STORE_B(3) H2_STORE_B(4) H2_STORE_B(5) H2_STORE_B(6)
         H2_STORE_B(7) H2_STORE_B(8) H2_STORE_B(9) H2_STORE_B(10) H2_STORE_B(11) H2_STORE_B(12) H2_STORE_B(13)
         __syncthreads();
@@ -231,17 +236,24 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) {
             const int to = hh ? tap_off(2 * p + 1) : tap_off(2 * p);
-            union { uint4 u; f16x8 v; } ah, al;
-            ah.u = AsH[aslot + to];
-            al.u = AsL[aslot + to];
+            union FR { uint4 u; f16x8 v; };
+            FR ah[MT], al[MT];
+            ah[0].u = AsH[aslot0 + to];
+            al[0].u = AsL[aslot0 + to];
+            if constexpr (MT > 1) { ah[1].u = AsH[aslot1 + to]; al[1].u = AsL[aslot1 + to]; }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                union { uint4 u; f16x8 v; } bh, bl;
+                FR bh, bl;
                 bh.u = bph[(2 * p) * BN + 32 * j];
                 bl.u = bpl[(2 * p) * BN + 32 * j];
-                acc_hi[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bh.v, acc_hi[j], 0, 0, 0);
-                acc_lo[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.v, bl.v, acc_lo[j], 0, 0, 0);
-                acc_lo[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.v, bh.v, acc_lo[j], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc_hi[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bh.v, acc_hi[m][j], 0, 0, 0);
+                    acc_lo[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bl.v, acc_lo[m][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc_lo[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m].v, bh.v, acc_lo[m][j], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -260,16 +272,18 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         const float bsv = a.bias[ch];
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int g = rowinfo[row];
-            if (g >= 0) {
-                const float v = fmaf(acc_lo[j][i], 1.f / H2_SCALE, acc_hi[j][i]) + bsv;
-                if (ch < a.store_cols) a.out[((int64_t)b * M + g) * a.store_cols + ch] = v;
-                s += v;
-                q += v * v;
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (wave * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const int g = rowinfo[row];
+                if (g >= 0) {
+                    const float v = fmaf(acc_lo[m][j][i], 1.f / H2_SCALE, acc_hi[m][j][i]) + bsv;
+                    if (ch < a.store_cols) a.out[((int64_t)b * M + g) * a.store_cols + ch] = v;
+                    s += v;
+                    q += v * v;
+                }
             }
-        }
         s += __shfl_xor(s, 32);
         q += __shfl_xor(q, 32);
         if (hh == 0) { red[(wave * BN + 32 * j + nn) * 2] = s; red[(wave * BN + 32 * j + nn) * 2 + 1] = q; }
@@ -288,6 +302,14 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 // host side
 // ------------------------------------------------------------------------------------------------
 // 64-column tiles whenever two work-groups still fit into the 160 KB of LDS (weight slab 57 KB + 32 B per halo slot)
+// two row tiles per wave for the 32-column tiles: only for launches that still fill the chip with 256-voxel tiles
+int h2_mt(const Level &l, int batch)
+{
+    const char *e = getenv("ISX_H2_MT2");                  // 0: never, 1 (default): big launches, 2: always (tests)
+    const int on = e ? atoi(e) : 1;
+    return on == 2 || (on && (int64_t)batch * l.M >= (1 << 21));
+}
+
 int conv_h2_bn(int slots, int cout)
 {
     const size_t lds64 = (size_t)(2 * 28 * 64 + 2 * slots) * 16 + (128 + 4 * 64 * 2) * sizeof(float);
@@ -340,7 +362,7 @@ void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_
 
 // fold != 0: the folded tail layer (TX = 1, 32 columns of which store_cols = 16 are stored, no statistics)
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold)
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used)
 {
     ConvArgs a;
     a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
@@ -352,24 +374,33 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.store_cols = fold ? 16 : cout;
     a.no_stats = no_stats;
     a.xcd_remap = xcd_remap;
-    ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     ISX_REQUIRE((fold || cout % 32 == 0) && sa.C % 8 == 0 && sb.C % 8 == 0, "internal: split-f16 conv needs Cout %% 32 == 0, Cin %% 8 == 0");
-    const int BN = fold ? 32 : conv_h2_bn(a.slots_max, cout);
+    int BN = fold ? 32 : conv_h2_bn(a.slots_max, cout);
+    // 32-column tiles get two row tiles per wave (256-voxel work-groups) when the launch is big enough to fill
+    // the chip that way; the partial-sum layout then follows that tiling (mt is fixed per workspace: h2_mt)
+    const int mt = (BN == 32 && h2_mt(l, ctx->unet->wbatch)) ? 2 : 1;
+    if (mt == 2) a.tiles_per_chunk = conv_tiles(l, a.mode, 2, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+    ISX_REQUIRE(a.slots_max <= (mt == 2 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     a.ntiles = fold ? 1 : cout / BN;
     const int npair = fold ? 5 : 14;
-    const size_t lds = (size_t)(2 * 2 * npair * BN + 2 * a.slots_max) * 16 + (128 + 4 * BN * 2) * sizeof(float);
+    const size_t lds = (size_t)(2 * 2 * npair * BN + 2 * a.slots_max) * 16 + (128 * mt + 4 * BN * 2) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
+    if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
     static bool attr_done = false;
     if (!attr_done) {
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    if (fold) conv_h2_kernel<32, 1><<<grid, 256, lds, ctx->stream>>>(a);
-    else if (BN == 64) conv_h2_kernel<64, 3><<<grid, 256, lds, ctx->stream>>>(a);
-    else conv_h2_kernel<32, 3><<<grid, 256, lds, ctx->stream>>>(a);
+    if (fold && mt == 2) conv_h2_kernel<32, 1, 2><<<grid, 256, lds, ctx->stream>>>(a);
+    else if (fold) conv_h2_kernel<32, 1, 1><<<grid, 256, lds, ctx->stream>>>(a);
+    else if (BN == 64) conv_h2_kernel<64, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
+    else if (mt == 2) conv_h2_kernel<32, 3, 2><<<grid, 256, lds, ctx->stream>>>(a);
+    else conv_h2_kernel<32, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
     ISX_CHECK_LAUNCH();
     return ISX_OK;
 }

@@ -1077,6 +1077,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
     UNetState *u = ctx->unet;
     ConvBN &L = u->cv[li];
     const int cin = sa.C + sb.C;
+    int stat_tiles = L.tiles;                 // tiles per chunk in the partial-sum layout the conv kernel wrote
     ISX_REQUIRE(cin == L.cin, "internal: layer %s fed %d channels, expects %d", L.conv.c_str(), cin, L.cin);
     if (use_mfma(L.cin, L.cout)) {
         ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
@@ -1085,7 +1086,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
         const void *wh = conv_h2_bn(slots, L.cout) == 64 ? L.w_h2_64 : L.w_h2_32;
         const bool in_range = std::max(sa.bound, sb.bound) < 6.0e4f;          // else operands could leave the f16 range
         if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && wh && in_range && conv_mt(l, u->wbatch, L.cout) == 1)
-            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, conv_xcd_remap(), 0));
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, conv_xcd_remap(), 0, &stat_tiles));
         else
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
     } else if (use_fold(L.cin, L.cout)) {
@@ -1094,7 +1095,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
             conv_mt(l, u->wbatch, 32) == 1) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, L.w_h2_32, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
-                                   conv_xcd_remap(), 1));
+                                   conv_xcd_remap(), 1, nullptr));
         } else {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ConvArgs a;
@@ -1153,7 +1154,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
     {
         ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
         bn_finalize_kernel<<<dim3((unsigned)L.cout, (unsigned)B), 256, 0, ctx->stream>>>(
-            L.psum, L.psq, L.tiles, L.cout, (double)l.M, L.gamma, L.beta, L.scale, L.shift, L.bmean, L.bvar, L.invstd);
+            L.psum, L.psq, stat_tiles, L.cout, (double)l.M, L.gamma, L.beta, L.scale, L.shift, L.bmean, L.bvar, L.invstd);
         ISX_CHECK_LAUNCH();
         bn_running_kernel<<<cdiv(L.cout, 64), 64, 0, ctx->stream>>>(L.bmean, L.bvar, B, L.cout, L.rmean, L.rvar);
         ISX_CHECK_LAUNCH();

@@ -107,10 +107,11 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
                      int cout, float *out, float *psum, float *psq, int no_stats);
 // split-f16 convolution (conv_h2.hip)
 int conv_h2_bn(int slots, int cout);
+int h2_mt(const Level &l, int batch);
 void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out);
 void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out);
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold);
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used);
 int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch);
 int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3]);
 int dev_alloc(UNetState *u, size_t floats, float **out);

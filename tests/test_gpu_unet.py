@@ -189,3 +189,23 @@ def test_split_f16_falls_back_to_fp32_out_of_range():
     with torch.no_grad():
         ref = ou.unet_forward(ou._as_params(sd), torch.from_numpy(x)[None, None]).numpy()
     assert np.isfinite(y).all() and np.abs(y - ref).max() <= ABS_TOL
+
+
+def test_split_f16_two_row_tiles_per_wave(golden, monkeypatch):
+    """The 256-voxel work-group variant of the 32-column split-f16 kernel (used for big launches only) on the
+    golden taps and on a ragged predict geometry."""
+    from iterseg_amd import weights, predict
+    from iterseg_amd.unet import UNet
+    monkeypatch.setenv("ISX_H2_MT2", "2")
+    u = UNet(1, 5, batch=4, precision="split-f16")
+    u.load_state_dict(weights.generate_state_dict(0))
+    d = golden("unet_taps_4x32x32")
+    y = u(d["x"][None, None])
+    for name in ["c0", "c1", "c4", "c5_0", "c8_0.conv1"]:
+        _close(u.tap(name), d[name][0], name)
+    assert np.abs(y[0] - d["c8_0"][0]).max() <= ABS_TOL
+    d = golden("predict_9x40x56")
+    out = np.zeros_like(d["feature_map"])
+    predict.process_chunks(d["volume"], tuple(int(c) for c in d["chunk"]), out, tuple(int(m) for m in d["margin"]),
+                           predict.predict_chunk_feature_map, config={"unet": u, "output_volume": out})
+    assert np.abs(out - d["feature_map"]).max() <= ABS_TOL
