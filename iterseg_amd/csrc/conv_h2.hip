@@ -378,8 +378,13 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     int BN = fold ? 32 : conv_h2_bn(a.slots_max, cout);
     // 32-column tiles get two row tiles per wave (256-voxel work-groups) when the launch is big enough to fill
     // the chip that way; the partial-sum layout then follows that tiling (mt is fixed per workspace: h2_mt)
-    const int mt = (BN == 32 && h2_mt(l, ctx->unet->wbatch)) ? 2 : 1;
-    if (mt == 2) a.tiles_per_chunk = conv_tiles(l, a.mode, 2, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+    int mt = (BN == 32 && h2_mt(l, ctx->unet->wbatch)) ? 2 : 1;
+    if (mt == 2) {
+        int ty, tx, tp, sl;
+        const int tiles2 = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
+        if (sl <= 1280) { a.tiles_per_chunk = tiles2; a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl; }
+        else mt = 1;                   // very narrow levels: the 256-position halo does not fit the staging plan
+    }
     ISX_REQUIRE(a.slots_max <= (mt == 2 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     a.ntiles = fold ? 1 : cout / BN;
     const int npair = fold ? 5 : 14;

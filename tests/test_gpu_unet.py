@@ -209,3 +209,25 @@ def test_split_f16_two_row_tiles_per_wave(golden, monkeypatch):
     predict.process_chunks(d["volume"], tuple(int(c) for c in d["chunk"]), out, tuple(int(m) for m in d["margin"]),
                            predict.predict_chunk_feature_map, config={"unet": u, "output_volume": out})
     assert np.abs(out - d["feature_map"]).max() <= ABS_TOL
+
+
+@pytest.mark.parametrize("precision", ["fp32", "split-f16", "split-f16/two-row-tiles"])
+@pytest.mark.parametrize("chunk", [(2, 16, 16), (6, 48, 80), (8, 96, 32), (4, 144, 16), (10, 64, 128)])
+def test_other_chunk_geometries_against_oracle(chunk, precision, monkeypatch):
+    """Chunk shapes other than the reference default: every tile mapping (box tiles, row-wrapped tiles with one and two
+    planes), partial tiles and the XCD-ordered grid on small launches, both arithmetic modes, against the torch oracle."""
+    from oracle import unet_torch as ou
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    from tests.synth import positive_volume
+    if precision.endswith("two-row-tiles"):            # the big-launch variant of the 32-column split kernel
+        monkeypatch.setenv("ISX_H2_MT2", "2")
+        precision = "split-f16"
+    sd = weights.generate_state_dict(0)
+    x = positive_volume(chunk, 21)
+    u = UNet(1, 5, batch=2, precision=precision)
+    u.load_state_dict(sd)
+    y = u(x[None, None])
+    with torch.no_grad():
+        ref = ou.unet_forward(ou._as_params(sd), torch.from_numpy(x)[None, None]).numpy()
+    assert y.shape == ref.shape and np.abs(y - ref).max() <= ABS_TOL, (chunk, precision, np.abs(y - ref).max())
