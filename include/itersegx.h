@@ -159,6 +159,23 @@ int isx_adam_step(isx_ctx *ctx, float lr, int n_steps);
 int isx_train_refresh_weights(isx_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------- *
+ * Training targets -- src/iterseg/labels.py (the producer side of train_unet). *
+ * ---------------------------------------------------------------------------------- */
+/* get_training_labels (labels.py:23-68) for int32 instance labels (Z,Y,X) on the device -> float32 (C,Z,Y,X):
+ *   ISX_TARGET_AFFINITY   "<axis>-<n>"  nth_affinity (labels.py:87-108): 1 where voxel i and voxel i - n along the axis
+ *                                       differ (reflected at the start), else 0;
+ *   ISX_TARGET_CENTRENESS "centreness"  get_centreness (labels.py:142-205, log/power off): per object
+ *                                       1 - d / d_max, d = |(centroid - voxel) * scale| in float64; 0 for background and
+ *                                       for single-voxel objects;
+ *   ISX_TARGET_MASK       "mask"        get_semantic_labels (labels.py:283-285): labels > 1.
+ * The reference returns float64 holding the same values (affinities / mask are 0 or 1, centreness is float32). */
+#define ISX_TARGET_AFFINITY 0
+#define ISX_TARGET_CENTRENESS 1
+#define ISX_TARGET_MASK 2
+int isx_training_labels(isx_ctx *ctx, const int32_t *labels, const int64_t shape[3], int n_channels,
+                        const int32_t *kind, const int32_t *axis, const int32_t *n, const double scale[3], float *out);
+
+/* ---------------------------------------------------------------------------------- *
  * Watershed post-processor -- src/iterseg/watershed.py.                                 *
  * ---------------------------------------------------------------------------------- */
 /* Multi-GPU flood: the flood decomposes exactly over 6-connected mask components (the heap order inside one

@@ -1,0 +1,56 @@
+"""CPU oracle for the training-target generation.  TEST INFRASTRUCTURE ONLY.
+
+numpy restatement of ``get_training_labels`` (reference src/iterseg/labels.py:23-68) for the channel kinds the
+default training uses: ``<axis>-<n>`` affinities (labels.py:87-108), ``centreness`` (labels.py:142-205, log/power
+off) and ``mask`` (labels.py:283-285).  Pinned against tests/golden/training_labels.npz (generated from the
+reference with tests/golden/gen_stage3_labels.py) by tests/test_oracle_labels.py.
+"""
+import re
+
+import numpy as np
+
+
+def nth_affinity(labels, n, axis):
+    """1.0 where voxel i and voxel i - n along ``axis`` carry different labels; the first n positions compare with the
+    reflected index n - i (np.pad(..., mode='reflect'), labels.py:89)."""
+    L = np.asarray(labels)
+    idx = np.arange(L.shape[axis]) - n
+    idx = np.where(idx < 0, -idx, idx)
+    other = np.take(L, idx, axis=axis)
+    return np.where(L - other != 0, 1.0, 0.0)
+
+
+def get_centreness(labels, scale=(4, 1, 1)):
+    """Per object: 1 - d / d_max with d the scaled Euclidean distance (float64) of the voxel to the object's
+    centroid; float32 result; single-voxel objects give 0/0 -> nan -> 0 (np.nan_to_num, labels.py:175)."""
+    L = np.asarray(labels)
+    scale = np.asarray(scale, np.float64)
+    out = np.zeros(L.shape, np.float32)
+    ids = np.unique(L)
+    coords = np.argwhere(L > 0)
+    lab = L[L > 0]
+    for i in ids[ids > 0]:
+        pts = coords[lab == i]
+        c = np.mean(pts, axis=0)
+        diff = (c - pts) * scale
+        d = np.sqrt(np.einsum("ij,ij->i", diff, diff))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            v = 1 - d / d.max()
+        out[tuple(pts.T)] = v
+    return np.nan_to_num(out)
+
+
+def get_training_labels(l, channels=('z-1', 'y-1', 'x-1', 'centreness'), scale=(4, 1, 1)):
+    labs = []
+    for chan in channels:
+        axis = {'z': 0, 'y': 1, 'x': 2}.get(chan[0])
+        n = re.search(r'\d+', chan)
+        if n is not None:
+            labs.append(nth_affinity(l, int(n[0]), axis))
+        elif chan == 'centreness':
+            labs.append(get_centreness(l, scale))
+        elif chan == 'mask':
+            labs.append(np.where(np.asarray(l) > 1, 1., 0.))
+        else:
+            raise ValueError(f'Unrecognised channel type: {chan}')
+    return np.stack(labs, axis=0)
