@@ -71,15 +71,39 @@ def cpu_baseline(sd, chunk, margin):
                       f"chunk over-compute 1.11x here vs 2.81x at 512^3"}
 
 
-def split_f16_leg(u, vol, fm, labels, chunk, margin, args, n_chunks, mfma_flops, n_inst_fp32):
-    """The same workload with the wide convolutions on the f16 matrix cores in split-operand (fp32-class)
-    arithmetic -- reported beside the fp32 headline, never as `value`.  Also measures how far the two feature maps
-    are apart on the first 64 planes of the volume."""
+DTYPE = {"fp32": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)",
+         "split-f16": "f32 operands split into two f16 halves each (x = x_h + x_l / 2^11), three v_mfma_f32_32x32x16_f16 per K "
+                      "block with separate fp32 accumulators: fp32-class results on the f16 matrix cores"}
+# L2-miss bytes per chunk-launch of the wide-conv kernels: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from separate
+# rocprofv3 --pmc passes over one 64-chunk launch set, 16 launches (profiles/r01g_pmc_*, r01i_pmc_*)
+TRAFFIC_PER_CHUNK_LAUNCH = {"fp32": 0.1054e9, "split-f16": 0.0848e9}
+TRAFFIC_ALGORITHMIC = 0.05725e9          # every activation read once + written once + weights, per chunk-launch
+
+
+def conv_roofline(precision, mfma_flops, n_chunks, steps, ms_mfma, n_mfma, batch):
+    peak = PEAK_MFMA_F32 if precision == "fp32" else PEAK_MFMA_F16
+    ach = (mfma_flops * n_chunks * steps) / (ms_mfma * 1e-3) / 1e12 if ms_mfma > 0 else 0.0
+    r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+         "traffic": TRAFFIC_PER_CHUNK_LAUNCH[precision] * batch, "traffic_algorithmic": TRAFFIC_ALGORITHMIC * batch,
+         "kernel": ("conv_mfma_kernel (fp32 32x32x2 implicit-GEMM conv, 16 of 18 layers)" if precision == "fp32" else
+                    "conv_h2_kernel (split-f16 32x32x16 implicit-GEMM conv, 16 of 18 layers)"),
+         "avg_launch_ms": ms_mfma / max(n_mfma, 1), "launches": n_mfma, "algorithmic_gflop_per_chunk": mfma_flops / 1e9}
+    if precision != "fp32":
+        r["note"] = ("achieved = algorithmic (fp32-equivalent) FLOPs; the split executes 3 f16 MFMAs per product (x 28/27 tap "
+                     "padding), so the f16 pipe runs at about 3.1x this fraction; against the fp32 matrix peak (157.3) the same "
+                     "work rate is %.2f" % (ach / PEAK_MFMA_F32))
+    return r
+
+
+def other_precision_leg(u, other, vol, fm, labels, chunk, margin, args, n_chunks, mfma_flops):
+    """The same workload in the other arithmetic mode, reported beside the headline (never as `value`), and how far
+    the two feature maps are apart on the first 64 planes of the volume."""
     from iterseg_amd import segmentation
     dev = vol.device
+    main = u.precision
     sub = vol[:64].contiguous()
     a = u.predict_volume(sub, chunk, margin).clone()
-    u.set_precision("split-f16")
+    u.set_precision(other)
     b = u.predict_volume(sub, chunk, margin)
     diff = float((a - b).abs().max().item())
     del a, b
@@ -101,16 +125,11 @@ def split_f16_leg(u, vol, fm, labels, chunk, margin, args, n_chunks, mfma_flops,
     el = time.perf_counter() - t0
     ms_mfma, n_mfma = u.ctx.prof_get("conv_mfma")
     n_inst = int(labels.max().item())
-    u.set_precision("fp32")
+    u.set_precision(main)
     nvox = float(vol.numel())
-    ach = (mfma_flops * n_chunks * args.steps) / (ms_mfma * 1e-3) / 1e12 if ms_mfma > 0 else 0.0
-    return {"dtype": "f32 operands split into two f16 halves, 3 x v_mfma_f32_32x32x16_f16 per K block, fp32 accumulate",
-            "value": nvox * args.steps / el, "unit": "voxels/s", "ms_per_step": 1e3 * el / args.steps,
-            "max_abs_diff_vs_fp32_feature_map": diff, "instances": n_inst, "instances_fp32": n_inst_fp32,
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F16, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F16,
-                         "note": "algorithmic fp32-equivalent FLOPs; the split executes 3 f16 MFMAs per product (x 28/27 tap "
-                                 "padding), i.e. the matrix pipe runs at about 3.1x this fraction",
-                         "avg_launch_ms": ms_mfma / max(n_mfma, 1), "launches": n_mfma}}
+    return {"dtype": DTYPE[other], "value": nvox * args.steps / el, "unit": "voxels/s", "ms_per_step": 1e3 * el / args.steps,
+            "max_abs_diff_of_feature_maps": diff, "instances": n_inst,
+            "roofline": conv_roofline(other, mfma_flops, n_chunks, args.steps, ms_mfma, n_mfma, args.batch)}
 
 
 def main():
@@ -121,7 +140,10 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume (default: the 512^3 north star)")
     ap.add_argument("--batch", type=int, default=64, help="chunks per launch set (1..64; ~0.6 GB of workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-split-f16", action="store_true", help="skip the extra split-f16 measurement (N = 1 only)")
+    ap.add_argument("--precision", default=None, choices=["fp32", "split-f16"],
+                    help="arithmetic of the wide convolutions (default: the library default, split-f16)")
+    ap.add_argument("--no-split-f16", "--no-other-precision", dest="no_other", action="store_true",
+                    help="skip the extra measurement in the other arithmetic mode (N = 1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,7 +172,8 @@ def main():
     chunk, margin = (10, 256, 256), (1, 64, 64)
     shape = (args.size,) * 3
     sd = weights.generate_state_dict(0)
-    u = UNet(1, 5, device=local_rank, batch=args.batch)
+    u = UNet(1, 5, device=local_rank, batch=args.batch, precision=args.precision)
+    precision = u.precision
     u.load_state_dict(sd)
 
     # one frame per rank, resident in HBM (seed = rank: frames of a stack differ)
@@ -195,7 +218,6 @@ def main():
         nvox = float(np.prod(shape))
         mfma_flops, direct_flops = conv_flops_per_chunk(chunk)
         ms_mfma, n_mfma = prof["conv_mfma"]
-        achieved = (mfma_flops * n_chunks * args.steps) / (ms_mfma * 1e-3) / 1e12 if ms_mfma > 0 else 0.0
         t_unet = sum(prof[k][0] for k in ("conv_mfma", "conv_direct", "elementwise")) / args.steps
         t_ws = sum(prof[k][0] for k in ("ws_filters", "ws_ccl", "ws_flood")) / args.steps
         out = {
@@ -209,21 +231,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE[precision],
             "data": "synthetic",
             "config": {"workload": f"{args.size}^3 float32 volume per GPU (one frame per rank), chunk (10,256,256), "
+                                   f"precision {precision}, "
                                    f"margin (1,64,64) = {n_chunks} chunks, seeded random U-Net weights (seed 0), "
                                    f"train-mode BatchNorm per chunk, watershed min_area 10 / max_area 1e7",
                        "chunks_per_launch_set": args.batch, "labelled_voxels": n_labelled, "instances": n_inst},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA_F32, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_MFMA_F32,
-                         # L2-miss bytes per launch from separate rocprofv3 --pmc passes over one 64-chunk launch
-                         # set (profiles/r01g_pmc_*: FETCH_SIZE x2 per the gfx950 correction = 84.7 GB, WRITE_SIZE =
-                         # 23.2 GB, 16 launches).  Algorithmic = every activation read once + written once + weights.
-                         "traffic": 0.1054e9 * args.batch, "traffic_algorithmic": 0.05725e9 * args.batch,
-                         "kernel": "conv_mfma_kernel (fp32 32x32x2 implicit-GEMM conv, 16 of 18 layers)",
-                         "avg_launch_ms": ms_mfma / max(n_mfma, 1), "launches": n_mfma,
-                         "algorithmic_gflop_per_chunk": mfma_flops / 1e9},
+            "roofline": conv_roofline(precision, mfma_flops, n_chunks, args.steps, ms_mfma, n_mfma, args.batch),
             "stages_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "watershed_roofline": {"bound": "hbm", "achieved": 24.0 * nvox / (t_ws * 1e-3) / 1e9 if t_ws > 0 else 0.0,
                                    "peak": PEAK_HBM, "unit": "GB/s",
@@ -232,11 +247,14 @@ def main():
             "t_unet_ms": t_unet, "t_ws_ms": t_ws,
         }
         # combined fraction t_ideal / t_measured, t_ideal = FLOPs / peak_MFMA + 24 B * ZYX / peak_HBM
-        t_ideal = ((mfma_flops + direct_flops) * n_chunks / (PEAK_MFMA_F32 * 1e12) + 24.0 * nvox / (PEAK_HBM * 1e9)) * 1e3
+        peak_tf = PEAK_MFMA_F32 if precision == "fp32" else PEAK_MFMA_F16
+        t_ideal = ((mfma_flops + direct_flops) * n_chunks / (peak_tf * 1e12) + 24.0 * nvox / (PEAK_HBM * 1e9)) * 1e3
         out["combined_roofline_frac"] = t_ideal / (1e3 * elapsed / args.steps)
         out["t_ideal_ms"] = t_ideal
-        if world == 1 and not args.no_split_f16:
-            out["split_f16"] = split_f16_leg(u, vol, fm, labels, chunk, margin, args, n_chunks, mfma_flops, n_inst)
+        if world == 1 and not args.no_other:
+            other = "fp32" if precision != "fp32" else "split-f16"
+            out["other_precision"] = {other: other_precision_leg(u, other, vol, fm, labels, chunk, margin, args, n_chunks,
+                                                                 mfma_flops)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, chunk, margin)
         print(json.dumps(out))

@@ -20,6 +20,12 @@ import torch
 from . import _lib, weights as _weights
 
 
+# Arithmetic of the wide inference convolutions when the caller does not choose: split-f16 is fp32-class (error against
+# a float64 oracle at or below the fp32 kernel's own) and about twice as fast; "fp32" keeps exact fp32
+# products.  Training always runs fp32.
+DEFAULT_PRECISION = "split-f16"
+
+
 class UNet:
     def __init__(self, in_channels=1, out_channels=5, down_factors=(1, 2, 2), up='convolution',
                  downsample_1_at_bottom=True, chan_final_activations=None, device=None, batch=32,
@@ -38,7 +44,7 @@ class UNet:
         self._loaded = False
         self._sd = None
         self.precision = "fp32"
-        self.set_precision(precision if precision is not None else os.environ.get("ISX_CONV_PRECISION", "fp32"))
+        self.set_precision(precision if precision is not None else os.environ.get("ISX_CONV_PRECISION", DEFAULT_PRECISION))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict, strict=True):

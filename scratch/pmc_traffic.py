@@ -4,7 +4,7 @@ tot = collections.defaultdict(float); n = collections.Counter()
 for path in sys.argv[1:]:
     for f in glob.glob(path):
         for r in csv.DictReader(open(f)):
-            if 'conv_mfma' not in r['Kernel_Name']: continue
+            if 'conv_mfma' not in r['Kernel_Name'] and 'conv_h2' not in r['Kernel_Name']: continue
             tot[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
 fetch = tot.get('FETCH_SIZE', 0) * 1024 * 2; write = tot.get('WRITE_SIZE', 0) * 1024
 nl = max(n.values()) if n else 1

@@ -21,7 +21,7 @@ def net():
     assert torch.cuda.is_available(), "these tests need the MI355X"
     from iterseg_amd import weights
     from iterseg_amd.unet import UNet
-    u = UNet(1, 5, batch=4)
+    u = UNet(1, 5, batch=4, precision="fp32")
     u.load_state_dict(weights.generate_state_dict(0))
     return u
 
