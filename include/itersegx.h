@@ -113,11 +113,12 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
                       int64_t shape_out[4]);
 /* Max chunks processed concurrently by one launch set (workspace sizing). */
 int isx_unet_set_batch(isx_ctx *ctx, int batch);
-/* Arithmetic of the wide convolutions at inference.  ISX_PRECISION_FP32 (default): v_mfma_f32_32x32x2_f32, exact
- * fp32 products.  ISX_PRECISION_SPLIT_F16: every fp32 operand split into two halves (hi + lo/2^11), three
- * v_mfma_f32_32x32x16_f16 per K block with fp32 accumulation -- fp32-class results (about 2^-21 per product, below
- * the fp32 accumulation noise) at the f16 matrix rate; operands are clamped to +-65504.  Training always runs
- * fp32.  Same reference operator either way: nn.Conv3d in ConvModule.forward (unet.py:63-79,91-106). */
+/* Arithmetic of the wide convolutions at inference.  ISX_PRECISION_SPLIT_F16 (default): every fp32 operand split into
+ * two halves (hi + lo/2^11), three v_mfma_f32_32x32x16_f16 per K block with separate fp32 accumulators -- fp32-class
+ * results (about 2^-21 per product, below the fp32 accumulation noise; measured error against a float64 oracle at or
+ * below the fp32 kernel's) at the f16 matrix rate; layers whose operands could leave the f16 range run the fp32 kernel.
+ * ISX_PRECISION_FP32: v_mfma_f32_32x32x2_f32, exact fp32 products.  Training always runs fp32.  Same reference
+ * operator either way: nn.Conv3d in ConvModule.forward (unet.py:63-79,91-106). */
 #define ISX_PRECISION_FP32 0
 #define ISX_PRECISION_SPLIT_F16 1
 int isx_unet_set_precision(isx_ctx *ctx, int mode);

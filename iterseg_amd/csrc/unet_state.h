@@ -49,7 +49,7 @@ struct UNetState {
     bool committed = false;
     int out_channels = 5;
     int batch = 4;
-    int precision = 0;          // ISX_PRECISION_FP32 | ISX_PRECISION_SPLIT_F16 (inference convolutions)
+    int precision = ISX_PRECISION_SPLIT_F16;     // arithmetic of the wide inference convolutions (isx_unet_set_precision)
     // layers: index 0..17 = c0.conv0, c0.conv1, c1.conv0, ... c4.conv1, c5.conv0 ... c8.conv1
     ConvBN cv[18];
     UpConv up[4];
