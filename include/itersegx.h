@@ -177,6 +177,17 @@ int isx_training_labels(isx_ctx *ctx, const int32_t *labels, const int64_t shape
                         const int32_t *kind, const int32_t *axis, const int32_t *n, const double scale[3], float *out);
 
 /* ---------------------------------------------------------------------------------- *
+ * Segmentation assessment -- src/iterseg/metrics.py (the pinnable part). *
+ * ---------------------------------------------------------------------------------- */
+/* Contingency table of two int32 label volumes of n voxels (device): the distinct (gt, mr) pairs, as
+ * (uint32 gt << 32 | uint32 mr) in ascending order, and their voxel counts, into device buffers of `cap` entries;
+ * *n_pairs (host) receives the number of distinct pairs (ISX_ERR_ARG if it exceeds cap).  This is the counting
+ * behind skimage.metrics.variation_of_information(gt, mr) and the np.unique object counts of get_accuracy_metrics
+ * (metrics.py:105-119); the entropies are computed from it in float64 on the host. */
+int isx_label_contingency(isx_ctx *ctx, const int32_t *gt, const int32_t *mr, int64_t n, uint64_t *pairs,
+                          int64_t *counts, int64_t cap, int64_t *n_pairs);
+
+/* ---------------------------------------------------------------------------------- *
  * Watershed post-processor -- src/iterseg/watershed.py.                                 *
  * ---------------------------------------------------------------------------------- */
 /* Multi-GPU flood: the flood decomposes exactly over 6-connected mask components (the heap order inside one

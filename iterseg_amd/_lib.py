@@ -54,6 +54,7 @@ SIGNATURES = {
     "isx_adam_step": (C.c_int, [_vp, _f32, C.c_int]),
     "isx_train_refresh_weights": (C.c_int, [_vp]),
     "isx_training_labels": (C.c_int, [_vp, _vp, _i64p, C.c_int, _i32p, _i32p, _i32p, C.POINTER(C.c_double), _vp]),
+    "isx_label_contingency": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64p]),
     "isx_ws_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
     "isx_ws_gaussian": (C.c_int, [_vp, _vp, _vp, _i64p, _i32p]),
     "isx_ws_threshold_otsu": (C.c_int, [_vp, _vp, _i64, _f32p]),
