@@ -378,7 +378,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     int BN = fold ? 32 : conv_h2_bn(a.slots_max, cout);
     // 32-column tiles get two row tiles per wave (256-voxel work-groups) when the launch is big enough to fill
     // the chip that way; the partial-sum layout then follows that tiling (mt is fixed per workspace: h2_mt)
-    int mt = (BN == 32 && h2_mt(l, ctx->unet->wbatch)) ? 2 : 1;
+    // (the folded layer stays at one row tile: measured 9.7 ms against 10.9 with two; 16-channel stages for it were
+    // tried as well and lost a wave per SIMD: 11.6-15.2 ms)
+    int mt = (!fold && BN == 32 && h2_mt(l, ctx->unet->wbatch)) ? 2 : 1;
     if (mt == 2) {
         int ty, tx, tp, sl;
         const int tiles2 = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
