@@ -406,24 +406,6 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
     }
 }
 
-__global__ void ccl_init_kernel(const uint8_t *__restrict__ mask, uint32_t *parent, int64_t N)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) parent[i] = mask[i] ? (uint32_t)i : NO_PARENT;
-}
-
-__global__ void ccl_merge_kernel(const uint8_t *__restrict__ mask, uint32_t *parent, int64_t PZ,
-                                 int64_t PY, int64_t PX)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t N = PZ * PY * PX;
-    if (i >= N || !mask[i]) return;
-    int64_t x = i % PX, y = (i / PX) % PY, z = i / (PX * PY);
-    if (x > 0 && mask[i - 1]) uf_union(parent, (uint32_t)i, (uint32_t)(i - 1));
-    if (y > 0 && mask[i - PX]) uf_union(parent, (uint32_t)i, (uint32_t)(i - PX));
-    if (z > 0 && mask[i - PX * PY]) uf_union(parent, (uint32_t)i, (uint32_t)(i - PX * PY));
-}
-
 __global__ void ccl_flatten_kernel(uint32_t *parent, int64_t N)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -487,15 +469,92 @@ __global__ void ccl_apply_kernel(const uint32_t *__restrict__ parent, const uint
     mask_out[i] = keep;
 }
 
+// Two-level labelling: a block first resolves its own 8 x 16 x 32 tile with a union-find in LDS (no global traffic
+// besides one mask read and one parent write per voxel), roots being the smallest raveled index inside the tile; then
+// only the voxels on the three low faces of every tile are merged across tiles with the global agent-scope union-find.
+// (The one-level version did three global unions per voxel: 10 ms of the 21 ms watershed stage at 512^3.)
+static constexpr int CT_Z = 8, CT_Y = 16, CT_X = 32, CT_N = CT_Z * CT_Y * CT_X;     // 4096 voxels, 16 per thread
+
+__device__ __forceinline__ uint32_t lds_find(uint32_t *lab, uint32_t a)
+{
+    uint32_t p = lab[a];
+    while (p != a) { const uint32_t gp = lab[p]; if (gp != p) atomicMin(&lab[a], gp); a = p; p = gp; }
+    return a;
+}
+
+__device__ __forceinline__ void lds_union(uint32_t *lab, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = lds_find(lab, a);
+        b = lds_find(lab, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }       // a > b: hang a under b
+        const uint32_t old = atomicMin(&lab[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t *__restrict__ mask, uint32_t *__restrict__ parent,
+                                                       int64_t PZ, int64_t PY, int64_t PX, int ntx, int nty)
+{
+    __shared__ uint32_t lab[CT_N];
+    __shared__ uint8_t mk[CT_N];
+    const int tx = blockIdx.x % ntx, ty = (blockIdx.x / ntx) % nty, tz = blockIdx.x / (ntx * nty);
+    const int64_t z0 = (int64_t)tz * CT_Z, y0 = (int64_t)ty * CT_Y, x0 = (int64_t)tx * CT_X;
+    for (int i = threadIdx.x; i < CT_N; i += 256) {
+        const int lx = i % CT_X, ly = (i / CT_X) % CT_Y, lz = i / (CT_X * CT_Y);
+        const int64_t z = z0 + lz, y = y0 + ly, x = x0 + lx;
+        const bool in = z < PZ && y < PY && x < PX;
+        mk[i] = in ? mask[(z * PY + y) * PX + x] : 0;
+        lab[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CT_N; i += 256) {
+        if (!mk[i]) continue;
+        const int lx = i % CT_X, ly = (i / CT_X) % CT_Y, lz = i / (CT_X * CT_Y);
+        if (lx > 0 && mk[i - 1]) lds_union(lab, (uint32_t)i, (uint32_t)(i - 1));
+        if (ly > 0 && mk[i - CT_X]) lds_union(lab, (uint32_t)i, (uint32_t)(i - CT_X));
+        if (lz > 0 && mk[i - CT_X * CT_Y]) lds_union(lab, (uint32_t)i, (uint32_t)(i - CT_X * CT_Y));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CT_N; i += 256) {
+        const int lx = i % CT_X, ly = (i / CT_X) % CT_Y, lz = i / (CT_X * CT_Y);
+        const int64_t z = z0 + lz, y = y0 + ly, x = x0 + lx;
+        if (!(z < PZ && y < PY && x < PX)) continue;
+        uint32_t out = NO_PARENT;
+        if (mk[i]) {
+            const uint32_t r = lds_find(lab, (uint32_t)i);
+            const int rx = r % CT_X, ry = (r / CT_X) % CT_Y, rz = r / (CT_X * CT_Y);
+            out = (uint32_t)(((z0 + rz) * PY + (y0 + ry)) * PX + (x0 + rx));
+        }
+        parent[(z * PY + y) * PX + x] = out;
+    }
+}
+
+// cross-tile links: voxels on the low x / y / z face of their tile
+__global__ void ccl_seam_kernel(const uint8_t *__restrict__ mask, uint32_t *parent, int64_t PZ, int64_t PY, int64_t PX)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = PZ * PY * PX;
+    if (i >= N || !mask[i]) return;
+    const int64_t x = i % PX, y = (i / PX) % PY, z = i / (PX * PY);
+    if (x > 0 && x % CT_X == 0 && mask[i - 1]) uf_union(parent, (uint32_t)i, (uint32_t)(i - 1));
+    if (y > 0 && y % CT_Y == 0 && mask[i - PX]) uf_union(parent, (uint32_t)i, (uint32_t)(i - PX));
+    if (z > 0 && z % CT_Z == 0 && mask[i - PX * PY]) uf_union(parent, (uint32_t)i, (uint32_t)(i - PX * PY));
+}
+
 static int ccl_impl(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], uint32_t *parent,
                     uint32_t *sizes)
 {
     int64_t N = pshape[0] * pshape[1] * pshape[2];
     ISX_REQUIRE(N < (int64_t)0xFFFFFFF0ll, "volume too large for 32-bit voxel indices");
     unsigned grid = cdiv(N, TPB);
-    ccl_init_kernel<<<grid, TPB, 0, ctx->stream>>>(mask, parent, N);
+    const int ntz = (int)((pshape[0] + CT_Z - 1) / CT_Z), nty = (int)((pshape[1] + CT_Y - 1) / CT_Y),
+              ntx = (int)((pshape[2] + CT_X - 1) / CT_X);
+    ccl_tile_kernel<<<(unsigned)(ntz * nty * ntx), 256, 0, ctx->stream>>>(mask, parent, pshape[0], pshape[1], pshape[2], ntx, nty);
     ISX_CHECK_LAUNCH();
-    ccl_merge_kernel<<<grid, TPB, 0, ctx->stream>>>(mask, parent, pshape[0], pshape[1], pshape[2]);
+    ccl_seam_kernel<<<grid, TPB, 0, ctx->stream>>>(mask, parent, pshape[0], pshape[1], pshape[2]);
     ISX_CHECK_LAUNCH();
     ccl_flatten_kernel<<<grid, TPB, 0, ctx->stream>>>(parent, N);
     ISX_CHECK_LAUNCH();
