@@ -23,13 +23,13 @@ IGNORE_CUDA = False          # kept for API compatibility; this build has no CPU
 DEFAULT_UNET_PATH = None     # upstream's default weights are not distributed (.MISSING_LARGE_BLOBS)
 
 
-def load_unet(u_state_fn=DEFAULT_UNET_PATH, device=None, batch=32):
+def load_unet(u_state_fn=DEFAULT_UNET_PATH, device=None, batch=32, precision=None):
     """``UNet(1, 5)`` with the state dict stored at ``u_state_fn`` (``torch.save`` format)."""
     if u_state_fn is None:
         raise FileNotFoundError(
             "no U-Net weights given: iterseg's default 232208_161159_plateseg.pt is not distributed; "
             "pass a .pt/.pth state dict (see iterseg_amd.weights.generate_state_dict for synthetic ones)")
-    u = unet_mod.UNet(in_channels=1, out_channels=5, device=device, batch=batch)
+    u = unet_mod.UNet(in_channels=1, out_channels=5, device=device, batch=batch, precision=precision)
     u.load_state_dict(torch.load(u_state_fn, map_location="cpu"))
     return u
 
