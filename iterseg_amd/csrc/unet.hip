@@ -64,12 +64,12 @@ __global__ void gather_chunks_kernel(const float *__restrict__ vol, int64_t Y, i
                                      const int32_t *__restrict__ table, int cz, int cy, int cx,
                                      float *__restrict__ x0, int64_t total)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int64_t M = (int64_t)cz * cy * cx;
-    int b = (int)(i / M);
-    int64_t m = i % M;
-    int x = (int)(m % cx), y = (int)((m / cx) % cy), z = (int)(m / ((int64_t)cx * cy));
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)total) return;
+    const uint32_t M = (uint32_t)cz * cy * cx;
+    const int b = (int)(i / M);
+    const uint32_t m = i % M;
+    const int x = (int)(m % (uint32_t)cx), y = (int)((m / (uint32_t)cx) % (uint32_t)cy), z = (int)(m / ((uint32_t)cx * cy));
     const int32_t *r = table + 9 * b;
     x0[i] = vol[((int64_t)(r[0] + z) * Y + (r[1] + y)) * X + (r[2] + x)];
 }
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
     const int64_t m = m0 + nn;                              // this lane's voxel (A rows)
     const bool mv = m < M;
     const int64_t mc = mv ? m : 0;
-    const int x = (int)(mc % W), y = (int)((mc / W) % H), z = (int)(mc / ((int64_t)W * H));
+    const uint32_t mc32 = (uint32_t)mc;                     // one chunk has far fewer than 2^32 voxels
+    const int x = (int)(mc32 % (uint32_t)W), y = (int)((mc32 / (uint32_t)W) % (uint32_t)H), z = (int)(mc32 / ((uint32_t)W * H));
     const float *src = x0 + (int64_t)b * M + mc;
     f32x16 acc;
 #pragma unroll
@@ -445,15 +446,18 @@ __global__ void pool_kernel(const float *__restrict__ src, const float *__restri
                             const float *__restrict__ shift, int C, int D, int H, int W, int kz, int Do, int Ho,
                             int Wo, float *__restrict__ dst, int64_t total)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int C4 = C >> 2;
-    int c4 = (int)(i % C4);
-    int64_t v = i / C4;
-    const int64_t Mo = (int64_t)Do * Ho * Wo, M = (int64_t)D * H * W;
-    int b = (int)(v / Mo);
-    int64_t m = v % Mo;
-    int x = (int)(m % Wo), y = (int)((m / Wo) % Ho), z = (int)(m / ((int64_t)Wo * Ho));
+    // 32-bit index arithmetic throughout (total < 2^32 is checked by the launcher): the 64-bit divisions this kernel
+    // started with cost more than its memory traffic
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)total) return;
+    const uint32_t C4 = (uint32_t)C >> 2;
+    const int c4 = (int)(i % C4);
+    const uint32_t v = i / C4;
+    const uint32_t Mo32 = (uint32_t)Do * Ho * Wo;
+    const int64_t Mo = Mo32, M = (int64_t)D * H * W;
+    const int b = (int)(v / Mo32);
+    const uint32_t m = v % Mo32;
+    const int x = (int)(m % (uint32_t)Wo), y = (int)((m / (uint32_t)Wo) % (uint32_t)Ho), z = (int)(m / ((uint32_t)Wo * Ho));
     const float4 vs = *(const float4 *)&scale[(int64_t)b * C + 4 * c4];
     const float4 vh = *(const float4 *)&shift[(int64_t)b * C + 4 * c4];
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -482,15 +486,16 @@ __global__ void upsample_kernel(const float *__restrict__ src, const float *__re
                                 const float *__restrict__ w, const float *__restrict__ bias, int Do, int Ho, int Wo,
                                 float *__restrict__ dst, int64_t total)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int C4 = C >> 2;
-    int c4 = (int)(i % C4);
-    int64_t v = i / C4;
-    const int64_t Mo = (int64_t)Do * Ho * Wo, M = (int64_t)D * H * W;
-    int b = (int)(v / Mo);
-    int64_t m = v % Mo;
-    int x = (int)(m % Wo), y = (int)((m / Wo) % Ho), z = (int)(m / ((int64_t)Wo * Ho));
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;       // 32-bit index arithmetic (see pool_kernel)
+    if (i >= (uint32_t)total) return;
+    const uint32_t C4 = (uint32_t)C >> 2;
+    const int c4 = (int)(i % C4);
+    const uint32_t v = i / C4;
+    const uint32_t Mo32 = (uint32_t)Do * Ho * Wo;
+    const int64_t Mo = Mo32, M = (int64_t)D * H * W;
+    const int b = (int)(v / Mo32);
+    const uint32_t m = v % Mo32;
+    const int x = (int)(m % (uint32_t)Wo), y = (int)((m / (uint32_t)Wo) % (uint32_t)Ho), z = (int)(m / ((uint32_t)Wo * Ho));
     int zs = z / kz, ys = (y + off) >> 1, xs = (x + off) >> 1;
     int kidx = ((z % kz) * 2 + ((y + off) & 1)) * 2 + ((x + off) & 1);
     const float4 vs = *(const float4 *)&scale[(int64_t)b * C + 4 * c4];
@@ -741,12 +746,14 @@ __global__ void final_kernel(const float *__restrict__ raw, const float *__restr
                              const int32_t *__restrict__ table, float *__restrict__ out_ncdhw,
                              float *__restrict__ fm, int64_t Z, int64_t Y, int64_t X, int64_t total)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int64_t M = (int64_t)cz * cy * cx;
-    int b = (int)(i / M);
-    int64_t m = i % M;
-    int x = (int)(m % cx), y = (int)((m / cx) % cy), z = (int)(m / ((int64_t)cx * cy));
+    const uint32_t i32 = blockIdx.x * blockDim.x + threadIdx.x;     // 32-bit index arithmetic (see pool_kernel)
+    if (i32 >= (uint32_t)total) return;
+    const int64_t i = i32;
+    const uint32_t M32 = (uint32_t)cz * cy * cx;
+    const int64_t M = M32;
+    const int b = (int)(i32 / M32);
+    const uint32_t m = i32 % M32;
+    const int x = (int)(m % (uint32_t)cx), y = (int)((m / (uint32_t)cx) % (uint32_t)cy), z = (int)(m / ((uint32_t)cx * cy));
     const int32_t *r = table + 9 * b;
     bool in_crop = fm && z >= r[3] && z < r[4] && y >= r[5] && y < r[6] && x >= r[7] && x < r[8];
     for (int c = 0; c < nout; ++c) {
@@ -1206,6 +1213,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             const Level &lo = lv[mi + 1];
             const ConvBN &L = u->cv[2 * mi + 1];
             int64_t total = (int64_t)B * lo.M * (L.cout / 4);
+            ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
             pool_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[2 * mi + 1], L.scale, L.shift, L.cout, l.D, l.H,
                                                                 l.W, mi == 3 ? 2 : 1, lo.D, lo.H, lo.W, u->pool[mi],
                                                                 total);
@@ -1223,6 +1231,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
         {
             ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
             int64_t total = (int64_t)B * lo.M * (U.C / 4);
+            ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
             upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D,
                                                                     ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, U.bias, lo.D,
                                                                     lo.H, lo.W, u->ups[k], total);
@@ -1237,6 +1246,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
         ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
         const ConvBN &L = u->cv[17];
         int64_t total = (int64_t)B * lv[0].M;
+        ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
         final_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[17], L.scale, L.shift, L.cout, lv[0].D, lv[0].H,
                                                              lv[0].W, u->d_table, out_ncdhw, fm, shape ? shape[0] : 0,
                                                              shape ? shape[1] : 0, shape ? shape[2] : 0, total);
