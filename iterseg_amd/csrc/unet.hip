@@ -484,7 +484,7 @@ __global__ void pool_kernel(const float *__restrict__ src, const float *__restri
 __global__ void upsample_kernel(const float *__restrict__ src, const float *__restrict__ scale,
                                 const float *__restrict__ shift, int C, int D, int H, int W, int kz, int off,
                                 const float *__restrict__ w, const float *__restrict__ bias, int Do, int Ho, int Wo,
-                                float *__restrict__ dst, int64_t total)
+                                float *__restrict__ dst, int64_t total, int nt_store)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;       // 32-bit index arithmetic (see pool_kernel)
     if (i >= (uint32_t)total) return;
@@ -507,7 +507,12 @@ __global__ void upsample_kernel(const float *__restrict__ src, const float *__re
     t.y = fmaf(fmaxf(fmaf(t.y, vs.y, vh.y), 0.f), wv.y, bv.y);
     t.z = fmaf(fmaxf(fmaf(t.z, vs.z, vh.z), 0.f), wv.z, bv.z);
     t.w = fmaf(fmaxf(fmaf(t.w, vs.w, vh.w), 0.f), wv.w, bv.w);
-    *(float4 *)&dst[((int64_t)b * Mo + m) * C + 4 * c4] = t;
+    if (nt_store) {
+        f32x4 tv = {t.x, t.y, t.z, t.w};
+        __builtin_nontemporal_store(tv, (f32x4 *)&dst[((int64_t)b * Mo + m) * C + 4 * c4]);
+    } else {
+        *(float4 *)&dst[((int64_t)b * Mo + m) * C + 4 * c4] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1234,7 +1239,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
             upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D,
                                                                     ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, U.bias, lo.D,
-                                                                    lo.H, lo.W, u->ups[k], total);
+                                                                    lo.H, lo.W, u->ups[k], total, 1 /* streaming stores: the 5.4 GB output is far larger than L2 */);
             ISX_CHECK_LAUNCH();
         }
         const int mi = 5 + k;                                  // c5..c8
