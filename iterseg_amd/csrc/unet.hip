@@ -111,18 +111,25 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
         const float wv = t < 27 ? w[t * 32 + nn] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, wv, acc, 0, 0, 0);
     }
-    // C/D layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+    // C/D layout of 32x32: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).  The tile goes through
+    // LDS so that the wave writes it as four fully contiguous 1 KB stores (float4 per lane) instead of sixteen
+    // 2 x 128-byte ones: this layer is bound by its 84 MB of output per chunk.
+    __shared__ __attribute__((aligned(16))) float T[4][32 * 36];
     const float bsv = bias[nn];
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int64_t mr = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (mr < M) {
-            const float v = acc[i] + bsv;
-            out[((int64_t)b * M + mr) * 32 + nn] = v;
-            s += v;
-            q += v * v;
-        }
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const float v = acc[i] + bsv;
+        T[wave][row * 36 + nn] = v;
+        if (m0 + row < M) { s += v; q += v * v; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = lane + 64 * k, row = f >> 3, c4 = f & 7;
+        if (m0 + row < M) *(float4 *)&out[((int64_t)b * M + m0 + row) * 32 + 4 * c4] = *(const float4 *)&T[wave][row * 36 + 4 * c4];
     }
     s += __shfl_xor(s, 32);
     q += __shfl_xor(q, 32);
