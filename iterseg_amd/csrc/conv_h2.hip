@@ -394,7 +394,8 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {false};             // the attribute is per device: one flag per device ordinal
+    bool &attr_done = attr_done_dev[ctx->device & 63];
     if (!attr_done) {
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
