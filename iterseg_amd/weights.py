@@ -94,7 +94,8 @@ def generate_state_dict(seed=0, in_channels=1, out_channels=5, bn_jitter=0.1):
 def to_torch_state_dict(sd):
     """numpy state dict -> torch tensors (for ``load_state_dict`` / ``torch.save``)."""
     import torch
-    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)).clone()) for k, v in sd.items())
+    # np.ascontiguousarray promotes 0-d arrays (num_batches_tracked) to shape (1,): keep their shape
+    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v)).clone().reshape(np.shape(v))) for k, v in sd.items())
 
 
 def from_torch_state_dict(tsd):

@@ -1,0 +1,94 @@
+"""GPU tests of the operator / plugin boundary (iterseg_amd/segmentation.py, mirror of the reference's
+src/iterseg/segmentation.py:24-195,700-916): same call sequence and error behaviour as the reference, labels written
+in place, and staged parity -- the labels equal the CPU oracle's watershed of the feature map the HIP U-Net produced
+(bit-exact), the feature map itself being covered by test_gpu_unet.py."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CHUNK, MARGIN = (4, 32, 32), (1, 8, 8)
+
+
+@pytest.fixture(scope="module")
+def unet():
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    u = UNet(1, 5, batch=8)
+    u.load_state_dict(weights.generate_state_dict(0))
+    return u
+
+
+def _oracle_labels(u, vol):
+    """oracle watershed of the feature map the HIP U-Net gives for the (already normalised) volume"""
+    from oracle import watershed as ows
+    fm = u.predict_volume(torch.from_numpy(vol).cuda(), CHUNK, MARGIN).cpu().numpy()
+    lab = np.zeros(tuple(s + 2 for s in vol.shape), np.uint32)
+    try:
+        ows.segment_output_image(fm, out=lab.ravel())
+    except ValueError:
+        return None
+    return lab
+
+
+def test_processing_function_writes_labels_in_place(unet):
+    from iterseg_amd import segmentation as seg
+    from tests.synth import positive_volume
+    vol = positive_volume((10, 48, 40), 3)
+    cur = np.zeros(tuple(s + 2 for s in vol.shape), np.uint32)
+    fm = np.ones((5,) + vol.shape, np.float32)
+    ret = seg.affinity_watershed_for_chunks(vol, cur, CHUNK, MARGIN, unet=unet, output_volume=fm)
+    assert ret is None and not fm.any()                         # labels by mutation; output_volume zeroed (:195)
+    ref = _oracle_labels(unet, vol)
+    assert ref is not None and np.array_equal(cur, ref) and cur.max() > 0
+    assert not cur[0].any() and not cur[:, 0].any() and not cur[:, :, -1].any()      # 1-voxel border stays 0
+
+
+def test_processing_function_errors_like_reference(unet):
+    from iterseg_amd import segmentation as seg
+    vol = np.ones((8, 32, 32), np.float32)
+    cur = np.zeros((10, 34, 34), np.uint32)
+    with pytest.raises(ValueError, match="output_volume must not be None"):
+        seg.affinity_watershed_for_chunks(vol, cur, CHUNK, MARGIN, unet=unet, output_volume=None)
+    with pytest.raises(ValueError, match="unet must not be none"):
+        seg.affinity_watershed_for_chunks(vol, cur, CHUNK, MARGIN, unet=None, output_volume=np.zeros((5, 8, 32, 32), np.float32))
+    with pytest.raises(ValueError):                             # a volume smaller than the chunk: make_chunks breaks upstream too
+        seg.affinity_watershed_for_chunks(vol[:2], np.zeros((4, 34, 34), np.uint32), CHUNK, MARGIN, unet=unet,
+                                          output_volume=np.zeros((5, 2, 32, 32), np.float32))
+
+
+def test_segment_single_volume_normalises_and_drops_empty_slices(unet):
+    from iterseg_amd import segmentation as seg
+    from tests.synth import positive_volume
+    vol = positive_volume((9, 40, 40), 5) * 7.0
+    vol[4] = 0.0                                                # an all-zero plane: min() == 0 -> remove_sum_zero_slices
+    work = vol.copy()
+    config = {"unet": unet, "output_volume": np.zeros((5, 8, 40, 40), np.float32)}
+    out = seg.segment_single_volume(work, CHUNK, config, MARGIN, seg.affinity_watershed_for_chunks)
+    assert out.shape == (8, 40, 40) and out.dtype == np.uint32  # the empty plane is gone (shape change, as upstream)
+    kept = np.delete(vol, 4, axis=0)
+    ref = _oracle_labels(unet, (kept / kept.max()).astype(np.float32))
+    assert ref is not None and np.array_equal(out, ref[1:-1, 1:-1, 1:-1])
+
+
+def test_operator_entry_on_a_stack(unet, tmp_path):
+    """affinity_unet_watershed(viewer, layer, ...) with a stand-in layer object and a .pt file: per-frame labels equal
+    the per-frame calls; frames are independent; a second call on a partly filled store skips finished frames."""
+    from iterseg_amd import segmentation as seg, weights
+    from tests.synth import positive_volume
+    path = str(tmp_path / "unet.pt")
+    torch.save(weights.to_torch_state_dict(weights.generate_state_dict(0)), path)
+    data = np.stack([positive_volume((8, 40, 48), s) for s in (1, 2, 3)])
+    layer = types.SimpleNamespace(data=data, scale=(4, 1, 1), translate=(0, 0, 0), metadata={})
+    labels = seg.segmenters['affinity-unet-watershed'](None, layer, save_dir=None, name='t', unet_or_config_file=path,
+                                                       layer_reference=None, chunk_size=CHUNK, margin=MARGIN, debug=True)
+    labels = np.asarray(labels)
+    assert labels.shape == data.shape and labels.dtype == np.int32
+    for t in range(3):
+        ref = _oracle_labels(unet, (data[t] / data[t].max()).astype(np.float32))
+        assert ref is not None and np.array_equal(labels[t].astype(np.uint32), ref[1:-1, 1:-1, 1:-1]), t
+    with pytest.raises(AssertionError):
+        seg.affinity_watershed_prep_config(layer, str(tmp_path / "missing.pt"), None)
