@@ -46,3 +46,12 @@ def test_errors_like_reference():
         gl.get_training_labels(lab, ('bogus',))
     with pytest.raises(NotImplementedError):
         gl.get_training_labels(lab, ('centreness-log',))
+
+
+def test_single_channel_helpers(golden):
+    from iterseg_amd import labels as gl
+    d = golden("training_labels")
+    lab, ref = d["a.labels"], d["a.targets"]
+    assert np.array_equal(gl.nth_affinity(lab, 1, 0), ref[0])
+    assert np.abs(gl.get_centreness(lab, (4, 1, 1)) - ref[3]).max() <= 2e-7
+    assert np.array_equal(gl.get_semantic_labels(lab), (lab > 1).astype(np.float32))

@@ -29,3 +29,15 @@ def test_contingency_large_volume_vs_oracle():
     assert np.allclose(gm.variation_of_information(gt, mr), om.variation_of_information(gt, mr), rtol=1e-13)
     with pytest.raises(ValueError):
         gm.contingency_table(gt, mr[:-1])
+
+
+def test_get_accuracy_metrics_table(golden):
+    from iterseg_amd import metrics as gm
+    d = golden("metrics_vi")
+    gt, mr = d["a.gt"], d["a.mr"]
+    full = (slice(None),) * 3
+    df = gm.get_accuracy_metrics([(full, full)], gt, mr, name="m", exclude_chunks=3)
+    assert len(df) == 1 and abs(df['VI: GT | Output'][0] - d["a.vi"][0]) < 1e-12
+    assert int(df['Number objects (GT)'][0]) == int(d["a.counts"][0]) and df['model_name'][0] == "m"
+    with pytest.raises(NotImplementedError):
+        gm.get_accuracy_metrics([(full, full)], gt, mr, AP=True)

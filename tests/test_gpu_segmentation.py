@@ -92,3 +92,25 @@ def test_operator_entry_on_a_stack(unet, tmp_path):
         assert ref is not None and np.array_equal(labels[t].astype(np.uint32), ref[1:-1, 1:-1, 1:-1]), t
     with pytest.raises(AssertionError):
         seg.affinity_watershed_prep_config(layer, str(tmp_path / "missing.pt"), None)
+
+
+def test_json_config_and_single_process_sharded_path(unet, tmp_path):
+    """The .json form of the network argument (segmentation.py:98-107, read as documented) and the world-size-1 path of
+    segment_volume_sharded (== segment_volume_device)."""
+    import json
+    from iterseg_amd import segmentation as seg, weights, predict
+    from iterseg_amd.distributed import segment_volume_sharded
+    from tests.synth import positive_volume
+    pt = str(tmp_path / "u.pt")
+    torch.save(weights.to_torch_state_dict(weights.generate_state_dict(0)), pt)
+    cfg = str(tmp_path / "cfg.json")
+    json.dump({"unet": pt}, open(cfg, "w"))
+    assert seg.read_config_json(cfg) == {"unet": pt}
+    layer = types.SimpleNamespace(data=np.zeros((8, 32, 32), np.float32))
+    config = seg.affinity_watershed_prep_config(layer, cfg, None)
+    assert config["output_volume"].shape == (5, 8, 32, 32) and config["unet"].out_channels == 5
+    assert predict.get_device() in ("cuda", "cuda:0") or "cuda" in str(predict.get_device())
+    vol = torch.from_numpy(positive_volume((8, 48, 48), 4)).cuda()
+    a = segment_volume_sharded(unet, vol, CHUNK, MARGIN)
+    b = seg.segment_volume_device(unet, vol, CHUNK, MARGIN)
+    assert torch.equal(a, b) and int(a.max()) > 0

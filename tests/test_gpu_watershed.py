@@ -209,3 +209,17 @@ def test_component_sharded_flood_union_is_exact(ws, world):
     assert int(nonseed_hits.max()) == 1 and len(seeds) > world            # disjoint supports
     with pytest.raises(ValueError):
         ctx.set_flood_shard(2, 2)
+
+
+def test_connected_components_helper(ws):
+    """ndi.label semantics: roots are the smallest raveled index, sizes the voxel counts."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(9)
+    mask = ndi.gaussian_filter(rng.random((12, 40, 44)), 1.5) > 0.5
+    roots, sizes = ws.connected_components(mask)
+    roots, sizes = np.asarray(roots.cpu() if hasattr(roots, "cpu") else roots), np.asarray(sizes.cpu() if hasattr(sizes, "cpu") else sizes)
+    lab, n = ndi.label(mask)
+    assert len(np.unique(roots[mask])) == n
+    for c in range(1, min(n, 20) + 1):
+        idx = np.flatnonzero(lab.ravel() == c)
+        assert (roots.ravel()[idx] == idx.min()).all() and sizes.ravel()[idx.min()] == idx.size
