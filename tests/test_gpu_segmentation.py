@@ -114,3 +114,17 @@ def test_json_config_and_single_process_sharded_path(unet, tmp_path):
     a = segment_volume_sharded(unet, vol, CHUNK, MARGIN)
     b = seg.segment_volume_device(unet, vol, CHUNK, MARGIN)
     assert torch.equal(a, b) and int(a.max()) > 0
+
+
+def test_two_rank_sharded_volume():
+    """One volume on two ranks (gloo, both on cuda:0): chunk-sharded U-Net + summed feature map, replicated W0-W3,
+    component-sharded flood + max of the labels == the single-GPU labels (tests/_sharded_worker.py)."""
+    import os, socket, subprocess, sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_sharded_worker.py")]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
