@@ -806,11 +806,12 @@ __global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__res
 static constexpr int COOP_SCAP = 2048;                      // LDS run capacity (entries of 16 B)
 static constexpr unsigned long long COOP_MIN_SIZE = 512;    // components below this stay on flood_kernel
 static constexpr unsigned long long COLD_MIN_SIZE = 32768;  // components from this size get a cold arena
+static constexpr uint32_t COLD_UNSORTED = 0x80000000u;
 static constexpr int COLD_NBK = 65536;                      // buckets: top 16 bits of the order-preserving key
 static constexpr int COLD_DRAIN = 1024;                     // elements moved from a bucket to the LDS run at once
 static constexpr uint32_t COLD_NONE = 0xFFFFFFFFu;
-// arena layout in 16-byte units: bhead | btail | bcount (u32[NBK] each), bm0 (u64[NBK/64]), bm1 (u64[NBK/4096]), pool
-static constexpr uint32_t COLD_META_ENTS = (3u * COLD_NBK * 4u + COLD_NBK / 64 * 8u + COLD_NBK / 4096 * 8u) / 16u;
+// arena layout in 16-byte units: bhead | btail | bcount | bmeta (u32[NBK] each), bm0 (u64[NBK/64]), bm1 (u64[NBK/4096]), pool
+static constexpr uint32_t COLD_META_ENTS = (4u * COLD_NBK * 4u + COLD_NBK / 64 * 8u + COLD_NBK / 4096 * 8u) / 16u;
 
 __host__ __device__ inline unsigned long long cold_arena_entries(unsigned long long size)
 {
@@ -841,9 +842,11 @@ __device__ __forceinline__ HeapEnt cld_ent(const HeapEnt *p)
 
 struct Cold {
     uint32_t *bhead, *btail, *bcount;
+    uint32_t *bmeta;           // bits 0..30: consumed prefix of the head segment; bit 31: appended out of key order
     unsigned long long *bm0, *bm1;
     HeapEnt *pool;             // a segment = header entry {key = next | n << 32, idx = cap} + cap entries
     uint32_t pool_cap, bump, count;
+    uint32_t fifo_drains;      // statistics: drains served by the prefix of an ascending list
     uint32_t low;              // lowest non-empty bucket (COLD_NBK when empty): decides which new elements may stay hot
     bool on, failed;
 };
@@ -857,14 +860,19 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // earlier arena stores of this wave are visible
     const uint32_t b = cold_bucket(key);
     int gleader = 0, grank = 0, gsize = 0;
-    bool todo = has;
+    bool todo = has, gviol = false;
     while (__any(todo)) {
         const unsigned long long act = __ballot(todo);
         const int ld = __ffsll((long long)act) - 1;
         const uint32_t lb = __shfl(b, ld);
         const bool same = todo && b == lb;
         const unsigned long long grp = __ballot(same);
+        // is this group's placement order (lane order) also its key order?
+        const unsigned long long before = grp & ((1ull << lane) - 1ull);
+        const unsigned long long pk = shfl64(key, before ? 63 - __clzll((long long)before) : lane);
+        const bool viol = __ballot(same && before && key < pk) != 0ull;
         if (same) {
+            gviol = viol;
             gleader = ld;
             grank = __popcll(grp & ((1ull << lane) - 1ull));
             gsize = __popcll(grp);
@@ -881,7 +889,10 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
             tnext = (uint32_t)h.key;
             tn = (uint32_t)(h.key >> 32);
             tcap = h.idx;
+            // a bucket stays FIFO-drainable while every append continues its ascending key order
+            if (!gviol && cnt > 0 && cld64(&c.pool[tail + tn].key) > key) gviol = true;
         }
+        if (gviol) c.bmeta[b] = cld32(&c.bmeta[b]) | COLD_UNSORTED;
     }
     const uint32_t free_tail = leader ? tcap - tn : 0u;
     const uint32_t need_new = (leader && (uint32_t)gsize > free_tail) ? (uint32_t)gsize - free_tail : 0u;
@@ -970,6 +981,7 @@ __device__ __forceinline__ void cold_mark_empty(Cold &c, uint32_t b, int lane)
         c.bhead[b] = COLD_NONE;
         c.btail[b] = COLD_NONE;
         c.bcount[b] = 0;
+        c.bmeta[b] = 0;
         const unsigned long long old = atomicAnd(&c.bm0[b >> 6], ~(1ull << (b & 63)));
         if ((old & ~(1ull << (b & 63))) == 0ull) atomicAnd(&c.bm1[b >> 12], ~(1ull << ((b >> 6) & 63)));
     }
@@ -1002,24 +1014,48 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
     const uint32_t b = cold_lowest(c, lane);
     const uint32_t cnt = cld32(&c.bcount[b]);
     const uint32_t head = cld32(&c.bhead[b]);
+    const uint32_t meta = cld32(&c.bmeta[b]);
+    const uint32_t off0 = meta & ~COLD_UNSORTED;        // consumed prefix of the head segment
+    const bool fifo = (meta & COLD_UNSORTED) == 0u;     // the bucket's list order is its key order
     int taken = 0;
     if (cnt <= (uint32_t)drain_n) {
-        uint32_t seg = head;
+        uint32_t seg = head, off = off0;
         while (seg != COLD_NONE) {
             const HeapEnt h = cld_ent(&c.pool[seg]);
-            const uint32_t n = (uint32_t)(h.key >> 32);
-            for (uint32_t j = lane; j < n; j += 64) srun[taken + j] = cld_ent(&c.pool[seg + 1u + j]);
+            const uint32_t n = (uint32_t)(h.key >> 32) - off;
+            for (uint32_t j = lane; j < n; j += 64) srun[taken + j] = cld_ent(&c.pool[seg + 1u + off + j]);
             taken += (int)n;
             seg = (uint32_t)h.key;
+            off = 0;
         }
         cold_mark_empty(c, b, lane);
+    } else if (fifo) {
+        // ---- ascending list (plateaus: equal values, growing ages): the smallest elements are its prefix ----
+        uint32_t seg = head, off = off0;
+        while (taken < drain_n) {                       // cnt > drain_n: the list cannot run out
+            const HeapEnt h = cld_ent(&c.pool[seg]);
+            const uint32_t n = (uint32_t)(h.key >> 32);
+            uint32_t m = n - off;
+            if (m > (uint32_t)(drain_n - taken)) m = (uint32_t)(drain_n - taken);
+            for (uint32_t j = lane; j < m; j += 64) srun[taken + j] = cld_ent(&c.pool[seg + 1u + off + j]);
+            taken += (int)m;
+            off += m;
+            if (off == n) { seg = (uint32_t)h.key; off = 0; }
+        }
+        ++c.fifo_drains;
+        if (lane == 0) {
+            c.bhead[b] = seg;
+            c.bmeta[b] = off;
+            c.bcount[b] = cnt - (uint32_t)taken;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         // ---- select by key: min / max, then 64-bin histograms until a non-empty prefix of <= COLD_DRAIN exists ----
         unsigned long long lo = ~0ull, hi = 0ull;
         for (uint32_t seg = head; seg != COLD_NONE;) {
             const HeapEnt h = cld_ent(&c.pool[seg]);
             const uint32_t n = (uint32_t)(h.key >> 32);
-            for (uint32_t j = lane; j < n; j += 64) {
+            for (uint32_t j = (seg == head ? off0 : 0u) + lane; j < n; j += 64) {
                 const unsigned long long k = cld64(&c.pool[seg + 1u + j].key);
                 lo = k < lo ? k : lo;
                 hi = k > hi ? k : hi;
@@ -1040,7 +1076,7 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
             for (uint32_t seg = head; seg != COLD_NONE;) {
                 const HeapEnt h = cld_ent(&c.pool[seg]);
                 const uint32_t n = (uint32_t)(h.key >> 32);
-                for (uint32_t j = lane; j < n; j += 64) {
+                for (uint32_t j = (seg == head ? off0 : 0u) + lane; j < n; j += 64) {
                     const unsigned long long k = cld64(&c.pool[seg + 1u + j].key);
                     if (k >= lo && k - lo < width) atomicAdd(&hist[(int)(((k - lo) * 64ull) / width)], 1);
                 }
@@ -1069,7 +1105,7 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
         for (uint32_t seg = head; seg != COLD_NONE;) {
             const HeapEnt h = cld_ent(&c.pool[seg]);
             const uint32_t n = (uint32_t)(h.key >> 32), nxt = (uint32_t)h.key;
-            for (uint32_t base = 0; base < n; base += 64) {
+            for (uint32_t base = (seg == head ? off0 : 0u); base < n; base += 64) {
                 const uint32_t j = base + lane;
                 HeapEnt e;
                 bool valid = j < n, take = false;
@@ -1110,11 +1146,12 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
             c.pool[wseg] = t2;
             c.btail[b] = wseg;
             c.bcount[b] = kept;
+            c.bmeta[b] = COLD_UNSORTED;                 // compacted from the start of the head segment
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    lds_sort(srun, taken, lane);
+    if (!fifo) lds_sort(srun, taken, lane);
     c.count -= (uint32_t)taken;
     c.low = c.count > 0 ? cold_lowest(c, lane) : (uint32_t)COLD_NBK;
     return taken;
@@ -1158,17 +1195,19 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     cold.bump = 0;
     cold.count = 0;
     cold.low = COLD_NBK;
+    cold.fifo_drains = 0;
     cold.pool_cap = 0;
     if (cold.on) {
         HeapEnt *base = arena + arena_off[c];
         cold.bhead = (uint32_t *)base;
         cold.btail = cold.bhead + COLD_NBK;
         cold.bcount = cold.btail + COLD_NBK;
-        cold.bm0 = (unsigned long long *)(cold.bcount + COLD_NBK);
+        cold.bmeta = cold.bcount + COLD_NBK;
+        cold.bm0 = (unsigned long long *)(cold.bmeta + COLD_NBK);
         cold.bm1 = cold.bm0 + COLD_NBK / 64;
         cold.pool = base + COLD_META_ENTS;
         cold.pool_cap = (uint32_t)(arena_off[c + 1] - arena_off[c] - COLD_META_ENTS);
-        for (int i = lane; i < COLD_NBK; i += 64) { cold.bhead[i] = COLD_NONE; cold.btail[i] = COLD_NONE; cold.bcount[i] = 0; }
+        for (int i = lane; i < COLD_NBK; i += 64) { cold.bhead[i] = COLD_NONE; cold.btail[i] = COLD_NONE; cold.bcount[i] = 0; cold.bmeta[i] = 0; }
         for (int i = lane; i < COLD_NBK / 64; i += 64) cold.bm0[i] = 0ull;
         if (lane < COLD_NBK / 4096) cold.bm1[lane] = 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1216,20 +1255,34 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         if (scount > run_limit) {
             // the run is full: evict its largest elements to their buckets (or leave the wave path)
             if (!cold.on) { serial = true; break; }
-            int ev = scount - run_limit / 2;
+            const int ev = scount - run_limit / 2, keep = scount - ev;
             st_evict += (unsigned long long)ev;
-            while (ev > 0 && !cold.failed) {
-                const int m = ev < 64 ? ev : 64;
+            int done = 0;                     // ascending, so that a bucket's list stays in key order (FIFO drains)
+            while (done < ev) {
+                const int m = ev - done < 64 ? ev - done : 64;
                 const bool has = lane < m;
                 HeapEnt e;
                 e.key = 0; e.idx = 0; e.pad = 0;
-                if (has) e = srun[(shead + scount - 1 - lane) & SMASK];
+                if (has) e = srun[(shead + keep + done + lane) & SMASK];
                 cold_append(cold, has, e.key, e.idx, e.pad, lane);
-                if (cold.failed) break;       // the batch is still in the run
-                scount -= m;
-                ev -= m;
+                if (cold.failed) break;       // this batch is still in the run, the earlier ones are not
+                done += m;
             }
-            if (cold.failed) { serial = true; break; }
+            if (cold.failed) {
+                // close the gap [keep, keep + done) so that the run again holds exactly what is not in the arena
+                for (int j0 = keep + done; j0 < scount; j0 += 64) {
+                    const bool mv = j0 + lane < scount;
+                    HeapEnt e;
+                    if (mv) e = srun[(shead + j0 + lane) & SMASK];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (mv) srun[(shead + j0 + lane - done) & SMASK] = e;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                scount -= done;
+                serial = true;
+                break;
+            }
+            scount = keep;
         }
         ++epoch;
         ++st_rounds;
@@ -1375,11 +1428,20 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                 }
                 ++st_run;
                 // sorted insert into the LDS run (circular: shift the shorter side by one)
-                int below = 0;
-                for (int j = lane; j < scount; j += 64) below += srun[(shead + j) & SMASK].key < ek;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
-                const int pos = below;
+                // position by two 64-wide probes of the sorted run (segment ends, then inside the segment) instead of a
+                // linear count over up to 2048 entries
+                int pos;
+                {
+                    const int stride = (scount + 63) >> 6;                       // <= 32 entries per segment
+                    int e = lane * stride + stride - 1;
+                    if (e > scount - 1) e = scount - 1;
+                    const bool seg_below = lane * stride < scount && srun[(shead + e) & SMASK].key < ek;
+                    const int base = __popcll(__ballot(seg_below)) * stride;     // segments entirely below ek
+                    const int j = base + lane;
+                    const bool in_below = lane < stride && j < scount && srun[(shead + j) & SMASK].key < ek;
+                    pos = base + __popcll(__ballot(in_below));
+                    if (pos > scount) pos = scount;
+                }
                 st_shift += (unsigned long long)(pos >= scount - pos ? scount - pos : pos);
                 if (pos >= scount - pos) {
                     for (int base = scount - 64; base > pos - 64; base -= 64) {
@@ -1429,6 +1491,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         atomicAdd(&stats[4], st_cold); atomicAdd(&stats[5], st_drain); atomicAdd(&stats[6], st_evict); atomicAdd(&stats[7], st_shift);
         if (serial) atomicAdd(&stats[8], 1ull);
         if (st_oob) atomicAdd(&stats[9], st_oob);
+        if (cold.fifo_drains) atomicAdd(&stats[10], (unsigned long long)cold.fifo_drains);
     }
     if (serial) {
         // Exact continuation on one lane: move the whole queue (registers, run, staged, buckets) into the binary heap.
@@ -1454,13 +1517,15 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                 while (cold.count > 0) {
                     const uint32_t b = cold_lowest(cold, lane);
                     uint32_t seg = cld32(&cold.bhead[b]);
+                    uint32_t off = cld32(&cold.bmeta[b]) & ~COLD_UNSORTED;
                     uint32_t got = 0;
                     while (seg != COLD_NONE) {
                         const HeapEnt h = cld_ent(&cold.pool[seg]);
                         const uint32_t n = (uint32_t)(h.key >> 32);
                         if (lane == 0)
-                            for (uint32_t j = 0; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
-                        got += n;
+                            for (uint32_t j = off; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
+                        got += n - off;
+                        off = 0;
                         seg = (uint32_t)h.key;
                     }
                     cold_mark_empty(cold, b, lane);
@@ -1573,8 +1638,8 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         unsigned long long hs[16];
         ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         ISX_HIP(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[isx flood] rounds %llu pops %llu (%.2f/round) reg_ins %llu run_ins %llu (avg shift %.1f) cold_app %llu drains %llu evicted %llu serial_handover %llu oob %llu\n",
-                hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[3], hs[3] ? (double)hs[7] / hs[3] : 0.0, hs[4], hs[5], hs[6], hs[8], hs[9]);
+        fprintf(stderr, "[isx flood] rounds %llu pops %llu (%.2f/round) reg_ins %llu run_ins %llu (avg shift %.1f) cold_app %llu drains %llu (prefix %llu) evicted %llu serial_handover %llu oob %llu\n",
+                hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[3], hs[3] ? (double)hs[7] / hs[3] : 0.0, hs[4], hs[5], hs[10], hs[6], hs[8], hs[9]);
     }
     return ISX_OK;
 }
