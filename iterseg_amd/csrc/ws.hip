@@ -847,6 +847,11 @@ struct Cold {
     HeapEnt *pool;             // a segment = header entry {key = next | n << 32, idx = cap} + cap entries
     uint32_t pool_cap, bump, count;
     uint32_t fifo_drains;      // statistics: drains served by the prefix of an ascending list
+    // write-through copy of one bucket's append state (plateaus append to the same bucket round after round):
+    // saves the three dependent loads of the leader.  Wave-uniform.  Dropped whenever a drain touches the bucket.
+    uint32_t cb, cb_tail, cb_tn, cb_tcap, cb_tnext, cb_cnt;
+    unsigned long long cb_last;
+    bool cb_unsorted;
     uint32_t low;              // lowest non-empty bucket (COLD_NBK when empty): decides which new elements may stay hot
     bool on, failed;
 };
@@ -857,8 +862,10 @@ __device__ __forceinline__ uint32_t cold_bucket(unsigned long long key) { return
 // lane); leaders do the bookkeeping in parallel, members get their slot from the leader.
 __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long long key, uint32_t idx, uint32_t lab, int lane)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // earlier arena stores of this wave are visible
     const uint32_t b = cold_bucket(key);
+    // earlier arena stores of this wave must be visible to the leaders' loads; a round whose elements all go to the
+    // cached bucket loads nothing and lets its stores (and the round's label stores) drain under the next round
+    if (__any(has && b != c.cb)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int gleader = 0, grank = 0, gsize = 0;
     bool todo = has, gviol = false;
     while (__any(todo)) {
@@ -881,18 +888,27 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
     }
     const bool leader = has && gleader == lane;
     uint32_t tail = COLD_NONE, cnt = 0, tn = 0, tcap = 0, tnext = COLD_NONE;
+    bool unsorted = false;
     if (leader) {
-        tail = cld32(&c.btail[b]);
-        cnt = cld32(&c.bcount[b]);
-        if (tail != COLD_NONE) {
-            const HeapEnt h = cld_ent(&c.pool[tail]);
-            tnext = (uint32_t)h.key;
-            tn = (uint32_t)(h.key >> 32);
-            tcap = h.idx;
-            // a bucket stays FIFO-drainable while every append continues its ascending key order
-            if (!gviol && cnt > 0 && cld64(&c.pool[tail + tn].key) > key) gviol = true;
+        // a bucket stays FIFO-drainable while every append continues its ascending key order
+        if (b == c.cb) {
+            tail = c.cb_tail; cnt = c.cb_cnt; tnext = c.cb_tnext; tn = c.cb_tn; tcap = c.cb_tcap;
+            unsorted = c.cb_unsorted;
+            if (!unsorted && (gviol || c.cb_last > key)) { unsorted = true; atomicOr(&c.bmeta[b], COLD_UNSORTED); }
+        } else {
+            tail = cld32(&c.btail[b]);
+            cnt = cld32(&c.bcount[b]);
+            if (tail != COLD_NONE) {
+                const HeapEnt h = cld_ent(&c.pool[tail]);
+                tnext = (uint32_t)h.key;
+                tn = (uint32_t)(h.key >> 32);
+                tcap = h.idx;
+                if (!gviol && cnt > 0 && cld64(&c.pool[tail + tn].key) > key) gviol = true;
+            }
+            const uint32_t meta = cld32(&c.bmeta[b]);
+            unsorted = (meta & COLD_UNSORTED) != 0u;
+            if (gviol && !unsorted) { unsorted = true; atomicOr(&c.bmeta[b], COLD_UNSORTED); }
         }
-        if (gviol) c.bmeta[b] = cld32(&c.bmeta[b]) | COLD_UNSORTED;
     }
     const uint32_t free_tail = leader ? tcap - tn : 0u;
     const uint32_t need_new = (leader && (uint32_t)gsize > free_tail) ? (uint32_t)gsize - free_tail : 0u;
@@ -943,6 +959,25 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
             atomicOr(&c.bm1[b >> 12], 1ull << ((b >> 6) & 63));
         }
     }
+    {
+        // the first group's bucket becomes the cached one
+        const int l0 = __ffsll((long long)__ballot(has)) - 1;
+        if (l0 >= 0) {
+            const unsigned long long g0 = __ballot(has && gleader == l0);
+            const uint32_t n_tail = need_new ? my_off : tail;
+            const uint32_t n_tn = need_new ? need_new : tn + (uint32_t)gsize;
+            const uint32_t n_tcap = need_new ? newcap : tcap;
+            const uint32_t n_tnext = need_new ? COLD_NONE : tnext;
+            c.cb = __shfl(b, l0);
+            c.cb_tail = __shfl(n_tail, l0);
+            c.cb_tn = __shfl(n_tn, l0);
+            c.cb_tcap = __shfl(n_tcap, l0);
+            c.cb_tnext = __shfl(n_tnext, l0);
+            c.cb_cnt = __shfl(cnt + (uint32_t)gsize, l0);
+            c.cb_unsorted = __shfl((int)unsorted, l0) != 0;
+            c.cb_last = shfl64(key, 63 - __clzll((long long)g0));
+        }
+    }
     const int gl = gleader & 63;
     const uint32_t l_tail = __shfl(tail, gl), l_tn = __shfl(tn, gl), l_free = __shfl(free_tail, gl), l_new = __shfl(my_off, gl);
     if (has) {
@@ -977,6 +1012,7 @@ __device__ __forceinline__ uint32_t cold_lowest(const Cold &c, int lane)
 
 __device__ __forceinline__ void cold_mark_empty(Cold &c, uint32_t b, int lane)
 {
+    if (b == c.cb) c.cb = COLD_NONE;
     if (lane == 0) {
         c.bhead[b] = COLD_NONE;
         c.btail[b] = COLD_NONE;
@@ -1012,6 +1048,7 @@ __device__ __forceinline__ void lds_sort(HeapEnt *srun, int n, int lane)
 __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int lane, int drain_n)
 {
     const uint32_t b = cold_lowest(c, lane);
+    if (b == c.cb) c.cb = COLD_NONE;                    // the drain rewrites this bucket's state
     const uint32_t cnt = cld32(&c.bcount[b]);
     const uint32_t head = cld32(&c.bhead[b]);
     const uint32_t meta = cld32(&c.bmeta[b]);
@@ -1196,6 +1233,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     cold.count = 0;
     cold.low = COLD_NBK;
     cold.fifo_drains = 0;
+    cold.cb = COLD_NONE;
     cold.pool_cap = 0;
     if (cold.on) {
         HeapEnt *base = arena + arena_off[c];
@@ -1382,11 +1420,46 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             shead = (shead + take) & SMASK;
             scount -= take;
         }
-        // ---- insert the new elements (wave-uniform loop over committed lanes x directions) ---------------
+        // ---- tier decision for all new elements at once ----------------------------------------------------
+        // An element is cold-bound when it does not sort below the hot maximum and its bucket is not below the lowest
+        // non-empty bucket.  Hot insertions of this round cannot change that: the hot maximum only grows by elements
+        // of lower buckets, which sort below every cold-bound element.  So the cold-bound set is staged in parallel,
+        // in (rank, direction) order, and only the hot-bound elements take the serial insert loop below.
         int nstage = 0;
-        for (int l = 0; l < ncommit; ++l) {
-            const uint32_t wm = __shfl(wm_all, l);
-            if (!wm) continue;
+        uint32_t cmask = 0;
+        if (cold.on && cold.count > 0) {
+            unsigned long long back0 = 0ull;
+            if (scount > 0) back0 = srun[(shead + scount - 1) & SMASK].key;
+            const unsigned long long reg_last0 = rcount > 0 ? shfl64(rk, rcount - 1) : 0ull;
+            const unsigned long long hot_max0 = scount > 0 ? back0 : reg_last0;
+            const bool hot_nonempty0 = scount > 0 || rcount > 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if ((wm_all & (1u << k)) && !(hot_nonempty0 && pkey[k] < hot_max0) && cold_bucket(pkey[k]) >= cold.low)
+                    cmask |= 1u << k;
+            const uint32_t ncold = (uint32_t)__popc(cmask);
+            uint32_t cincl = ncold;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(cincl, o);
+                if (lane >= o) cincl += t;
+            }
+            nstage = (int)__shfl(cincl, 63);
+            uint32_t slot = cincl - ncold;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (cmask & (1u << k)) {
+                    HeapEnt e;
+                    e.key = pkey[k]; e.idx = (uint32_t)nbv[k]; e.pad = lab_all;
+                    stage[slot++] = e;
+                }
+            st_cold += (unsigned long long)nstage;
+        }
+        // ---- insert the hot-bound elements (wave-uniform loop over committed lanes x directions) -----------
+        const uint32_t wm_hot = wm_all & ~cmask;
+        for (unsigned long long todo_l = __ballot(wm_hot != 0u); todo_l; todo_l &= todo_l - 1ull) {
+            const int l = __ffsll((long long)todo_l) - 1;
+            const uint32_t wm = __shfl(wm_hot, l);
             const uint32_t el = __shfl(lab_all, l);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
