@@ -53,7 +53,8 @@ def build(force=False, verbose=False, jobs=4):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        # ISX_EXTRA_HIPCC_FLAGS: development builds only (e.g. -DISX_FLOOD_PROF for the flood's phase timers)
+        cmd = [hipcc] + FLAGS + os.environ.get("ISX_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -806,12 +806,18 @@ __global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__res
 static constexpr int COOP_SCAP = 2048;                      // LDS run capacity (entries of 16 B)
 static constexpr unsigned long long COOP_MIN_SIZE = 512;    // components below this stay on flood_kernel
 static constexpr unsigned long long COLD_MIN_SIZE = 32768;  // components from this size get a cold arena
+#ifndef ISX_CLAIM_PF
+#define ISX_CLAIM_PF 0
+#endif
+#ifndef ISX_CLAIM_WG
+#define ISX_CLAIM_WG 0
+#endif
 static constexpr uint32_t COLD_UNSORTED = 0x80000000u;
 static constexpr int COLD_NBK = 65536;                      // buckets: top 16 bits of the order-preserving key
 static constexpr int COLD_DRAIN = 1024;                     // elements moved from a bucket to the LDS run at once
 static constexpr uint32_t COLD_NONE = 0xFFFFFFFFu;
-// arena layout in 16-byte units: bhead | btail | bcount | bmeta (u32[NBK] each), bm0 (u64[NBK/64]), bm1 (u64[NBK/4096]), pool
-static constexpr uint32_t COLD_META_ENTS = (4u * COLD_NBK * 4u + COLD_NBK / 64 * 8u + COLD_NBK / 4096 * 8u) / 16u;
+// arena layout in 16-byte units: bhead | btail | bcount | bmeta | bfill (u32[NBK] each), blast (u64[NBK]), bm0 (u64[NBK/64]), bm1 (u64[NBK/4096]), pool
+static constexpr uint32_t COLD_META_ENTS = (5u * COLD_NBK * 4u + COLD_NBK * 8u + COLD_NBK / 64 * 8u + COLD_NBK / 4096 * 8u) / 16u;
 
 __host__ __device__ inline unsigned long long cold_arena_entries(unsigned long long size)
 {
@@ -824,6 +830,41 @@ __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int s
     lo = __shfl(lo, src);
     hi = __shfl(hi, src);
     return ((unsigned long long)hi << 32) | lo;
+}
+
+// Broadcast from a wave-uniform lane: v_readlane (scalar result, a few cycles) instead of ds_bpermute.
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ unsigned long long rdlane64(unsigned long long v, int l)
+{
+    return ((unsigned long long)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
+}
+
+// 16-byte queue entries are moved as vector values (a conditionally assigned struct temporary across an asm
+// barrier was kept in scratch memory by the compiler: a private-memory round trip per 64 entries shifted)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct HeapEnt;
+__device__ __forceinline__ u32x4 run_ld(const HeapEnt *run, int i) { return ((const u32x4 *)run)[i]; }
+__device__ __forceinline__ void run_st(HeapEnt *run, int i, u32x4 v) { ((u32x4 *)run)[i] = v; }
+
+// Cross-lane moves on the DPP path (a few cycles) instead of ds_bpermute (an LDS-crossbar round trip each).
+// wave_shr:1 -- lane i receives lane i - 1, lane 0 receives `fill`.
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+}
+// inclusive prefix minimum over the 64 lanes: row_shr 1/2/4/8 inside each row of 16, then row_bcast 15 and 31
+__device__ __forceinline__ uint32_t wave_prefix_min(uint32_t v)
+{
+    const int id = -1;       // 0xFFFFFFFF: the identity of an unsigned minimum
+#define ISX_SCAN_STEP(ctrl, rmask) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, ctrl, rmask, 0xf, false); v = t < v ? t : v; }
+    ISX_SCAN_STEP(0x111, 0xf)
+    ISX_SCAN_STEP(0x112, 0xf)
+    ISX_SCAN_STEP(0x114, 0xf)
+    ISX_SCAN_STEP(0x118, 0xf)
+    ISX_SCAN_STEP(0x142, 0xa)
+    ISX_SCAN_STEP(0x143, 0xc)
+#undef ISX_SCAN_STEP
+    return v;
 }
 
 // Every read of the cold structures bypasses the (non-coherent, possibly stale) vector L1: they are rewritten
@@ -842,6 +883,8 @@ __device__ __forceinline__ HeapEnt cld_ent(const HeapEnt *p)
 
 struct Cold {
     uint32_t *bhead, *btail, *bcount;
+    uint32_t *bfill;           // tail segment: entries used | log2(capacity) << 24 (a copy of its header: one load trip per append)
+    unsigned long long *blast; // key of the last appended element
     uint32_t *bmeta;           // bits 0..30: consumed prefix of the head segment; bit 31: appended out of key order
     unsigned long long *bm0, *bm1;
     HeapEnt *pool;             // a segment = header entry {key = next | n << 32, idx = cap} + cap entries
@@ -849,12 +892,23 @@ struct Cold {
     uint32_t fifo_drains;      // statistics: drains served by the prefix of an ascending list
     // write-through copy of one bucket's append state (plateaus append to the same bucket round after round):
     // saves the three dependent loads of the leader.  Wave-uniform.  Dropped whenever a drain touches the bucket.
-    uint32_t cb, cb_tail, cb_tn, cb_tcap, cb_tnext, cb_cnt;
+    uint32_t cb, cb_tail, cb_tn, cb_tcap, cb_cnt;
     unsigned long long cb_last;
     bool cb_unsorted;
     uint32_t low;              // lowest non-empty bucket (COLD_NBK when empty): decides which new elements may stay hot
     bool on, failed;
+#ifdef ISX_FLOOD_PROF
+    unsigned long long tk[8], tk_prev, n_groups;
+#endif
 };
+
+#ifdef ISX_FLOOD_PROF
+#define COLD_TICK0(c) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); (c).tk_prev = __builtin_readcyclecounter(); } while (0)
+#define COLD_TICK(c, i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); (c).tk[i] += t_ - (c).tk_prev; (c).tk_prev = t_; } while (0)
+#else
+#define COLD_TICK0(c) do { } while (0)
+#define COLD_TICK(c, i) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint32_t cold_bucket(unsigned long long key) { return (uint32_t)(key >> 48); }
 
@@ -862,54 +916,80 @@ __device__ __forceinline__ uint32_t cold_bucket(unsigned long long key) { return
 // lane); leaders do the bookkeeping in parallel, members get their slot from the leader.
 __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long long key, uint32_t idx, uint32_t lab, int lane)
 {
+    COLD_TICK0(c);
     const uint32_t b = cold_bucket(key);
     // earlier arena stores of this wave must be visible to the leaders' loads; a round whose elements all go to the
     // cached bucket loads nothing and lets its stores (and the round's label stores) drain under the next round
-    if (__any(has && b != c.cb)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool uncached = has && b != c.cb;
+    if (__any(uncached)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // every member loads its bucket's append state now (five independent loads, same addresses within a group): the
+    // round trip runs under the grouping below instead of after it
+    uint32_t m_tail = COLD_NONE, m_cnt = 0, m_fill = 0, m_meta = 0;
+    unsigned long long m_last = 0ull;
+    if (uncached) {
+        m_tail = cld32(&c.btail[b]);
+        m_cnt = cld32(&c.bcount[b]);
+        m_fill = cld32(&c.bfill[b]);
+        m_meta = cld32(&c.bmeta[b]);
+        m_last = cld64(&c.blast[b]);
+    }
+    COLD_TICK(c, 0);
     int gleader = 0, grank = 0, gsize = 0;
+    unsigned long long glast = 0ull, ggrp = 0ull;
+    uint32_t minb = (uint32_t)COLD_NBK;            // lowest bucket of this batch (wave-uniform)
     bool todo = has, gviol = false;
     while (__any(todo)) {
         const unsigned long long act = __ballot(todo);
+#ifdef ISX_FLOOD_PROF
+        ++c.n_groups;
+#endif
         const int ld = __ffsll((long long)act) - 1;
-        const uint32_t lb = __shfl(b, ld);
+        const uint32_t lb = rdlane(b, ld);
+        minb = lb < minb ? lb : minb;
         const bool same = todo && b == lb;
         const unsigned long long grp = __ballot(same);
-        // is this group's placement order (lane order) also its key order?
-        const unsigned long long before = grp & ((1ull << lane) - 1ull);
-        const unsigned long long pk = shfl64(key, before ? 63 - __clzll((long long)before) : lane);
-        const bool viol = __ballot(same && before && key < pk) != 0ull;
         if (same) {
-            gviol = viol;
+            ggrp = grp;
             gleader = ld;
             grank = __popcll(grp & ((1ull << lane) - 1ull));
             gsize = __popcll(grp);
             todo = false;
         }
     }
+    {
+        // is each group's placement order (lane order) also its key order?  what is its last key?
+        const unsigned long long before = ggrp & ((1ull << lane) - 1ull);
+        const unsigned long long pk = shfl64(key, before ? 63 - __clzll((long long)before) : lane);
+        const unsigned long long vb = __ballot(has && before && key < pk);
+        gviol = (vb & ggrp) != 0ull;
+        glast = shfl64(key, has ? 63 - __clzll((long long)ggrp) : lane);
+    }
+    COLD_TICK(c, 1);
     const bool leader = has && gleader == lane;
-    uint32_t tail = COLD_NONE, cnt = 0, tn = 0, tcap = 0, tnext = COLD_NONE;
+    uint32_t tail = COLD_NONE, cnt = 0, tn = 0, tcap = 0;
     bool unsorted = false;
     if (leader) {
         // a bucket stays FIFO-drainable while every append continues its ascending key order
         if (b == c.cb) {
-            tail = c.cb_tail; cnt = c.cb_cnt; tnext = c.cb_tnext; tn = c.cb_tn; tcap = c.cb_tcap;
+            tail = c.cb_tail; cnt = c.cb_cnt; tn = c.cb_tn; tcap = c.cb_tcap;
             unsorted = c.cb_unsorted;
             if (!unsorted && (gviol || c.cb_last > key)) { unsorted = true; atomicOr(&c.bmeta[b], COLD_UNSORTED); }
         } else {
-            tail = cld32(&c.btail[b]);
-            cnt = cld32(&c.bcount[b]);
+            tail = m_tail;
+            cnt = m_cnt;
             if (tail != COLD_NONE) {
-                const HeapEnt h = cld_ent(&c.pool[tail]);
-                tnext = (uint32_t)h.key;
-                tn = (uint32_t)(h.key >> 32);
-                tcap = h.idx;
-                if (!gviol && cnt > 0 && cld64(&c.pool[tail + tn].key) > key) gviol = true;
+                tn = m_fill & 0xFFFFFFu;
+                tcap = 1u << (m_fill >> 24);
+                if (cnt > 0 && m_last > key) gviol = true;
             }
-            const uint32_t meta = cld32(&c.bmeta[b]);
-            unsorted = (meta & COLD_UNSORTED) != 0u;
+            unsorted = (m_meta & COLD_UNSORTED) != 0u;
             if (gviol && !unsorted) { unsorted = true; atomicOr(&c.bmeta[b], COLD_UNSORTED); }
         }
     }
+#ifdef ISX_FLOOD_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    COLD_TICK(c, 2);
     const uint32_t free_tail = leader ? tcap - tn : 0u;
     const uint32_t need_new = (leader && (uint32_t)gsize > free_tail) ? (uint32_t)gsize - free_tail : 0u;
     uint32_t newcap = 0;
@@ -919,15 +999,14 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
         while (newcap < need_new) newcap *= 2u;
     }
     const uint32_t alloc = need_new ? newcap + 1u : 0u;
-    uint32_t incl = alloc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
+    // bump allocation for the (few) leaders that open a segment: a scalar loop over them
+    uint32_t my_off = 0, total = 0;
+    for (unsigned long long am = __ballot(alloc != 0u); am; am &= am - 1ull) {
+        const int l = __ffsll((long long)am) - 1;
+        if (lane == l) my_off = c.bump + total;
+        total += rdlane(alloc, l);
     }
-    const uint32_t total = __shfl(incl, 63);
     if ((unsigned long long)c.bump + total > c.pool_cap) { c.failed = true; return; }
-    const uint32_t my_off = c.bump + incl - alloc;
     c.bump += total;
     if (leader) {
         if (need_new) {
@@ -948,12 +1027,17 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
             c.btail[b] = my_off;
         } else {
             HeapEnt ht;
-            ht.key = (unsigned long long)tnext | ((unsigned long long)(tn + (uint32_t)gsize) << 32);
+            ht.key = (unsigned long long)COLD_NONE | ((unsigned long long)(tn + (uint32_t)gsize) << 32);   // a tail has no successor
             ht.idx = tcap;
             ht.pad = 0;
             c.pool[tail] = ht;
         }
         c.bcount[b] = cnt + (uint32_t)gsize;
+        {
+            const uint32_t f_tn = need_new ? need_new : tn + (uint32_t)gsize, f_cap = need_new ? newcap : tcap;
+            c.bfill[b] = f_tn | ((uint32_t)(31 - __clz((int)f_cap)) << 24);
+            c.blast[b] = glast;
+        }
         if (cnt == 0) {
             atomicOr(&c.bm0[b >> 6], 1ull << (b & 63));
             atomicOr(&c.bm1[b >> 12], 1ull << ((b >> 6) & 63));
@@ -963,19 +1047,16 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
         // the first group's bucket becomes the cached one
         const int l0 = __ffsll((long long)__ballot(has)) - 1;
         if (l0 >= 0) {
-            const unsigned long long g0 = __ballot(has && gleader == l0);
             const uint32_t n_tail = need_new ? my_off : tail;
             const uint32_t n_tn = need_new ? need_new : tn + (uint32_t)gsize;
             const uint32_t n_tcap = need_new ? newcap : tcap;
-            const uint32_t n_tnext = need_new ? COLD_NONE : tnext;
-            c.cb = __shfl(b, l0);
-            c.cb_tail = __shfl(n_tail, l0);
-            c.cb_tn = __shfl(n_tn, l0);
-            c.cb_tcap = __shfl(n_tcap, l0);
-            c.cb_tnext = __shfl(n_tnext, l0);
-            c.cb_cnt = __shfl(cnt + (uint32_t)gsize, l0);
-            c.cb_unsorted = __shfl((int)unsorted, l0) != 0;
-            c.cb_last = shfl64(key, 63 - __clzll((long long)g0));
+            c.cb = rdlane(b, l0);
+            c.cb_tail = rdlane(n_tail, l0);
+            c.cb_tn = rdlane(n_tn, l0);
+            c.cb_tcap = rdlane(n_tcap, l0);
+            c.cb_cnt = rdlane(cnt + (uint32_t)gsize, l0);
+            c.cb_unsorted = rdlane((uint32_t)unsorted, l0) != 0u;
+            c.cb_last = rdlane64(glast, l0);
         }
     }
     const int gl = gleader & 63;
@@ -988,11 +1069,9 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
         e.pad = lab;
         c.pool[slot] = e;
     }
+    COLD_TICK(c, 3);
     c.count += (uint32_t)__popcll(__ballot(has));
-    uint32_t bl = has ? b : (uint32_t)COLD_NBK;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(bl, o); bl = t < bl ? t : bl; }
-    c.low = bl < c.low ? bl : c.low;
+    c.low = minb < c.low ? minb : c.low;
     // no wait here: every reader of the arena (cold_append, cold_drain, cold_lowest, the hand-over) starts with
     // s_waitcnt vmcnt(0), so these stores complete under the LDS work that follows
 }
@@ -1182,6 +1261,7 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
             t2.pad = 0;
             c.pool[wseg] = t2;
             c.btail[b] = wseg;
+            c.bfill[b] = wn | ((uint32_t)(31 - __clz((int)wcap)) << 24);
             c.bcount[b] = kept;
             c.bmeta[b] = COLD_UNSORTED;                 // compacted from the start of the head segment
         }
@@ -1233,6 +1313,10 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     cold.count = 0;
     cold.low = COLD_NBK;
     cold.fifo_drains = 0;
+#ifdef ISX_FLOOD_PROF
+    for (int i = 0; i < 8; ++i) cold.tk[i] = 0;
+    cold.n_groups = 0;
+#endif
     cold.cb = COLD_NONE;
     cold.pool_cap = 0;
     if (cold.on) {
@@ -1241,7 +1325,9 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         cold.btail = cold.bhead + COLD_NBK;
         cold.bcount = cold.btail + COLD_NBK;
         cold.bmeta = cold.bcount + COLD_NBK;
-        cold.bm0 = (unsigned long long *)(cold.bmeta + COLD_NBK);
+        cold.bfill = cold.bmeta + COLD_NBK;
+        cold.blast = (unsigned long long *)(cold.bfill + COLD_NBK);
+        cold.bm0 = cold.blast + COLD_NBK;
         cold.bm1 = cold.bm0 + COLD_NBK / 64;
         cold.pool = base + COLD_META_ENTS;
         cold.pool_cap = (uint32_t)(arena_off[c + 1] - arena_off[c] - COLD_META_ENTS);
@@ -1261,6 +1347,13 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     bool serial = (ns > hot_cap) && !cold.on;
     bool started = false;
     int stage_from = 0, stage_to = 0;       // staged elements that never reached a bucket (arena exhausted)
+#ifdef ISX_FLOOD_PROF
+    // phase timers (shader clock): tk_acc[i] = cycles between tick i-1 and tick i, tick 0 closes the previous round
+    unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk_prev = __builtin_readcyclecounter();
+#define FLOOD_TICK(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); tk_acc[i] += t_ - tk_prev; tk_prev = t_; } while (0)
+#else
+#define FLOOD_TICK(i) do { } while (0)
+#endif
     unsigned long long st_rounds = 0, st_pops = 0, st_reg = 0, st_run = 0, st_cold = 0, st_drain = 0, st_evict = 0, st_shift = 0, st_oob = 0;
 
     if (!serial) {
@@ -1310,10 +1403,10 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                 // close the gap [keep, keep + done) so that the run again holds exactly what is not in the arena
                 for (int j0 = keep + done; j0 < scount; j0 += 64) {
                     const bool mv = j0 + lane < scount;
-                    HeapEnt e;
-                    if (mv) e = srun[(shead + j0 + lane) & SMASK];
+                    u32x4 e = {0u, 0u, 0u, 0u};
+                    if (mv) e = run_ld(srun, (shead + j0 + lane) & SMASK);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (mv) srun[(shead + j0 + lane - done) & SMASK] = e;
+                    if (mv) run_st(srun, (shead + j0 + lane - done) & SMASK, e);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 scount -= done;
@@ -1324,11 +1417,13 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         }
         ++epoch;
         ++st_rounds;
+        FLOOD_TICK(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // last round's label stores are in L2
+        FLOOD_TICK(1);
         const bool act = lane < rcount;
         // idle lanes look at rank 0's voxel (an interior mask voxel): their loads below are unconditional and
         // must stay inside the padded volume
-        const uint32_t ri0 = __shfl(ri, 0);            // outside the select: a shuffle in a ternary arm runs divergent
+        const uint32_t ri0 = rdlane(ri, 0);            // outside the select: a shuffle in a ternary arm runs divergent
         const int64_t idx = act ? (int64_t)ri : (int64_t)ri0;
         // ---- every lane looks at its six neighbours as if it were popped now -------------------------
         // mask, label and edge value of all six neighbours are loaded unconditionally and together: one memory
@@ -1345,46 +1440,60 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             mk[k] = mask[nbv[k]];
             lb[k] = __hip_atomic_load(&out[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             val[k] = aff[(int64_t)ax[k] * PN + (k < 3 ? idx : nbv[k])];
+            // bring the claim word's line into L2 with the same round trip: the atomic below then hits in L2 instead of
+            // paying its own HBM miss (measured: 4000 -> under 1000 cycles per round)
+#if ISX_CLAIM_PF == 1
+            const uint32_t warm = claim[nbv[k]];
+            asm volatile("" ::"v"(warm));
+#elif ISX_CLAIM_PF == 2
+            const uint32_t warm = __hip_atomic_load(&claim[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(warm));
+#endif
         }
         const uint32_t mytag = (epoch << 6) | (uint32_t)(63 - lane);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             cand[k] = act && mk[k] && lb[k] == 0u;
+#if ISX_CLAIM_WG
+            if (cand[k]) __hip_atomic_fetch_max(&claim[nbv[k]], mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
             if (cand[k]) atomicMax(&claim[nbv[k]], mytag);
+#endif
             val[k] = val[k] * sc[ax[k]] + 0.0f;                          // -0.0 == +0.0 in the order
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every lane's claims are performed
+        FLOOD_TICK(2);
         // ---- who won what; smallest value each lane would push ------------------------------------------
         uint32_t wonmask = 0, mymin = 0xFFFFFFFFu;
+        // all six reads are issued together and unconditionally (a load inside the short-circuit condition is waited
+        // for before the next one is issued: six dependent L2 round trips instead of one)
+        uint32_t ctag[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ctag[k] = __hip_atomic_load(&claim[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 6; ++k)
-            if (cand[k] && __hip_atomic_load(&claim[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mytag) {
+            if (cand[k] && ctag[k] == mytag) {
                 wonmask |= 1u << k;
                 const uint32_t ov = ford(val[k]);
                 mymin = ov < mymin ? ov : mymin;
             }
+        FLOOD_TICK(3);
         // exclusive prefix-min over ranks; the first rank whose own value exceeds it ends the batch
-        uint32_t pm = mymin;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(pm, o);
-            if (lane >= o) pm = t < pm ? t : pm;
-        }
-        uint32_t epm = __shfl_up(pm, 1);
-        if (lane == 0) epm = 0xFFFFFFFFu;
+        const uint32_t epm = wave_shr1(wave_prefix_min(mymin), 0xFFFFFFFFu);
         const unsigned long long vb = __ballot(act && epm < (uint32_t)(rk >> 32));
         const int ncommit = vb ? (__ffsll((long long)vb) - 1) : rcount;   // >= 1: rank 0 never violates
         const bool commit = lane < ncommit;
         // ---- label + ages in (rank, direction) order: the reference's push order ------------------------
-        const uint32_t npush = commit ? (uint32_t)__popc(wonmask) : 0u;
-        uint32_t incl = npush;
+        // exclusive prefix of the push counts from six ballots (scalar work, no cross-lane LDS traffic)
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        uint32_t before_me = 0, total = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
+        for (int k = 0; k < 6; ++k) {
+            const unsigned long long bk = __ballot(commit && (wonmask & (1u << k)));
+            before_me += (uint32_t)__popcll(bk & lt_mask);
+            total += (uint32_t)__popcll(bk);
         }
-        const uint32_t total = __shfl(incl, 63);
-        uint32_t myage = age + (incl - npush);
+        uint32_t myage = age + before_me;
         unsigned long long pkey[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -1398,6 +1507,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         st_pops += (unsigned long long)ncommit;
         const uint32_t wm_all = commit ? wonmask : 0u;
         const uint32_t lab_all = rl;
+        FLOOD_TICK(4);
         // ---- drop the committed ranks from the front, refill from the LDS run (and the cold tier) ----------
         {
             const int src = (lane + ncommit) & 63;
@@ -1420,6 +1530,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             shead = (shead + take) & SMASK;
             scount -= take;
         }
+        FLOOD_TICK(5);
         // ---- tier decision for all new elements at once ----------------------------------------------------
         // An element is cold-bound when it does not sort below the hot maximum and its bucket is not below the lowest
         // non-empty bucket.  Hot insertions of this round cannot change that: the hot maximum only grows by elements
@@ -1430,22 +1541,20 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         if (cold.on && cold.count > 0) {
             unsigned long long back0 = 0ull;
             if (scount > 0) back0 = srun[(shead + scount - 1) & SMASK].key;
-            const unsigned long long reg_last0 = rcount > 0 ? shfl64(rk, rcount - 1) : 0ull;
+            const unsigned long long reg_last0 = rcount > 0 ? rdlane64(rk, rcount - 1) : 0ull;
             const unsigned long long hot_max0 = scount > 0 ? back0 : reg_last0;
             const bool hot_nonempty0 = scount > 0 || rcount > 0;
 #pragma unroll
             for (int k = 0; k < 6; ++k)
                 if ((wm_all & (1u << k)) && !(hot_nonempty0 && pkey[k] < hot_max0) && cold_bucket(pkey[k]) >= cold.low)
                     cmask |= 1u << k;
-            const uint32_t ncold = (uint32_t)__popc(cmask);
-            uint32_t cincl = ncold;
+            uint32_t slot = 0;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = __shfl_up(cincl, o);
-                if (lane >= o) cincl += t;
+            for (int k = 0; k < 6; ++k) {
+                const unsigned long long bk = __ballot((cmask & (1u << k)) != 0u);
+                slot += (uint32_t)__popcll(bk & lt_mask);
+                nstage += __popcll(bk);
             }
-            nstage = (int)__shfl(cincl, 63);
-            uint32_t slot = cincl - ncold;
 #pragma unroll
             for (int k = 0; k < 6; ++k)
                 if (cmask & (1u << k)) {
@@ -1459,19 +1568,19 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         const uint32_t wm_hot = wm_all & ~cmask;
         for (unsigned long long todo_l = __ballot(wm_hot != 0u); todo_l; todo_l &= todo_l - 1ull) {
             const int l = __ffsll((long long)todo_l) - 1;
-            const uint32_t wm = __shfl(wm_hot, l);
-            const uint32_t el = __shfl(lab_all, l);
+            const uint32_t wm = rdlane(wm_hot, l);
+            const uint32_t el = rdlane(lab_all, l);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 if (!(wm & (1u << k))) continue;
-                const unsigned long long ek = shfl64(pkey[k], l);
-                const uint32_t ei = __shfl((uint32_t)nbv[k], l);
+                const unsigned long long ek = rdlane64(pkey[k], l);
+                const uint32_t ei = rdlane((uint32_t)nbv[k], l);
                 // Tier rule (keeps "every cold element sorts after every hot element"): an element stays hot if it sorts
                 // below the current hot maximum, or if nothing in the cold tier can precede it (cold empty, or its
                 // bucket lies below the lowest non-empty bucket); otherwise it goes to its bucket.
                 unsigned long long back = 0ull;
                 if (scount > 0) back = srun[(shead + scount - 1) & SMASK].key;
-                const unsigned long long reg_last = rcount > 0 ? shfl64(rk, rcount - 1) : 0ull;
+                const unsigned long long reg_last = rcount > 0 ? rdlane64(rk, rcount - 1) : 0ull;
                 const unsigned long long hot_max = scount > 0 ? back : reg_last;
                 const bool hot_nonempty = scount > 0 || rcount > 0;
                 const bool below_hot_max = hot_nonempty && ek < hot_max;
@@ -1490,9 +1599,8 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                         --rcount;
                     }
                     const int pos = __popcll(__ballot(lane < rcount && rk < ek));
-                    const int up = (lane - 1) & 63;
-                    const unsigned long long upk = shfl64(rk, up);
-                    const uint32_t upi = __shfl(ri, up), upl = __shfl(rl, up);
+                    const unsigned long long upk = ((unsigned long long)wave_shr1((uint32_t)(rk >> 32), 0u) << 32) | wave_shr1((uint32_t)rk, 0u);
+                    const uint32_t upi = wave_shr1(ri, 0u), upl = wave_shr1(rl, 0u);
                     if (lane > pos && lane <= rcount) { rk = upk; ri = upi; rl = upl; }
                     if (lane == pos) { rk = ek; ri = ei; rl = el; }
                     ++rcount;
@@ -1520,19 +1628,19 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                     for (int base = scount - 64; base > pos - 64; base -= 64) {
                         const int j = base + lane;
                         const bool mv = j >= pos && j >= 0 && j < scount;
-                        HeapEnt e;
-                        if (mv) e = srun[(shead + j) & SMASK];
+                        u32x4 e = {0u, 0u, 0u, 0u};          // a vector value, not a struct: stays in registers
+                        if (mv) e = run_ld(srun, (shead + j) & SMASK);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (mv) srun[(shead + j + 1) & SMASK] = e;
+                        if (mv) run_st(srun, (shead + j + 1) & SMASK, e);
                     }
                 } else {
                     for (int base = 0; base < pos; base += 64) {
                         const int j = base + lane;
                         const bool mv = j < pos;
-                        HeapEnt e;
-                        if (mv) e = srun[(shead + j) & SMASK];
+                        u32x4 e = {0u, 0u, 0u, 0u};
+                        if (mv) e = run_ld(srun, (shead + j) & SMASK);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (mv) srun[(shead + j - 1) & SMASK] = e;
+                        if (mv) run_st(srun, (shead + j - 1) & SMASK, e);
                     }
                     shead = (shead - 1) & SMASK;
                 }
@@ -1542,6 +1650,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
+        FLOOD_TICK(6);
         // ---- this round's cold-bound elements, 64 at a time ------------------------------------------------
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int s0i = 0; s0i < nstage; s0i += 64) {
@@ -1559,6 +1668,11 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
         }
     }
 
+#ifdef ISX_FLOOD_PROF
+    if (stats && lane == 0)
+        for (int i = 0; i < 8; ++i) { atomicAdd(&stats[16 + i], tk_acc[i]); if (i < 4) atomicAdd(&stats[24 + i], cold.tk[i]); }
+    if (stats && lane == 0) atomicAdd(&stats[28], cold.n_groups);
+#endif
     if (stats && lane == 0) {
         atomicAdd(&stats[0], st_rounds); atomicAdd(&stats[1], st_pops); atomicAdd(&stats[2], st_reg); atomicAdd(&stats[3], st_run);
         atomicAdd(&stats[4], st_cold); atomicAdd(&stats[5], st_drain); atomicAdd(&stats[6], st_evict); atomicAdd(&stats[7], st_shift);
@@ -1689,9 +1803,9 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     Scratch<HeapEnt> pool(ctx, (size_t)total + 1);
     Scratch<HeapEnt> arena(ctx, (size_t)arena_total + 1);
     Scratch<uint32_t> claim(ctx, (size_t)PN);
-    Scratch<unsigned long long> stats(ctx, 16);
+    Scratch<unsigned long long> stats(ctx, 32);
     if (!pool.ok() || !claim.ok() || !arena.ok() || !stats.ok()) return ISX_ERR_NOMEM;
-    ISX_HIP(hipMemsetAsync(stats.p, 0, 16 * 8, ctx->stream));
+    ISX_HIP(hipMemsetAsync(stats.p, 0, 32 * 8, ctx->stream));
     float s[3] = {1.f, 1.f, 1.f};
     if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
     // small components: one lane each; large ones: one wave each (both launched over all components,
@@ -1708,11 +1822,18 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                                                       ctx->ws_shard_rank, ctx->ws_shard_world);
     ISX_CHECK_LAUNCH();
     if (getenv("ISX_FLOOD_STATS")) {
-        unsigned long long hs[16];
+        unsigned long long hs[32];
         ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         ISX_HIP(hipStreamSynchronize(ctx->stream));
         fprintf(stderr, "[isx flood] rounds %llu pops %llu (%.2f/round) reg_ins %llu run_ins %llu (avg shift %.1f) cold_app %llu drains %llu (prefix %llu) evicted %llu serial_handover %llu oob %llu\n",
                 hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[3], hs[3] ? (double)hs[7] / hs[3] : 0.0, hs[4], hs[5], hs[10], hs[6], hs[8], hs[9]);
+#ifdef ISX_FLOOD_PROF
+        fprintf(stderr, "[isx flood] cycles/round: append+loop %.0f | wait-stores %.0f | loads+claims %.0f | claim-read %.0f | scan+label %.0f | refill/drain %.0f | insert %.0f\n",
+                (double)hs[16] / hs[0], (double)hs[17] / hs[0], (double)hs[18] / hs[0], (double)hs[19] / hs[0], (double)hs[20] / hs[0],
+                (double)hs[21] / hs[0], (double)hs[22] / hs[0]);
+        fprintf(stderr, "[isx flood] append cycles/round: wait %.0f | groups %.0f (%.2f groups/round) | leader loads %.0f | bookkeeping+stores %.0f\n",
+                (double)hs[24] / hs[0], (double)hs[25] / hs[0], (double)hs[28] / hs[0], (double)hs[26] / hs[0], (double)hs[27] / hs[0]);
+#endif
     }
     return ISX_OK;
 }
