@@ -806,12 +806,6 @@ __global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__res
 static constexpr int COOP_SCAP = 2048;                      // LDS run capacity (entries of 16 B)
 static constexpr unsigned long long COOP_MIN_SIZE = 512;    // components below this stay on flood_kernel
 static constexpr unsigned long long COLD_MIN_SIZE = 32768;  // components from this size get a cold arena
-#ifndef ISX_CLAIM_PF
-#define ISX_CLAIM_PF 0
-#endif
-#ifndef ISX_CLAIM_WG
-#define ISX_CLAIM_WG 0
-#endif
 static constexpr uint32_t COLD_UNSORTED = 0x80000000u;
 static constexpr int COLD_NBK = 65536;                      // buckets: top 16 bits of the order-preserving key
 static constexpr int COLD_DRAIN = 1024;                     // elements moved from a bucket to the LDS run at once
@@ -1440,25 +1434,12 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             mk[k] = mask[nbv[k]];
             lb[k] = __hip_atomic_load(&out[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             val[k] = aff[(int64_t)ax[k] * PN + (k < 3 ? idx : nbv[k])];
-            // bring the claim word's line into L2 with the same round trip: the atomic below then hits in L2 instead of
-            // paying its own HBM miss (measured: 4000 -> under 1000 cycles per round)
-#if ISX_CLAIM_PF == 1
-            const uint32_t warm = claim[nbv[k]];
-            asm volatile("" ::"v"(warm));
-#elif ISX_CLAIM_PF == 2
-            const uint32_t warm = __hip_atomic_load(&claim[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("" ::"v"(warm));
-#endif
         }
         const uint32_t mytag = (epoch << 6) | (uint32_t)(63 - lane);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             cand[k] = act && mk[k] && lb[k] == 0u;
-#if ISX_CLAIM_WG
-            if (cand[k]) __hip_atomic_fetch_max(&claim[nbv[k]], mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
             if (cand[k]) atomicMax(&claim[nbv[k]], mytag);
-#endif
             val[k] = val[k] * sc[ax[k]] + 0.0f;                          // -0.0 == +0.0 in the order
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every lane's claims are performed
