@@ -2,7 +2,7 @@
 import csv, sys, glob
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 f = glob.glob(sys.argv[1])[0]
-rows = [r for r in csv.DictReader(open(f)) if 'conv_h2' in r['Kernel_Name'] or 'conv_mfma' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(f)) if any(k in r['Kernel_Name'] for k in ('conv_h2', 'conv_mfma', 'conv_fold'))]
 lv = [(10,256,256),(10,129,129),(10,65,65),(10,33,33),(5,17,17)]
 mods = [(1,32,0),(32,64,1),(64,128,2),(128,256,3),(256,256,4),(512,128,3),(256,64,2),(128,32,1),(64,5,0)]
 layers = []
