@@ -1161,12 +1161,25 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         // ---- select by key: min / max, then 64-bin histograms until a non-empty prefix of <= COLD_DRAIN exists ----
+        // Bins are (key - lo) >> sh: any monotone binning selects a prefix in key order, and a shift costs nothing
+        // (the proportional binning it replaces needed a 64-bit division per element and pass).  Every pass keeps
+        // four independent loads per lane in flight instead of waiting for each 64-element row.
         unsigned long long lo = ~0ull, hi = 0ull;
         for (uint32_t seg = head; seg != COLD_NONE;) {
             const HeapEnt h = cld_ent(&c.pool[seg]);
             const uint32_t n = (uint32_t)(h.key >> 32);
-            for (uint32_t j = (seg == head ? off0 : 0u) + lane; j < n; j += 64) {
-                const unsigned long long k = cld64(&c.pool[seg + 1u + j].key);
+            const HeapEnt *el = &c.pool[seg + 1u];
+            uint32_t j = (seg == head ? off0 : 0u) + lane;
+            for (; j + 192u < n; j += 256u) {
+                const unsigned long long k0 = cld64(&el[j].key), k1 = cld64(&el[j + 64u].key), k2 = cld64(&el[j + 128u].key),
+                                         k3 = cld64(&el[j + 192u].key);
+                const unsigned long long a0 = k0 < k1 ? k0 : k1, a1 = k2 < k3 ? k2 : k3, b0 = k0 > k1 ? k0 : k1, b1 = k2 > k3 ? k2 : k3;
+                const unsigned long long mn = a0 < a1 ? a0 : a1, mx = b0 > b1 ? b0 : b1;
+                lo = mn < lo ? mn : lo;
+                hi = mx > hi ? mx : hi;
+            }
+            for (; j < n; j += 64u) {
+                const unsigned long long k = cld64(&el[j].key);
                 lo = k < lo ? k : lo;
                 hi = k > hi ? k : hi;
             }
@@ -1178,17 +1191,26 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
             lo = l2 < lo ? l2 : lo;
             hi = h2 > hi ? h2 : hi;
         }
-        unsigned long long width = hi - lo + 1ull;      // < 2^48: all keys share their top 16 bits
+        int sh = (hi - lo) ? 64 - __clzll((long long)(hi - lo)) - 6 : 0;       // (hi - lo) >> sh < 64
+        if (sh < 0) sh = 0;
         int B = 0;
+#define ISX_BIN_ADD(k) { const unsigned long long d_ = (k) - lo; if ((k) >= lo && (d_ >> sh) < 64ull) atomicAdd(&hist[(int)(d_ >> sh)], 1); }
         for (;;) {
             hist[lane] = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             for (uint32_t seg = head; seg != COLD_NONE;) {
                 const HeapEnt h = cld_ent(&c.pool[seg]);
                 const uint32_t n = (uint32_t)(h.key >> 32);
-                for (uint32_t j = (seg == head ? off0 : 0u) + lane; j < n; j += 64) {
-                    const unsigned long long k = cld64(&c.pool[seg + 1u + j].key);
-                    if (k >= lo && k - lo < width) atomicAdd(&hist[(int)(((k - lo) * 64ull) / width)], 1);
+                const HeapEnt *el = &c.pool[seg + 1u];
+                uint32_t j = (seg == head ? off0 : 0u) + lane;
+                for (; j + 192u < n; j += 256u) {
+                    const unsigned long long k0 = cld64(&el[j].key), k1 = cld64(&el[j + 64u].key), k2 = cld64(&el[j + 128u].key),
+                                             k3 = cld64(&el[j + 192u].key);
+                    ISX_BIN_ADD(k0) ISX_BIN_ADD(k1) ISX_BIN_ADD(k2) ISX_BIN_ADD(k3)
+                }
+                for (; j < n; j += 64u) {
+                    const unsigned long long k = cld64(&el[j].key);
+                    ISX_BIN_ADD(k)
                 }
                 seg = (uint32_t)h.key;
             }
@@ -1204,47 +1226,56 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
             B = (~fits) ? (__ffsll((long long)~fits) - 1) : 64;
             const int cumB = B > 0 ? __shfl(incl, B - 1) : 0;
             if (cumB > 0) break;
-            // the first non-empty bin is bin B and it alone is too large: zoom into it
-            const unsigned long long nlo = lo + (B * width + 63ull) / 64ull;
-            const unsigned long long nhi = lo + ((B + 1) * width + 63ull) / 64ull - 1ull;
-            lo = nlo;
-            width = nhi - nlo + 1ull;
+            // the first non-empty bin is bin B and it alone is too large: zoom into it (keys are unique, so a bin of
+            // width 1 holds one element and this cannot happen with sh == 0)
+            lo += (unsigned long long)B << sh;
+            sh = sh > 6 ? sh - 6 : 0;
         }
+#undef ISX_BIN_ADD
         // ---- extract bins < B into the run; compact the rest in place (write cursor trails the read cursor) ----
+        // A row's loads are issued before any store of that row and later rows lie at higher addresses than anything
+        // stored so far, so no load ever has to wait for a store: two rows are loaded ahead.
         uint32_t wseg = head, wn = 0, wcap = cld_ent(&c.pool[head]).idx, kept = 0;
         for (uint32_t seg = head; seg != COLD_NONE;) {
             const HeapEnt h = cld_ent(&c.pool[seg]);
             const uint32_t n = (uint32_t)(h.key >> 32), nxt = (uint32_t)h.key;
-            for (uint32_t base = (seg == head ? off0 : 0u); base < n; base += 64) {
-                const uint32_t j = base + lane;
-                HeapEnt e;
-                bool valid = j < n, take = false;
-                if (valid) {
-                    e = cld_ent(&c.pool[seg + 1u + j]);
-                    take = e.key >= lo && e.key - lo < width && (int)(((e.key - lo) * 64ull) / width) < B;
+            for (uint32_t base0 = (seg == head ? off0 : 0u); base0 < n; base0 += 128u) {
+                HeapEnt e2[2];
+                bool valid2[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t j = base0 + 64u * (uint32_t)u + lane;
+                    valid2[u] = j < n;
+                    e2[u].key = 0; e2[u].idx = 0; e2[u].pad = 0;
+                    if (valid2[u]) e2[u] = cld_ent(&c.pool[seg + 1u + j]);
                 }
-                const unsigned long long tb = __ballot(valid && take), kb = __ballot(valid && !take);
-                if (valid && take) srun[taken + __popcll(tb & ((1ull << lane) - 1ull))] = e;
-                taken += __popcll(tb);
-                int krank = __popcll(kb & ((1ull << lane) - 1ull));
-                int remaining = __popcll(kb), done = 0;
-                while (remaining > 0) {
-                    const int room = (int)(wcap - wn);
-                    const int m = room < remaining ? room : remaining;
-                    if (valid && !take && krank >= done && krank < done + m) c.pool[wseg + 1u + wn + (uint32_t)(krank - done)] = e;
-                    wn += (uint32_t)m;
-                    done += m;
-                    remaining -= m;
-                    if (wn == wcap && remaining > 0) {
-                        const HeapEnt wh = cld_ent(&c.pool[wseg]);
-                        if (lane == 0) { HeapEnt t2 = wh; t2.key = (wh.key & 0xFFFFFFFFull) | ((unsigned long long)wcap << 32); c.pool[wseg] = t2; }
-                        wseg = (uint32_t)wh.key;
-                        wn = 0;
-                        wcap = cld_ent(&c.pool[wseg]).idx;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const HeapEnt e = e2[u];
+                    const bool valid = valid2[u];
+                    const bool take = valid && e.key >= lo && ((e.key - lo) >> sh) < (unsigned long long)B;
+                    const unsigned long long tb = __ballot(take), kb = __ballot(valid && !take);
+                    if (take) srun[taken + __popcll(tb & ((1ull << lane) - 1ull))] = e;
+                    taken += __popcll(tb);
+                    int krank = __popcll(kb & ((1ull << lane) - 1ull));
+                    int remaining = __popcll(kb), done = 0;
+                    while (remaining > 0) {
+                        const int room = (int)(wcap - wn);
+                        const int m = room < remaining ? room : remaining;
+                        if (valid && !take && krank >= done && krank < done + m) c.pool[wseg + 1u + wn + (uint32_t)(krank - done)] = e;
+                        wn += (uint32_t)m;
+                        done += m;
+                        remaining -= m;
+                        if (wn == wcap && remaining > 0) {
+                            const HeapEnt wh = cld_ent(&c.pool[wseg]);
+                            if (lane == 0) { HeapEnt t2 = wh; t2.key = (wh.key & 0xFFFFFFFFull) | ((unsigned long long)wcap << 32); c.pool[wseg] = t2; }
+                            wseg = (uint32_t)wh.key;
+                            wn = 0;
+                            wcap = cld_ent(&c.pool[wseg]).idx;
+                        }
                     }
+                    kept += (uint32_t)__popcll(kb);
                 }
-                kept += (uint32_t)__popcll(kb);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             seg = nxt;
         }
