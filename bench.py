@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume (default: the 512^3 north star)")
+    ap.add_argument("--shape", type=int, nargs=3, default=None, metavar=("Z", "Y", "X"),
+                    help="non-cubic volume instead of --size, e.g. 64 512 512 (BASELINE.json configs[1])")
     ap.add_argument("--batch", type=int, default=64, help="chunks per launch set (1..64; ~0.6 GB of workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default=None, choices=["fp32", "split-f16"],
@@ -195,7 +197,8 @@ def main():
     from tests.synth import positive_volume
 
     chunk, margin = (10, 256, 256), (1, 64, 64)
-    shape = (args.size,) * 3
+    shape = tuple(args.shape) if args.shape else (args.size,) * 3
+    shape_name = "x".join(str(v) for v in shape) if args.shape else f"{args.size}^3"
     sd = weights.generate_state_dict(0)
     u = UNet(1, 5, device=local_rank, batch=args.batch, precision=args.precision)
     precision = u.precision
@@ -258,7 +261,7 @@ def main():
             "vs_baseline": None,
             "dtype": DTYPE[precision],
             "data": "synthetic",
-            "config": {"workload": f"{args.size}^3 float32 volume per GPU (one frame per rank), chunk (10,256,256), "
+            "config": {"workload": f"{shape_name} float32 volume per GPU (one frame per rank), chunk (10,256,256), "
                                    f"precision {precision}, "
                                    f"margin (1,64,64) = {n_chunks} chunks, seeded random U-Net weights (seed 0), "
                                    f"train-mode BatchNorm per chunk, watershed min_area 10 / max_area 1e7",
