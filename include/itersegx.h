@@ -168,11 +168,18 @@ int isx_train_refresh_weights(isx_ctx *ctx);
  *   ISX_TARGET_CENTRENESS "centreness"  get_centreness (labels.py:142-205, log/power off): per object
  *                                       1 - d / d_max, d = |(centroid - voxel) * scale| in float64; 0 for background and
  *                                       for single-voxel objects;
- *   ISX_TARGET_MASK       "mask"        get_semantic_labels (labels.py:283-285): labels > 1.
- * The reference returns float64 holding the same values (affinities / mask are 0 or 1, centreness is float32). */
+ *   ISX_TARGET_MASK       "mask"        get_semantic_labels (labels.py:283-285): labels > 1;
+ *   ISX_TARGET_CENTRENESS_LOG "centreness-log"  get_centreness(log=True) (labels.py:178-205): d -> ln d for d > 0, shifted
+ *                                       by |min| over the object, then 1 - d / d_max;
+ *   ISX_TARGET_OFFSET     "offsets-<axis>"  get_centre_offsets (labels.py:212-276), axis in axis[c]: per object
+ *                                       o = (centroid - voxel) * scale along the axis, o / max(o) for o > 0, -(o / min(o))
+ *                                       for o < 0, mapped to [0, 1] by (v + 1) / 2 and rounded to float32; background 0.5.
+ * The reference returns float64 holding the same values (affinities / mask are 0 or 1, the others are float32). */
 #define ISX_TARGET_AFFINITY 0
 #define ISX_TARGET_CENTRENESS 1
 #define ISX_TARGET_MASK 2
+#define ISX_TARGET_CENTRENESS_LOG 3
+#define ISX_TARGET_OFFSET 4
 int isx_training_labels(isx_ctx *ctx, const int32_t *labels, const int64_t shape[3], int n_channels,
                         const int32_t *kind, const int32_t *axis, const int32_t *n, const double scale[3], float *out);
 

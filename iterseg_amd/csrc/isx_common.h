@@ -97,6 +97,12 @@ struct Scratch {
     Scratch &operator=(const Scratch &) = delete;
     operator T *() const { return p; }
     bool ok() const { return p != nullptr; }
+    void resize(size_t count)          // contents are not kept
+    {
+        if (p) ctx->release(p);
+        p = (T *)ctx->alloc(count * sizeof(T));
+        n = count;
+    }
 };
 
 struct ProfScope {

@@ -1,8 +1,7 @@
 // labels.hip -- training-target generation on the GPU (the producer side of train_unet).
 //
-// Replaces, for the channel kinds the default training uses, the reference's get_training_labels
-// (src/iterseg/labels.py:23-68): nth_affinity (:87-108), get_centreness (:142-205, log / power off) and
-// get_semantic_labels (:283-285).  The reference walks regionprops objects in Python and computes one
+// Replaces the reference's get_training_labels (src/iterseg/labels.py:23-68) for: nth_affinity (:87-108),
+// get_centreness (:142-205, plain and log), get_centre_offsets (:212-276) and get_semantic_labels (:283-285).  The reference walks regionprops objects in Python and computes one
 // np.linalg.norm per voxel; here: one pass of integer atomics for the per-object coordinate sums, one pass for the
 // per-object maximum distance, one pass writing 1 - d / d_max.  Distances are float64 like upstream.
 #include <hip/hip_runtime.h>
@@ -124,6 +123,99 @@ __global__ void centre_write_kernel(const int32_t *__restrict__ lab, int64_t Z, 
     out[i] = v;
 }
 
+// ---- centreness-log (labels.py:178-205, log=True): t = ln d for d > 0 (0 stays 0), per object t += |min t|, then
+// 1 - t / max t.  Doubles of either sign are ordered through a monotone map to uint64.
+__device__ __forceinline__ unsigned long long ord_key(double v)
+{
+    const long long b = __double_as_longlong(v);
+    return b < 0 ? ~(unsigned long long)b : (unsigned long long)b | 0x8000000000000000ull;
+}
+__device__ __forceinline__ double ord_val(unsigned long long k)
+{
+    return __longlong_as_double((long long)((k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
+__device__ __forceinline__ double log_dist(double d) { return fabs(d) > 0.0 ? log(d) : d; }
+
+__global__ void centre_log_range_kernel(const int32_t *__restrict__ lab, int64_t Z, int64_t Y, int64_t X,
+                                        const unsigned long long *__restrict__ sums, double s0, double s1, double s2,
+                                        unsigned long long *__restrict__ tmin, unsigned long long *__restrict__ tmax)
+{
+    const int64_t N = Z * Y * X;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int32_t l = lab[i];
+    if (l <= 0) return;
+    const unsigned long long k = ord_key(log_dist(centre_dist(sums + (int64_t)l * 4, i / (X * Y), (i / X) % Y, i % X, s0, s1, s2)));
+    atomicMin(tmin + l, k);
+    atomicMax(tmax + l, k);
+}
+
+__global__ void centre_log_write_kernel(const int32_t *__restrict__ lab, int64_t Z, int64_t Y, int64_t X,
+                                        const unsigned long long *__restrict__ sums, double s0, double s1, double s2,
+                                        const unsigned long long *__restrict__ tmin, const unsigned long long *__restrict__ tmax,
+                                        float *__restrict__ out)
+{
+    const int64_t N = Z * Y * X;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int32_t l = lab[i];
+    float v = 0.0f;
+    if (l > 0) {
+        const double t = log_dist(centre_dist(sums + (int64_t)l * 4, i / (X * Y), (i / X) % Y, i % X, s0, s1, s2));
+        const double shift = fabs(ord_val(tmin[l]));
+        const double m = ord_val(tmax[l]) + shift;
+        const float f = (float)(1.0 - (t + shift) / m);
+        v = (f != f) ? 0.0f : f;                      // nan -> np.nan_to_num -> 0 (single-voxel objects)
+    }
+    out[i] = v;
+}
+
+// ---- centre offsets (labels.py:212-276): the per-object extremes of (centroid - voxel) * scale along an axis are
+// attained at the ends of the object's bounding box, so one pass of integer min / max atomics is enough.
+__global__ void bbox_kernel(const int32_t *__restrict__ lab, int64_t Z, int64_t Y, int64_t X, int32_t *__restrict__ box /* [L+1][6] */)
+{
+    const int64_t N = Z * Y * X;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int32_t l = lab[i];
+    if (l <= 0) return;
+    const int32_t p[3] = {(int32_t)(i / (X * Y)), (int32_t)((i / X) % Y), (int32_t)(i % X)};
+    int32_t *b = box + (int64_t)l * 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { atomicMin(b + a, p[a]); atomicMax(b + 3 + a, p[a]); }
+}
+
+__global__ void bbox_init_kernel(int32_t *box, int64_t L1)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L1 * 6) box[i] = (i % 6) < 3 ? 0x7FFFFFFF : -1;
+}
+
+__global__ void offset_write_kernel(const int32_t *__restrict__ lab, int64_t Z, int64_t Y, int64_t X,
+                                    const unsigned long long *__restrict__ sums, const int32_t *__restrict__ box, int axis,
+                                    double sc, float *__restrict__ out)
+{
+    const int64_t N = Z * Y * X;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int32_t l = lab[i];
+    float v = 0.5f;                                   // background (labels.py:228)
+    if (l > 0) {
+        const int64_t p[3] = {i / (X * Y), (i / X) % Y, i % X};
+        const unsigned long long *s = sums + (int64_t)l * 4;
+        const double c = (double)s[axis] / (double)s[3];
+        const double d = (c - (double)p[axis]) * sc;
+        const double e0 = (c - (double)box[(int64_t)l * 6 + axis]) * sc, e1 = (c - (double)box[(int64_t)l * 6 + 3 + axis]) * sc;
+        const double mx = e0 > e1 ? e0 : e1, mn = e0 < e1 ? e0 : e1;
+        double r = 0.0;
+        if (d > 0.0) r = d / mx;
+        else if (d < 0.0) r = -(d / mn);
+        r = (r - (-1.0)) / 2.0;
+        v = (float)r;
+    }
+    out[i] = v;
+}
+
 }  // namespace isx
 
 using namespace isx;
@@ -137,8 +229,30 @@ extern "C" int isx_training_labels(isx_ctx *ctx, const int32_t *labels, const in
     const int64_t Z = shape[0], Y = shape[1], X = shape[2], N = Z * Y * X;
     ISX_REQUIRE(Z > 0 && Y > 0 && X > 0, "empty volume");
     const unsigned grid = cdiv(N, LTPB);
-    bool centre_done = false;
-    int centre_channel = -1;
+    // per-object statistics shared by the centreness and offset channels (computed once, on first use)
+    int64_t L = -1;
+    Scratch<unsigned long long> sums(ctx, 0), dmax(ctx, 0), tmin(ctx, 0), tmax(ctx, 0);
+    Scratch<int32_t> box(ctx, 0);
+    bool have_dmax = false, have_log = false, have_box = false;
+    auto need_sums = [&]() -> int {
+        if (L >= 0) return ISX_OK;
+        Scratch<int32_t> mm(ctx, 2);
+        if (!mm.ok()) return ISX_ERR_NOMEM;
+        ISX_HIP(hipMemsetAsync(mm.p, 0, 8, ctx->stream));
+        label_max_kernel<<<1024, LTPB, 0, ctx->stream>>>(labels, N, mm.p, mm.p + 1);
+        ISX_CHECK_LAUNCH();
+        int32_t h[2];
+        ISX_HIP(hipMemcpyAsync(h, mm.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        ISX_REQUIRE(h[1] >= 0, "negative labels are not supported (regionprops ignores them upstream)");
+        L = h[0];
+        sums.resize((size_t)(L + 1) * 4);
+        if (!sums.ok()) return ISX_ERR_NOMEM;
+        ISX_HIP(hipMemsetAsync(sums.p, 0, (size_t)(L + 1) * 32, ctx->stream));
+        centroid_sums_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, sums.p);
+        ISX_CHECK_LAUNCH();
+        return ISX_OK;
+    };
     for (int c = 0; c < n_channels; ++c) {
         float *dst = out + (int64_t)c * N;
         if (kind[c] == ISX_TARGET_AFFINITY) {
@@ -150,37 +264,50 @@ extern "C" int isx_training_labels(isx_ctx *ctx, const int32_t *labels, const in
             mask_target_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, N, dst);
             ISX_CHECK_LAUNCH();
         } else if (kind[c] == ISX_TARGET_CENTRENESS) {
-            if (centre_done) {           // a second centreness channel is a copy of the first
-                ISX_HIP(hipMemcpyAsync(dst, out + (int64_t)centre_channel * N, N * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-                continue;
+            ISX_TRY(need_sums());
+            if (!have_dmax) {
+                dmax.resize((size_t)(L + 1));
+                if (!dmax.ok()) return ISX_ERR_NOMEM;
+                ISX_HIP(hipMemsetAsync(dmax.p, 0, (size_t)(L + 1) * 8, ctx->stream));
+                centre_dmax_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, sums.p, scale[0], scale[1], scale[2], dmax.p);
+                ISX_CHECK_LAUNCH();
+                have_dmax = true;
             }
-            Scratch<int32_t> mm(ctx, 2);
-            if (!mm.ok()) return ISX_ERR_NOMEM;
-            ISX_HIP(hipMemsetAsync(mm.p, 0, 8, ctx->stream));
-            label_max_kernel<<<1024, LTPB, 0, ctx->stream>>>(labels, N, mm.p, mm.p + 1);
-            ISX_CHECK_LAUNCH();
-            int32_t h[2];
-            ISX_HIP(hipMemcpyAsync(h, mm.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-            ISX_HIP(hipStreamSynchronize(ctx->stream));
-            ISX_REQUIRE(h[1] >= 0, "negative labels are not supported (regionprops ignores them upstream)");
-            const int64_t L = h[0];
-            Scratch<unsigned long long> sums(ctx, (size_t)(L + 1) * 4), dmax(ctx, (size_t)(L + 1));
-            if (!sums.ok() || !dmax.ok()) return ISX_ERR_NOMEM;
-            ISX_HIP(hipMemsetAsync(sums.p, 0, (size_t)(L + 1) * 32, ctx->stream));
-            ISX_HIP(hipMemsetAsync(dmax.p, 0, (size_t)(L + 1) * 8, ctx->stream));
-            centroid_sums_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, sums.p);
-            ISX_CHECK_LAUNCH();
-            centre_dmax_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, sums.p, scale[0], scale[1], scale[2], dmax.p);
-            ISX_CHECK_LAUNCH();
             centre_write_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, sums.p, scale[0], scale[1], scale[2], dmax.p, dst);
             ISX_CHECK_LAUNCH();
-            ISX_HIP(hipStreamSynchronize(ctx->stream));          // scratch goes back to the cache after this
-            centre_done = true;
-            centre_channel = c;
+        } else if (kind[c] == ISX_TARGET_CENTRENESS_LOG) {
+            ISX_TRY(need_sums());
+            if (!have_log) {
+                tmin.resize((size_t)(L + 1));
+                tmax.resize((size_t)(L + 1));
+                if (!tmin.ok() || !tmax.ok()) return ISX_ERR_NOMEM;
+                ISX_HIP(hipMemsetAsync(tmin.p, 0xFF, (size_t)(L + 1) * 8, ctx->stream));
+                ISX_HIP(hipMemsetAsync(tmax.p, 0, (size_t)(L + 1) * 8, ctx->stream));
+                centre_log_range_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, sums.p, scale[0], scale[1], scale[2], tmin.p, tmax.p);
+                ISX_CHECK_LAUNCH();
+                have_log = true;
+            }
+            centre_log_write_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, sums.p, scale[0], scale[1], scale[2], tmin.p, tmax.p, dst);
+            ISX_CHECK_LAUNCH();
+        } else if (kind[c] == ISX_TARGET_OFFSET) {
+            ISX_REQUIRE(axis[c] >= 0 && axis[c] < 3, "channel %d: offset axis %d", c, axis[c]);
+            ISX_TRY(need_sums());
+            if (!have_box) {
+                box.resize((size_t)(L + 1) * 6);
+                if (!box.ok()) return ISX_ERR_NOMEM;
+                bbox_init_kernel<<<cdiv((L + 1) * 6, LTPB), LTPB, 0, ctx->stream>>>(box.p, L + 1);
+                ISX_CHECK_LAUNCH();
+                bbox_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, box.p);
+                ISX_CHECK_LAUNCH();
+                have_box = true;
+            }
+            offset_write_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, sums.p, box.p, axis[c], scale[axis[c]], dst);
+            ISX_CHECK_LAUNCH();
         } else {
             set_error("channel %d: unknown target kind %d", c, kind[c]);
             return ISX_ERR_ARG;
         }
     }
+    ISX_HIP(hipStreamSynchronize(ctx->stream));          // the scratch buffers go back to the cache after this
     return ISX_OK;
 }

@@ -1,9 +1,9 @@
 """Mirror of the target-generating part of ``iterseg.labels`` (reference: src/iterseg/labels.py) on the MI355X.
 
-``get_training_labels(l, channels, scale)`` -- labels.py:23-68 -- for the channel kinds the default training uses
-(``'z-1', 'y-1', 'x-1', 'centreness'``, plus any ``<axis>-<n>`` affinity and ``'mask'``).  ``l`` may be a numpy array
-(result: numpy, float32) or a CUDA tensor (result stays on the device).  Other channel kinds of the reference
-(``centreness-log``, ``centroid-gauss``, ``offsets-*``, ``*-smooth``) raise ``NotImplementedError``.
+``get_training_labels(l, channels, scale)`` -- labels.py:23-68 -- for ``<axis>-<n>`` affinities, ``'centreness'``,
+``'centreness-log'``, ``'offsets-<axis>'`` and ``'mask'``.  ``l`` may be a numpy array (result: numpy, float32) or a
+CUDA tensor (result stays on the device).  The remaining channel kinds of the reference (``centroid-gauss``,
+``*-smooth``: per-plane scikit-image Gaussians) raise ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -23,9 +23,15 @@ def _parse(channels):
     kind, axis, n = [], [], []
     for chan in channels:
         m = re.search(r'\d+', chan)
-        if chan.endswith('-smooth') or chan in ('centreness-log', 'centroid-gauss') or chan.startswith('offsets-'):
+        if chan.endswith('-smooth') or chan == 'centroid-gauss':
             raise NotImplementedError(f"channel '{chan}' is not on the accelerated path")
-        if m is not None and chan[0] in 'zyx':
+        if chan == 'centreness-log':
+            kind.append(3); axis.append(0); n.append(0)
+        elif chan.startswith('offsets-'):
+            if chan[-1] not in 'zyx':
+                raise ValueError(f'Incompatible offset axis name: {chan}')        # labels.py:71-80
+            kind.append(4); axis.append('zyx'.index(chan[-1])); n.append(0)
+        elif m is not None and chan[0] in 'zyx':
             kind.append(0); axis.append('zyx'.index(chan[0])); n.append(int(m[0]))
         elif chan == 'centreness':
             kind.append(1); axis.append(0); n.append(0)
@@ -63,10 +69,15 @@ def nth_affinity(labels, n, axis):
 
 
 def get_centreness(labels, scale=(4, 1, 1), log=False, power=False):
-    """labels.py:142-178 (``log`` / ``power`` are not on the accelerated path)."""
-    if log or power:
-        raise NotImplementedError("log / power centreness")
-    return get_training_labels(labels, ('centreness',), scale)[0]
+    """labels.py:142-178 (``power`` is not on the accelerated path)."""
+    if power:
+        raise NotImplementedError("power centreness")
+    return get_training_labels(labels, ('centreness-log' if log else 'centreness',), scale)[0]
+
+
+def get_centre_offsets(labels, scale):
+    """labels.py:212-242 -> (3, Z, Y, X)"""
+    return get_training_labels(labels, ('offsets-z', 'offsets-y', 'offsets-x'), scale)
 
 
 def get_semantic_labels(labels):

@@ -1,9 +1,9 @@
 """CPU oracle for the training-target generation.  TEST INFRASTRUCTURE ONLY.
 
-numpy restatement of ``get_training_labels`` (reference src/iterseg/labels.py:23-68) for the channel kinds the
-default training uses: ``<axis>-<n>`` affinities (labels.py:87-108), ``centreness`` (labels.py:142-205, log/power
-off) and ``mask`` (labels.py:283-285).  Pinned against tests/golden/training_labels.npz (generated from the
-reference with tests/golden/gen_stage3_labels.py) by tests/test_oracle_labels.py.
+numpy restatement of ``get_training_labels`` (reference src/iterseg/labels.py:23-68): ``<axis>-<n>`` affinities
+(labels.py:87-108), ``centreness`` and ``centreness-log`` (labels.py:142-205), ``offsets-<axis>`` (labels.py:212-276)
+and ``mask`` (labels.py:283-285).  Pinned against tests/golden/training_labels.npz and training_labels_ext.npz
+(generated from the reference with tests/golden/gen_stage3_labels.py) by tests/test_oracle_labels.py.
 """
 import re
 
@@ -20,9 +20,10 @@ def nth_affinity(labels, n, axis):
     return np.where(L - other != 0, 1.0, 0.0)
 
 
-def get_centreness(labels, scale=(4, 1, 1)):
+def get_centreness(labels, scale=(4, 1, 1), log=False):
     """Per object: 1 - d / d_max with d the scaled Euclidean distance (float64) of the voxel to the object's
-    centroid; float32 result; single-voxel objects give 0/0 -> nan -> 0 (np.nan_to_num, labels.py:175)."""
+    centroid; float32 result; single-voxel objects give 0/0 -> nan -> 0 (np.nan_to_num, labels.py:175).
+    ``log`` (labels.py:191-201): d -> ln d where d > 0, then d += |min d| over the object."""
     L = np.asarray(labels)
     scale = np.asarray(scale, np.float64)
     out = np.zeros(L.shape, np.float32)
@@ -34,14 +35,39 @@ def get_centreness(labels, scale=(4, 1, 1)):
         c = np.mean(pts, axis=0)
         diff = (c - pts) * scale
         d = np.sqrt(np.einsum("ij,ij->i", diff, diff))
+        if log:
+            pos = np.abs(d) > 0
+            d = np.where(pos, np.log(np.where(pos, d, 1.0)), d)
+            d = d + np.abs(d.min())
         with np.errstate(invalid="ignore", divide="ignore"):
             v = 1 - d / d.max()
         out[tuple(pts.T)] = v
     return np.nan_to_num(out)
 
 
+def get_centre_offsets(labels, scale):
+    """(3, Z, Y, X) float64 holding float32 values: per object and axis o = (centroid - voxel) * scale, o / max o for
+    o > 0, -(o / min o) for o < 0, then (v + 1) / 2; background 0.5 (labels.py:212-276)."""
+    L = np.asarray(labels)
+    scale = np.asarray(scale, np.float64)
+    new = np.where(np.stack([L > 0] * 3, axis=0), 0., 0.5)
+    coords = np.argwhere(L > 0)
+    lab = L[L > 0]
+    for i in np.unique(lab):
+        pts = coords[lab == i]
+        diff = (np.mean(pts, axis=0) - pts) * scale
+        for a in range(3):
+            d = diff[:, a]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                v = np.where(d > 0, d / d.max(), np.where(d < 0, -(d / d.min()), 0.0))
+            v = ((v - (-1)) / 2).astype(np.float32)
+            new[(a,) + tuple(pts.T)] += v
+    return np.nan_to_num(new)
+
+
 def get_training_labels(l, channels=('z-1', 'y-1', 'x-1', 'centreness'), scale=(4, 1, 1)):
     labs = []
+    offsets = get_centre_offsets(l, scale) if any(c.startswith('offsets-') for c in channels) else None
     for chan in channels:
         axis = {'z': 0, 'y': 1, 'x': 2}.get(chan[0])
         n = re.search(r'\d+', chan)
@@ -49,6 +75,10 @@ def get_training_labels(l, channels=('z-1', 'y-1', 'x-1', 'centreness'), scale=(
             labs.append(nth_affinity(l, int(n[0]), axis))
         elif chan == 'centreness':
             labs.append(get_centreness(l, scale))
+        elif chan == 'centreness-log':
+            labs.append(get_centreness(l, scale, log=True))
+        elif chan.startswith('offsets-'):
+            labs.append(offsets['zyx'.index(chan[-1])])
         elif chan == 'mask':
             labs.append(np.where(np.asarray(l) > 1, 1., 0.))
         else:

@@ -7,7 +7,8 @@ Run ONLY in the build container (needs /root/reference and the scikit-image 0.18
 
 Imports the reference's ``labels.py`` unmodified (torch / zarr / the package-relative helpers are stubbed: the
 functions called here never touch them) and records ``get_training_labels`` (labels.py:23-68) for seeded label
-volumes: nth affinities (labels.py:87-108), centreness (labels.py:142-205) and the semantic mask (labels.py:283-285).
+volumes: nth affinities (labels.py:87-108), centreness (labels.py:142-205) and the semantic mask (labels.py:283-285);
+second fixture (training_labels_ext.npz): centre offsets (labels.py:212-276) and centreness-log.
 """
 import importlib.util
 import os
@@ -67,6 +68,21 @@ def main():
         out[f"{tag}.scale"] = np.array(scale, np.float64)
         print(tag, l.shape, int(l.max()), t.shape, t.dtype, [float(t[i].sum()) for i in range(t.shape[0])])
     np.savez_compressed(os.path.join(HERE, "training_labels.npz"), **out)
+    # second fixture: the per-axis centre offsets (labels.py:212-276) and the log variant of the centreness
+    # (labels.py:178-205 with log=True); small volumes, the reference loops over voxels in Python
+    ext = {}
+    cases = {"c": ((8, 32, 36), 3, 0.3, ('offsets-z', 'offsets-y', 'offsets-x', 'centreness-log'), (4, 1, 1)),
+             "d": ((6, 25, 31), 5, 0.45, ('offsets-x', 'centreness-log', 'centreness', 'offsets-z'), (2, 1, 0.5))}
+    for tag, (shape, seed, dens, chans, scale) in cases.items():
+        l = label_volume(shape, seed, dens)
+        t = labels.get_training_labels(l, channels=chans, scale=scale)
+        ext[f"{tag}.labels"] = l.astype(np.int32)
+        ext[f"{tag}.targets"] = t.astype(np.float32)
+        ext[f"{tag}.targets_dtype"] = np.array(str(t.dtype))
+        ext[f"{tag}.channels"] = np.array(chans)
+        ext[f"{tag}.scale"] = np.array(scale, np.float64)
+        print(tag, l.shape, int(l.max()), t.shape, t.dtype, [float(t[i].sum()) for i in range(t.shape[0])])
+    np.savez_compressed(os.path.join(HERE, "training_labels_ext.npz"), **ext)
 
 
 if __name__ == "__main__":
