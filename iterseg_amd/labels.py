@@ -1,9 +1,10 @@
 """Mirror of the target-generating part of ``iterseg.labels`` (reference: src/iterseg/labels.py) on the MI355X.
 
 ``get_training_labels(l, channels, scale)`` -- labels.py:23-68 -- for ``<axis>-<n>`` affinities, ``'centreness'``,
-``'centreness-log'``, ``'offsets-<axis>'`` and ``'mask'``.  ``l`` may be a numpy array (result: numpy, float32) or a
-CUDA tensor (result stays on the device).  The remaining channel kinds of the reference (``centroid-gauss``,
-``*-smooth``: per-plane scikit-image Gaussians) raise ``NotImplementedError``.
+``'centreness-log'``, ``'offsets-<axis>'``, ``'mask'`` and the ``'<axis>-<n>-smooth'`` affinities (the only kind the
+reference's ``-smooth`` suffix parses for: labels.py:36-65).  ``l`` may be a numpy array (result: numpy, float32) or a
+CUDA tensor (result stays on the device).  ``centroid-gauss`` (marked "not used" upstream) raises
+``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -23,7 +24,7 @@ def _parse(channels):
     kind, axis, n = [], [], []
     for chan in channels:
         m = re.search(r'\d+', chan)
-        if chan.endswith('-smooth') or chan == 'centroid-gauss':
+        if chan == 'centroid-gauss':
             raise NotImplementedError(f"channel '{chan}' is not on the accelerated path")
         if chan == 'centreness-log':
             kind.append(3); axis.append(0); n.append(0)
@@ -60,6 +61,10 @@ def get_training_labels(l, channels=('z-1', 'y-1', 'x-1', 'centreness'), scale=(
     _lib.check(ctx.lib.isx_training_labels(ctx.handle, C.c_void_p(lab.data_ptr()), _lib._dims(lab.shape), nc, arr(kind),
                                            arr(axis), arr(n), (C.c_double * 3)(*[float(s) for s in scale]),
                                            C.c_void_p(out.data_ptr())))
+    for i, chan in enumerate(channels):
+        if chan.endswith('-smooth'):              # labels.py:64-65,312-325: skimage gaussian(sigma=1) plane by plane
+            from . import watershed
+            out[i] = watershed.gaussian(out[i], (0, 1, 1))
     return out.cpu().numpy() if was_np else out
 
 

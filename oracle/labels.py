@@ -65,6 +65,13 @@ def get_centre_offsets(labels, scale):
     return np.nan_to_num(new)
 
 
+def smooth(image):
+    """labels.py:312-325: skimage.filters.gaussian(plane, sigma=1) for every z plane = scipy's gaussian_filter with
+    mode='nearest', truncate=4 on (Y, X) (scikit-image 0.18 `_shared/filters.py`), in the image's float dtype."""
+    from scipy import ndimage as ndi
+    return ndi.gaussian_filter(np.asarray(image, np.float64), (0, 1, 1), mode='nearest', truncate=4.0)
+
+
 def get_training_labels(l, channels=('z-1', 'y-1', 'x-1', 'centreness'), scale=(4, 1, 1)):
     labs = []
     offsets = get_centre_offsets(l, scale) if any(c.startswith('offsets-') for c in channels) else None
@@ -72,7 +79,8 @@ def get_training_labels(l, channels=('z-1', 'y-1', 'x-1', 'centreness'), scale=(
         axis = {'z': 0, 'y': 1, 'x': 2}.get(chan[0])
         n = re.search(r'\d+', chan)
         if n is not None:
-            labs.append(nth_affinity(l, int(n[0]), axis))
+            a = nth_affinity(l, int(n[0]), axis)
+            labs.append(smooth(a) if chan.endswith('-smooth') else a)
         elif chan == 'centreness':
             labs.append(get_centreness(l, scale))
         elif chan == 'centreness-log':
