@@ -173,13 +173,16 @@ int isx_train_refresh_weights(isx_ctx *ctx);
  *                                       by |min| over the object, then 1 - d / d_max;
  *   ISX_TARGET_OFFSET     "offsets-<axis>"  get_centre_offsets (labels.py:212-276), axis in axis[c]: per object
  *                                       o = (centroid - voxel) * scale along the axis, o / max(o) for o > 0, -(o / min(o))
- *                                       for o < 0, mapped to [0, 1] by (v + 1) / 2 and rounded to float32; background 0.5.
+ *                                       for o < 0, mapped to [0, 1] by (v + 1) / 2 and rounded to float32; background 0.5;
+ *   ISX_TARGET_CENTROID_GAUSS "centroid-gauss"  get_gauss_centroids (labels.py:293-309): 1 at every object's rounded
+ *                                       centroid, Gaussian (sigma 1) plane by plane, shifted and scaled to [0, 1].
  * The reference returns float64 holding the same values (affinities / mask are 0 or 1, the others are float32). */
 #define ISX_TARGET_AFFINITY 0
 #define ISX_TARGET_CENTRENESS 1
 #define ISX_TARGET_MASK 2
 #define ISX_TARGET_CENTRENESS_LOG 3
 #define ISX_TARGET_OFFSET 4
+#define ISX_TARGET_CENTROID_GAUSS 5
 int isx_training_labels(isx_ctx *ctx, const int32_t *labels, const int64_t shape[3], int n_channels,
                         const int32_t *kind, const int32_t *axis, const int32_t *n, const double scale[3], float *out);
 

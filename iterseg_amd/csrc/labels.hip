@@ -216,6 +216,39 @@ __global__ void offset_write_kernel(const int32_t *__restrict__ lab, int64_t Z, 
     out[i] = v;
 }
 
+// ---- centroid-gauss (labels.py:293-309): impulses at the rounded centroids (np.round: half to even)
+__global__ void centroid_scatter_kernel(const unsigned long long *__restrict__ sums, int64_t L1, int64_t Y, int64_t X,
+                                        float *__restrict__ out)
+{
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < 1 || l >= L1) return;
+    const unsigned long long *s = sums + l * 4;
+    if (s[3] == 0ull) return;                         // label value not present
+    const double n = (double)s[3];
+    const int64_t z = (int64_t)rint((double)s[0] / n), y = (int64_t)rint((double)s[1] / n), x = (int64_t)rint((double)s[2] / n);
+    out[(z * Y + y) * X + x] = 1.0f;
+}
+
+__global__ void fminmax_kernel(const float *__restrict__ a, int64_t N, unsigned long long *mn, unsigned long long *mx)
+{
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = ord_key((double)a[i]);
+        lo = k < lo ? k : lo;
+        hi = k > hi ? k : hi;
+    }
+    atomicMin(mn, lo);
+    atomicMax(mx, hi);
+}
+
+__global__ void shift_scale_kernel(float *__restrict__ a, int64_t N, const unsigned long long *mn, const unsigned long long *mx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double lo = ord_val(*mn), hi = ord_val(*mx);
+    a[i] = (float)(((double)a[i] - lo) / (hi - lo));
+}
+
 }  // namespace isx
 
 using namespace isx;
@@ -303,6 +336,24 @@ extern "C" int isx_training_labels(isx_ctx *ctx, const int32_t *labels, const in
             }
             offset_write_kernel<<<grid, LTPB, 0, ctx->stream>>>(labels, Z, Y, X, sums.p, box.p, axis[c], scale[axis[c]], dst);
             ISX_CHECK_LAUNCH();
+        } else if (kind[c] == ISX_TARGET_CENTROID_GAUSS) {
+            ISX_TRY(need_sums());
+            ISX_HIP(hipMemsetAsync(dst, 0, (size_t)N * sizeof(float), ctx->stream));
+            centroid_scatter_kernel<<<cdiv(L + 1, LTPB), LTPB, 0, ctx->stream>>>(sums.p, L + 1, Y, X, dst);
+            ISX_CHECK_LAUNCH();
+            Scratch<float> g(ctx, (size_t)N);
+            Scratch<unsigned long long> mm(ctx, 2);
+            if (!g.ok() || !mm.ok()) return ISX_ERR_NOMEM;
+            const int32_t sig[3] = {0, 1, 1};
+            ISX_TRY(isx_ws_gaussian(ctx, dst, g.p, shape, sig));
+            ISX_HIP(hipMemsetAsync(mm.p, 0xFF, 8, ctx->stream));
+            ISX_HIP(hipMemsetAsync(mm.p + 1, 0, 8, ctx->stream));
+            fminmax_kernel<<<1024, LTPB, 0, ctx->stream>>>(g.p, N, mm.p, mm.p + 1);
+            ISX_CHECK_LAUNCH();
+            ISX_HIP(hipMemcpyAsync(dst, g.p, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            shift_scale_kernel<<<grid, LTPB, 0, ctx->stream>>>(dst, N, mm.p, mm.p + 1);
+            ISX_CHECK_LAUNCH();
+            ISX_HIP(hipStreamSynchronize(ctx->stream));
         } else {
             set_error("channel %d: unknown target kind %d", c, kind[c]);
             return ISX_ERR_ARG;

@@ -3,8 +3,7 @@
 ``get_training_labels(l, channels, scale)`` -- labels.py:23-68 -- for ``<axis>-<n>`` affinities, ``'centreness'``,
 ``'centreness-log'``, ``'offsets-<axis>'``, ``'mask'`` and the ``'<axis>-<n>-smooth'`` affinities (the only kind the
 reference's ``-smooth`` suffix parses for: labels.py:36-65).  ``l`` may be a numpy array (result: numpy, float32) or a
-CUDA tensor (result stays on the device).  ``centroid-gauss`` (marked "not used" upstream) raises
-``NotImplementedError``.
+CUDA tensor (result stays on the device); ``'centroid-gauss'`` (labels.py:293-309) too.
 """
 from __future__ import annotations
 
@@ -25,8 +24,8 @@ def _parse(channels):
     for chan in channels:
         m = re.search(r'\d+', chan)
         if chan == 'centroid-gauss':
-            raise NotImplementedError(f"channel '{chan}' is not on the accelerated path")
-        if chan == 'centreness-log':
+            kind.append(5); axis.append(0); n.append(0)
+        elif chan == 'centreness-log':
             kind.append(3); axis.append(0); n.append(0)
         elif chan.startswith('offsets-'):
             if chan[-1] not in 'zyx':

@@ -72,6 +72,21 @@ def smooth(image):
     return ndi.gaussian_filter(np.asarray(image, np.float64), (0, 1, 1), mode='nearest', truncate=4.0)
 
 
+def get_gauss_centroids(labels):
+    """labels.py:293-309: 1 at every object's rounded centroid (np.round), Gaussian (sigma 1) plane by plane in
+    float64, then (out - min) / max."""
+    L = np.asarray(labels)
+    img = np.zeros(L.shape, np.float64)
+    coords = np.argwhere(L > 0)
+    lab = L[L > 0]
+    for i in np.unique(lab):
+        c = np.round(np.mean(coords[lab == i], axis=0)).astype(int)
+        img[tuple(c)] = 1.
+    out = smooth(img)
+    out = out - out.min()
+    return out / out.max()
+
+
 def get_training_labels(l, channels=('z-1', 'y-1', 'x-1', 'centreness'), scale=(4, 1, 1)):
     labs = []
     offsets = get_centre_offsets(l, scale) if any(c.startswith('offsets-') for c in channels) else None
@@ -85,6 +100,8 @@ def get_training_labels(l, channels=('z-1', 'y-1', 'x-1', 'centreness'), scale=(
             labs.append(get_centreness(l, scale))
         elif chan == 'centreness-log':
             labs.append(get_centreness(l, scale, log=True))
+        elif chan == 'centroid-gauss':
+            labs.append(get_gauss_centroids(l))
         elif chan.startswith('offsets-'):
             labs.append(offsets['zyx'.index(chan[-1])])
         elif chan == 'mask':

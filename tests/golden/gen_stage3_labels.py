@@ -74,7 +74,8 @@ def main():
     cases = {"c": ((8, 32, 36), 3, 0.3, ('offsets-z', 'offsets-y', 'offsets-x', 'centreness-log'), (4, 1, 1)),
              "d": ((6, 25, 31), 5, 0.45, ('offsets-x', 'centreness-log', 'centreness', 'offsets-z'), (2, 1, 0.5)),
              # '<axis>-<n>-smooth' (labels.py:64-65,312-325): the only channel kind the '-smooth' suffix parses for
-             "e": ((5, 30, 28), 7, 0.35, ('z-1-smooth', 'y-2-smooth', 'x-1'), (4, 1, 1))}
+             "e": ((5, 30, 28), 7, 0.35, ('z-1-smooth', 'y-2-smooth', 'x-1'), (4, 1, 1)),
+             "f": ((7, 36, 30), 9, 0.3, ('centroid-gauss', 'mask'), (4, 1, 1))}      # labels.py:293-309
     for tag, (shape, seed, dens, chans, scale) in cases.items():
         l = label_volume(shape, seed, dens)
         t = labels.get_training_labels(l, channels=chans, scale=scale)

@@ -44,13 +44,15 @@ def test_offsets_and_log_centreness_match_reference(golden):
     """Centre offsets (labels.py:212-276) bit-exact, centreness-log (labels.py:178-205, log=True) within 2e-7."""
     from iterseg_amd import labels as gl
     d = golden("training_labels_ext")
-    for tag in ("c", "d", "e"):              # e: '<axis>-<n>-smooth' (float64 Gaussian upstream, float32 here: 2e-7)
+    for tag in ("c", "d", "e", "f"):         # e: '<axis>-<n>-smooth' (float64 Gaussian upstream, float32 here: 2e-7)
         chans = tuple(str(c) for c in d[f"{tag}.channels"])
         got = gl.get_training_labels(d[f"{tag}.labels"], chans, tuple(d[f"{tag}.scale"]))
         ref = d[f"{tag}.targets"]
         assert got.shape == ref.shape and got.dtype == np.float32
         for i, c in enumerate(chans):
-            tol = 0.0 if c.startswith("offsets-") or c == "x-1" else 2e-7
+            tol = 0.0 if c.startswith("offsets-") or c in ("x-1", "mask") else 2e-7
+            if c == "centroid-gauss":        # float32 Gaussian passes, then divided by the maximum (about 0.16)
+                tol = 1e-6
             assert np.abs(got[i] - ref[i]).max() <= tol, (tag, c, np.abs(got[i] - ref[i]).max())
 
 
@@ -76,8 +78,6 @@ def test_errors_like_reference():
     lab = np.zeros((4, 8, 8), np.int32)
     with pytest.raises(ValueError):
         gl.get_training_labels(lab, ('bogus',))
-    with pytest.raises(NotImplementedError):
-        gl.get_training_labels(lab, ('centroid-gauss',))
     with pytest.raises(ValueError):
         gl.get_training_labels(lab, ('offsets-q',))
 
