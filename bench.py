@@ -132,6 +132,29 @@ def other_precision_leg(u, other, vol, fm, labels, chunk, margin, args, n_chunks
             "roofline": conv_roofline(other, mfma_flops, n_chunks, args.steps, ms_mfma, n_mfma, args.batch)}
 
 
+def train_step_leg(sd, patch=(10, 256, 256), steps=5):
+    """The other entry point of the path (train_unet, train.py:25-183): one training step on one (10,256,256) patch --
+    forward, BCE loss, backward, the reference's two Adam updates per sample -- in fp32 (training never uses the split
+    arithmetic).  Reported beside the headline, never as `value`."""
+    from iterseg_amd.train import Trainer
+    from tests.synth import positive_volume
+    t = Trainer(sd, 5, patch)
+    x = torch.from_numpy(positive_volume(patch, 1)).cuda()
+    y = torch.from_numpy((np.random.default_rng(1).random((5,) + patch) < 0.5).astype(np.float32)).cuda()
+    for _ in range(2):
+        t.train_step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = t.train_step(x, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fwd, direct = conv_flops_per_chunk(patch)
+    return {"patch": list(patch), "ms_per_step": 1e3 * dt, "voxels_per_s": float(np.prod(patch)) / dt, "loss": float(loss),
+            "tflops_of_3x_forward": 3.0 * (fwd + direct) / dt / 1e12, "peak_tflops_fp32_matrix": PEAK_MFMA_F32,
+            "note": "forward + BCE + backward (dgrad, wgrad, BatchNorm) + the reference's double Adam update, batch 1"}
+
+
 def structured_watershed_leg(u, n=256, volume_fraction=0.12):
     """the watershed stage alone on a *structured* feature map -- blobs / distance-transform centroid
     channel / gradient affinities as in the reference's own demo (watershed.py:256-262; tests/synth.blob_feature_map) --
@@ -285,6 +308,7 @@ def main():
                                                                  mfma_flops)}
         if world == 1 and not args.no_cpu_baseline:
             out["watershed_structured"] = structured_watershed_leg(u)
+            out["train_step"] = train_step_leg(sd)
             out["cpu_baseline"] = cpu_baseline(sd, chunk, margin)
         print(json.dumps(out))
     if world > 1:
