@@ -36,6 +36,7 @@ extern "C" {
                                     (np.apply_along_axis in watershed.py:50)            */
 #define ISX_ERR_STATE (-5)       /* weights not loaded / workspace not prepared         */
 #define ISX_ERR_NOMEM (-6)       /* device allocation failed                            */
+#define ISX_ERR_INTERNAL (-7)    /* an internal invariant failed (a bug: never expected) */
 
 typedef struct isx_ctx isx_ctx;
 

@@ -1746,6 +1746,8 @@ __global__ void arena_need_kernel(const unsigned long long *comp_cap, uint32_t n
     need[c] = (sz >= coop_min && sz >= cold_min) ? (unsigned long long)COLD_META_ENTS + 4ull * sz + 5ull * COLD_NBK + 4096ull : 0ull;
 }
 
+#include "ws_flood_window.h"
+
 // Flood given raveled seed indices (device u32) in list order (label = position + 1).
 // parent/sizes: CCL of `mask` if the caller already has it, else nullptr.
 static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint32_t n_seeds,
@@ -1814,9 +1816,18 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     ISX_HIP(hipStreamSynchronize(ctx->stream));
     Scratch<HeapEnt> pool(ctx, (size_t)total + 1);
     Scratch<HeapEnt> arena(ctx, (size_t)arena_total + 1);
-    Scratch<uint32_t> claim(ctx, (size_t)PN);
+    // large components: ISX_FLOOD_MODE=wave selects the round-based kernel of round 1 (kept for A/B runs), default is the
+    // ordered speculative window (ws_flood_window.h)
+    bool window_mode = true;
+    if (const char *e = getenv("ISX_FLOOD_MODE")) window_mode = strcmp(e, "wave") != 0;
+    int wcap = WIN_W, tcap = WIN_T;
+    if (const char *e = getenv("ISX_FLOOD_WIN")) wcap = atoi(e);                      // tests: tiny windows / lists
+    if (const char *e = getenv("ISX_FLOOD_LIST")) tcap = atoi(e);
+    ISX_REQUIRE(wcap >= 1 && wcap <= WIN_W && tcap >= 6 && tcap <= WIN_T, "ISX_FLOOD_WIN / ISX_FLOOD_LIST out of range");
+    Scratch<uint32_t> claim(ctx, window_mode ? 1 : (size_t)PN);
+    Scratch<unsigned long long> vstate(ctx, window_mode ? (size_t)PN : 1);
     Scratch<unsigned long long> stats(ctx, 32);
-    if (!pool.ok() || !claim.ok() || !arena.ok() || !stats.ok()) return ISX_ERR_NOMEM;
+    if (!pool.ok() || !claim.ok() || !arena.ok() || !stats.ok() || !vstate.ok()) return ISX_ERR_NOMEM;
     ISX_HIP(hipMemsetAsync(stats.p, 0, 32 * 8, ctx->stream));
     float s[3] = {1.f, 1.f, 1.f};
     if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
@@ -1827,12 +1838,46 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                                                           pshape[1], pshape[2], PN, s[0], s[1], s[2], coop_min,
                                                           ctx->ws_shard_rank, ctx->ws_shard_world);
     ISX_CHECK_LAUNCH();
-    ISX_HIP(hipMemsetAsync(claim.p, 0, (size_t)PN * sizeof(uint32_t), ctx->stream));
-    flood_wave_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, claim.p, keys_sorted.p, n_seeds, comp_first.p,
-                                                      comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
-                                                      pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, stats.p,
-                                                      ctx->ws_shard_rank, ctx->ws_shard_world);
-    ISX_CHECK_LAUNCH();
+    if (window_mode) {
+        flood_state_init_kernel<<<cdiv(PN, TPB), TPB, 0, ctx->stream>>>(mask, out, vstate.p, PN);
+        ISX_CHECK_LAUNCH();
+        flood_window_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
+                                                            comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
+                                                            pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, wcap, tcap,
+                                                            stats.p, ctx->ws_shard_rank, ctx->ws_shard_world);
+        ISX_CHECK_LAUNCH();
+    } else {
+        ISX_HIP(hipMemsetAsync(claim.p, 0, (size_t)PN * sizeof(uint32_t), ctx->stream));
+        flood_wave_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, claim.p, keys_sorted.p, n_seeds, comp_first.p,
+                                                          comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
+                                                          pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, stats.p,
+                                                          ctx->ws_shard_rank, ctx->ws_shard_world);
+        ISX_CHECK_LAUNCH();
+    }
+    if (window_mode) {
+        unsigned long long hs[32];
+        ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        if (hs[9]) {
+            fprintf(stderr, "[isx flood/window] WATCHDOG: %llu component(s) exceeded the sub-round limit; front: nw %llu run %llu cold %llu cur|meta %016llx key %016llx "
+                            "qhead %016llx maxnew|nstage %016llx pops %llu | pos1 key %016llx cur|meta %016llx wh %llu npfree %llu\n", hs[9], hs[24], hs[25], hs[26], hs[27], hs[28], hs[29], hs[30], hs[31], hs[20], hs[21], hs[22], hs[23]);
+            fprintf(stderr, "[isx flood/window] sub-rounds %llu pops %llu executed %llu rows %llu hot_ins %llu mid_ins %llu cold_app %llu drains %llu evicted %llu squashes %llu (bound %llu) "
+                            "squashed eps %llu forced %llu\n", hs[0], hs[1], hs[2], hs[13], hs[3], hs[7], hs[4], hs[5], hs[6], hs[11], hs[14], hs[12], hs[15]);
+            set_error("flood watchdog tripped (internal error)");
+            return ISX_ERR_INTERNAL;
+        }
+        if (!getenv("ISX_FLOOD_STATS")) return ISX_OK;
+        fprintf(stderr, "[isx flood/window] sub-rounds %llu pops %llu (%.2f/sub-round) executed %llu (useful %.2f) rows %llu hot_ins %llu mid_ins %llu cold_app %llu drains %llu (prefix %llu) "
+                        "evicted %llu squashes %llu (bound %llu) squashed eps %llu forced %llu serial_handover %llu\n",
+                hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[2] ? (double)hs[1] / hs[2] : 0.0, hs[13], hs[3], hs[7], hs[4], hs[5], hs[10],
+                hs[6], hs[11], hs[14], hs[12], hs[15], hs[8]);
+#ifdef ISX_FLOOD_PROF
+        fprintf(stderr, "[isx flood/window] cycles/sub-round: loop+evict %.0f | scan %.0f | trip %.0f | lists %.0f | squash %.0f | commit %.0f | refill %.0f\n",
+                (double)hs[16] / hs[0], (double)hs[17] / hs[0], (double)hs[18] / hs[0], (double)hs[19] / hs[0], (double)hs[20] / hs[0],
+                (double)hs[21] / hs[0], (double)hs[22] / hs[0]);
+#endif
+        return ISX_OK;
+    }
     if (getenv("ISX_FLOOD_STATS")) {
         unsigned long long hs[32];
         ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));

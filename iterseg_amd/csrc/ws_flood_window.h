@@ -1,0 +1,786 @@
+// ws_flood_window.h -- the flood of one large mask component as an ORDERED SPECULATIVE WINDOW (one wave per component).
+// Included by ws.hip inside namespace isx (uses HeapEnt, Cold, cold_append/cold_drain, serial_flood, ...).
+//
+// Replaces raveled_affinity_watershed (watershed.py:95-159) for components of >= COOP_MIN_SIZE voxels, bit-exactly.
+//
+// The reference pops the minimum (value, age) element, labels + pushes its unlabelled mask neighbours, repeats.  Call
+// the EPISODE of a queued element x the pops the sequential loop makes from popping x until it pops the next element
+// that was already queued: x itself, then every newly discovered voxel that sorts below the next queued key (a new
+// element is younger than every queued one, so that is `value < value(next)`), in (value, discovery order) order.  An
+// episode is a small local flood around x; the sequential pop sequence is the concatenation of the episodes of the
+// queued elements in key order.  This kernel keeps the W smallest queued elements in a window (LDS, sorted by key) and
+// runs their episodes concurrently, one pop per episode per sub-round, one dependent memory trip per sub-round:
+//
+//   * discovery = claim: one returning 64-bit atomicMin per neighbour on state[nb] with the episode's ROOT KEY as
+//     priority.  state[v]: 0 = not in the mask, 1..2^32-1 = final label, ~0 = free, otherwise the root key of the
+//     speculative episode holding the voxel (keys are >= 2^32).  A smaller key (earlier episode) takes a voxel over;
+//   * commit is in window order: the front episode commits when it is idle (nothing left below its bound): labels are
+//     written, its unpopped discoveries ("residuals") get their ages and enter the queue;
+//   * an episode is WRONG -- squashed together with everything behind it, claims released -- when (a) an earlier
+//     episode took over a voxel it had already used, or (b) its bound dropped below something it popped (a residual
+//     or re-inserted root landed between its root and its largest pop).  Everything else stays valid: residuals that
+//     land inside the window's key range simply become new roots at their sorted position.
+// By induction over window positions every committed episode made exactly the sequential pops (the front episode is
+// never wrong: it has the highest priority and its bound is the true next key).  scratch/window_sim.c is the model
+// of these rules on the CPU; it reproduces the sequential labels on every test input.
+//
+// Queue = window (roots) + sorted run in LDS + the cold bucket arena in HBM (unchanged: cold_append / cold_drain).
+
+static constexpr int WIN_W = 192;                 // episodes in flight (physical slots)
+static constexpr int WIN_T = 48;                  // discoveries one episode holds before it must become the front
+static constexpr int WIN_RCAP = 2048;             // LDS run capacity
+static constexpr int WIN_STAGE = 128;             // staged cold-bound elements (flushed 64 at a time)
+static constexpr uint32_t WIN_NONE = 0xFFFFFFFFu;
+static constexpr unsigned long long ST_FREE = ~0ull;
+
+#define WIN_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__global__ void flood_state_init_kernel(const uint8_t *__restrict__ mask, const uint32_t *__restrict__ out,
+                                        unsigned long long *__restrict__ state, int64_t PN)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= PN) return;
+    const uint32_t l = out[i];
+    state[i] = mask[i] ? (l ? (unsigned long long)l : ST_FREE) : 0ull;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, int lane)
+{
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    return incl - v;
+}
+
+__global__ __launch_bounds__(64) void flood_window_kernel(
+    const float *__restrict__ aff, const uint8_t *__restrict__ mask, uint32_t *__restrict__ out,
+    unsigned long long *__restrict__ state, const unsigned long long *__restrict__ keys, uint32_t n_seeds,
+    const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
+    HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
+    int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long coop_min_size, int run_limit,
+    int drain_n, int wcap, int tcap, unsigned long long *stats, int shard_rank, int shard_world)
+{
+    __shared__ HeapEnt srun[WIN_RCAP];            // .pad carries the element's label
+    __shared__ HeapEnt stage[WIN_STAGE];
+    __shared__ u32x4 winq0[WIN_W];                // {key.lo, key.hi, root voxel, label}
+    __shared__ u32x4 winq1[WIN_W];                // {cur voxel | WIN_NONE, meta, maxnew, -}; meta = npush | started << 8 | plist << 16 | cur entry << 24
+    __shared__ uint2 plist[WIN_W * WIN_T];        // discoveries of an episode: {voxel, ordered value}
+    __shared__ unsigned long long ppop[WIN_W];    // popped bits of a plist
+    __shared__ unsigned short pfree[WIN_W];
+    __shared__ unsigned short actpos[WIN_W];
+    __shared__ HeapEnt ovl[6 * 64];               // take-overs of this row (at most one per lane and direction): key = old holder, idx = voxel
+    __shared__ int hist[64];
+    const uint32_t c = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (c >= n_comp) return;
+    if (!comp_owned(comp_off, c, n_comp, shard_rank, shard_world)) return;
+    const uint32_t first = comp_first[c];
+    const uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
+    if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;
+    const unsigned long long csize = comp_off[c + 1] - comp_off[c];
+    if (csize < coop_min_size) return;
+    HeapEnt *heap = heap_pool + comp_off[c];
+    const uint32_t ns = end - first;
+
+    const int64_t SZ = PY * PX, SY = PX;
+    const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
+    const int ax[6] = {0, 1, 2, 2, 1, 0};
+    const float sc[3] = {s0, s1, s2};
+    const unsigned long long ZKEY = (unsigned long long)0x80000000u << 32;
+    constexpr int SMASK = WIN_RCAP - 1;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // ---- cold tier (large components only): arena views + clean metadata (as flood_wave_kernel) ---------------
+    Cold cold;
+    cold.on = arena_off && (arena_off[c + 1] > arena_off[c]);
+    cold.failed = false;
+    cold.bump = 0;
+    cold.count = 0;
+    cold.low = COLD_NBK;
+    cold.fifo_drains = 0;
+#ifdef ISX_FLOOD_PROF
+    for (int i = 0; i < 8; ++i) cold.tk[i] = 0;
+    cold.n_groups = 0;
+#endif
+    cold.cb = COLD_NONE;
+    cold.pool_cap = 0;
+    if (cold.on) {
+        HeapEnt *base = arena + arena_off[c];
+        cold.bhead = (uint32_t *)base;
+        cold.btail = cold.bhead + COLD_NBK;
+        cold.bcount = cold.btail + COLD_NBK;
+        cold.bmeta = cold.bcount + COLD_NBK;
+        cold.bfill = cold.bmeta + COLD_NBK;
+        cold.blast = (unsigned long long *)(cold.bfill + COLD_NBK);
+        cold.bm0 = cold.blast + COLD_NBK;
+        cold.bm1 = cold.bm0 + COLD_NBK / 64;
+        cold.pool = base + COLD_META_ENTS;
+        cold.pool_cap = (uint32_t)(arena_off[c + 1] - arena_off[c] - COLD_META_ENTS);
+        for (int i = lane; i < COLD_NBK; i += 64) { cold.bhead[i] = COLD_NONE; cold.btail[i] = COLD_NONE; cold.bcount[i] = 0; cold.bmeta[i] = 0; }
+        for (int i = lane; i < COLD_NBK / 64; i += 64) cold.bm0[i] = 0ull;
+        if (lane < COLD_NBK / 4096) cold.bm1[lane] = 0ull;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // ---- queue state (wave-uniform) ---------------------------------------------------------------------------
+    int wh = 0, nw = 0, npfree = 0;               // window: circular over WIN_W slots, at most wcap used
+    int shead = 0, scount = 0, nstage = 0;
+    uint32_t agebase = ns - 1;                    // seeds carry ages 0..ns-1 in index order; pushes continue
+    uint32_t nspill = 0;                          // elements that could not be queued (kept for the serial continuation)
+    bool serial = false, started_any = false;
+    unsigned long long st_sub = 0, st_pops = 0, st_exec = 0, st_sq_ev = 0, st_sq_eps = 0, st_mid = 0, st_evict = 0, st_drain = 0,
+                       st_cold = 0, st_hot = 0, st_rows = 0, st_over = 0, st_forced = 0;
+#ifdef ISX_FLOOD_PROF
+    unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk_prev = __builtin_readcyclecounter();
+#define WTICK(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); tk_acc[i] += t_ - tk_prev; tk_prev = t_; } while (0)
+#else
+#define WTICK(i) do { } while (0)
+#endif
+
+    auto slot_of = [&](int p) -> int { const int s = wh + p; return s >= WIN_W ? s - WIN_W : s; };
+    auto key_at = [&](int s) -> unsigned long long { const u32x4 q = winq0[s]; return ((unsigned long long)q.y << 32) | q.x; };
+    auto fresh_q1 = [&](uint32_t root_idx, int pl) -> u32x4 { u32x4 q = {root_idx, ((uint32_t)pl << 16) | (0xFFu << 24), 0u, 0u}; return q; };
+
+    // elements that can no longer be queued go to the far end of this component's heap area (the serial
+    // continuation picks them up); the queue never holds more than csize elements, so the two ends cannot meet
+    auto spill64 = [&](bool has, unsigned long long key, uint32_t idx) {
+        const unsigned long long b = __ballot(has);
+        if (has) { HeapEnt e; e.key = key; e.idx = idx; e.pad = 0; heap[csize - 1ull - (nspill + (uint32_t)__popcll(b & lt_mask))] = e; }
+        nspill += (uint32_t)__popcll(b);
+    };
+
+    auto flush_stage = [&](int upto) {            // append stage[0, upto) to the buckets, 64 at a time; keeps the rest
+        int done = 0;
+        while (done < upto && !serial) {
+            const int m = upto - done < 64 ? upto - done : 64;
+            const bool has = lane < m;
+            HeapEnt e; e.key = 0; e.idx = 0; e.pad = 0;
+            if (has) e = stage[done + lane];
+            cold_append(cold, has, e.key, e.idx, e.pad, lane);
+            if (cold.failed) { serial = true; break; }       // nothing of this batch was written: it stays staged
+            done += m;
+        }
+        // compact what is left
+        const int rest = nstage - done;
+        if (done > 0 && rest > 0) {
+            HeapEnt t0, t1; t0.key = 0; t0.idx = 0; t0.pad = 0; t1 = t0;
+            if (lane < rest) t0 = stage[done + lane];
+            if (lane + 64 < rest) t1 = stage[done + lane + 64];
+            WIN_FENCE();
+            if (lane < rest) stage[lane] = t0;
+            if (lane + 64 < rest) stage[lane + 64] = t1;
+            WIN_FENCE();
+        }
+        nstage = rest;
+    };
+
+    // the run is full: its largest elements go to their buckets (ascending, so that a bucket's list stays FIFO)
+    auto run_evict = [&]() {
+        if (!cold.on) { serial = true; return; }
+        const int keep = run_limit / 2, ev = scount - keep;
+        if (ev <= 0) return;
+        st_evict += (unsigned long long)ev;
+        int done = 0;
+        while (done < ev) {
+            const int m = ev - done < 64 ? ev - done : 64;
+            const bool has = lane < m;
+            HeapEnt e; e.key = 0; e.idx = 0; e.pad = 0;
+            if (has) e = srun[(shead + keep + done + lane) & SMASK];
+            cold_append(cold, has, e.key, e.idx, e.pad, lane);
+            if (cold.failed) break;
+            done += m;
+        }
+        if (cold.failed) {
+            for (int j0 = keep + done; j0 < scount; j0 += 64) {      // close the gap [keep, keep + done)
+                const bool mv = j0 + lane < scount;
+                u32x4 e = {0u, 0u, 0u, 0u};
+                if (mv) e = run_ld(srun, (shead + j0 + lane) & SMASK);
+                WIN_FENCE();
+                if (mv) run_st(srun, (shead + j0 + lane - done) & SMASK, e);
+                WIN_FENCE();
+            }
+            scount -= done;
+            serial = true;
+            return;
+        }
+        scount = keep;
+    };
+
+    // sorted insert of one (wave-uniform) element into the circular LDS run
+    auto run_insert = [&](unsigned long long ek, uint32_t ei, uint32_t el) {
+        int pos;
+        {
+            const int stride = (scount + 63) >> 6;
+            int e = lane * stride + stride - 1;
+            if (e > scount - 1) e = scount - 1;
+            const bool seg_below = scount > 0 && lane * stride < scount && srun[(shead + e) & SMASK].key < ek;
+            const int base = __popcll(__ballot(seg_below)) * stride;
+            const int j = base + lane;
+            const bool in_below = lane < stride && j < scount && srun[(shead + j) & SMASK].key < ek;
+            pos = base + __popcll(__ballot(in_below));
+            if (pos > scount) pos = scount;
+        }
+        if (pos >= scount - pos) {
+            for (int base = scount - 64; base > pos - 64; base -= 64) {
+                const int j = base + lane;
+                const bool mv = j >= pos && j >= 0 && j < scount;
+                u32x4 e = {0u, 0u, 0u, 0u};
+                if (mv) e = run_ld(srun, (shead + j) & SMASK);
+                WIN_FENCE();
+                if (mv) run_st(srun, (shead + j + 1) & SMASK, e);
+            }
+        } else {
+            for (int base = 0; base < pos; base += 64) {
+                const int j = base + lane;
+                const bool mv = j < pos;
+                u32x4 e = {0u, 0u, 0u, 0u};
+                if (mv) e = run_ld(srun, (shead + j) & SMASK);
+                WIN_FENCE();
+                if (mv) run_st(srun, (shead + j - 1) & SMASK, e);
+            }
+            shead = (shead - 1) & SMASK;
+        }
+        WIN_FENCE();
+        if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; srun[(shead + pos) & SMASK] = e; }
+        ++scount;
+        WIN_FENCE();
+    };
+
+    // give the claims of one episode back (lane-parallel over its discoveries)
+    auto release_one = [&](unsigned long long key, int pl, int np) {
+        for (int i = lane; i < np; i += 64) {
+            const uint32_t v = plist[pl * WIN_T + i].x;
+            atomicCAS(&state[v], key, ST_FREE);
+        }
+    };
+
+    // squash every episode from window position sp on: claims released, back to "root not popped yet"
+    auto squash_from = [&](int sp) {
+        ++st_sq_ev;
+        for (int base = sp; base < nw; base += 64) {
+            const int p = base + lane;
+            const bool valid = p < nw;
+            const int s = valid ? slot_of(p) : 0;
+            u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u};
+            if (valid) { q0 = winq0[s]; q1 = winq1[s]; }
+            const bool st = valid && ((q1.y >> 8) & 1u);
+            const int np = st ? (int)(q1.y & 0xFFu) : 0, pl = (int)((q1.y >> 16) & 0xFFu);
+            const unsigned long long key = ((unsigned long long)q0.y << 32) | q0.x;
+            st_sq_eps += (unsigned long long)__popcll(__ballot(st));
+            for (int i = 0; __any(i < np); ++i)
+                if (i < np) { const uint32_t v = plist[pl * WIN_T + i].x; atomicCAS(&state[v], key, ST_FREE); }
+            if (valid) { winq1[s] = fresh_q1(q0.z, pl); ppop[pl] = 0ull; }
+        }
+        WIN_FENCE();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    // a new root at its sorted position in the window (wave-uniform element, ek sorts below the last root or the
+    // window has room at its end)
+    auto win_insert = [&](unsigned long long ek, uint32_t ei, uint32_t el) {
+        int pos = 0;
+        for (int base = 0; base < nw; base += 64) {
+            const int p = base + lane;
+            const bool lt = p < nw && key_at(slot_of(p)) < ek;
+            pos += __popcll(__ballot(lt));
+        }
+        int pl;
+        if (nw == wcap || npfree == 0) {
+            // full: the last root goes back to the front of the run (it sorts below everything there)
+            const int s = slot_of(nw - 1);
+            const u32x4 q0 = winq0[s], q1 = winq1[s];
+            pl = (int)((q1.y >> 16) & 0xFFu);
+            if ((q1.y >> 8) & 1u) {
+                release_one(((unsigned long long)q0.y << 32) | q0.x, pl, (int)(q1.y & 0xFFu));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ++st_sq_eps;
+            }
+            shead = (shead - 1) & SMASK;
+            if (lane == 0) { u32x4 e = {q0.x, q0.y, q0.z, q0.w}; run_st(srun, shead, e); }
+            ++scount;
+            --nw;
+            ++st_evict;
+            if (pos > nw) pos = nw;
+        } else {
+            pl = (int)pfree[--npfree];
+        }
+        if (pos < nw) {
+            ++st_mid;
+            u32x4 a[3], b[3];
+            bool mv[3];
+#pragma unroll
+            for (int cidx = 0; cidx < 3; ++cidx) {
+                const int p = pos + cidx * 64 + lane;
+                mv[cidx] = p < nw;
+                a[cidx] = b[cidx] = u32x4{0u, 0u, 0u, 0u};
+                if (mv[cidx]) { const int s = slot_of(p); a[cidx] = winq0[s]; b[cidx] = winq1[s]; }
+            }
+            WIN_FENCE();
+#pragma unroll
+            for (int cidx = 0; cidx < 3; ++cidx)
+                if (mv[cidx]) { const int s = slot_of(pos + cidx * 64 + lane + 1); winq0[s] = a[cidx]; winq1[s] = b[cidx]; }
+            WIN_FENCE();
+        }
+        if (lane == 0) {
+            const int s = slot_of(pos);
+            u32x4 q0 = {(uint32_t)ek, (uint32_t)(ek >> 32), ei, el};
+            winq0[s] = q0;
+            winq1[s] = fresh_q1(ei, pl);
+            ppop[pl] = 0ull;
+        }
+        ++nw;
+        WIN_FENCE();
+    };
+
+    // One (wave-uniform) element that the tier rule keeps hot: window if it sorts into it, else the run.
+    auto hot_insert = [&](unsigned long long ek, uint32_t ei, uint32_t el) {
+        ++st_hot;
+        if (nw > 0 && ek < key_at(slot_of(nw - 1))) {
+            if ((nw == wcap || npfree == 0) && scount >= WIN_RCAP - 2) { run_evict(); if (serial) { spill64(lane == 0, ek, ei); return; } }
+            win_insert(ek, ei, el);
+            return;
+        }
+        if (scount == 0 && nw < wcap && npfree > 0) { win_insert(ek, ei, el); return; }
+        if (scount >= WIN_RCAP - 2) { run_evict(); if (serial) { spill64(lane == 0, ek, ei); return; } }
+        run_insert(ek, ei, el);
+    };
+
+    // Up to one new queue element per lane.  Tier rule (keeps "every cold element sorts after every hot element"): an
+    // element stays hot if it sorts below the hot maximum, or if nothing cold can precede it (cold tier empty, or its
+    // bucket lies below the lowest non-empty bucket); otherwise it is staged for its bucket.
+    auto enqueue64 = [&](bool has, unsigned long long key, uint32_t idx, uint32_t lab) {
+        if (serial) { spill64(has, key, idx); return; }
+        bool tocold = false;
+        if (cold.on && (cold.count > 0 || nstage > 0)) {
+            unsigned long long hot_max = 0ull;
+            const bool hot_ne = nw > 0 || scount > 0;
+            if (scount > 0) hot_max = srun[(shead + scount - 1) & SMASK].key;
+            else if (nw > 0) hot_max = key_at(slot_of(nw - 1));
+            tocold = has && !(hot_ne && key < hot_max) && cold_bucket(key) >= cold.low;
+        }
+        {
+            const unsigned long long b = __ballot(tocold);
+            if (tocold) { HeapEnt e; e.key = key; e.idx = idx; e.pad = lab; stage[nstage + __popcll(b & lt_mask)] = e; }
+            nstage += __popcll(b);
+            st_cold += (unsigned long long)__popcll(b);
+        }
+        WIN_FENCE();
+        for (unsigned long long todo = __ballot(has && !tocold); todo; todo &= todo - 1ull) {
+            const int l = __ffsll((long long)todo) - 1;
+            const unsigned long long ek = rdlane64(key, l);
+            const uint32_t ei = rdlane(idx, l), el = rdlane(lab, l);
+            if (serial) { spill64(lane == 0, ek, ei); continue; }
+            // re-evaluate against the current tiers (an eviction in this loop may have moved them)
+            bool below_hot_max = false;
+            if (scount > 0) below_hot_max = ek < srun[(shead + scount - 1) & SMASK].key;
+            else if (nw > 0) below_hot_max = ek < key_at(slot_of(nw - 1));
+            const bool cold_free = !cold.on || (cold.count == 0 && nstage == 0) || cold_bucket(ek) < cold.low;
+            if (!below_hot_max && !cold_free) {
+                if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; stage[nstage] = e; }
+                ++nstage; ++st_cold;
+                WIN_FENCE();
+                if (nstage >= WIN_STAGE - 64) flush_stage(64);
+                continue;
+            }
+            hot_insert(ek, ei, el);
+        }
+        if (nstage >= 64 && !serial) flush_stage(64);
+    };
+
+    // ---- start: seeds (value 0, age = rank in index order) -------------------------------------------------------
+    if (wcap > WIN_W) wcap = WIN_W;
+    if (tcap > WIN_T) tcap = WIN_T;
+    for (int i = lane; i < WIN_W; i += 64) pfree[i] = (unsigned short)(WIN_W - 1 - i);
+    npfree = WIN_W;
+    WIN_FENCE();
+    {
+        started_any = true;
+        const uint32_t in_win = ns < (uint32_t)wcap ? ns : (uint32_t)wcap;
+        for (uint32_t j = lane; j < in_win; j += 64) {
+            const uint32_t vi = (uint32_t)(keys[first + j] & 0xFFFFFFFFull);
+            const unsigned long long k = ZKEY | (unsigned long long)j;
+            const int pl = (int)pfree[npfree - 1 - (int)j];
+            u32x4 q0 = {(uint32_t)k, (uint32_t)(k >> 32), vi, out[vi]};
+            winq0[j] = q0;
+            winq1[j] = fresh_q1(vi, pl);
+            ppop[pl] = 0ull;
+        }
+        nw = (int)in_win;
+        npfree -= (int)in_win;
+        const uint32_t hot_cap = (uint32_t)wcap + (uint32_t)run_limit;
+        const uint32_t in_hot = ns > hot_cap ? hot_cap : ns;
+        for (uint32_t j = in_win + lane; j < in_hot; j += 64) {
+            HeapEnt e;
+            e.key = ZKEY | (unsigned long long)j;
+            e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull);
+            e.pad = out[e.idx];
+            srun[j - in_win] = e;
+        }
+        scount = in_hot > in_win ? (int)(in_hot - in_win) : 0;
+        WIN_FENCE();
+        if (ns > in_hot && !cold.on) { serial = true; started_any = false; }
+        for (uint32_t j0 = in_hot; j0 < ns && !serial; j0 += 64) {       // seeds beyond the hot tiers start cold
+            const uint32_t j = j0 + lane;
+            const bool has = j < ns;
+            const uint32_t vi = has ? (uint32_t)(keys[first + j] & 0xFFFFFFFFull) : 0u;
+            cold_append(cold, has, ZKEY | (unsigned long long)j, vi, has ? out[vi] : 0u, lane);
+            if (cold.failed) { serial = true; started_any = false; }    // restart from the seeds on the serial heap
+        }
+    }
+
+    // ================================================= sub-rounds ==================================================
+    // Watchdog (never expected to trip): the loop below commits at least the front episode every few sub-rounds, so far
+    // fewer than this many are ever needed.  A trip is reported to the host as an error (stats[9]) with the state of
+    // the front of the window; the component is then finished by the serial heap so that the grid always drains.
+    const unsigned long long sub_limit = 4096ull + 64ull * csize;
+    while (!serial && nw > 0) {
+        ++st_sub;
+        if (st_sub > sub_limit) {
+            if (stats && lane == 0) {
+                const u32x4 f0 = winq0[slot_of(0)], f1 = winq1[slot_of(0)];
+                atomicAdd(&stats[9], 1ull);
+                stats[24] = (unsigned long long)nw; stats[25] = (unsigned long long)scount; stats[26] = (unsigned long long)cold.count;
+                stats[27] = ((unsigned long long)f1.x << 32) | f1.y; stats[28] = ((unsigned long long)f0.y << 32) | f0.x;
+                stats[29] = scount > 0 ? srun[shead].key : ~0ull; stats[30] = ((unsigned long long)f1.z << 32) | (uint32_t)nstage;
+                stats[31] = st_pops;
+                const u32x4 g0 = winq0[slot_of(1)], g1 = winq1[slot_of(1)];
+                stats[20] = ((unsigned long long)g0.y << 32) | g0.x; stats[21] = ((unsigned long long)g1.x << 32) | g1.y; stats[22] = (unsigned long long)wh;
+                stats[23] = (unsigned long long)npfree;
+            }
+            serial = true;
+            break;
+        }
+        WTICK(0);
+        if (scount > run_limit) { run_evict(); if (serial) break; }
+        // ---- A: an episode that popped past its bound (bound = value of the next larger queued key) is wrong ----
+        const unsigned long long qhead = scount > 0 ? srun[shead].key : ~0ull;
+        {
+            int sp = -1;
+            for (int base = 0; base < nw && sp < 0; base += 64) {
+                const int p = base + lane;
+                const bool valid = p < nw;
+                bool over = false;
+                if (valid) {
+                    const u32x4 q1 = winq1[slot_of(p)];
+                    const unsigned long long nk = p + 1 < nw ? key_at(slot_of(p + 1)) : qhead;
+                    over = q1.z != 0u && q1.z >= (uint32_t)(nk >> 32);
+                }
+                const unsigned long long ob = __ballot(over);
+                if (ob) sp = base + __ffsll((long long)ob) - 1;
+            }
+            if (sp >= 0) { ++st_over; squash_from(sp); }
+        }
+        // ---- B: episodes that want to pop ------------------------------------------------------------------------
+        int nact = 0;
+        bool front_forced = false;
+        for (int base = 0; base < nw; base += 64) {
+            const int p = base + lane;
+            bool act = false, stalled = false;
+            if (p < nw) {
+                const u32x4 q1 = winq1[slot_of(p)];
+                const bool st = (q1.y >> 8) & 1u;
+                const bool wants = q1.x != WIN_NONE;
+                const bool room = !st || (int)(q1.y & 0xFFu) + 6 <= tcap;
+                act = wants && room;
+                stalled = wants && !room;
+            }
+            if (base == 0) front_forced = rdlane((uint32_t)stalled, 0) != 0u;
+            const unsigned long long ab = __ballot(act);
+            if (act) actpos[nact + __popcll(ab & lt_mask)] = (unsigned short)p;
+            nact += __popcll(ab);
+        }
+        WIN_FENCE();
+        WTICK(1);
+        // ---- C: one pop per active episode, 64 episodes per row -----------------------------------------------------
+        unsigned long long squash_key = ~0ull;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // label stores / releases of earlier sub-rounds are performed
+        for (int r0 = 0; r0 < nact; r0 += 64) {
+            ++st_rows;
+            const bool act = r0 + lane < nact;
+            const int p = act ? (int)actpos[r0 + lane] : 0;
+            const int s = slot_of(p);
+            const u32x4 q0 = winq0[s];
+            u32x4 q1 = winq1[s];
+            const unsigned long long mykey = ((unsigned long long)q0.y << 32) | q0.x;
+            const int64_t cv = (int64_t)q1.x;                     // the voxel popped now (idle lanes: front root, unused)
+            const int pl = (int)((q1.y >> 16) & 0xFFu);
+            int np = ((q1.y >> 8) & 1u) ? (int)(q1.y & 0xFFu) : 0;
+            unsigned long long old[6];
+            float val[6];
+            int64_t nbv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                nbv[k] = cv + noff[k];
+                old[k] = 0ull;
+                val[k] = 0.0f;
+                if (act && nbv[k] >= 0 && nbv[k] < PN) {      // always true with the padded border; never fault
+                    old[k] = __hip_atomic_fetch_min(&state[nbv[k]], mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    val[k] = aff[(int64_t)ax[k] * PN + (k < 3 ? cv : nbv[k])];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WTICK(2);
+            // old > mykey: the voxel was free or held by a later episode -- it is mine now
+            uint32_t won = 0;
+            int novr = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (act && old[k] > mykey) {
+                    won |= 1u << k;
+                    if (old[k] != ST_FREE) ++novr;
+                }
+            }
+            // take-overs: a claim made in this very row is simply lost by its lane; an older one squashes its episode
+            const unsigned long long ovb = __ballot(novr > 0);
+            if (ovb) {
+                int slot = (int)wave_excl_sum((uint32_t)novr, lane);
+                int n_ovl = 0;
+                {
+                    uint32_t tot = (uint32_t)novr;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+                    n_ovl = (int)tot;
+                }
+                {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        if ((won & (1u << k)) && old[k] != ST_FREE) { HeapEnt e; e.key = old[k]; e.idx = (uint32_t)nbv[k]; e.pad = 0; ovl[slot++] = e; }
+                    WIN_FENCE();
+                    for (int i = 0; i < n_ovl; ++i) {
+                        const HeapEnt e = ovl[i];
+                        bool mine = false;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+                            if ((won & (1u << k)) && (uint32_t)nbv[k] == e.idx && mykey == e.key) { won &= ~(1u << k); mine = true; }
+                        if (!__any(mine) && e.key < squash_key) squash_key = e.key;
+                    }
+                }
+            }
+            // discoveries in direction order = the reference's push order (watershed.py:146-158)
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (won & (1u << k)) {
+                        const float v = val[k] * sc[ax[k]] + 0.0f;              // -0.0 == +0.0 in the order
+                        plist[pl * WIN_T + np] = uint2{(uint32_t)nbv[k], ford(v)};
+                        ++np;
+                    }
+            }
+            WIN_FENCE();
+            // next pop: the smallest unpopped discovery, if it sorts below the next queued key
+            unsigned long long pop = act ? ppop[pl] : 0ull;
+            uint32_t bf = 0xFFFFFFFFu;
+            int bi = -1;
+            for (int i = 0; __any(act && i < np); ++i) {
+                if (act && i < np && !((pop >> i) & 1ull)) {
+                    const uint32_t fv = plist[pl * WIN_T + i].y;
+                    if (fv < bf) { bf = fv; bi = i; }
+                }
+            }
+            if (act) {
+                const unsigned long long nk = p + 1 < nw ? key_at(slot_of(p + 1)) : qhead;
+                const uint32_t bound = (uint32_t)(nk >> 32);
+                uint32_t mx = q1.z;
+                uint32_t cur = WIN_NONE, curi = 0xFFu;
+                if (bi >= 0 && bf < bound) {
+                    cur = plist[pl * WIN_T + bi].x;
+                    curi = (uint32_t)bi;
+                    pop |= 1ull << bi;
+                    if (bf > mx) mx = bf;
+                }
+                q1.x = cur;
+                q1.y = (uint32_t)np | (1u << 8) | ((uint32_t)pl << 16) | (curi << 24);
+                q1.z = mx;
+                winq1[s] = q1;
+                ppop[pl] = pop;
+            }
+            st_exec += (unsigned long long)__popcll(__ballot(act));
+            WIN_FENCE();
+            WTICK(3);
+        }
+        // ---- D: squash from the first episode that lost a discovery it had already used --------------------------------
+        if (squash_key != ~0ull) {
+            int sp = 0;
+            for (int base = 0; base < nw; base += 64) {
+                const int p = base + lane;
+                const bool lt = p < nw && key_at(slot_of(p)) < squash_key;
+                sp += __popcll(__ballot(lt));
+            }
+            if (sp < nw) squash_from(sp);
+        }
+        WTICK(4);
+        // ---- E: commit the idle episodes at the front, in order -----------------------------------------------------------
+        {
+            const int j = lane;
+            const bool valid = j < nw;
+            const int s = valid ? slot_of(j) : 0;
+            u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u};
+            if (valid) { q0 = winq0[s]; q1 = winq1[s]; }
+            const bool st = valid && ((q1.y >> 8) & 1u);
+            const int np = st ? (int)(q1.y & 0xFFu) : 0, pl = (int)((q1.y >> 16) & 0xFFu);
+            unsigned long long pop = st ? ppop[pl] : 0ull;
+            bool idle = st && q1.x == WIN_NONE;
+            // the front episode with a full list commits what it has done: the element it was about to pop goes back to
+            // the queue like any other residual
+            const bool forced = front_forced && j == 0 && st && q1.x != WIN_NONE && np + 6 > tcap;
+            if (forced) { pop &= ~(1ull << ((q1.y >> 24) & 0xFFu)); idle = true; }
+            const unsigned long long nb_ = ~__ballot(idle);
+            const int m = nb_ ? __ffsll((long long)nb_) - 1 : 64;       // leading idle episodes
+            uint32_t resmin = 0xFFFFFFFFu, maxpop = 0u;
+            for (int i = 0; __any(j < m && i < np); ++i) {
+                if (j < m && i < np) {
+                    const uint32_t fv = plist[pl * WIN_T + i].y;
+                    if ((pop >> i) & 1ull) { if (fv > maxpop) maxpop = fv; }
+                    else if (fv < resmin) resmin = fv;
+                }
+            }
+            const uint32_t maxnew = forced ? maxpop : q1.z;
+            // residuals of the episodes committing before me must all sort after everything I popped (they are older
+            // than my discoveries: strict for those; my root is older than any residual: ties go to the root)
+            uint32_t F = wave_shr1(wave_prefix_min(j < m ? resmin : 0xFFFFFFFFu), 0xFFFFFFFFu);
+            const uint32_t qv = (uint32_t)(qhead >> 32);
+            if (qv < F) F = qv;
+            const bool ok = j < m && q0.y <= F && (maxnew == 0u || maxnew < F);
+            const unsigned long long nok = ~__ballot(ok);
+            const int ncommit = nok ? __ffsll((long long)nok) - 1 : 64;
+            if (ncommit > 0) {
+                if (rdlane((uint32_t)forced, 0)) ++st_forced;
+                const bool cm = j < ncommit;
+                const uint32_t mybase = agebase + wave_excl_sum(cm ? (uint32_t)np : 0u, lane);
+                {
+                    uint32_t tot = cm ? (uint32_t)np : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+                    agebase += tot;
+                }
+                st_pops += (unsigned long long)__popcll(__ballot(cm));
+                {
+                    uint32_t pc = cm ? (uint32_t)__popcll(pop) : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) pc += __shfl_xor(pc, o);
+                    st_pops += pc;
+                }
+                const uint32_t lab = q0.w;
+                // the committed slots leave the window now; their lists stay untouched until the loop below is done
+                wh = slot_of(ncommit);
+                nw -= ncommit;
+                for (int i = 0; __any(cm && i < np); ++i) {
+                    const bool has = cm && i < np;
+                    uint2 e = uint2{0u, 0u};
+                    if (has) {
+                        e = plist[pl * WIN_T + i];
+                        __hip_atomic_store(&state[e.x], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        out[e.x] = lab;                                  // label at discovery (watershed.py:153)
+                    }
+                    const bool pending = has && !((pop >> i) & 1ull);
+                    enqueue64(pending, ((unsigned long long)e.y << 32) | (unsigned long long)(mybase + (uint32_t)i + 1u), e.x, lab);
+                }
+                if (cm) pfree[npfree + j] = (unsigned short)pl;
+                npfree += ncommit;
+                WIN_FENCE();
+            }
+        }
+        WTICK(5);
+        if (serial) break;
+        // ---- G: refill the window from the run (from the buckets when the run is empty) ----------------------------------
+        // invariant for the bounds above: the run is empty only if nothing is queued behind the window
+        {
+            if (scount == 0 && cold.on && (cold.count > 0 || nstage > 0)) {
+                if (nstage > 0) { flush_stage(nstage); if (serial) break; }
+                if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; ++st_drain; }
+            }
+            while (nw < wcap && scount > 0) {
+                int take = wcap - nw;
+                if (take > scount) take = scount;
+                if (take > 64) take = 64;
+                if (take > npfree) take = npfree;
+                if (take <= 0) break;
+                if (lane < take) {
+                    const u32x4 e = run_ld(srun, (shead + lane) & SMASK);
+                    const int pl = (int)pfree[npfree - 1 - lane];
+                    const int s = slot_of(nw + lane);
+                    winq0[s] = e;
+                    winq1[s] = fresh_q1(e.z, pl);
+                    ppop[pl] = 0ull;
+                }
+                npfree -= take;
+                nw += take;
+                shead = (shead + take) & SMASK;
+                scount -= take;
+                WIN_FENCE();
+                if (scount == 0 && cold.on && (cold.count > 0 || nstage > 0)) {
+                    if (nstage > 0) { flush_stage(nstage); if (serial) break; }
+                    if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; ++st_drain; }
+                }
+            }
+            if (serial) break;
+        }
+        WTICK(6);
+    }
+
+#ifdef ISX_FLOOD_PROF
+    if (stats && lane == 0)
+        for (int i = 0; i < 8; ++i) { atomicAdd(&stats[16 + i], tk_acc[i]); if (i < 4) atomicAdd(&stats[24 + i], cold.tk[i]); }
+#endif
+    if (stats && lane == 0) {
+        atomicAdd(&stats[0], st_sub); atomicAdd(&stats[1], st_pops); atomicAdd(&stats[2], st_exec); atomicAdd(&stats[3], st_hot);
+        atomicAdd(&stats[4], st_cold); atomicAdd(&stats[5], st_drain); atomicAdd(&stats[6], st_evict); atomicAdd(&stats[7], st_mid);
+        if (serial) atomicAdd(&stats[8], 1ull);
+        if (cold.fifo_drains) atomicAdd(&stats[10], (unsigned long long)cold.fifo_drains);
+        atomicAdd(&stats[11], st_sq_ev); atomicAdd(&stats[12], st_sq_eps); atomicAdd(&stats[13], st_rows); atomicAdd(&stats[14], st_over);
+        atomicAdd(&stats[15], st_forced);
+    }
+    if (serial) {
+        // Exact continuation on one lane: every queued element (window roots -- their speculative work is dropped,
+        // `out` only ever holds committed labels --, run, staged, buckets, spilled) goes into the binary heap.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t hn = 0;
+        if (!started_any) {
+            if (lane == 0)
+                for (uint32_t j = 0; j < ns; ++j) {
+                    HeapEnt e; e.key = ZKEY | (unsigned long long)j; e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull); e.pad = 0;
+                    heap_push(heap, hn, e);
+                }
+        } else {
+            if (lane == 0) {
+                for (int p = 0; p < nw; ++p) {
+                    const u32x4 q0 = winq0[slot_of(p)];
+                    HeapEnt e; e.key = ((unsigned long long)q0.y << 32) | q0.x; e.idx = q0.z; e.pad = 0;
+                    heap_push(heap, hn, e);
+                }
+                for (int j = 0; j < scount; ++j) { HeapEnt e = srun[(shead + j) & SMASK]; e.pad = 0; heap_push(heap, hn, e); }
+                for (int j = 0; j < nstage; ++j) { HeapEnt e = stage[j]; e.pad = 0; heap_push(heap, hn, e); }
+            }
+            if (cold.on) {
+                while (cold.count > 0) {
+                    const uint32_t b = cold_lowest(cold, lane);
+                    uint32_t seg = cld32(&cold.bhead[b]);
+                    uint32_t off = cld32(&cold.bmeta[b]) & ~COLD_UNSORTED;
+                    uint32_t got = 0;
+                    while (seg != COLD_NONE) {
+                        const HeapEnt h = cld_ent(&cold.pool[seg]);
+                        const uint32_t n = (uint32_t)(h.key >> 32);
+                        if (lane == 0)
+                            for (uint32_t j = off; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
+                        got += n - off;
+                        off = 0;
+                        seg = (uint32_t)h.key;
+                    }
+                    cold_mark_empty(cold, b, lane);
+                    cold.count -= got;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                for (uint32_t j = 0; j < nspill; ++j) {            // lowest address first: the growing heap may only reach slots already read
+                    HeapEnt e = cld_ent(&heap[csize - (unsigned long long)nspill + j]); e.pad = 0;
+                    heap_push(heap, hn, e);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane == 0) serial_flood(heap, hn, agebase, aff, mask, out, PY, PX, PN, s0, s1, s2);
+    }
+}
