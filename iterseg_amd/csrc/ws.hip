@@ -876,12 +876,23 @@ __device__ __forceinline__ HeapEnt cld_ent(const HeapEnt *p)
 }
 
 struct Cold {
-    uint32_t *bhead, *btail, *bcount;
-    uint32_t *bfill;           // tail segment: entries used | log2(capacity) << 24 (a copy of its header: one load trip per append)
-    unsigned long long *blast; // key of the last appended element
-    uint32_t *bmeta;           // bits 0..30: consumed prefix of the head segment; bit 31: appended out of key order
-    unsigned long long *bm0, *bm1;
-    HeapEnt *pool;             // a segment = header entry {key = next | n << 32, idx = cap} + cap entries
+    // arena of one component; its views are computed from the base on use (eight live pointers cost 16 SGPRs in kernels
+    // that are short of them).  Layout in 16-byte units: bhead | btail | bcount | bmeta | bfill (u32[NBK] each),
+    // blast (u64[NBK]), bm0 (u64[NBK/64]), bm1 (u64[NBK/4096]), pool
+    uint32_t *base;
+    __device__ __forceinline__ uint32_t *bhead() const { return base; }
+    __device__ __forceinline__ uint32_t *btail() const { return base + COLD_NBK; }
+    __device__ __forceinline__ uint32_t *bcount() const { return base + 2 * COLD_NBK; }
+    // bits 0..30: consumed prefix of the head segment; bit 31: appended out of key order
+    __device__ __forceinline__ uint32_t *bmeta() const { return base + 3 * COLD_NBK; }
+    // tail segment: entries used | log2(capacity) << 24 (a copy of its header: one load trip per append)
+    __device__ __forceinline__ uint32_t *bfill() const { return base + 4 * COLD_NBK; }
+    // key of the last appended element
+    __device__ __forceinline__ unsigned long long *blast() const { return (unsigned long long *)(base + 5 * COLD_NBK); }
+    __device__ __forceinline__ unsigned long long *bm0() const { return blast() + COLD_NBK; }
+    __device__ __forceinline__ unsigned long long *bm1() const { return bm0() + COLD_NBK / 64; }
+    // a segment = header entry {key = next | n << 32, idx = cap} + cap entries
+    __device__ __forceinline__ HeapEnt *pool() const { return (HeapEnt *)base + COLD_META_ENTS; }
     uint32_t pool_cap, bump, count;
     uint32_t fifo_drains;      // statistics: drains served by the prefix of an ascending list
     // write-through copy of one bucket's append state (plateaus append to the same bucket round after round):
@@ -890,6 +901,7 @@ struct Cold {
     unsigned long long cb_last;
     bool cb_unsorted;
     uint32_t low;              // lowest non-empty bucket (COLD_NBK when empty): decides which new elements may stay hot
+    float vlo, vinv;           // bucket = (value - vlo) * vinv, clamped
     bool on, failed;
 #ifdef ISX_FLOOD_PROF
     unsigned long long tk[8], tk_prev, n_groups;
@@ -904,14 +916,21 @@ struct Cold {
 #define COLD_TICK(c, i) do { } while (0)
 #endif
 
-__device__ __forceinline__ uint32_t cold_bucket(unsigned long long key) { return (uint32_t)(key >> 48); }
+// Bucket of a key: a monotone (non-strict) map of the edge VALUE onto [0, COLD_NBK): linear between the smallest and the
+// largest scaled affinity of the volume (host: flood_impl), so that the buckets in use are evenly filled whatever binade
+// the values live in (the top 16 bits of the ordered float gave 128 buckets per binade: ~250 buckets for [0.25, 1)).
+__device__ __forceinline__ uint32_t cold_bucket(const Cold &c, unsigned long long key)
+{
+    const float t = (funord((uint32_t)(key >> 32)) - c.vlo) * c.vinv;
+    return t >= (float)(COLD_NBK - 1) ? (uint32_t)(COLD_NBK - 1) : (t > 0.0f ? (uint32_t)t : 0u);
+}
 
 // Append up to one element per lane to the buckets.  Lanes with the same bucket form a group (leader = lowest
 // lane); leaders do the bookkeeping in parallel, members get their slot from the leader.
 __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long long key, uint32_t idx, uint32_t lab, int lane)
 {
     COLD_TICK0(c);
-    const uint32_t b = cold_bucket(key);
+    const uint32_t b = cold_bucket(c, key);
     // earlier arena stores of this wave must be visible to the leaders' loads; a round whose elements all go to the
     // cached bucket loads nothing and lets its stores (and the round's label stores) drain under the next round
     const bool uncached = has && b != c.cb;
@@ -921,11 +940,11 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
     uint32_t m_tail = COLD_NONE, m_cnt = 0, m_fill = 0, m_meta = 0;
     unsigned long long m_last = 0ull;
     if (uncached) {
-        m_tail = cld32(&c.btail[b]);
-        m_cnt = cld32(&c.bcount[b]);
-        m_fill = cld32(&c.bfill[b]);
-        m_meta = cld32(&c.bmeta[b]);
-        m_last = cld64(&c.blast[b]);
+        m_tail = cld32(&c.btail()[b]);
+        m_cnt = cld32(&c.bcount()[b]);
+        m_fill = cld32(&c.bfill()[b]);
+        m_meta = cld32(&c.bmeta()[b]);
+        m_last = cld64(&c.blast()[b]);
     }
     COLD_TICK(c, 0);
     int gleader = 0, grank = 0, gsize = 0;
@@ -967,7 +986,7 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
         if (b == c.cb) {
             tail = c.cb_tail; cnt = c.cb_cnt; tn = c.cb_tn; tcap = c.cb_tcap;
             unsorted = c.cb_unsorted;
-            if (!unsorted && (gviol || c.cb_last > key)) { unsorted = true; atomicOr(&c.bmeta[b], COLD_UNSORTED); }
+            if (!unsorted && (gviol || c.cb_last > key)) { unsorted = true; atomicOr(&c.bmeta()[b], COLD_UNSORTED); }
         } else {
             tail = m_tail;
             cnt = m_cnt;
@@ -977,7 +996,7 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
                 if (cnt > 0 && m_last > key) gviol = true;
             }
             unsorted = (m_meta & COLD_UNSORTED) != 0u;
-            if (gviol && !unsorted) { unsorted = true; atomicOr(&c.bmeta[b], COLD_UNSORTED); }
+            if (gviol && !unsorted) { unsorted = true; atomicOr(&c.bmeta()[b], COLD_UNSORTED); }
         }
     }
 #ifdef ISX_FLOOD_PROF
@@ -1008,33 +1027,33 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
             h.key = (unsigned long long)COLD_NONE | ((unsigned long long)need_new << 32);
             h.idx = newcap;
             h.pad = 0;
-            c.pool[my_off] = h;
+            c.pool()[my_off] = h;
             if (tail != COLD_NONE) {
                 HeapEnt ht;
                 ht.key = (unsigned long long)my_off | ((unsigned long long)tcap << 32);    // old tail is now full
                 ht.idx = tcap;
                 ht.pad = 0;
-                c.pool[tail] = ht;
+                c.pool()[tail] = ht;
             } else {
-                c.bhead[b] = my_off;
+                c.bhead()[b] = my_off;
             }
-            c.btail[b] = my_off;
+            c.btail()[b] = my_off;
         } else {
             HeapEnt ht;
             ht.key = (unsigned long long)COLD_NONE | ((unsigned long long)(tn + (uint32_t)gsize) << 32);   // a tail has no successor
             ht.idx = tcap;
             ht.pad = 0;
-            c.pool[tail] = ht;
+            c.pool()[tail] = ht;
         }
-        c.bcount[b] = cnt + (uint32_t)gsize;
+        c.bcount()[b] = cnt + (uint32_t)gsize;
         {
             const uint32_t f_tn = need_new ? need_new : tn + (uint32_t)gsize, f_cap = need_new ? newcap : tcap;
-            c.bfill[b] = f_tn | ((uint32_t)(31 - __clz((int)f_cap)) << 24);
-            c.blast[b] = glast;
+            c.bfill()[b] = f_tn | ((uint32_t)(31 - __clz((int)f_cap)) << 24);
+            c.blast()[b] = glast;
         }
         if (cnt == 0) {
-            atomicOr(&c.bm0[b >> 6], 1ull << (b & 63));
-            atomicOr(&c.bm1[b >> 12], 1ull << ((b >> 6) & 63));
+            atomicOr(&c.bm0()[b >> 6], 1ull << (b & 63));
+            atomicOr(&c.bm1()[b >> 12], 1ull << ((b >> 6) & 63));
         }
     }
     {
@@ -1061,7 +1080,7 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
         e.key = key;
         e.idx = idx;
         e.pad = lab;
-        c.pool[slot] = e;
+        c.pool()[slot] = e;
     }
     COLD_TICK(c, 3);
     c.count += (uint32_t)__popcll(__ballot(has));
@@ -1074,12 +1093,12 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
 __device__ __forceinline__ uint32_t cold_lowest(const Cold &c, int lane)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long w1 = lane < COLD_NBK / 4096 ? cld64(&c.bm1[lane]) : 0ull;
+    const unsigned long long w1 = lane < COLD_NBK / 4096 ? cld64(&c.bm1()[lane]) : 0ull;
     const unsigned long long nz = __ballot(w1 != 0ull);
     const int wi = __ffsll((long long)nz) - 1;
     const unsigned long long word1 = shfl64(w1, wi);
     const int i0 = wi * 64 + (__ffsll((long long)word1) - 1);
-    const unsigned long long word0 = cld64(&c.bm0[i0]);
+    const unsigned long long word0 = cld64(&c.bm0()[i0]);
     return (uint32_t)i0 * 64u + (uint32_t)(__ffsll((long long)word0) - 1);
 }
 
@@ -1087,12 +1106,12 @@ __device__ __forceinline__ void cold_mark_empty(Cold &c, uint32_t b, int lane)
 {
     if (b == c.cb) c.cb = COLD_NONE;
     if (lane == 0) {
-        c.bhead[b] = COLD_NONE;
-        c.btail[b] = COLD_NONE;
-        c.bcount[b] = 0;
-        c.bmeta[b] = 0;
-        const unsigned long long old = atomicAnd(&c.bm0[b >> 6], ~(1ull << (b & 63)));
-        if ((old & ~(1ull << (b & 63))) == 0ull) atomicAnd(&c.bm1[b >> 12], ~(1ull << ((b >> 6) & 63)));
+        c.bhead()[b] = COLD_NONE;
+        c.btail()[b] = COLD_NONE;
+        c.bcount()[b] = 0;
+        c.bmeta()[b] = 0;
+        const unsigned long long old = atomicAnd(&c.bm0()[b >> 6], ~(1ull << (b & 63)));
+        if ((old & ~(1ull << (b & 63))) == 0ull) atomicAnd(&c.bm1()[b >> 12], ~(1ull << ((b >> 6) & 63)));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1122,18 +1141,18 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
 {
     const uint32_t b = cold_lowest(c, lane);
     if (b == c.cb) c.cb = COLD_NONE;                    // the drain rewrites this bucket's state
-    const uint32_t cnt = cld32(&c.bcount[b]);
-    const uint32_t head = cld32(&c.bhead[b]);
-    const uint32_t meta = cld32(&c.bmeta[b]);
+    const uint32_t cnt = cld32(&c.bcount()[b]);
+    const uint32_t head = cld32(&c.bhead()[b]);
+    const uint32_t meta = cld32(&c.bmeta()[b]);
     const uint32_t off0 = meta & ~COLD_UNSORTED;        // consumed prefix of the head segment
     const bool fifo = (meta & COLD_UNSORTED) == 0u;     // the bucket's list order is its key order
     int taken = 0;
     if (cnt <= (uint32_t)drain_n) {
         uint32_t seg = head, off = off0;
         while (seg != COLD_NONE) {
-            const HeapEnt h = cld_ent(&c.pool[seg]);
+            const HeapEnt h = cld_ent(&c.pool()[seg]);
             const uint32_t n = (uint32_t)(h.key >> 32) - off;
-            for (uint32_t j = lane; j < n; j += 64) srun[taken + j] = cld_ent(&c.pool[seg + 1u + off + j]);
+            for (uint32_t j = lane; j < n; j += 64) srun[taken + j] = cld_ent(&c.pool()[seg + 1u + off + j]);
             taken += (int)n;
             seg = (uint32_t)h.key;
             off = 0;
@@ -1143,20 +1162,20 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
         // ---- ascending list (plateaus: equal values, growing ages): the smallest elements are its prefix ----
         uint32_t seg = head, off = off0;
         while (taken < drain_n) {                       // cnt > drain_n: the list cannot run out
-            const HeapEnt h = cld_ent(&c.pool[seg]);
+            const HeapEnt h = cld_ent(&c.pool()[seg]);
             const uint32_t n = (uint32_t)(h.key >> 32);
             uint32_t m = n - off;
             if (m > (uint32_t)(drain_n - taken)) m = (uint32_t)(drain_n - taken);
-            for (uint32_t j = lane; j < m; j += 64) srun[taken + j] = cld_ent(&c.pool[seg + 1u + off + j]);
+            for (uint32_t j = lane; j < m; j += 64) srun[taken + j] = cld_ent(&c.pool()[seg + 1u + off + j]);
             taken += (int)m;
             off += m;
             if (off == n) { seg = (uint32_t)h.key; off = 0; }
         }
         ++c.fifo_drains;
         if (lane == 0) {
-            c.bhead[b] = seg;
-            c.bmeta[b] = off;
-            c.bcount[b] = cnt - (uint32_t)taken;
+            c.bhead()[b] = seg;
+            c.bmeta()[b] = off;
+            c.bcount()[b] = cnt - (uint32_t)taken;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -1166,9 +1185,9 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
         // four independent loads per lane in flight instead of waiting for each 64-element row.
         unsigned long long lo = ~0ull, hi = 0ull;
         for (uint32_t seg = head; seg != COLD_NONE;) {
-            const HeapEnt h = cld_ent(&c.pool[seg]);
+            const HeapEnt h = cld_ent(&c.pool()[seg]);
             const uint32_t n = (uint32_t)(h.key >> 32);
-            const HeapEnt *el = &c.pool[seg + 1u];
+            const HeapEnt *el = &c.pool()[seg + 1u];
             uint32_t j = (seg == head ? off0 : 0u) + lane;
             for (; j + 192u < n; j += 256u) {
                 const unsigned long long k0 = cld64(&el[j].key), k1 = cld64(&el[j + 64u].key), k2 = cld64(&el[j + 128u].key),
@@ -1199,9 +1218,9 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
             hist[lane] = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             for (uint32_t seg = head; seg != COLD_NONE;) {
-                const HeapEnt h = cld_ent(&c.pool[seg]);
+                const HeapEnt h = cld_ent(&c.pool()[seg]);
                 const uint32_t n = (uint32_t)(h.key >> 32);
-                const HeapEnt *el = &c.pool[seg + 1u];
+                const HeapEnt *el = &c.pool()[seg + 1u];
                 uint32_t j = (seg == head ? off0 : 0u) + lane;
                 for (; j + 192u < n; j += 256u) {
                     const unsigned long long k0 = cld64(&el[j].key), k1 = cld64(&el[j + 64u].key), k2 = cld64(&el[j + 128u].key),
@@ -1235,9 +1254,9 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
         // ---- extract bins < B into the run; compact the rest in place (write cursor trails the read cursor) ----
         // A row's loads are issued before any store of that row and later rows lie at higher addresses than anything
         // stored so far, so no load ever has to wait for a store: two rows are loaded ahead.
-        uint32_t wseg = head, wn = 0, wcap = cld_ent(&c.pool[head]).idx, kept = 0;
+        uint32_t wseg = head, wn = 0, wcap = cld_ent(&c.pool()[head]).idx, kept = 0;
         for (uint32_t seg = head; seg != COLD_NONE;) {
-            const HeapEnt h = cld_ent(&c.pool[seg]);
+            const HeapEnt h = cld_ent(&c.pool()[seg]);
             const uint32_t n = (uint32_t)(h.key >> 32), nxt = (uint32_t)h.key;
             for (uint32_t base0 = (seg == head ? off0 : 0u); base0 < n; base0 += 128u) {
                 HeapEnt e2[2];
@@ -1247,7 +1266,7 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
                     const uint32_t j = base0 + 64u * (uint32_t)u + lane;
                     valid2[u] = j < n;
                     e2[u].key = 0; e2[u].idx = 0; e2[u].pad = 0;
-                    if (valid2[u]) e2[u] = cld_ent(&c.pool[seg + 1u + j]);
+                    if (valid2[u]) e2[u] = cld_ent(&c.pool()[seg + 1u + j]);
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -1262,16 +1281,16 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
                     while (remaining > 0) {
                         const int room = (int)(wcap - wn);
                         const int m = room < remaining ? room : remaining;
-                        if (valid && !take && krank >= done && krank < done + m) c.pool[wseg + 1u + wn + (uint32_t)(krank - done)] = e;
+                        if (valid && !take && krank >= done && krank < done + m) c.pool()[wseg + 1u + wn + (uint32_t)(krank - done)] = e;
                         wn += (uint32_t)m;
                         done += m;
                         remaining -= m;
                         if (wn == wcap && remaining > 0) {
-                            const HeapEnt wh = cld_ent(&c.pool[wseg]);
-                            if (lane == 0) { HeapEnt t2 = wh; t2.key = (wh.key & 0xFFFFFFFFull) | ((unsigned long long)wcap << 32); c.pool[wseg] = t2; }
+                            const HeapEnt wh = cld_ent(&c.pool()[wseg]);
+                            if (lane == 0) { HeapEnt t2 = wh; t2.key = (wh.key & 0xFFFFFFFFull) | ((unsigned long long)wcap << 32); c.pool()[wseg] = t2; }
                             wseg = (uint32_t)wh.key;
                             wn = 0;
-                            wcap = cld_ent(&c.pool[wseg]).idx;
+                            wcap = cld_ent(&c.pool()[wseg]).idx;
                         }
                     }
                     kept += (uint32_t)__popcll(kb);
@@ -1284,11 +1303,11 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
             t2.key = (unsigned long long)COLD_NONE | ((unsigned long long)wn << 32);     // truncate the list here
             t2.idx = wcap;
             t2.pad = 0;
-            c.pool[wseg] = t2;
-            c.btail[b] = wseg;
-            c.bfill[b] = wn | ((uint32_t)(31 - __clz((int)wcap)) << 24);
-            c.bcount[b] = kept;
-            c.bmeta[b] = COLD_UNSORTED;                 // compacted from the start of the head segment
+            c.pool()[wseg] = t2;
+            c.btail()[b] = wseg;
+            c.bfill()[b] = wn | ((uint32_t)(31 - __clz((int)wcap)) << 24);
+            c.bcount()[b] = kept;
+            c.bmeta()[b] = COLD_UNSORTED;                 // compacted from the start of the head segment
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1305,7 +1324,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
     const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
     HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
     int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long coop_min_size, int run_limit,
-    int drain_n, unsigned long long *stats, int shard_rank, int shard_world)
+    int drain_n, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world)
 {
     __shared__ HeapEnt srun[COOP_SCAP];          // .pad carries the element's label
     __shared__ HeapEnt stage[6 * 64];            // elements of this round bound for the cold tier
@@ -1344,21 +1363,15 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
 #endif
     cold.cb = COLD_NONE;
     cold.pool_cap = 0;
+    cold.vlo = bk_lo;
+    cold.vinv = bk_inv;
     if (cold.on) {
         HeapEnt *base = arena + arena_off[c];
-        cold.bhead = (uint32_t *)base;
-        cold.btail = cold.bhead + COLD_NBK;
-        cold.bcount = cold.btail + COLD_NBK;
-        cold.bmeta = cold.bcount + COLD_NBK;
-        cold.bfill = cold.bmeta + COLD_NBK;
-        cold.blast = (unsigned long long *)(cold.bfill + COLD_NBK);
-        cold.bm0 = cold.blast + COLD_NBK;
-        cold.bm1 = cold.bm0 + COLD_NBK / 64;
-        cold.pool = base + COLD_META_ENTS;
+        cold.base = (uint32_t *)base;
         cold.pool_cap = (uint32_t)(arena_off[c + 1] - arena_off[c] - COLD_META_ENTS);
-        for (int i = lane; i < COLD_NBK; i += 64) { cold.bhead[i] = COLD_NONE; cold.btail[i] = COLD_NONE; cold.bcount[i] = 0; cold.bmeta[i] = 0; }
-        for (int i = lane; i < COLD_NBK / 64; i += 64) cold.bm0[i] = 0ull;
-        if (lane < COLD_NBK / 4096) cold.bm1[lane] = 0ull;
+        for (int i = lane; i < COLD_NBK; i += 64) { cold.bhead()[i] = COLD_NONE; cold.btail()[i] = COLD_NONE; cold.bcount()[i] = 0; cold.bmeta()[i] = 0; }
+        for (int i = lane; i < COLD_NBK / 64; i += 64) cold.bm0()[i] = 0ull;
+        if (lane < COLD_NBK / 4096) cold.bm1()[lane] = 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
@@ -1558,7 +1571,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
             const bool hot_nonempty0 = scount > 0 || rcount > 0;
 #pragma unroll
             for (int k = 0; k < 6; ++k)
-                if ((wm_all & (1u << k)) && !(hot_nonempty0 && pkey[k] < hot_max0) && cold_bucket(pkey[k]) >= cold.low)
+                if ((wm_all & (1u << k)) && !(hot_nonempty0 && pkey[k] < hot_max0) && cold_bucket(cold, pkey[k]) >= cold.low)
                     cmask |= 1u << k;
             uint32_t slot = 0;
 #pragma unroll
@@ -1596,7 +1609,7 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                 const unsigned long long hot_max = scount > 0 ? back : reg_last;
                 const bool hot_nonempty = scount > 0 || rcount > 0;
                 const bool below_hot_max = hot_nonempty && ek < hot_max;
-                const bool cold_free = !cold.on || cold.count == 0 || cold_bucket(ek) < cold.low;
+                const bool cold_free = !cold.on || cold.count == 0 || cold_bucket(cold, ek) < cold.low;
                 if (!below_hot_max && !cold_free) {
                     if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; stage[nstage] = e; }
                     ++nstage;
@@ -1715,14 +1728,14 @@ __global__ __launch_bounds__(64) void flood_wave_kernel(
                 // gather the buckets
                 while (cold.count > 0) {
                     const uint32_t b = cold_lowest(cold, lane);
-                    uint32_t seg = cld32(&cold.bhead[b]);
-                    uint32_t off = cld32(&cold.bmeta[b]) & ~COLD_UNSORTED;
+                    uint32_t seg = cld32(&cold.bhead()[b]);
+                    uint32_t off = cld32(&cold.bmeta()[b]) & ~COLD_UNSORTED;
                     uint32_t got = 0;
                     while (seg != COLD_NONE) {
-                        const HeapEnt h = cld_ent(&cold.pool[seg]);
+                        const HeapEnt h = cld_ent(&cold.pool()[seg]);
                         const uint32_t n = (uint32_t)(h.key >> 32);
                         if (lane == 0)
-                            for (uint32_t j = off; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
+                            for (uint32_t j = off; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool()[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
                         got += n - off;
                         off = 0;
                         seg = (uint32_t)h.key;
@@ -1831,6 +1844,29 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     ISX_HIP(hipMemsetAsync(stats.p, 0, 32 * 8, ctx->stream));
     float s[3] = {1.f, 1.f, 1.f};
     if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
+    // value range of the (scaled) edge values -> linear bucket map of the cold tier (any monotone map is correct; this
+    // one fills the buckets evenly).  ISX_FLOOD_BUCKETS: number of buckets spread over the range (tests / tuning).
+    float bk_lo = 0.0f, bk_inv = 0.0f;
+    {
+        Scratch<uint32_t> mm(ctx, 2);
+        if (!mm.ok()) return ISX_ERR_NOMEM;
+        const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+        ISX_HIP(hipMemcpyAsync(mm.p, init, 8, hipMemcpyHostToDevice, ctx->stream));
+        minmax_kernel<<<1024, TPB, 0, ctx->stream>>>(aff, 3 * PN, mm.p);
+        ISX_CHECK_LAUNCH();
+        uint32_t hmm[2];
+        ISX_HIP(hipMemcpyAsync(hmm, mm.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        auto unord = [](uint32_t u) { uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &b, 4); return f; };
+        const float rlo = unord(hmm[0]), rhi = unord(hmm[1]);
+        const float smin = std::min(s[0], std::min(s[1], s[2])), smax = std::max(s[0], std::max(s[1], s[2]));
+        const float vlo = std::min(std::min(rlo * smin, rlo * smax), 0.0f), vhi = std::max(std::max(rhi * smin, rhi * smax), vlo);
+        int nbuckets = 16384;
+        if (const char *e = getenv("ISX_FLOOD_BUCKETS")) nbuckets = atoi(e);
+        ISX_REQUIRE(nbuckets >= 1 && nbuckets <= COLD_NBK, "ISX_FLOOD_BUCKETS out of range");
+        bk_lo = vlo;
+        bk_inv = (vhi > vlo && std::isfinite(vhi - vlo)) ? (float)nbuckets / (vhi - vlo) : 0.0f;
+    }
     // small components: one lane each; large ones: one wave each (both launched over all components,
     // each picks its own by size -- no host round trip to split the list)
     flood_kernel<<<cdiv(n_comp, 64), 64, 0, ctx->stream>>>(aff, mask, out, keys_sorted.p, n_seeds,
@@ -1844,13 +1880,13 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         flood_window_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                             comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
                                                             pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, wcap, tcap,
-                                                            stats.p, ctx->ws_shard_rank, ctx->ws_shard_world);
+                                                            bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world);
         ISX_CHECK_LAUNCH();
     } else {
         ISX_HIP(hipMemsetAsync(claim.p, 0, (size_t)PN * sizeof(uint32_t), ctx->stream));
         flood_wave_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, claim.p, keys_sorted.p, n_seeds, comp_first.p,
                                                           comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
-                                                          pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, stats.p,
+                                                          pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, bk_lo, bk_inv, stats.p,
                                                           ctx->ws_shard_rank, ctx->ws_shard_world);
         ISX_CHECK_LAUNCH();
     }

@@ -30,8 +30,10 @@ static constexpr int WIN_W = 192;                 // episodes in flight (physica
 static constexpr int WIN_T = 48;                  // discoveries one episode holds before it must become the front
 static constexpr int WIN_RCAP = 2048;             // LDS run capacity
 static constexpr int WIN_STAGE = 128;             // staged cold-bound elements (flushed 64 at a time)
+static constexpr int WIN_PEND = 512;              // residuals of one commit burst, in age order
 static constexpr uint32_t WIN_NONE = 0xFFFFFFFFu;
 static constexpr unsigned long long ST_FREE = ~0ull;
+static constexpr uint32_t WIN_POPPED = 0xFFFFFFFFu;     // ford() of no real value
 
 #define WIN_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -44,15 +46,19 @@ __global__ void flood_state_init_kernel(const uint8_t *__restrict__ mask, const 
     state[i] = mask[i] ? (l ? (unsigned long long)l : ST_FREE) : 0ull;
 }
 
-__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, int lane)
+// inclusive prefix sum over the 64 lanes on the DPP path (row_shr 1/2/4/8, then row_bcast 15 and 31): a few cycles per
+// step where a ds_bpermute shuffle costs an LDS round trip.  Lane 63 holds the total.
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
 {
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    return incl - v;
+#define ISX_SUM_STEP(ctrl, rmask) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false); v += t; }
+    ISX_SUM_STEP(0x111, 0xf)
+    ISX_SUM_STEP(0x112, 0xf)
+    ISX_SUM_STEP(0x114, 0xf)
+    ISX_SUM_STEP(0x118, 0xf)
+    ISX_SUM_STEP(0x142, 0xa)
+    ISX_SUM_STEP(0x143, 0xc)
+#undef ISX_SUM_STEP
+    return v;
 }
 
 __global__ __launch_bounds__(64) void flood_window_kernel(
@@ -61,18 +67,20 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
     HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
     int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long coop_min_size, int run_limit,
-    int drain_n, int wcap, int tcap, unsigned long long *stats, int shard_rank, int shard_world)
+    int drain_n, int wcap, int tcap, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world)
 {
     __shared__ HeapEnt srun[WIN_RCAP];            // .pad carries the element's label
     __shared__ HeapEnt stage[WIN_STAGE];
+    __shared__ HeapEnt pend[WIN_PEND];            // residuals of the episodes committing now, in (episode, discovery) = age order
     __shared__ u32x4 winq0[WIN_W];                // {key.lo, key.hi, root voxel, label}
-    __shared__ u32x4 winq1[WIN_W];                // {cur voxel | WIN_NONE, meta, maxnew, -}; meta = npush | started << 8 | plist << 16 | cur entry << 24
-    __shared__ uint2 plist[WIN_W * WIN_T];        // discoveries of an episode: {voxel, ordered value}
-    __shared__ unsigned long long ppop[WIN_W];    // popped bits of a plist
+    __shared__ u32x4 winq1[WIN_W];                // {cur voxel | WIN_NONE, meta, max popped value excl. cur, value of cur}; meta = npush | started << 8 | plist << 16 | cur entry << 24
+    __shared__ __attribute__((aligned(16))) uint32_t pidx[WIN_W * WIN_T];   // discoveries of an episode: voxel ...
+    __shared__ __attribute__((aligned(16))) uint32_t pval[WIN_W * WIN_T];   // ... and ordered value (WIN_POPPED once popped)
     __shared__ unsigned short pfree[WIN_W];
     __shared__ unsigned short actpos[WIN_W];
     __shared__ HeapEnt ovl[6 * 64];               // take-overs of this row (at most one per lane and direction): key = old holder, idx = voxel
     __shared__ int hist[64];
+    __shared__ uint32_t lstat[16];
     const uint32_t c = blockIdx.x;
     const int lane = threadIdx.x;
     if (c >= n_comp) return;
@@ -85,8 +93,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     HeapEnt *heap = heap_pool + comp_off[c];
     const uint32_t ns = end - first;
 
-    const int64_t SZ = PY * PX, SY = PX;
-    const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
+    const int noff32[6] = {-(int)(PY * PX), -(int)PX, -1, 1, (int)PX, (int)(PY * PX)};    // voxel indices are 32-bit (host-checked)
     const int ax[6] = {0, 1, 2, 2, 1, 0};
     const float sc[3] = {s0, s1, s2};
     const unsigned long long ZKEY = (unsigned long long)0x80000000u << 32;
@@ -107,21 +114,15 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
 #endif
     cold.cb = COLD_NONE;
     cold.pool_cap = 0;
+    cold.vlo = bk_lo;
+    cold.vinv = bk_inv;
     if (cold.on) {
         HeapEnt *base = arena + arena_off[c];
-        cold.bhead = (uint32_t *)base;
-        cold.btail = cold.bhead + COLD_NBK;
-        cold.bcount = cold.btail + COLD_NBK;
-        cold.bmeta = cold.bcount + COLD_NBK;
-        cold.bfill = cold.bmeta + COLD_NBK;
-        cold.blast = (unsigned long long *)(cold.bfill + COLD_NBK);
-        cold.bm0 = cold.blast + COLD_NBK;
-        cold.bm1 = cold.bm0 + COLD_NBK / 64;
-        cold.pool = base + COLD_META_ENTS;
+        cold.base = (uint32_t *)base;
         cold.pool_cap = (uint32_t)(arena_off[c + 1] - arena_off[c] - COLD_META_ENTS);
-        for (int i = lane; i < COLD_NBK; i += 64) { cold.bhead[i] = COLD_NONE; cold.btail[i] = COLD_NONE; cold.bcount[i] = 0; cold.bmeta[i] = 0; }
-        for (int i = lane; i < COLD_NBK / 64; i += 64) cold.bm0[i] = 0ull;
-        if (lane < COLD_NBK / 4096) cold.bm1[lane] = 0ull;
+        for (int i = lane; i < COLD_NBK; i += 64) { cold.bhead()[i] = COLD_NONE; cold.btail()[i] = COLD_NONE; cold.bcount()[i] = 0; cold.bmeta()[i] = 0; }
+        for (int i = lane; i < COLD_NBK / 64; i += 64) cold.bm0()[i] = 0ull;
+        if (lane < COLD_NBK / 4096) cold.bm1()[lane] = 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
@@ -131,8 +132,12 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     uint32_t agebase = ns - 1;                    // seeds carry ages 0..ns-1 in index order; pushes continue
     uint32_t nspill = 0;                          // elements that could not be queued (kept for the serial continuation)
     bool serial = false, started_any = false;
-    unsigned long long st_sub = 0, st_pops = 0, st_exec = 0, st_sq_ev = 0, st_sq_eps = 0, st_mid = 0, st_evict = 0, st_drain = 0,
-                       st_cold = 0, st_hot = 0, st_rows = 0, st_over = 0, st_forced = 0;
+    bool dirty = false;                           // a key landed right behind an episode since the last bound check
+    // statistics (ISX_FLOOD_STATS) live in LDS, bumped by lane 0: every live scalar costs SGPRs this kernel is short of
+    enum { ST_SUB, ST_POPS, ST_EXEC, ST_HOT, ST_COLD, ST_DRAIN, ST_EVICT, ST_MID, ST_SQ_EV, ST_SQ_EPS, ST_ROWS, ST_OVER, ST_FORCED, ST_SLOW, ST_N };
+    for (int i = lane; i < ST_N; i += 64) lstat[i] = 0u;
+#define WSTAT(i, n) do { if (lane == 0) lstat[i] += (uint32_t)(n); } while (0)
+    uint32_t st_sub = 0;                          // the watchdog's counter stays in a register
 #ifdef ISX_FLOOD_PROF
     unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk_prev = __builtin_readcyclecounter();
 #define WTICK(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); tk_acc[i] += t_ - tk_prev; tk_prev = t_; } while (0)
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
 
     auto slot_of = [&](int p) -> int { const int s = wh + p; return s >= WIN_W ? s - WIN_W : s; };
     auto key_at = [&](int s) -> unsigned long long { const u32x4 q = winq0[s]; return ((unsigned long long)q.y << 32) | q.x; };
-    auto fresh_q1 = [&](uint32_t root_idx, int pl) -> u32x4 { u32x4 q = {root_idx, ((uint32_t)pl << 16) | (0xFFu << 24), 0u, 0u}; return q; };
+    auto fresh_q1 = [&](uint32_t root_idx, int pl) -> u32x4 { u32x4 q = {root_idx, ((uint32_t)pl << 16) | (0xFFu << 24), 0u, 0u}; return q; };   // root not popped yet
 
     // elements that can no longer be queued go to the far end of this component's heap area (the serial
     // continuation picks them up); the queue never holds more than csize elements, so the two ends cannot meet
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         if (!cold.on) { serial = true; return; }
         const int keep = run_limit / 2, ev = scount - keep;
         if (ev <= 0) return;
-        st_evict += (unsigned long long)ev;
+        WSTAT(ST_EVICT, (uint32_t)ev);
         int done = 0;
         while (done < ev) {
             const int m = ev - done < 64 ? ev - done : 64;
@@ -246,20 +251,21 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         WIN_FENCE();
         if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; srun[(shead + pos) & SMASK] = e; }
         ++scount;
+        if (pos == 0) dirty = true;                // new head of the run: the last window episode has a new, lower bound
         WIN_FENCE();
     };
 
     // give the claims of one episode back (lane-parallel over its discoveries)
     auto release_one = [&](unsigned long long key, int pl, int np) {
         for (int i = lane; i < np; i += 64) {
-            const uint32_t v = plist[pl * WIN_T + i].x;
+            const uint32_t v = pidx[pl * WIN_T + i];
             atomicCAS(&state[v], key, ST_FREE);
         }
     };
 
     // squash every episode from window position sp on: claims released, back to "root not popped yet"
     auto squash_from = [&](int sp) {
-        ++st_sq_ev;
+        WSTAT(ST_SQ_EV, 1);
         for (int base = sp; base < nw; base += 64) {
             const int p = base + lane;
             const bool valid = p < nw;
@@ -269,10 +275,10 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             const bool st = valid && ((q1.y >> 8) & 1u);
             const int np = st ? (int)(q1.y & 0xFFu) : 0, pl = (int)((q1.y >> 16) & 0xFFu);
             const unsigned long long key = ((unsigned long long)q0.y << 32) | q0.x;
-            st_sq_eps += (unsigned long long)__popcll(__ballot(st));
+            WSTAT(ST_SQ_EPS, (uint32_t)__popcll(__ballot(st)));
             for (int i = 0; __any(i < np); ++i)
-                if (i < np) { const uint32_t v = plist[pl * WIN_T + i].x; atomicCAS(&state[v], key, ST_FREE); }
-            if (valid) { winq1[s] = fresh_q1(q0.z, pl); ppop[pl] = 0ull; }
+                if (i < np) { const uint32_t v = pidx[pl * WIN_T + i]; atomicCAS(&state[v], key, ST_FREE); }
+            if (valid) winq1[s] = fresh_q1(q0.z, pl);
         }
         WIN_FENCE();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -296,19 +302,19 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             if ((q1.y >> 8) & 1u) {
                 release_one(((unsigned long long)q0.y << 32) | q0.x, pl, (int)(q1.y & 0xFFu));
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                ++st_sq_eps;
+                WSTAT(ST_SQ_EPS, 1);
             }
             shead = (shead - 1) & SMASK;
             if (lane == 0) { u32x4 e = {q0.x, q0.y, q0.z, q0.w}; run_st(srun, shead, e); }
             ++scount;
             --nw;
-            ++st_evict;
+            WSTAT(ST_EVICT, 1);
             if (pos > nw) pos = nw;
         } else {
             pl = (int)pfree[--npfree];
         }
         if (pos < nw) {
-            ++st_mid;
+            WSTAT(ST_MID, 1);
             u32x4 a[3], b[3];
             bool mv[3];
 #pragma unroll
@@ -324,12 +330,12 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 if (mv[cidx]) { const int s = slot_of(pos + cidx * 64 + lane + 1); winq0[s] = a[cidx]; winq1[s] = b[cidx]; }
             WIN_FENCE();
         }
+        dirty = true;                              // the episode before `pos` has a new, lower bound
         if (lane == 0) {
             const int s = slot_of(pos);
             u32x4 q0 = {(uint32_t)ek, (uint32_t)(ek >> 32), ei, el};
             winq0[s] = q0;
             winq1[s] = fresh_q1(ei, pl);
-            ppop[pl] = 0ull;
         }
         ++nw;
         WIN_FENCE();
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
 
     // One (wave-uniform) element that the tier rule keeps hot: window if it sorts into it, else the run.
     auto hot_insert = [&](unsigned long long ek, uint32_t ei, uint32_t el) {
-        ++st_hot;
+        WSTAT(ST_HOT, 1);
         if (nw > 0 && ek < key_at(slot_of(nw - 1))) {
             if ((nw == wcap || npfree == 0) && scount >= WIN_RCAP - 2) { run_evict(); if (serial) { spill64(lane == 0, ek, ei); return; } }
             win_insert(ek, ei, el);
@@ -359,13 +365,13 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             const bool hot_ne = nw > 0 || scount > 0;
             if (scount > 0) hot_max = srun[(shead + scount - 1) & SMASK].key;
             else if (nw > 0) hot_max = key_at(slot_of(nw - 1));
-            tocold = has && !(hot_ne && key < hot_max) && cold_bucket(key) >= cold.low;
+            tocold = has && !(hot_ne && key < hot_max) && cold_bucket(cold, key) >= cold.low;
         }
         {
             const unsigned long long b = __ballot(tocold);
             if (tocold) { HeapEnt e; e.key = key; e.idx = idx; e.pad = lab; stage[nstage + __popcll(b & lt_mask)] = e; }
             nstage += __popcll(b);
-            st_cold += (unsigned long long)__popcll(b);
+            WSTAT(ST_COLD, (uint32_t)__popcll(b));
         }
         WIN_FENCE();
         for (unsigned long long todo = __ballot(has && !tocold); todo; todo &= todo - 1ull) {
@@ -377,10 +383,10 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             bool below_hot_max = false;
             if (scount > 0) below_hot_max = ek < srun[(shead + scount - 1) & SMASK].key;
             else if (nw > 0) below_hot_max = ek < key_at(slot_of(nw - 1));
-            const bool cold_free = !cold.on || (cold.count == 0 && nstage == 0) || cold_bucket(ek) < cold.low;
+            const bool cold_free = !cold.on || (cold.count == 0 && nstage == 0) || cold_bucket(cold, ek) < cold.low;
             if (!below_hot_max && !cold_free) {
                 if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; stage[nstage] = e; }
-                ++nstage; ++st_cold;
+                ++nstage; WSTAT(ST_COLD, 1);
                 WIN_FENCE();
                 if (nstage >= WIN_STAGE - 64) flush_stage(64);
                 continue;
@@ -406,7 +412,6 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             u32x4 q0 = {(uint32_t)k, (uint32_t)(k >> 32), vi, out[vi]};
             winq0[j] = q0;
             winq1[j] = fresh_q1(vi, pl);
-            ppop[pl] = 0ull;
         }
         nw = (int)in_win;
         npfree -= (int)in_win;
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     // Watchdog (never expected to trip): the loop below commits at least the front episode every few sub-rounds, so far
     // fewer than this many are ever needed.  A trip is reported to the host as an error (stats[9]) with the state of
     // the front of the window; the component is then finished by the serial heap so that the grid always drains.
-    const unsigned long long sub_limit = 4096ull + 64ull * csize;
+    const uint32_t sub_limit = csize > 60000000ull ? 0xFFFFFFFFu : 4096u + 64u * (uint32_t)csize;
     while (!serial && nw > 0) {
         ++st_sub;
         if (st_sub > sub_limit) {
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 stats[24] = (unsigned long long)nw; stats[25] = (unsigned long long)scount; stats[26] = (unsigned long long)cold.count;
                 stats[27] = ((unsigned long long)f1.x << 32) | f1.y; stats[28] = ((unsigned long long)f0.y << 32) | f0.x;
                 stats[29] = scount > 0 ? srun[shead].key : ~0ull; stats[30] = ((unsigned long long)f1.z << 32) | (uint32_t)nstage;
-                stats[31] = st_pops;
+                stats[31] = (unsigned long long)lstat[ST_POPS];
                 const u32x4 g0 = winq0[slot_of(1)], g1 = winq1[slot_of(1)];
                 stats[20] = ((unsigned long long)g0.y << 32) | g0.x; stats[21] = ((unsigned long long)g1.x << 32) | g1.y; stats[22] = (unsigned long long)wh;
                 stats[23] = (unsigned long long)npfree;
@@ -455,23 +460,26 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         }
         WTICK(0);
         if (scount > run_limit) { run_evict(); if (serial) break; }
-        // ---- A: an episode that popped past its bound (bound = value of the next larger queued key) is wrong ----
+        // ---- A: an episode that popped past its bound (bound = value of the next larger queued key) is wrong.  A bound
+        //         only ever drops when a new key lands right behind an episode, so the scan runs after such insertions only
         const unsigned long long qhead = scount > 0 ? srun[shead].key : ~0ull;
-        {
+        if (dirty) {
+            dirty = false;
             int sp = -1;
             for (int base = 0; base < nw && sp < 0; base += 64) {
                 const int p = base + lane;
-                const bool valid = p < nw;
                 bool over = false;
-                if (valid) {
+                if (p < nw) {
                     const u32x4 q1 = winq1[slot_of(p)];
                     const unsigned long long nk = p + 1 < nw ? key_at(slot_of(p + 1)) : qhead;
-                    over = q1.z != 0u && q1.z >= (uint32_t)(nk >> 32);
+                    uint32_t mx = q1.z;
+                    if ((q1.y >> 24) != 0xFFu && q1.w > mx) mx = q1.w;          // the element it is about to pop counts
+                    over = mx != 0u && mx >= (uint32_t)(nk >> 32);
                 }
                 const unsigned long long ob = __ballot(over);
                 if (ob) sp = base + __ffsll((long long)ob) - 1;
             }
-            if (sp >= 0) { ++st_over; squash_from(sp); }
+            if (sp >= 0) { WSTAT(ST_OVER, 1); squash_from(sp); }
         }
         // ---- B: episodes that want to pop ------------------------------------------------------------------------
         int nact = 0;
@@ -498,66 +506,78 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         unsigned long long squash_key = ~0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // label stores / releases of earlier sub-rounds are performed
         for (int r0 = 0; r0 < nact; r0 += 64) {
-            ++st_rows;
+            WSTAT(ST_ROWS, 1);
             const bool act = r0 + lane < nact;
             const int p = act ? (int)actpos[r0 + lane] : 0;
             const int s = slot_of(p);
             const u32x4 q0 = winq0[s];
             u32x4 q1 = winq1[s];
             const unsigned long long mykey = ((unsigned long long)q0.y << 32) | q0.x;
-            const int64_t cv = (int64_t)q1.x;                     // the voxel popped now (idle lanes: front root, unused)
+            const uint32_t cv = q1.x;                             // the voxel popped now (idle lanes: front root, unused)
             const int pl = (int)((q1.y >> 16) & 0xFFu);
-            int np = ((q1.y >> 8) & 1u) ? (int)(q1.y & 0xFFu) : 0;
+            const bool was_started = (q1.y >> 8) & 1u;
+            int np = was_started ? (int)(q1.y & 0xFFu) : 0;
+            uint32_t mx = q1.z;
+            if (was_started && q1.w > mx) mx = q1.w;              // the popped element joins "everything this episode popped"
             unsigned long long old[6];
             float val[6];
-            int64_t nbv[6];
+            uint32_t nbv[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                nbv[k] = cv + noff[k];
+                nbv[k] = cv + (uint32_t)noff32[k];
                 old[k] = 0ull;
                 val[k] = 0.0f;
-                if (act && nbv[k] >= 0 && nbv[k] < PN) {      // always true with the padded border; never fault
+                if (act && nbv[k] < (uint32_t)PN) {           // always true with the padded border; never fault
                     old[k] = __hip_atomic_fetch_min(&state[nbv[k]], mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    val[k] = aff[(int64_t)ax[k] * PN + (k < 3 ? cv : nbv[k])];
+                    val[k] = (aff + (int64_t)ax[k] * PN)[k < 3 ? cv : nbv[k]];
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             WTICK(2);
             // old > mykey: the voxel was free or held by a later episode -- it is mine now
-            uint32_t won = 0;
-            int novr = 0;
+            uint32_t won = 0, tookmask = 0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 if (act && old[k] > mykey) {
                     won |= 1u << k;
-                    if (old[k] != ST_FREE) ++novr;
+                    if (old[k] != ST_FREE) tookmask |= 1u << k;
                 }
             }
-            // take-overs: a claim made in this very row is simply lost by its lane; an older one squashes its episode
-            const unsigned long long ovb = __ballot(novr > 0);
-            if (ovb) {
-                int slot = (int)wave_excl_sum((uint32_t)novr, lane);
-                int n_ovl = 0;
-                {
-                    uint32_t tot = (uint32_t)novr;
+            // Take-overs.  A lane whose claim of THIS row was taken over again (a later arrival of an earlier episode) simply
+            // loses it: it finds out by reading the voxel back.  A take-over from an episode that had claimed the voxel in an
+            // earlier sub-round makes that episode wrong.  Every fresh loss corresponds to exactly one take-over, so the
+            // counts differ iff an older claim was hit; only then is the list of take-overs matched entry by entry.
+            if (__ballot(tookmask != 0u)) {
+                unsigned long long now[6];
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-                    n_ovl = (int)tot;
+                for (int k = 0; k < 6; ++k) {
+                    now[k] = mykey;
+                    if (won & (1u << k)) now[k] = __hip_atomic_load(&state[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t lost = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if ((won & (1u << k)) && now[k] != mykey) lost |= 1u << k;
+                const uint32_t took_incl = wave_incl_sum((uint32_t)__popc(tookmask));
+                const uint32_t n_took = rdlane(took_incl, 63), n_lost = rdlane(wave_incl_sum((uint32_t)__popc(lost)), 63);
+                if (n_took != n_lost) {
+                    WSTAT(ST_SLOW, 1);
+                    int slot = (int)(took_incl - (uint32_t)__popc(tookmask));
 #pragma unroll
                     for (int k = 0; k < 6; ++k)
-                        if ((won & (1u << k)) && old[k] != ST_FREE) { HeapEnt e; e.key = old[k]; e.idx = (uint32_t)nbv[k]; e.pad = 0; ovl[slot++] = e; }
+                        if (tookmask & (1u << k)) { HeapEnt e; e.key = old[k]; e.idx = nbv[k]; e.pad = 0; ovl[slot++] = e; }
                     WIN_FENCE();
-                    for (int i = 0; i < n_ovl; ++i) {
+                    for (int i = 0; i < (int)n_took; ++i) {
                         const HeapEnt e = ovl[i];
                         bool mine = false;
 #pragma unroll
                         for (int k = 0; k < 6; ++k)
-                            if ((won & (1u << k)) && (uint32_t)nbv[k] == e.idx && mykey == e.key) { won &= ~(1u << k); mine = true; }
+                            if ((won & (1u << k)) && nbv[k] == e.idx && mykey == e.key) mine = true;
                         if (!__any(mine) && e.key < squash_key) squash_key = e.key;
                     }
                 }
+                won &= ~lost;
             }
             // discoveries in direction order = the reference's push order (watershed.py:146-158)
             if (act) {
@@ -565,39 +585,45 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 for (int k = 0; k < 6; ++k)
                     if (won & (1u << k)) {
                         const float v = val[k] * sc[ax[k]] + 0.0f;              // -0.0 == +0.0 in the order
-                        plist[pl * WIN_T + np] = uint2{(uint32_t)nbv[k], ford(v)};
+                        pidx[pl * WIN_T + np] = nbv[k];
+                        pval[pl * WIN_T + np] = ford(v);
                         ++np;
                     }
             }
             WIN_FENCE();
-            // next pop: the smallest unpopped discovery, if it sorts below the next queued key
-            unsigned long long pop = act ? ppop[pl] : 0ull;
-            uint32_t bf = 0xFFFFFFFFu;
+            // next pop: the smallest unpopped discovery (ties: the earliest), if it sorts below the next queued key
+            uint32_t bf = WIN_POPPED;
             int bi = -1;
-            for (int i = 0; __any(act && i < np); ++i) {
-                if (act && i < np && !((pop >> i) & 1ull)) {
-                    const uint32_t fv = plist[pl * WIN_T + i].y;
-                    if (fv < bf) { bf = fv; bi = i; }
+            {
+                const u32x4 *pv4 = (const u32x4 *)&pval[pl * WIN_T];
+                for (int i4 = 0; __any(act && 4 * i4 < np); ++i4) {
+                    if (act && 4 * i4 < np) {
+                        const u32x4 v4 = pv4[i4];
+                        const int i = 4 * i4;
+                        if (v4.x < bf) { bf = v4.x; bi = i; }
+                        if (i + 1 < np && v4.y < bf) { bf = v4.y; bi = i + 1; }
+                        if (i + 2 < np && v4.z < bf) { bf = v4.z; bi = i + 2; }
+                        if (i + 3 < np && v4.w < bf) { bf = v4.w; bi = i + 3; }
+                    }
                 }
             }
             if (act) {
                 const unsigned long long nk = p + 1 < nw ? key_at(slot_of(p + 1)) : qhead;
                 const uint32_t bound = (uint32_t)(nk >> 32);
-                uint32_t mx = q1.z;
-                uint32_t cur = WIN_NONE, curi = 0xFFu;
+                uint32_t cur = WIN_NONE, curi = 0xFFu, curv = 0u;
                 if (bi >= 0 && bf < bound) {
-                    cur = plist[pl * WIN_T + bi].x;
+                    cur = pidx[pl * WIN_T + bi];
                     curi = (uint32_t)bi;
-                    pop |= 1ull << bi;
-                    if (bf > mx) mx = bf;
+                    curv = bf;
+                    pval[pl * WIN_T + bi] = WIN_POPPED;
                 }
                 q1.x = cur;
                 q1.y = (uint32_t)np | (1u << 8) | ((uint32_t)pl << 16) | (curi << 24);
                 q1.z = mx;
+                q1.w = curv;
                 winq1[s] = q1;
-                ppop[pl] = pop;
             }
-            st_exec += (unsigned long long)__popcll(__ballot(act));
+            WSTAT(ST_EXEC, (uint32_t)__popcll(__ballot(act)));
             WIN_FENCE();
             WTICK(3);
         }
@@ -621,23 +647,29 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             if (valid) { q0 = winq0[s]; q1 = winq1[s]; }
             const bool st = valid && ((q1.y >> 8) & 1u);
             const int np = st ? (int)(q1.y & 0xFFu) : 0, pl = (int)((q1.y >> 16) & 0xFFu);
-            unsigned long long pop = st ? ppop[pl] : 0ull;
             bool idle = st && q1.x == WIN_NONE;
             // the front episode with a full list commits what it has done: the element it was about to pop goes back to
             // the queue like any other residual
             const bool forced = front_forced && j == 0 && st && q1.x != WIN_NONE && np + 6 > tcap;
-            if (forced) { pop &= ~(1ull << ((q1.y >> 24) & 0xFFu)); idle = true; }
+            if (forced) { pval[pl * WIN_T + (int)(q1.y >> 24)] = q1.w; idle = true; }
+            WIN_FENCE();
             const unsigned long long nb_ = ~__ballot(idle);
             const int m = nb_ ? __ffsll((long long)nb_) - 1 : 64;       // leading idle episodes
-            uint32_t resmin = 0xFFFFFFFFu, maxpop = 0u;
-            for (int i = 0; __any(j < m && i < np); ++i) {
-                if (j < m && i < np) {
-                    const uint32_t fv = plist[pl * WIN_T + i].y;
-                    if ((pop >> i) & 1ull) { if (fv > maxpop) maxpop = fv; }
-                    else if (fv < resmin) resmin = fv;
+            uint32_t resmin = 0xFFFFFFFFu, pc = 0u;                     // smallest residual, number of residuals
+            {
+                const u32x4 *pv4 = (const u32x4 *)&pval[pl * WIN_T];
+                for (int i4 = 0; __any(j < m && 4 * i4 < np); ++i4) {
+                    if (j < m && 4 * i4 < np) {
+                        const u32x4 v4 = pv4[i4];
+                        const int i = 4 * i4;
+                        if (v4.x != WIN_POPPED) { ++pc; if (v4.x < resmin) resmin = v4.x; }
+                        if (i + 1 < np && v4.y != WIN_POPPED) { ++pc; if (v4.y < resmin) resmin = v4.y; }
+                        if (i + 2 < np && v4.z != WIN_POPPED) { ++pc; if (v4.z < resmin) resmin = v4.z; }
+                        if (i + 3 < np && v4.w != WIN_POPPED) { ++pc; if (v4.w < resmin) resmin = v4.w; }
+                    }
                 }
             }
-            const uint32_t maxnew = forced ? maxpop : q1.z;
+            const uint32_t maxnew = q1.z;                               // an idle episode has no element in hand; forced: excluded
             // residuals of the episodes committing before me must all sort after everything I popped (they are older
             // than my discoveries: strict for those; my root is older than any residual: ties go to the root)
             uint32_t F = wave_shr1(wave_prefix_min(j < m ? resmin : 0xFFFFFFFFu), 0xFFFFFFFFu);
@@ -645,42 +677,61 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             if (qv < F) F = qv;
             const bool ok = j < m && q0.y <= F && (maxnew == 0u || maxnew < F);
             const unsigned long long nok = ~__ballot(ok);
-            const int ncommit = nok ? __ffsll((long long)nok) - 1 : 64;
+            int ncommit = nok ? __ffsll((long long)nok) - 1 : 64;
             if (ncommit > 0) {
-                if (rdlane((uint32_t)forced, 0)) ++st_forced;
+                // residuals enter the queue in age order (a bucket whose appends arrive in key order drains as a FIFO):
+                // they are gathered in `pend` first, episode by episode; the burst is cut where `pend` would overflow
+                if (j >= ncommit) pc = 0u;
+                uint32_t poff = wave_incl_sum(pc) - pc;
+                {
+                    const unsigned long long fits = __ballot(j >= ncommit || poff + pc <= (uint32_t)WIN_PEND);
+                    const int nf = (~fits) ? __ffsll((long long)~fits) - 1 : 64;
+                    if (nf < ncommit) ncommit = nf;                    // >= 1: one list always fits
+                }
                 const bool cm = j < ncommit;
-                const uint32_t mybase = agebase + wave_excl_sum(cm ? (uint32_t)np : 0u, lane);
-                {
-                    uint32_t tot = cm ? (uint32_t)np : 0u;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-                    agebase += tot;
-                }
-                st_pops += (unsigned long long)__popcll(__ballot(cm));
-                {
-                    uint32_t pc = cm ? (uint32_t)__popcll(pop) : 0u;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) pc += __shfl_xor(pc, o);
-                    st_pops += pc;
-                }
+                if (!cm) pc = 0u;
+                if (rdlane((uint32_t)forced, 0)) WSTAT(ST_FORCED, 1);
+                const uint32_t np_incl = wave_incl_sum(cm ? (uint32_t)np : 0u);
+                const uint32_t mybase = agebase + np_incl - (cm ? (uint32_t)np : 0u);
+                const uint32_t tot = rdlane(np_incl, 63), ptotal = rdlane(wave_incl_sum(pc), 63);
+                agebase += tot;
+                WSTAT(ST_POPS, tot - ptotal + (uint32_t)ncommit);           // popped discoveries + the roots
                 const uint32_t lab = q0.w;
-                // the committed slots leave the window now; their lists stay untouched until the loop below is done
-                wh = slot_of(ncommit);
-                nw -= ncommit;
-                for (int i = 0; __any(cm && i < np); ++i) {
-                    const bool has = cm && i < np;
-                    uint2 e = uint2{0u, 0u};
-                    if (has) {
-                        e = plist[pl * WIN_T + i];
-                        __hip_atomic_store(&state[e.x], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        out[e.x] = lab;                                  // label at discovery (watershed.py:153)
+                {
+                    const u32x4 *pi4 = (const u32x4 *)&pidx[pl * WIN_T], *pv4 = (const u32x4 *)&pval[pl * WIN_T];
+                    for (int i4 = 0; __any(cm && 4 * i4 < np); ++i4) {
+                        if (cm && 4 * i4 < np) {
+                            const u32x4 v4 = pi4[i4], f4 = pv4[i4];
+                            const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w}, ff[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int i = 4 * i4 + e;
+                                if (i < np) {
+                                    __hip_atomic_store(&state[vv[e]], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    out[vv[e]] = lab;                    // label at discovery (watershed.py:153)
+                                    if (ff[e] != WIN_POPPED) {
+                                        HeapEnt r;
+                                        r.key = ((unsigned long long)ff[e] << 32) | (unsigned long long)(mybase + (uint32_t)i + 1u);
+                                        r.idx = vv[e];
+                                        r.pad = lab;
+                                        pend[poff++] = r;
+                                    }
+                                }
+                            }
+                        }
                     }
-                    const bool pending = has && !((pop >> i) & 1ull);
-                    enqueue64(pending, ((unsigned long long)e.y << 32) | (unsigned long long)(mybase + (uint32_t)i + 1u), e.x, lab);
                 }
                 if (cm) pfree[npfree + j] = (unsigned short)pl;
                 npfree += ncommit;
+                wh = slot_of(ncommit);
+                nw -= ncommit;
                 WIN_FENCE();
+                for (uint32_t b0 = 0; b0 < ptotal; b0 += 64u) {
+                    const bool has = b0 + (uint32_t)lane < ptotal;
+                    HeapEnt r; r.key = 0; r.idx = 0; r.pad = 0;
+                    if (has) r = pend[b0 + lane];
+                    enqueue64(has, r.key, r.idx, r.pad);
+                }
             }
         }
         WTICK(5);
@@ -690,7 +741,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         {
             if (scount == 0 && cold.on && (cold.count > 0 || nstage > 0)) {
                 if (nstage > 0) { flush_stage(nstage); if (serial) break; }
-                if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; ++st_drain; }
+                if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; WSTAT(ST_DRAIN, 1); }
             }
             while (nw < wcap && scount > 0) {
                 int take = wcap - nw;
@@ -704,7 +755,6 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                     const int s = slot_of(nw + lane);
                     winq0[s] = e;
                     winq1[s] = fresh_q1(e.z, pl);
-                    ppop[pl] = 0ull;
                 }
                 npfree -= take;
                 nw += take;
@@ -713,7 +763,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 WIN_FENCE();
                 if (scount == 0 && cold.on && (cold.count > 0 || nstage > 0)) {
                     if (nstage > 0) { flush_stage(nstage); if (serial) break; }
-                    if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; ++st_drain; }
+                    if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; WSTAT(ST_DRAIN, 1); }
                 }
             }
             if (serial) break;
@@ -726,12 +776,9 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         for (int i = 0; i < 8; ++i) { atomicAdd(&stats[16 + i], tk_acc[i]); if (i < 4) atomicAdd(&stats[24 + i], cold.tk[i]); }
 #endif
     if (stats && lane == 0) {
-        atomicAdd(&stats[0], st_sub); atomicAdd(&stats[1], st_pops); atomicAdd(&stats[2], st_exec); atomicAdd(&stats[3], st_hot);
-        atomicAdd(&stats[4], st_cold); atomicAdd(&stats[5], st_drain); atomicAdd(&stats[6], st_evict); atomicAdd(&stats[7], st_mid);
-        if (serial) atomicAdd(&stats[8], 1ull);
-        if (cold.fifo_drains) atomicAdd(&stats[10], (unsigned long long)cold.fifo_drains);
-        atomicAdd(&stats[11], st_sq_ev); atomicAdd(&stats[12], st_sq_eps); atomicAdd(&stats[13], st_rows); atomicAdd(&stats[14], st_over);
-        atomicAdd(&stats[15], st_forced);
+        atomicAdd(&stats[0], (unsigned long long)st_sub);
+        const int gidx[ST_N] = {0, 1, 2, 3, 4, 5, 6, 7, 11, 12, 13, 14, 15, 19};
+        for (int i = 1; i < ST_N; ++i) atomicAdd(&stats[gidx[i]], (unsigned long long)lstat[i]);
     }
     if (serial) {
         // Exact continuation on one lane: every queued element (window roots -- their speculative work is dropped,
@@ -757,14 +804,14 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             if (cold.on) {
                 while (cold.count > 0) {
                     const uint32_t b = cold_lowest(cold, lane);
-                    uint32_t seg = cld32(&cold.bhead[b]);
-                    uint32_t off = cld32(&cold.bmeta[b]) & ~COLD_UNSORTED;
+                    uint32_t seg = cld32(&cold.bhead()[b]);
+                    uint32_t off = cld32(&cold.bmeta()[b]) & ~COLD_UNSORTED;
                     uint32_t got = 0;
                     while (seg != COLD_NONE) {
-                        const HeapEnt h = cld_ent(&cold.pool[seg]);
+                        const HeapEnt h = cld_ent(&cold.pool()[seg]);
                         const uint32_t n = (uint32_t)(h.key >> 32);
                         if (lane == 0)
-                            for (uint32_t j = off; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
+                            for (uint32_t j = off; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool()[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
                         got += n - off;
                         off = 0;
                         seg = (uint32_t)h.key;
