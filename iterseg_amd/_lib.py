@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libitersegx.so")
 
 ISX_OK = 0
-ISX_ERR_NO_DEVICE, ISX_ERR_HIP, ISX_ERR_ARG, ISX_ERR_NO_SEEDS, ISX_ERR_STATE, ISX_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+ISX_ERR_NO_DEVICE, ISX_ERR_HIP, ISX_ERR_ARG, ISX_ERR_NO_SEEDS, ISX_ERR_STATE, ISX_ERR_NOMEM, ISX_ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7
 PROF_CLASSES = {"conv_mfma": 0, "conv_direct": 1, "elementwise": 2, "ws_filters": 3, "ws_ccl": 4, "ws_flood": 5}
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -105,6 +105,11 @@ def _dims(shape):
     return a
 
 
+class NoSeedsError(ValueError):
+    """Zero seeds survive (ISX_ERR_NO_SEEDS).  A ValueError like the reference's own failure at this point
+    (np.apply_along_axis, watershed.py:50), as its own subclass so that callers can tell it from a bad argument."""
+
+
 def check(rc):
     if rc == ISX_OK:
         return
@@ -112,7 +117,7 @@ def check(rc):
     if rc == ISX_ERR_NO_SEEDS:
         # the reference fails here with this exact exception type (np.apply_along_axis on an
         # empty seed list, src/iterseg/watershed.py:50)
-        raise ValueError("Cannot apply_along_axis when any iteration dimensions are 0 [" + msg + "]")
+        raise NoSeedsError("Cannot apply_along_axis when any iteration dimensions are 0 [" + msg + "]")
     if rc == ISX_ERR_ARG:
         raise ValueError(msg)
     raise IsxError(rc, msg)

@@ -303,17 +303,16 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 // ------------------------------------------------------------------------------------------------
 // 64-column tiles whenever two work-groups still fit into the 160 KB of LDS (weight slab 57 KB + 32 B per halo slot)
 // two row tiles per wave for the 32-column tiles: only for launches that still fill the chip with 256-voxel tiles
-int h2_mt(const Level &l, int batch)
+int h2_mt(const isx_tune &tune, const Level &l, int batch)
 {
-    const char *e = getenv("ISX_H2_MT2");                  // 0: never, 1 (default): big launches, 2: always (tests)
-    const int on = e ? atoi(e) : 1;
+    const int on = tune.h2_mt2;                            // 0: never, 1 (default): big launches, 2: always (tests)
     return on == 2 || (on && (int64_t)batch * l.M >= (1 << 21));
 }
 
-int conv_h2_bn(int slots, int cout)
+int conv_h2_bn(const isx_tune &tune, int slots, int cout)
 {
     const size_t lds64 = (size_t)(2 * 28 * 64 + 2 * slots) * 16 + (128 + 4 * 64 * 2) * sizeof(float);
-    static const int force64 = getenv("ISX_H2_FORCE_BN64") ? atoi(getenv("ISX_H2_FORCE_BN64")) : 0;
+    const int force64 = tune.h2_force_bn64;
     return (cout % 64 == 0 && (force64 || 2 * lds64 <= 160 * 1024)) ? 64 : 32;
 }
 
@@ -375,12 +374,12 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.no_stats = no_stats;
     a.xcd_remap = xcd_remap;
     ISX_REQUIRE((fold || cout % 32 == 0) && sa.C % 8 == 0 && sb.C % 8 == 0, "internal: split-f16 conv needs Cout %% 32 == 0, Cin %% 8 == 0");
-    int BN = fold ? 32 : conv_h2_bn(a.slots_max, cout);
+    int BN = fold ? 32 : conv_h2_bn(ctx->tune, a.slots_max, cout);
     // 32-column tiles get two row tiles per wave (256-voxel work-groups) when the launch is big enough to fill
     // the chip that way; the partial-sum layout then follows that tiling (mt is fixed per workspace: h2_mt)
     // (the folded layer stays at one row tile: measured 9.7 ms against 10.9 with two; 16-channel stages for it were
     // tried as well and lost a wave per SIMD: 11.6-15.2 ms)
-    int mt = (!fold && BN == 32 && h2_mt(l, ctx->unet->wbatch)) ? 2 : 1;
+    int mt = (!fold && BN == 32 && h2_mt(ctx->tune, l, ctx->unet->wbatch)) ? 2 : 1;
     if (mt == 2) {
         int ty, tx, tp, sl;
         const int tiles2 = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
@@ -394,8 +393,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
-    static bool attr_done_dev[64] = {false};             // the attribute is per device: one flag per device ordinal
-    bool &attr_done = attr_done_dev[ctx->device & 63];
+    bool &attr_done = ctx->h2_attr_done;                  // per context (setting it again from another context is harmless)
     if (!attr_done) {
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

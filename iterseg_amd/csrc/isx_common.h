@@ -58,8 +58,19 @@ struct UNetState;   // unet.hip
 
 // Size-bucketed cache of hipMalloc'd blocks: the hot path allocates its scratch once and
 // then reuses it for every chunk / frame (no hipMalloc inside steady-state steps).
+// Development knobs (environment, read ONCE per context at isx_ctx_create): the library keeps no process-global mutable
+// state -- everything lives in the handle, so contexts can be driven from different host threads.
+struct isx_tune {
+    int h2_mt2 = 1;                 // ISX_H2_MT2: 0 never, 1 big launches, 2 always -- two row tiles per wave in conv_h2
+    int h2_force_bn64 = 0;          // ISX_H2_FORCE_BN64
+    int xcd_remap = 1;              // ISX_CONV_XCD_REMAP
+    long mt2_min_vox = 1L << 60;    // ISX_CONV_MT2_MIN_VOX
+};
+
 struct isx_ctx {
     int device = 0;
+    isx_tune tune;
+    bool h2_attr_done = false;      // dynamic-LDS attribute of the conv_h2 kernels set for this context's device
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     std::multimap<size_t, void *> free_blocks;

@@ -985,6 +985,10 @@ static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dic
     ISX_HIP(hipSetDevice(ctx->device));
     UNetState *u = ctx->unet;
     TrainState *t = u->train;
+    // the context's U-Net workspace may have been re-shaped by an inference call with another chunk geometry since the
+    // last step (the trained UNet object is handed back to the caller): the backward buffers are sized for the patch
+    // bound at isx_train_bind, so the forward workspace is brought back to it first (a no-op when nothing changed)
+    ISX_TRY(prepare_workspace(ctx, t->cz, t->cy, t->cx, 1));
     const Level &l0 = u->lv[0];
     const int C = u->out_channels;
     ISX_REQUIRE(C <= 8, "at most 8 output channels");
@@ -1067,7 +1071,8 @@ int isx_train_step(isx_ctx *ctx, const float *x, const float *y, int loss_kind, 
     if (!ctx->unet || !ctx->unet->train) { set_error("call isx_train_bind first"); return ISX_ERR_STATE; }
     ISX_REQUIRE(loss_kind >= 0 && loss_kind <= 3 && (loss_kind != 2 || chan_weights), "loss kind");
     const int C = ctx->unet->out_channels;
-    const double MC = (double)ctx->unet->lv[0].M * C;
+    const TrainState *tb = ctx->unet->train;                   // the bound patch, not whatever the workspace currently holds
+    const double MC = (double)tb->cz * tb->cy * tb->cx * C;
     LossSpec spec;
     for (int c = 0; c < 8; ++c) {
         spec.kind[c] = loss_kind == 1 ? 1 : 0;
@@ -1082,7 +1087,8 @@ int isx_train_step_channelwise(isx_ctx *ctx, const float *x, const float *y, con
     ISX_REQUIRE(ctx && x && y && loss_out && chan_kind && chan_weight, "null argument");
     if (!ctx->unet || !ctx->unet->train) { set_error("call isx_train_bind first"); return ISX_ERR_STATE; }
     const int C = ctx->unet->out_channels;
-    const double M = (double)ctx->unet->lv[0].M;
+    const TrainState *tb = ctx->unet->train;                   // the bound patch, not whatever the workspace currently holds
+    const double M = (double)tb->cz * tb->cy * tb->cx;
     LossSpec spec;
     for (int c = 0; c < 8; ++c) {
         spec.kind[c] = 0;

@@ -987,17 +987,10 @@ int conv_mode(const Level &l)
 // the 64-column layers; for the 32-column layers +3 % at level 0 and -5 % at 129^2 (16-wide tiles pad more), a wash
 // end to end.  So it is off; ISX_CONV_MT2_MIN_VOX turns it on for launches above that many voxels.  Decided from
 // the workspace batch so that the partial-sum layout of a layer never changes.
-int conv_mt(const Level &l, int batch, int cout)
+int conv_mt(const isx_tune &tune, const Level &l, int batch, int cout)
 {
-    static const long min_vox = getenv("ISX_CONV_MT2_MIN_VOX") ? atol(getenv("ISX_CONV_MT2_MIN_VOX")) : (1L << 60);
     (void)cout;
-    return ((int64_t)batch * l.M >= min_vox) ? 2 : 1;
-}
-
-static int conv_xcd_remap()
-{
-    static const int v = getenv("ISX_CONV_XCD_REMAP") ? atoi(getenv("ISX_CONV_XCD_REMAP")) : 1;
-    return v;
+    return ((int64_t)batch * l.M >= tune.mt2_min_vox) ? 2 : 1;
 }
 
 int conv_tiles(const Level &l, int mode, int mt, int *nty, int *ntx, int *ntp, int *slots)
@@ -1023,7 +1016,7 @@ static int layer_tiles(const UNetState *u, int li, const Level &l, int batch)
     const ConvBN &L = u->cv[li];
     if (use_mfma(L.cin, L.cout)) {
         int a, b, c, d;
-        return conv_tiles(l, conv_mode(l), conv_mt(l, batch, L.cout > 8 ? L.cout : 32), &a, &b, &c, &d);
+        return conv_tiles(l, conv_mode(l), conv_mt(u->tune, l, batch, L.cout > 8 ? L.cout : 32), &a, &b, &c, &d);
     }
     if (L.cin == 1) return (int)((l.M + 127) / 128);
     if (L.cin == 5 && L.cout == 5) return ((l.D + 1) / 2) * ((l.H + 7) / 8) * ((l.W + 15) / 16);     // conv55 tiles
@@ -1085,11 +1078,11 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     a.w = w_packed; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
     a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = cout;
     a.mode = conv_mode(l);
-    const int mt = conv_mt(l, ctx->unet->wbatch, cout);
+    const int mt = conv_mt(ctx->tune, l, ctx->unet->wbatch, cout);
     a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
     a.store_cols = cout;
     a.no_stats = no_stats;
-    a.xcd_remap = conv_xcd_remap();
+    a.xcd_remap = ctx->tune.xcd_remap;
     ISX_REQUIRE(a.slots_max <= (mt > 1 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     ISX_REQUIRE(cout % 32 == 0 && (sa.C + sb.C) % 4 == 0, "internal: MFMA conv needs Cout %% 32 == 0, Cin %% 4 == 0");
     const int BN = (cout % 64 == 0) ? 64 : 32;
@@ -1115,19 +1108,19 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
         ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
         int t0, t1, t2, slots;
         conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
-        const void *wh = conv_h2_bn(slots, L.cout) == 64 ? L.w_h2_64 : L.w_h2_32;
+        const void *wh = conv_h2_bn(ctx->tune, slots, L.cout) == 64 ? L.w_h2_64 : L.w_h2_32;
         const bool in_range = std::max(sa.bound, sb.bound) < 6.0e4f;          // else operands could leave the f16 range
-        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && wh && in_range && conv_mt(l, u->wbatch, L.cout) == 1)
-            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, conv_xcd_remap(), 0, &stat_tiles));
+        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && wh && in_range && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1)
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, 0, &stat_tiles));
         else
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
     } else if (use_fold(L.cin, L.cout)) {
         // pass 1 on the matrix cores: 9 (dz,dy) taps, x-taps folded into 3*cout <= 16 output columns
         if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && L.w_h2_32 && std::max(sa.bound, sb.bound) < 6.0e4f &&
-            conv_mt(l, u->wbatch, 32) == 1) {
+            conv_mt(ctx->tune, l, u->wbatch, 32) == 1) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, L.w_h2_32, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
-                                   conv_xcd_remap(), 1, nullptr));
+                                   ctx->tune.xcd_remap, 1, nullptr));
         } else {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ConvArgs a;
@@ -1136,11 +1129,11 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
             a.w = L.w; a.bias = u->zeros32; a.out = u->ptail; a.psum = nullptr; a.psq = nullptr;
             a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = 32;
             a.mode = conv_mode(l);
-            const int mt = conv_mt(l, u->wbatch, 32);
+            const int mt = conv_mt(ctx->tune, l, u->wbatch, 32);
             a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
             a.store_cols = 16;
             a.no_stats = 1;
-            a.xcd_remap = conv_xcd_remap();
+            a.xcd_remap = ctx->tune.xcd_remap;
             ISX_REQUIRE(a.slots_max <= (mt > 1 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
             size_t lds = (size_t)(9 * 4 * 32 + a.slots_max * A_STRIDE + 128 * mt + 4 * 32 * 2) * sizeof(float);
             a.ntiles = 1;
@@ -1320,7 +1313,7 @@ extern "C" {
 int isx_load_weight_host(isx_ctx *ctx, const char *key, const void *data, const int64_t *shape, int ndim)
 {
     ISX_REQUIRE(ctx && key && data && ndim >= 0 && ndim <= 5 && (shape || ndim == 0), "bad argument");
-    if (!ctx->unet) ctx->unet = new UNetState();
+    if (!ctx->unet) { ctx->unet = new UNetState(); ctx->unet->tune = ctx->tune; }
     UNetState *u = ctx->unet;
     if (u->committed) { set_error("weights already committed; create a new context to load another network"); return ISX_ERR_STATE; }
     HostTensor t;
@@ -1380,7 +1373,7 @@ int isx_get_weight_host(isx_ctx *ctx, const char *key, void *data, int64_t nbyte
 int isx_unet_set_precision(isx_ctx *ctx, int mode)
 {
     ISX_REQUIRE(ctx && (mode == ISX_PRECISION_FP32 || mode == ISX_PRECISION_SPLIT_F16), "precision mode %d", mode);
-    if (!ctx->unet) ctx->unet = new UNetState();
+    if (!ctx->unet) { ctx->unet = new UNetState(); ctx->unet->tune = ctx->tune; }
     ctx->unet->precision = mode;
     return ISX_OK;
 }
@@ -1388,7 +1381,7 @@ int isx_unet_set_precision(isx_ctx *ctx, int mode)
 int isx_unet_set_batch(isx_ctx *ctx, int batch)
 {
     ISX_REQUIRE(ctx && batch >= 1 && batch <= 64, "batch must be 1..64");
-    if (!ctx->unet) ctx->unet = new UNetState();
+    if (!ctx->unet) { ctx->unet = new UNetState(); ctx->unet->tune = ctx->tune; }
     ctx->unet->batch = batch;
     if (batch > ctx->unet->wbatch) ctx->unet->wz = 0;      // forces a re-allocation at the next forward
     return ISX_OK;

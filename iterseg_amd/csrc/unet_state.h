@@ -45,6 +45,7 @@ struct UpConv {
 struct Level { int D = 0, H = 0, W = 0; int64_t M = 0; };
 
 struct UNetState {
+    isx_tune tune;                   // copy of the owning context's knobs (isx_ctx_create)
     std::map<std::string, HostTensor> host;
     bool committed = false;
     int out_channels = 5;
@@ -100,14 +101,14 @@ extern const char *UPS[4];
 bool use_mfma(int cin, int cout);
 bool use_fold(int cin, int cout);
 int conv_mode(const Level &l);
-int conv_mt(const Level &l, int batch, int cout);
+int conv_mt(const isx_tune &tune, const Level &l, int batch, int cout);
 int conv_tiles(const Level &l, int mode, int mt, int *nty, int *ntx, int *ntp, int *slots);
 // raw launch of the MFMA conv (no BN finalize): used by the forward and by dgrad
 int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const float *w_packed, const float *bias,
                      int cout, float *out, float *psum, float *psq, int no_stats);
 // split-f16 convolution (conv_h2.hip)
-int conv_h2_bn(int slots, int cout);
-int h2_mt(const Level &l, int batch);
+int conv_h2_bn(const isx_tune &tune, int slots, int cout);
+int h2_mt(const isx_tune &tune, const Level &l, int batch);
 void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out);
 void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out);
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,

@@ -1839,9 +1839,9 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     ISX_REQUIRE(wcap >= 1 && wcap <= WIN_W && tcap >= 6 && tcap <= WIN_T, "ISX_FLOOD_WIN / ISX_FLOOD_LIST out of range");
     Scratch<uint32_t> claim(ctx, window_mode ? 1 : (size_t)PN);
     Scratch<unsigned long long> vstate(ctx, window_mode ? (size_t)PN : 1);
-    Scratch<unsigned long long> stats(ctx, 32);
+    Scratch<unsigned long long> stats(ctx, 48);
     if (!pool.ok() || !claim.ok() || !arena.ok() || !stats.ok() || !vstate.ok()) return ISX_ERR_NOMEM;
-    ISX_HIP(hipMemsetAsync(stats.p, 0, 32 * 8, ctx->stream));
+    ISX_HIP(hipMemsetAsync(stats.p, 0, 48 * 8, ctx->stream));
     float s[3] = {1.f, 1.f, 1.f};
     if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
     // value range of the (scaled) edge values -> linear bucket map of the cold tier (any monotone map is correct; this
@@ -1891,7 +1891,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         ISX_CHECK_LAUNCH();
     }
     if (window_mode) {
-        unsigned long long hs[32];
+        unsigned long long hs[48];
         ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         ISX_HIP(hipStreamSynchronize(ctx->stream));
         if (hs[9]) {
@@ -1908,9 +1908,9 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                 hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[2] ? (double)hs[1] / hs[2] : 0.0, hs[13], hs[3], hs[7], hs[4], hs[5], hs[10],
                 hs[6], hs[11], hs[14], hs[12], hs[15], hs[8]);
 #ifdef ISX_FLOOD_PROF
-        fprintf(stderr, "[isx flood/window] cycles/sub-round: loop+evict %.0f | scan %.0f | trip %.0f | lists %.0f | squash %.0f | commit %.0f | refill %.0f\n",
-                (double)hs[16] / hs[0], (double)hs[17] / hs[0], (double)hs[18] / hs[0], (double)hs[19] / hs[0], (double)hs[20] / hs[0],
-                (double)hs[21] / hs[0], (double)hs[22] / hs[0]);
+        fprintf(stderr, "[isx flood/window] cycles/sub-round: loop+evict %.0f | scan %.0f | trip %.0f | lists %.0f | squash %.0f | commit: decide %.0f labels %.0f enqueue %.0f | refill %.0f\n",
+                (double)hs[32] / hs[0], (double)hs[33] / hs[0], (double)hs[34] / hs[0], (double)hs[35] / hs[0], (double)hs[36] / hs[0],
+                (double)hs[37] / hs[0], (double)hs[38] / hs[0], (double)hs[39] / hs[0], (double)hs[40] / hs[0]);
 #endif
         return ISX_OK;
     }

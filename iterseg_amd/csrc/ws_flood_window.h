@@ -136,10 +136,10 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     // statistics (ISX_FLOOD_STATS) live in LDS, bumped by lane 0: every live scalar costs SGPRs this kernel is short of
     enum { ST_SUB, ST_POPS, ST_EXEC, ST_HOT, ST_COLD, ST_DRAIN, ST_EVICT, ST_MID, ST_SQ_EV, ST_SQ_EPS, ST_ROWS, ST_OVER, ST_FORCED, ST_SLOW, ST_N };
     for (int i = lane; i < ST_N; i += 64) lstat[i] = 0u;
-#define WSTAT(i, n) do { if (lane == 0) lstat[i] += (uint32_t)(n); } while (0)
+#define WSTAT(i, n) do { const uint32_t n_ = (uint32_t)(n); if (lane == 0) lstat[i] += n_; } while (0)
     uint32_t st_sub = 0;                          // the watchdog's counter stays in a register
 #ifdef ISX_FLOOD_PROF
-    unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk_prev = __builtin_readcyclecounter();
+    unsigned long long tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_prev = __builtin_readcyclecounter();
 #define WTICK(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); tk_acc[i] += t_ - tk_prev; tk_prev = t_; } while (0)
 #else
 #define WTICK(i) do { } while (0)
@@ -678,6 +678,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             const bool ok = j < m && q0.y <= F && (maxnew == 0u || maxnew < F);
             const unsigned long long nok = ~__ballot(ok);
             int ncommit = nok ? __ffsll((long long)nok) - 1 : 64;
+            WTICK(5);
             if (ncommit > 0) {
                 // residuals enter the queue in age order (a bucket whose appends arrive in key order drains as a FIFO):
                 // they are gathered in `pend` first, episode by episode; the burst is cut where `pend` would overflow
@@ -726,6 +727,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 wh = slot_of(ncommit);
                 nw -= ncommit;
                 WIN_FENCE();
+                WTICK(6);
                 for (uint32_t b0 = 0; b0 < ptotal; b0 += 64u) {
                     const bool has = b0 + (uint32_t)lane < ptotal;
                     HeapEnt r; r.key = 0; r.idx = 0; r.pad = 0;
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 }
             }
         }
-        WTICK(5);
+        WTICK(7);
         if (serial) break;
         // ---- G: refill the window from the run (from the buckets when the run is empty) ----------------------------------
         // invariant for the bounds above: the run is empty only if nothing is queued behind the window
@@ -768,12 +770,12 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             }
             if (serial) break;
         }
-        WTICK(6);
+        WTICK(8);
     }
 
 #ifdef ISX_FLOOD_PROF
     if (stats && lane == 0)
-        for (int i = 0; i < 8; ++i) { atomicAdd(&stats[16 + i], tk_acc[i]); if (i < 4) atomicAdd(&stats[24 + i], cold.tk[i]); }
+        for (int i = 0; i < 10; ++i) { atomicAdd(&stats[32 + i], tk_acc[i]); if (i < 4) atomicAdd(&stats[44 + i], cold.tk[i]); }
 #endif
     if (stats && lane == 0) {
         atomicAdd(&stats[0], (unsigned long long)st_sub);

@@ -76,8 +76,9 @@ def trainable_layout(out_channels=5):
 class Trainer:
     """One U-Net replica being trained on this rank's GPU."""
 
-    def __init__(self, state_dict=None, out_channels=5, patch=(10, 256, 256), device=None, seed=0):
-        self.unet = UNet(1, out_channels, device=device, batch=1)
+    def __init__(self, state_dict=None, out_channels=5, patch=(10, 256, 256), device=None, seed=0,
+                 chan_final_activations=None):
+        self.unet = UNet(1, out_channels, device=device, batch=1, chan_final_activations=chan_final_activations)
         if state_dict is None:
             state_dict = _weights.generate_state_dict(seed, 1, out_channels)
         self.unet.load_state_dict(state_dict)
@@ -96,6 +97,7 @@ class Trainer:
         _lib.check(lib.isx_train_bind(h, _lib._dims(self.patch), C.c_void_p(self.params.data_ptr()),
                                       C.c_void_p(self.grads.data_ptr()), C.c_void_p(self.adam_m.data_ptr()),
                                       C.c_void_p(self.adam_v.data_ptr()), n))
+        self.unet.trainer = self                  # UNet.state_dict() reads the live parameters from here
 
     # ------------------------------------------------------------------ steps
     def _call(self, x, y, loss, chan_weights, lr, n_adam, backward, channelwise=None):
@@ -158,10 +160,7 @@ class Trainer:
 
     def state_dict(self):
         """Reference-format state dict: current parameters + running statistics."""
-        sd = self.unet.state_dict()
-        for k, shape, off in self.layout:
-            sd[k] = self.params[off:off + int(np.prod(shape))].view(shape).detach().cpu().clone()
-        return sd
+        return self.unet.state_dict()
 
 
 # --------------------------------------------------------------------------------------------------
@@ -180,7 +179,10 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
     leaves it unbound there, train.py:177-183)."""
     import pandas as pd
     if fork_channels is not None:
-        raise NotImplementedError("forked decoders are not on the accelerated path yet")
+        raise NotImplementedError("forked decoders (train.py:139-141, unet.py:313-325) are not on the accelerated path")
+    if chan_final_activations is not None and list(chan_final_activations) != ['sigmoid']:
+        # never accepted-and-ignored: the reference hands it to UNet (train.py:135-137) where it changes the arithmetic
+        raise NotImplementedError(f"chan_final_activations={chan_final_activations!r}: only the default 'sigmoid' is built")
     save_output = out_dir is not None
     print('Output will be saved: ', save_output)
     print('Save directory: ', out_dir)
@@ -194,7 +196,8 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
     sd = None
     if weights is not None:
         sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in weights.items()}
-    trainer = Trainer(sd, out_channels=n_out, patch=patch, seed=kwargs.get('seed', 0))
+    trainer = Trainer(sd, out_channels=n_out, patch=patch, seed=kwargs.get('seed', 0),
+                      chan_final_activations=chan_final_activations)
     cwise = channelwise_spec(losses, chan_losses, n_out) if loss_function == 'Channelwise' else None
     loss_dict = {'epoch': [], 'batch_num': [], 'loss': [], 'data_id': []}
     for c in channels:
@@ -218,6 +221,15 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
         if len(vx):
             print(f'Epoch {e} - validation loss: {total / len(vx)}')
 
+    if log and save_output:
+        # helpers.write_log (helpers.py:50-53): one line per call appended to <out_dir>/log.txt
+        _write_log('Training U-Net (MI355X path)', out_dir)
+        _write_log(f'Loss function: {loss_function}', out_dir)
+        if chan_weights is not None:
+            _write_log(f'Channel weights: {chan_weights}', out_dir)
+        _write_log(f'Epochs: {epochs}; learning rate: {lr}; patches: {len(x)} training / {len(vx)} validation', out_dir)
+        _write_log('Initial weights: ' + ('supplied state dict' if weights is not None else 'seeded generator'), out_dir)
+        _write_log(f'Channels: {channels}', out_dir)
     unet_path = None
     for e in range(epochs):
         if validate and e == 0:
@@ -244,9 +256,36 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
         unet_path = _save_checkpoint(trainer.state_dict(), out_dir, name, r=True)
         pd.DataFrame(loss_dict).to_csv(os.path.join(out_dir, 'loss_' + name + '.csv'))
         if validate:
+            # _save_output (train.py:425-432): the last validation predictions, one file per validation patch
+            trainer.unet.set_precision("fp32")
+            v_y_hats = [trainer.unet(np.asarray(_load(i, vx), np.float32)[None, None])[0] for i in range(len(vx))]
+            _save_output(v_y_hats, vids, out_dir, name='_validation')
             pd.DataFrame(validation_dict).to_csv(os.path.join(out_dir, 'validation-loss_' + name + '.csv'))
-    trainer.unet.trainer = trainer
     return trainer.unet, unet_path
+
+
+def _write_log(string, out_dir, log_name='log.txt'):
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, log_name), 'a') as f:
+        f.write(string + '\n')
+
+
+def _save_output(y_hats, ids, out_dir, name=''):
+    """``<id><name>_output.tif`` per prediction like the reference (tifffile); without tifffile in the environment
+    the same array goes to ``<id><name>_output.npy``."""
+    assert len(y_hats) == len(ids)
+    os.makedirs(out_dir, exist_ok=True)
+    try:
+        from tifffile import TiffWriter
+    except ImportError:
+        TiffWriter = None
+    for yh, i in zip(y_hats, ids):
+        a = np.asarray(yh, np.float32)
+        if TiffWriter is not None:
+            with TiffWriter(os.path.join(out_dir, i + name + '_output.tif')) as tiff:
+                tiff.write(a)
+        else:
+            np.save(os.path.join(out_dir, i + name + '_output.npy'), a)
 
 
 def _save_checkpoint(checkpoint, out_dir, name, r=False):

@@ -34,8 +34,10 @@ class UNet:
             raise NotImplementedError("forked decoders (out_channels tuple) are not on the accelerated path")
         if in_channels != 1 or tuple(down_factors) != (1, 2, 2) or up != 'convolution' or not downsample_1_at_bottom:
             raise NotImplementedError("only the configuration iterseg ships (in=1, (1,2,2), transposed conv) is built")
-        if chan_final_activations not in (None, ['sigmoid'], ('sigmoid',)):
-            raise NotImplementedError("final activation other than sigmoid")
+        if chan_final_activations is not None and list(chan_final_activations) != ['sigmoid']:
+            # unet.py:205-209: one entry per decoder, handed to ConvModule(final=...); only the default is built
+            raise NotImplementedError(f"chan_final_activations={chan_final_activations!r}: only the reference's default "
+                                      "final activation ('sigmoid', single decoder) is on the accelerated path")
         self.in_channels, self.out_channels = in_channels, int(out_channels)
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.ctx = _lib.Context(self.device)
@@ -43,6 +45,7 @@ class UNet:
         self._batch = int(batch)
         self._loaded = False
         self._sd = None
+        self.trainer = None
         self.precision = "fp32"
         self.set_precision(precision if precision is not None else os.environ.get("ISX_CONV_PRECISION", DEFAULT_PRECISION))
 
@@ -83,6 +86,13 @@ class UNet:
                 out[k] = torch.from_numpy(buf.copy())
             else:
                 out[k] = torch.from_numpy(np.array(v, copy=True))
+        # a U-Net that is (or was) being trained: the live parameters are the trainer's flat buffer, not the arrays
+        # this object was loaded from (``unet, _ = train_unet(...); torch.save(unet.state_dict(), ...)`` is the
+        # reference idiom, train.py:183)
+        tr = getattr(self, "trainer", None)
+        if tr is not None:
+            for k, shape, off in tr.layout:
+                out[k] = tr.params[off:off + int(np.prod(shape))].view(shape).detach().cpu().clone()
         return out
 
     def set_precision(self, precision):

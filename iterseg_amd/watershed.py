@@ -214,15 +214,20 @@ def segment_output_image(unet_output, affinities_channels, centroids_channel, th
         seg, seeds, mask = _segment_piecewise(ctx, fm, lab, scale, absolute_thresh)
     else:
         cap = max(1024, fm[0].numel() // 8)
-        seeds = torch.empty((cap, 3), dtype=torch.int64, device=dev)
-        mask = torch.empty(pshape, dtype=torch.uint8, device=dev)
-        ns = C.c_int64(0)
         at = C.byref(C.c_float(absolute_thresh)) if absolute_thresh is not None else None
-        _lib.check(ctx.lib.isx_segment_output_image(ctx.handle, _ptr(fm), _lib._dims(shape), _ptr(lab), 10,
-                                                    10000000, at, _ptr(seeds), cap, C.byref(ns), _ptr(mask),
-                                                    None))
-        if ns.value > cap:      # more seeds than the report buffer: fetch them again, labels are done
-            raise RuntimeError("seed report buffer too small")
+        while True:
+            seeds = torch.empty((cap, 3), dtype=torch.int64, device=dev)
+            mask = torch.empty(pshape, dtype=torch.uint8, device=dev)
+            ns = C.c_int64(0)
+            _lib.check(ctx.lib.isx_segment_output_image(ctx.handle, _ptr(fm), _lib._dims(shape), _ptr(lab), 10,
+                                                        10000000, at, _ptr(seeds), cap, C.byref(ns), _ptr(mask),
+                                                        None))
+            if ns.value <= cap:
+                break
+            # more seeds than the report buffer (large plateaus keep every voxel as a seed): run again with room for all of
+            # them, on a clean label buffer, as _get_centroids does
+            cap = int(ns.value)
+            lab.zero_()
         seeds = seeds[:ns.value]
     seg_dev = lab.reshape(pshape)[1:-1, 1:-1, 1:-1]
     if out_host is not None:

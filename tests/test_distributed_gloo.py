@@ -67,6 +67,9 @@ def _worker(rank, world, port, q):
     try:
         data = _stack()
         out = segment_stack(data, _frame_labels)
+        # fewer frames than ranks: the rank without a frame still takes part in the gather
+        one = segment_stack(data[:1], _frame_labels)
+        assert tuple(one.shape) == (1,) + data.shape[1:] and torch.equal(one[0], out[0])
         # chunk-sharded predict: every chunk's crop is filled with (chunk id + 1)
         shape, chunk, margin = (12, 48, 40), (4, 32, 32), (1, 8, 8)
         tab = chunking.chunk_table(shape, chunk, margin)
@@ -76,7 +79,7 @@ def _worker(rank, world, port, q):
                 r = tab[i]
                 fm[:, r[0] + r[3]:r[0] + r[4], r[1] + r[5]:r[1] + r[6], r[2] + r[7]:r[2] + r[8]] = float(i + 1)
         fm = torch.empty((2,) + shape)
-        predict_volume_sharded(predict_chunks, len(tab), fm)
+        predict_volume_sharded(predict_chunks, tab, fm)
         # data-parallel gradient averaging on a flat buffer the size of the U-Net's parameters
         from iterseg_amd.distributed import average_gradients
         g = torch.full((9972673,), float(rank + 1))

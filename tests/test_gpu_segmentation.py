@@ -128,3 +128,47 @@ def test_two_rank_sharded_volume():
            "--master-port", str(port), os.path.join(root, "tests", "_sharded_worker.py")]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_plugin_call_from_worker_threads_two_contexts():
+    """SURVEY.md 8(b) Threading: the reference drives the processing function from a napari thread_worker QThread
+    (segmentation.py:808-825).  Two contexts (two UNet objects) are driven concurrently from two non-main threads, one
+    frame sequence each; every result equals the same call made alone on the main thread."""
+    import threading
+    from iterseg_amd import segmentation as seg, weights
+    from iterseg_amd.unet import UNet
+    from tests.synth import positive_volume
+    sd = weights.generate_state_dict(0)
+    nets = [UNet(1, 5, batch=4) for _ in range(2)]
+    for u in nets:
+        u.load_state_dict(sd)
+    vols = [[positive_volume((8, 40, 48), 10 * k + t) for t in range(3)] for k in range(2)]
+
+    def run(u, vol):
+        cur = np.zeros(tuple(s + 2 for s in vol.shape), np.uint32)
+        seg.affinity_watershed_for_chunks(vol.copy(), cur, CHUNK, MARGIN, unet=u,
+                                          output_volume=np.zeros((5,) + vol.shape, np.float32))
+        return cur
+
+    expected = [[run(nets[k], v) for v in vols[k]] for k in range(2)]
+    got = [[None] * 3 for _ in range(2)]
+    errors = []
+
+    def worker(k):
+        try:
+            assert threading.current_thread() is not threading.main_thread()
+            for rep in range(2):
+                for t, v in enumerate(vols[k]):
+                    got[k][t] = run(nets[k], v)
+        except BaseException as e:          # surfaced on the main thread like napari's handle_errors
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
+    for k in range(2):
+        for t in range(3):
+            assert got[k][t] is not None and np.array_equal(got[k][t], expected[k][t]) and expected[k][t].max() > 0

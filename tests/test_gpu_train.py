@@ -179,3 +179,78 @@ def test_train_unet_accepts_dice_and_channelwise():
                      losses=[torch.nn.BCELoss(), torch.nn.MSELoss()], chan_losses=[slice(0, 4), 4])
     with pytest.raises(ValueError):
         train.train_unet(xs, xs[:1], ys, ys[:1], epochs=1, loss_function="NoSuchLoss")
+
+
+def test_returned_unet_state_dict_is_the_trained_one(tmp_path):
+    """The reference idiom ``unet, _ = train_unet(...); torch.save(unet.state_dict(), ...)`` (train.py:183): the
+    returned object's state dict must be the trained parameters, i.e. equal to the checkpoint training wrote."""
+    from iterseg_amd import train, weights
+    from tests.synth import positive_volume
+    rng = np.random.default_rng(7)
+    xs = [positive_volume((4, 32, 32), s) for s in range(2)]
+    ys = [(rng.random((5, 4, 32, 32)) < 0.3).astype(np.float32) for _ in range(2)]
+    unet, path = train.train_unet(xs, xs[:1], ys, ys[:1], out_dir=str(tmp_path), name="s", channels=("a", "b", "c", "d", "e"),
+                                  epochs=1, lr=0.01)
+    saved = torch.load(path)
+    live = unet.state_dict()
+    init = weights.generate_state_dict(0)
+    assert set(saved) == set(live)
+    moved = 0
+    for k in saved:
+        if k.endswith("num_batches_tracked") or ".running_" in k:
+            continue            # the validation-output forward after the checkpoint advances the running statistics
+        assert torch.equal(saved[k], live[k]), k
+        moved += int(not np.array_equal(saved[k].numpy(), init[k]))
+    assert moved > 50           # and they are not the initial weights
+    # log.txt (helpers.write_log) and the validation predictions (_save_output) are written next to the checkpoint
+    import glob
+    assert "Loss function: BCELoss" in open(tmp_path / "log.txt").read()
+    outs = glob.glob(str(tmp_path / "s_val_0_validation_output.*"))
+    assert len(outs) == 1
+
+
+def test_inference_with_another_chunk_between_training_steps():
+    """the returned U-Net keeps its training state; a predict with another chunk geometry re-shapes the
+    shared workspace.  The next step must restore it (same parameters as an undisturbed run), not write out of bounds."""
+    from tests.synth import positive_volume
+    rng = np.random.default_rng(3)
+    x = positive_volume((4, 32, 32), 1)
+    y = (rng.random((5, 4, 32, 32)) < 0.4).astype(np.float32)
+    a, b = _trainer(), _trainer()
+    a.train_step(x, y)
+    a.train_step(x, y)
+    b.train_step(x, y)
+    vol = torch.from_numpy(positive_volume((6, 48, 64), 2)).cuda()
+    fm = b.unet.predict_volume(vol, (6, 48, 64), (1, 8, 8))            # another geometry through the same context
+    assert fm.shape == (5, 6, 48, 64) and bool(torch.isfinite(fm).all())
+    l2, _ = b.train_step(x, y)
+    assert np.isfinite(l2)
+    assert torch.equal(a.params, b.params)
+
+
+def test_unsupported_final_activation_is_rejected_not_ignored():
+    from iterseg_amd import train
+    from tests.synth import positive_volume
+    xs = [positive_volume((4, 32, 32), 0)]
+    ys = [np.zeros((5, 4, 32, 32), np.float32)]
+    with pytest.raises(NotImplementedError):
+        train.train_unet(xs, xs, ys, ys, epochs=1, chan_final_activations=['tanh'])
+    with pytest.raises(NotImplementedError):
+        train.train_unet(xs, xs, ys, ys, epochs=1, fork_channels=(3, 2))
+    train.train_unet(xs, xs, ys, ys, epochs=1, chan_final_activations=['sigmoid'], validate=False)
+
+
+def test_two_rank_data_parallel_step():
+    """BASELINE config 4 / SURVEY.md 8(e): data-parallel training, batch 1 per rank, one all-reduce of the flat gradient
+    buffer between backward and Adam (train.py:344-363 per rank).  Two gloo ranks on cuda:0 (tests/_dp_worker.py): the
+    world-size-2 branch of Trainer.train_step and isx_adam_step reproduce the single-process update on the averaged
+    gradient bit for bit, with and without the reference's duplicated optimiser step."""
+    import os, socket, subprocess, sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_dp_worker.py")]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
