@@ -8,6 +8,15 @@ src/iterseg/segmentation.py:873-882), inputs resident in HBM when the timed regi
 N > 1 is launched by the driver with torch.distributed.run (one rank per GPU); every rank segments
 its own frame (weak scaling, no data-path collective), the timed region is bracketed by a barrier +
 synchronize on both sides and the maximum over ranks is reported.  Rank 0 prints ONE JSON line.
+
+Beside the headline the same line carries (N = 1): the exact-fp32 arithmetic (`other_precision`), BASELINE
+configs[1] end to end (`config2`: 64x512x512, where one 8.3 M-voxel component is NOT dropped by max_area and the
+flood carries the frame), the watershed stage on a structured 512^3 input (`watershed_structured`), one training
+step (`train_step`) and the CPU oracle on a bounded sample (`cpu_baseline`).  For N > 1 it also carries the
+strong-scaling job (`strong_scaling`: ONE 512^3 volume on all ranks, feature-map slab all-gather + component-sharded
+flood + label max-reduce inside the timed region) and BASELINE configs[2] (`config3_stack`: 16 frames of 32x512x512,
+frame t on rank t mod N, label all-gather inside the timed region); `--mode strong|stack` makes one of them the
+headline instead.
 """
 import argparse
 import json
@@ -48,43 +57,60 @@ def conv_flops_per_chunk(chunk, out_channels=5):
 
 
 def cpu_baseline(sd, chunk, margin):
-    """The oracle (CPU restatement) timed on a bounded sample of the same workload."""
+    """The oracle (CPU restatement) timed on a bounded sample of the same workload: a 26x512x512 slab = 27 chunks at the
+    headline's chunk over-compute (z starts 0, 8, 16; 3 x 3 in y, x: 2.60x against 2.81x at 512^3), U-Net on all host
+    threads, watershed with the flood component by component on the same threads."""
     from oracle import unet_torch as ou, watershed as ows
     from tests.synth import positive_volume
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    shape = (18, chunk[1], chunk[2])                     # 2 chunks in z, one in y/x
+    shape = (26, 2 * chunk[1], 2 * chunk[2])
     vol = positive_volume(shape, seed=123)
     t0 = time.perf_counter()
     fm = ou.predict_volume(sd, vol, chunk, margin)
     t1 = time.perf_counter()
     lab = np.zeros(tuple(s + 2 for s in shape), np.uint32)
     try:
-        ows.segment_output_image(fm, out=lab.ravel())
+        ows.segment_output_image(fm, out=lab.ravel(), threads=cores)
     except ValueError:
         pass
     t2 = time.perf_counter()
     nvox = float(np.prod(shape))
+    n_chunks = len(__import__("iterseg_amd.chunking", fromlist=["x"]).chunk_table(shape, chunk, margin))
+    over = n_chunks * float(np.prod(chunk)) / nvox
     return {"value": nvox / (t2 - t0), "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"{shape[0]}x{shape[1]}x{shape[2]} volume = 2 chunks {chunk} through the torch-CPU U-Net oracle "
-                      f"({t1 - t0:.2f} s, {cores} threads) + C watershed oracle ({t2 - t1:.2f} s, 1 thread); "
-                      f"chunk over-compute 1.11x here vs 2.81x at 512^3"}
+            "sample": f"{shape[0]}x{shape[1]}x{shape[2]} slab = {n_chunks} chunks {chunk} (over-compute {over:.2f}x; 2.81x at 512^3) "
+                      f"through the torch-CPU U-Net oracle ({t1 - t0:.2f} s, {cores} threads) + C watershed oracle with the "
+                      f"flood component-parallel on {cores} threads ({t2 - t1:.2f} s; {int((lab > 0).sum())} voxels labelled)"}
 
 
 DTYPE = {"fp32": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)",
          "split-f16": "f32 operands split into two f16 halves each (x = x_h + x_l / 2^11), three v_mfma_f32_32x32x16_f16 per K "
                       "block with separate fp32 accumulators: fp32-class results on the f16 matrix cores"}
-# L2-miss bytes per chunk-launch of the wide-conv kernels: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from separate
-# rocprofv3 --pmc passes over one 64-chunk launch set, 16 launches (profiles/r01g_pmc_*, r01i_pmc_*)
-TRAFFIC_PER_CHUNK_LAUNCH = {"fp32": 0.1054e9, "split-f16": 0.0848e9}
+# roofline.traffic: HBM bytes per launch of the wide-conv kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+# (separate passes, FETCH x2 on gfx950, MI355X_MICROARCH.md) over one launch set of THIS build's kernels.  bench.py
+# cannot collect PMC counters on itself, so it reads the summary that scratch/pmc_traffic_json.py wrote from those
+# passes (committed under profiles/ with the CSVs); without one, or if it was made for another kernel build, traffic
+# is null.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 TRAFFIC_ALGORITHMIC = 0.05725e9          # every activation read once + written once + weights, per chunk-launch
+
+
+def measured_traffic(precision, batch):
+    try:
+        d = json.load(open(TRAFFIC_FILE))
+        e = d[precision]
+        return float(e["bytes_per_chunk_launch"]) * batch, e.get("source")
+    except Exception:
+        return None, None
 
 
 def conv_roofline(precision, mfma_flops, n_chunks, steps, ms_mfma, n_mfma, batch):
     peak = PEAK_MFMA_F32 if precision == "fp32" else PEAK_MFMA_F16
     ach = (mfma_flops * n_chunks * steps) / (ms_mfma * 1e-3) / 1e12 if ms_mfma > 0 else 0.0
+    traffic, traffic_src = measured_traffic(precision, batch)
     r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-         "traffic": TRAFFIC_PER_CHUNK_LAUNCH[precision] * batch, "traffic_algorithmic": TRAFFIC_ALGORITHMIC * batch,
+         "traffic": traffic, "traffic_source": traffic_src, "traffic_algorithmic": TRAFFIC_ALGORITHMIC * batch,
          "kernel": ("conv_mfma_kernel (fp32 32x32x2 implicit-GEMM conv, 16 of 18 layers)" if precision == "fp32" else
                     "conv_h2_kernel (split-f16 32x32x16 implicit-GEMM conv, 16 of 18 layers)"),
          "avg_launch_ms": ms_mfma / max(n_mfma, 1), "launches": n_mfma, "algorithmic_gflop_per_chunk": mfma_flops / 1e9}
@@ -110,10 +136,7 @@ def other_precision_leg(u, other, vol, fm, labels, chunk, margin, args, n_chunks
 
     def step():
         labels.zero_()
-        try:
-            segmentation.segment_volume_device(u, vol, chunk, margin, feature_map=fm, labels=labels)
-        except ValueError:
-            pass
+        segmentation.segment_volume_device(u, vol, chunk, margin, feature_map=fm, labels=labels)
     step()
     u.ctx.prof_enable(False)
     u.ctx.prof_enable(True)
@@ -155,29 +178,78 @@ def train_step_leg(sd, patch=(10, 256, 256), steps=5):
             "note": "forward + BCE + backward (dgrad, wgrad, BatchNorm) + the reference's double Adam update, batch 1"}
 
 
-def structured_watershed_leg(u, n=256, volume_fraction=0.12):
+def structured_watershed_leg(u, n=512, volume_fraction=0.12, t_unet_ms=None):
     """the watershed stage alone on a *structured* feature map -- blobs / distance-transform centroid
-    channel / gradient affinities as in the reference's own demo (watershed.py:256-262; tests/synth.blob_feature_map) --
-    where the mask falls into many components and the per-component parallelism of the flood is visible."""
+    channel / gradient affinities as in the reference's own demo (watershed.py:256-262; tests/synth.blob_feature_map,
+    mirror-tiled to n^3) -- where the mask falls into many components of every size, which is what a trained network
+    produces.  `end_to_end_voxels_per_s` prices a whole frame with this watershed behind the measured U-Net stage."""
     from iterseg_amd import watershed as ws
-    from tests.synth import blob_feature_map
+    from tests.synth import blob_feature_map_mirrored
     shape = (n, n, n)
-    fm = torch.from_numpy(blob_feature_map(shape, 0, volume_fraction, 3.0)).cuda()
+    fm = torch.from_numpy(blob_feature_map_mirrored(n, 0, volume_fraction, 3.0)).cuda()
     lab = torch.zeros(tuple(s + 2 for s in shape), dtype=torch.int32, device=fm.device)
-    best = None
+    best, stages = None, None
     for _ in range(2):
         lab.zero_()
         u.ctx.prof_enable(False)
+        wctx = ws.get_context(fm.device.index)
+        wctx.prof_enable(False)
+        wctx.prof_enable(True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=lab)
+        _, _, mask = ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=lab)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        best = dt if best is None or dt < best else best
+        if best is None or dt < best:
+            best, stages = dt, {k: wctx.prof_get(k)[0] for k in ("ws_filters", "ws_ccl", "ws_flood")}
     nvox = float(np.prod(shape))
-    return {"shape": list(shape), "volume_fraction": volume_fraction, "ms": 1e3 * best, "voxels_per_s": nvox / best,
-            "instances": int(lab.max().item()), "labelled_voxels": int((lab > 0).sum().item()),
-            "hbm_frac": (24.0 * nvox / best / 1e9) / PEAK_HBM}
+    roots, sizes = ws.connected_components(mask)
+    sz = torch.as_tensor(sizes).flatten()
+    sz = torch.sort(sz[sz > 0], descending=True).values
+    n_lab = int((lab > 0).sum().item())
+    out = {"shape": list(shape), "volume_fraction": volume_fraction, "ms": 1e3 * best, "voxels_per_s": nvox / best,
+           "stages_ms": stages, "instances": int(lab.max().item()), "labelled_voxels": n_lab,
+           "components": int(sz.numel()), "largest_components": [int(v) for v in sz[:4].tolist()],
+           "flood_pops_per_s": n_lab / max(stages["ws_flood"], 1e-9) * 1e3,
+           "hbm_frac": (24.0 * nvox / best / 1e9) / PEAK_HBM}
+    if t_unet_ms is not None:
+        out["end_to_end_voxels_per_s"] = nvox / (t_unet_ms * 1e-3 + best)
+        out["unet_voxels_per_s"] = nvox / (t_unet_ms * 1e-3)
+    return out
+
+
+def config2_leg(u, sd_seed_rank, chunk, margin, batch):
+    """BASELINE.json configs[1]: one 64x512x512 volume end to end (72 chunks + watershed).  With the seeded random-weight
+    network the foreground is ONE 8.3 M-voxel component below max_area, so unlike at 512^3 it is flooded, not dropped:
+    the frame is the flood of a single chain-like component (the worst case for the speculative-window kernel)."""
+    from iterseg_amd import segmentation
+    from tests.synth import positive_volume
+    shape = (64, 512, 512)
+    dev = torch.device("cuda", u.device)
+    vol = torch.from_numpy(positive_volume(shape, seed=sd_seed_rank)).to(dev)
+    fm = torch.empty((5,) + shape, dtype=torch.float32, device=dev)
+    labels = torch.zeros(tuple(s + 2 for s in shape), dtype=torch.int32, device=dev)
+    best, prof = None, None
+    for _ in range(2):
+        labels.zero_()
+        u.ctx.prof_enable(False)
+        u.ctx.prof_enable(True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        segmentation.segment_volume_device(u, vol, chunk, margin, feature_map=fm, labels=labels)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best = dt
+            prof = {k: u.ctx.prof_get(k)[0] for k in ("conv_mfma", "conv_direct", "elementwise", "ws_filters", "ws_ccl", "ws_flood")}
+    u.ctx.prof_enable(False)
+    nvox = float(np.prod(shape))
+    n_lab = int((labels > 0).sum().item())
+    assert n_lab > 0
+    return {"workload": "64x512x512 float32 volume, chunk (10,256,256), margin (1,64,64) = 72 chunks, same weights",
+            "value": nvox / best, "unit": "voxels/s", "ms_per_step": 1e3 * best, "stages_ms": prof,
+            "labelled_voxels": n_lab, "instances": int(labels.max().item()),
+            "flood_pops_per_s": n_lab / max(prof["ws_flood"], 1e-9) * 1e3}
 
 
 def main():
@@ -194,6 +266,11 @@ def main():
                     help="arithmetic of the wide convolutions (default: the library default, split-f16)")
     ap.add_argument("--no-split-f16", "--no-other-precision", dest="no_other", action="store_true",
                     help="skip the extra measurement in the other arithmetic mode (N = 1 only)")
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong", "stack"],
+                    help="weak (default): one frame per rank; strong: ONE volume sharded over all ranks (chunk-sharded "
+                         "U-Net, feature-map slab all-gather, component-sharded flood, label max-reduce); stack: BASELINE "
+                         "configs[2], 16 frames of 32x512x512, frame t on rank t mod N, label all-gather in the timed region")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline only (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,12 +310,59 @@ def main():
     labels = torch.zeros(tuple(s + 2 for s in shape), dtype=torch.int32, device=dev)
     n_chunks = len(__import__("iterseg_amd.chunking", fromlist=["x"]).chunk_table(shape, chunk, margin))
 
+    from iterseg_amd._lib import NoSeedsError
+    from iterseg_amd import distributed as isx_dist
+    group = None
+
+    def strong_step(volume, fmap, labs):
+        """one volume on all ranks; `volume` is identical on every rank (seed 0)"""
+        labs.zero_()
+        try:
+            isx_dist.segment_volume_sharded(u, volume, chunk, margin, group=group, feature_map=fmap, labels=labs)
+        except NoSeedsError:
+            pass
+
+    stack_shape, stack_T = (32, 512, 512), 16
+
+    def stack_step(frames, fmap, labs, gathered):
+        """configs[2]: this rank's frames (t mod N), then ONE all-gather of the int32 label tiles"""
+        mine = isx_dist.frames_for_rank(stack_T, rank, world)
+        for i, t in enumerate(mine):
+            labs.zero_()
+            try:
+                segmentation.segment_volume_device(u, frames[i], chunk, margin, feature_map=fmap, labels=labs)
+            except NoSeedsError:
+                pass
+            gathered[rank, i] = labs[1:-1, 1:-1, 1:-1]
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_gather(list(gathered_views), gathered[rank].clone())
+
     def step():
+        if args.mode == "strong":
+            return strong_step(vol, fm, labels)
+        if args.mode == "stack":
+            return stack_step(stack_frames, stack_fm, stack_labels, stack_gathered)
         labels.zero_()
         try:
             segmentation.segment_volume_device(u, vol, chunk, margin, feature_map=fm, labels=labels)
-        except ValueError:
-            pass            # zero surviving seeds on this frame: labels stay 0 (the reference raises)
+        except NoSeedsError:
+            pass            # zero surviving seeds on this frame: labels stay 0 (the reference raises); anything else is a bug
+
+    def make_stack():
+        mine = isx_dist.frames_for_rank(stack_T, rank, world)
+        frames = [torch.from_numpy(positive_volume(stack_shape, seed=t)).to(dev) for t in mine]
+        per = (stack_T + world - 1) // world
+        gathered = torch.zeros((world, per) + stack_shape, dtype=torch.int32, device=dev)
+        return (frames, torch.empty((5,) + stack_shape, dtype=torch.float32, device=dev),
+                torch.zeros(tuple(s + 2 for s in stack_shape), dtype=torch.int32, device=dev), gathered)
+
+    stack_frames = stack_fm = stack_labels = stack_gathered = gathered_views = None
+    if args.mode == "stack":
+        stack_frames, stack_fm, stack_labels, stack_gathered = make_stack()
+        gathered_views = stack_gathered.unbind(0)
+    if args.mode == "strong" and rank != 0:
+        vol.copy_(torch.from_numpy(positive_volume(shape, seed=0)).to(dev))       # the SAME volume everywhere
 
     def sync_all():
         if world > 1:
@@ -262,32 +386,50 @@ def main():
         elapsed = float(tt.item())
 
     prof = {k: u.ctx.prof_get(k) for k in ("conv_mfma", "conv_direct", "elementwise", "ws_filters", "ws_ccl", "ws_flood")}
-    n_labelled = int((labels > 0).sum().item())
-    n_inst = int(labels.max().item())
+    if args.mode == "stack":
+        n_labelled = int((stack_gathered > 0).sum().item())
+        n_inst = int(stack_gathered.max().item())
+    else:
+        n_labelled = int((labels > 0).sum().item())
+        n_inst = int(labels.max().item())
+    assert n_labelled > 0 and n_inst > 0, "the timed steps produced no labels: not a valid measurement"
 
     if rank == 0:
         nvox = float(np.prod(shape))
+        jobs = world                                              # weak: one frame per rank
+        scaling = "weak"
+        work = (f"{shape_name} float32 volume per GPU (one frame per rank), chunk (10,256,256), precision {precision}, "
+                f"margin (1,64,64) = {n_chunks} chunks")
+        if args.mode == "strong":
+            jobs, scaling = 1, "strong"
+            work = (f"ONE {shape_name} float32 volume on {world} rank(s): chunk table cut by z-rows, feature-map slab all-gather, "
+                    f"W0-W3 replicated, component-sharded flood, label max-reduce; chunk (10,256,256), margin (1,64,64) = "
+                    f"{n_chunks} chunks, precision {precision}")
+        elif args.mode == "stack":
+            nvox, jobs, scaling = float(np.prod(stack_shape)), stack_T, "strong"
+            n_chunks = len(__import__("iterseg_amd.chunking", fromlist=["x"]).chunk_table(stack_shape, chunk, margin))
+            work = (f"BASELINE configs[2]: t = {stack_T} frames of 32x512x512, frame t on rank t mod {world}, "
+                    f"{n_chunks} chunks per frame, label all-gather (int32 tiles) inside the timed region, precision {precision}")
+            n_chunks *= len(isx_dist.frames_for_rank(stack_T, 0, world))
         mfma_flops, direct_flops = conv_flops_per_chunk(chunk)
         ms_mfma, n_mfma = prof["conv_mfma"]
         t_unet = sum(prof[k][0] for k in ("conv_mfma", "conv_direct", "elementwise")) / args.steps
         t_ws = sum(prof[k][0] for k in ("ws_filters", "ws_ccl", "ws_flood")) / args.steps
         out = {
             "metric": "voxels/sec end-to-end (U-Net + watershed)",
-            "value": world * nvox * args.steps / elapsed,
+            "value": jobs * nvox * args.steps / elapsed,
             "unit": "voxels/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": DTYPE[precision],
             "data": "synthetic",
-            "config": {"workload": f"{shape_name} float32 volume per GPU (one frame per rank), chunk (10,256,256), "
-                                   f"precision {precision}, "
-                                   f"margin (1,64,64) = {n_chunks} chunks, seeded random U-Net weights (seed 0), "
-                                   f"train-mode BatchNorm per chunk, watershed min_area 10 / max_area 1e7",
+            "config": {"workload": work + ", seeded random U-Net weights (seed 0), train-mode BatchNorm per chunk, "
+                                          "watershed min_area 10 / max_area 1e7", "mode": args.mode,
                        "chunks_per_launch_set": args.batch, "labelled_voxels": n_labelled, "instances": n_inst},
             "roofline": conv_roofline(precision, mfma_flops, n_chunks, args.steps, ms_mfma, n_mfma, args.batch),
             "stages_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
@@ -302,14 +444,49 @@ def main():
         t_ideal = ((mfma_flops + direct_flops) * n_chunks / (peak_tf * 1e12) + 24.0 * nvox / (PEAK_HBM * 1e9)) * 1e3
         out["combined_roofline_frac"] = t_ideal / (1e3 * elapsed / args.steps)
         out["t_ideal_ms"] = t_ideal
-        if world == 1 and not args.no_other:
+        extra = world == 1 and args.mode == "weak" and not args.no_extra_legs
+        if extra and not args.no_other:
             other = "fp32" if precision != "fp32" else "split-f16"
             out["other_precision"] = {other: other_precision_leg(u, other, vol, fm, labels, chunk, margin, args, n_chunks,
                                                                  mfma_flops)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["watershed_structured"] = structured_watershed_leg(u)
+        if extra:
+            del vol, fm, labels
+            out["config2"] = config2_leg(u, 0, chunk, margin, args.batch)
+            out["watershed_structured"] = structured_watershed_leg(u, t_unet_ms=t_unet if shape == (512, 512, 512) else None)
             out["train_step"] = train_step_leg(sd)
+        if extra and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, chunk, margin)
+    # N > 1, default mode: the two jobs with a collective in the timed region ride along (one step each, all ranks)
+    if world > 1 and args.mode == "weak" and not args.no_extra_legs:
+        import torch.distributed as dist
+        legs = {}
+        v0 = torch.from_numpy(positive_volume((512, 512, 512), seed=0)).to(dev)
+        f0 = torch.empty((5, 512, 512, 512), dtype=torch.float32, device=dev)
+        l0 = torch.zeros((514, 514, 514), dtype=torch.int32, device=dev)
+        for name in ("strong_scaling", "config3_stack"):
+            if name == "config3_stack":
+                del v0, f0, l0
+                stack_frames, stack_fm, stack_labels, stack_gathered = make_stack()
+                gathered_views = stack_gathered.unbind(0)
+                run = lambda: stack_step(stack_frames, stack_fm, stack_labels, stack_gathered)
+                total_vox = float(np.prod(stack_shape)) * stack_T
+            else:
+                run = lambda: strong_step(v0, f0, l0)
+                total_vox = 512.0 ** 3
+            run()                                                  # warm-up (workspace shapes, RCCL channels)
+            sync_all()
+            t0 = time.perf_counter()
+            run()
+            sync_all()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            legs[name] = {"value": total_vox / float(tt.item()), "unit": "voxels/s", "ms": 1e3 * float(tt.item()), "n_gpus": world,
+                          "scaling": "strong"}
+        if rank == 0:
+            legs["strong_scaling"]["workload"] = "ONE 512^3 volume on all ranks (segment_volume_sharded): slab all-gather of the feature map, component-sharded flood, int32 label max-reduce"
+            legs["config3_stack"]["workload"] = "BASELINE configs[2]: 16 frames of 32x512x512, frame t on rank t mod N, int32 label all-gather in the timed region"
+            out.update(legs)
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

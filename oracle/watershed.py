@@ -61,6 +61,10 @@ def lib():
         L.orc_segment_output_image.argtypes = [_f32p, _i64p, _u32p, C.POINTER(C.c_float), C.c_void_p,
                                                C.c_int64, C.c_void_p, C.c_int64, C.c_int64]
         L.orc_segment_output_image.restype = C.c_int64
+        L.orc_segment_output_image_mt.argtypes = L.orc_segment_output_image.argtypes + [C.c_int]
+        L.orc_segment_output_image_mt.restype = C.c_int64
+        L.orc_affinity_watershed_mt.argtypes = L.orc_affinity_watershed.argtypes + [C.c_int]
+        L.orc_affinity_watershed_mt.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -119,7 +123,7 @@ def _remove_unwanted_objects(mask, centroids, min_area=0, max_area=1000000):
     return new_mask, centroids[keep]
 
 
-def affinity_watershed(image, marker_coords, mask, scale=None, out=None):
+def affinity_watershed(image, marker_coords, mask, scale=None, out=None, threads=0):
     """Kernel-boundary entry: ``image`` (3,Z,Y,X) f32 zero-padded, ``marker_coords`` (n,3)."""
     image = np.ascontiguousarray(image, np.float32)
     shape = image.shape[1:]
@@ -135,13 +139,17 @@ def affinity_watershed(image, marker_coords, mask, scale=None, out=None):
     m = np.ascontiguousarray(mask, np.uint8).reshape(-1)
     if out is None:
         out = np.zeros(m.size, np.int32)
-    lib().orc_affinity_watershed(raveled, seeds, len(seeds), m, out.view(np.uint32), _dims(shape))
+    if threads > 0:
+        lib().orc_affinity_watershed_mt(raveled, seeds, len(seeds), m, out.view(np.uint32), _dims(shape), int(threads))
+    else:
+        lib().orc_affinity_watershed(raveled, seeds, len(seeds), m, out.view(np.uint32), _dims(shape))
     return out.reshape(shape)
 
 
 def segment_output_image(unet_output, affinities_channels=(0, 1, 2), centroids_channel=4,
-                         thresholding_channel=3, out=None, min_area=10, max_area=10000000):
-    """Plugin-path form (segmentation.py:190-194).  Returns ``(segmentation, seeds, mask)``."""
+                         thresholding_channel=3, out=None, min_area=10, max_area=10000000, threads=0):
+    """Plugin-path form (segmentation.py:190-194).  Returns ``(segmentation, seeds, mask)``.
+    ``threads`` > 0: the flood runs component by component on that many threads (same labels)."""
     fm = np.asarray(np.squeeze(unet_output), np.float32)
     order = list(affinities_channels) + [thresholding_channel, centroids_channel]
     fm = np.ascontiguousarray(fm[order])
@@ -153,9 +161,9 @@ def segment_output_image(unet_output, affinities_channels=(0, 1, 2), centroids_c
     seeds = np.empty(fm[0].size, np.int64)
     maskp = np.empty(pshape, np.uint8)
     th = C.c_float()
-    ns = lib().orc_segment_output_image(fm, _dims(shape), labels, C.byref(th),
-                                        seeds.ctypes.data_as(C.c_void_p), seeds.size,
-                                        maskp.ctypes.data_as(C.c_void_p), int(min_area), int(max_area))
+    ns = lib().orc_segment_output_image_mt(fm, _dims(shape), labels, C.byref(th),
+                                           seeds.ctypes.data_as(C.c_void_p), seeds.size,
+                                           maskp.ctypes.data_as(C.c_void_p), int(min_area), int(max_area), int(threads))
     if ns == 0:
         raise ValueError("Cannot apply_along_axis when any iteration dimensions are 0")
     seg = out.reshape(pshape)[1:-1, 1:-1, 1:-1]

@@ -312,15 +312,14 @@ static inline int elem_less(const orc_elem_t *a, const orc_elem_t *b)
     return a->idx < b->idx;
 }
 
-int64_t orc_affinity_watershed(const float *aff, const int64_t *seeds, int64_t nseeds,
-                               const uint8_t *mask, uint32_t *out, const int64_t dims[3])
+/* the heap loop (watershed.py:127-158) over the given seeds, whose labels are already in `out` */
+static int64_t flood_core(const float *aff, const int64_t *seeds, int64_t nseeds,
+                          const uint8_t *mask, uint32_t *out, const int64_t dims[3])
 {
-    if (nseeds <= 0) return -1;
     int64_t N = dims[0] * dims[1] * dims[2];
     int64_t SZ = dims[1] * dims[2], SY = dims[2];
     const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
     const int ax[6] = {0, 1, 2, 2, 1, 0};
-    for (int64_t i = 0; i < nseeds; ++i) out[seeds[i]] = (uint32_t)(i + 1);
     int64_t cap = nseeds + 16, hn = 0;
     orc_elem_t *heap = (orc_elem_t *)malloc(sizeof(orc_elem_t) * (size_t)cap);
 #define HPUSH(E)                                                                   \
@@ -370,6 +369,92 @@ int64_t orc_affinity_watershed(const float *aff, const int64_t *seeds, int64_t n
     return pops;
 }
 
+int64_t orc_affinity_watershed(const float *aff, const int64_t *seeds, int64_t nseeds,
+                               const uint8_t *mask, uint32_t *out, const int64_t dims[3])
+{
+    if (nseeds <= 0) return -1;
+    for (int64_t i = 0; i < nseeds; ++i) out[seeds[i]] = (uint32_t)(i + 1);      /* _prep_data, watershed.py:61-62 */
+    return flood_core(aff, seeds, nseeds, mask, out, dims);
+}
+
+/* ------------------------------------------------------------------------------------
+ * The same flood, one 6-connected mask component at a time, components spread over
+ * `nthreads` OpenMP threads.  Exact: the pop order inside a component does not depend on
+ * the other components (pops are ordered by (value, age), ages are monotone in push order,
+ * floods never cross mask == 0; SURVEY.md F4, checked by
+ * tests/test_oracle_watershed.py::test_flood_decomposes_over_components), and seeds keep
+ * their list order inside a component.  This is the CPU baseline bench.py times beside
+ * the GPU path ("W4 single-threaded per component + component-parallel").
+ * ---------------------------------------------------------------------------------- */
+typedef struct { int64_t comp, order; } seed_key_t;
+static int seed_key_cmp(const void *a, const void *b)
+{
+    const seed_key_t *x = (const seed_key_t *)a, *y = (const seed_key_t *)b;
+    if (x->comp != y->comp) return x->comp < y->comp ? -1 : 1;
+    return x->order < y->order ? -1 : (x->order > y->order ? 1 : 0);
+}
+
+int64_t orc_affinity_watershed_mt(const float *aff, const int64_t *seeds, int64_t nseeds,
+                                  const uint8_t *mask, uint32_t *out, const int64_t dims[3], int nthreads)
+{
+    if (nseeds <= 0) return -1;
+    int64_t N = dims[0] * dims[1] * dims[2];
+    int64_t SZ = dims[1] * dims[2], SY = dims[2];
+    const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
+    for (int64_t i = 0; i < nseeds; ++i) out[seeds[i]] = (uint32_t)(i + 1);
+    /* component id of every seed: flood fill of the mask from each not yet visited seed */
+    int32_t *comp = (int32_t *)calloc((size_t)N, sizeof(int32_t));
+    int64_t *stack = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    seed_key_t *keys = (seed_key_t *)malloc(sizeof(seed_key_t) * (size_t)nseeds);
+    int32_t ncomp = 0;
+    for (int64_t i = 0; i < nseeds; ++i) {
+        int64_t s0 = seeds[i];
+        if (!mask[s0]) { keys[i].comp = -1 - i; keys[i].order = i; continue; }   /* off-mask seed: never spreads */
+        if (!comp[s0]) {
+            ++ncomp;
+            int64_t sp = 0;
+            stack[sp++] = s0;
+            comp[s0] = ncomp;
+            while (sp > 0) {
+                int64_t v = stack[--sp];
+                for (int k = 0; k < 6; ++k) {
+                    int64_t nb = v + noff[k];
+                    if (nb < 0 || nb >= N || !mask[nb] || comp[nb]) continue;
+                    comp[nb] = ncomp;
+                    stack[sp++] = nb;
+                }
+            }
+        }
+        keys[i].comp = comp[s0];
+        keys[i].order = i;
+    }
+    free(stack);
+    free(comp);
+    qsort(keys, (size_t)nseeds, sizeof(seed_key_t), seed_key_cmp);
+    /* runs of equal component id */
+    int64_t *first = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nseeds + 1));
+    int64_t *sorted = (int64_t *)malloc(sizeof(int64_t) * (size_t)nseeds);
+    int64_t nrun = 0;
+    for (int64_t i = 0; i < nseeds; ++i) {
+        sorted[i] = seeds[keys[i].order];
+        if (i == 0 || keys[i].comp != keys[i - 1].comp) first[nrun++] = i;
+    }
+    first[nrun] = nseeds;
+    int64_t pops = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : pops)
+#endif
+    for (int64_t r = 0; r < nrun; ++r) {
+        if (keys[first[r]].comp < 0) continue;
+        pops += flood_core(aff, sorted + first[r], first[r + 1] - first[r], mask, out, dims);
+    }
+    (void)nthreads;
+    free(first);
+    free(sorted);
+    free(keys);
+    return pops;
+}
+
 /* ------------------------------------------------------------------------------------
  * segment_output_image (watershed.py:165-223), plugin-path argument set
  * (segmentation.py:190-194): fm is (5, Z, Y, X); channels 0..2 affinities, 3 mask, 4 centres.
@@ -394,9 +479,23 @@ void orc_normalise_pad(const float *fm3, const int64_t dims[3], float *aff_padde
     }
 }
 
+int64_t orc_segment_output_image_mt(const float *fm, const int64_t dims[3], uint32_t *labels_padded,
+                                    float *thresh_out, int64_t *seeds_out, int64_t seeds_cap,
+                                    uint8_t *mask_out_padded, int64_t min_area, int64_t max_area, int nthreads);
+
 int64_t orc_segment_output_image(const float *fm, const int64_t dims[3], uint32_t *labels_padded,
                                  float *thresh_out, int64_t *seeds_out, int64_t seeds_cap,
                                  uint8_t *mask_out_padded, int64_t min_area, int64_t max_area)
+{
+    return orc_segment_output_image_mt(fm, dims, labels_padded, thresh_out, seeds_out, seeds_cap, mask_out_padded,
+                                       min_area, max_area, 0);
+}
+
+/* nthreads = 0: the flood as one heap over the whole volume (the reference's loop, verbatim);
+ * nthreads >= 1: the same flood component by component on that many threads */
+int64_t orc_segment_output_image_mt(const float *fm, const int64_t dims[3], uint32_t *labels_padded,
+                                    float *thresh_out, int64_t *seeds_out, int64_t seeds_cap,
+                                    uint8_t *mask_out_padded, int64_t min_area, int64_t max_area, int nthreads)
 {
     int64_t Z = dims[0], Y = dims[1], X = dims[2], n = Z * Y * X;
     int64_t pd[3] = {Z + 2, Y + 2, X + 2};
@@ -432,7 +531,10 @@ int64_t orc_segment_output_image(const float *fm, const int64_t dims[3], uint32_
     }
     free(pidx);
     if (seeds_out) for (int64_t i = 0; i < ns && i < seeds_cap; ++i) seeds_out[i] = sd[i];
-    if (ns > 0) orc_affinity_watershed(aff, sd, ns, mf, labels_padded, pd);
+    if (ns > 0) {
+        if (nthreads > 0) orc_affinity_watershed_mt(aff, sd, ns, mf, labels_padded, pd, nthreads);
+        else orc_affinity_watershed(aff, sd, ns, mf, labels_padded, pd);
+    }
     free(sd);
     free(aff);
     if (!mask_out_padded) free(mf);

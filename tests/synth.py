@@ -39,3 +39,15 @@ def blob_feature_map(shape, seed, volume_fraction=0.3, blob_sigma=3.0):
     affs = [a / max(a.max(), 1e-6) for a in affs]
     soft = ndi.gaussian_filter(fg.astype(np.float32), 1.0)
     return np.ascontiguousarray(np.stack(affs + [soft, cent]), np.float32)
+
+
+def blob_feature_map_mirrored(n, seed, volume_fraction=0.3, blob_sigma=3.0):
+    """``blob_feature_map`` at ``(n, n, n)`` built from the ``(n/2)^3`` one by mirror tiling (2 x 2 x 2 reflections).  This
+    IS the same construction applied to the mirrored foreground -- the distance transform and the reflect-mode filters of
+    a mirrored image are the mirrored results -- at an eighth of the scipy time (the 512^3 bench input in seconds);
+    components that touch a mirror plane merge with their images, so the largest ones are up to 8x larger."""
+    assert n % 2 == 0
+    h = blob_feature_map((n // 2,) * 3, seed, volume_fraction, blob_sigma)
+    for ax in (1, 2, 3):
+        h = np.concatenate([h, np.flip(h, axis=ax)], axis=ax)
+    return np.ascontiguousarray(h, np.float32)

@@ -138,3 +138,24 @@ def test_flood_decomposes_over_components(golden):
         ids = np.flatnonzero(sel) + 1                                    # local label k -> global id
         merged[part > 0] = ids[part[part > 0] - 1]
     assert np.array_equal(merged, ref)
+
+
+@pytest.mark.parametrize("name", ["ws_k_ties", "ws_k_noseed_comp", "ws_k_negvals", "ws_blobs40"])
+def test_component_parallel_flood_equals_single_heap(golden, name):
+    """The cpu_baseline of bench.py floods component by component on several threads; same labels as
+    the single heap (and as the reference's fixture)."""
+    d = golden(name)
+    ref = d["labels_padded"] if "labels_padded" in d.files else np.pad(d["labels"], 1)
+    for threads in (1, 4):
+        lab = ows.affinity_watershed(d["aff_padded"], d["seeds_padded"], d["mask_padded"], threads=threads)
+        assert np.array_equal(lab, ref)
+
+
+def test_component_parallel_segment_output_image():
+    from tests.synth import blob_feature_map
+    fm = blob_feature_map((24, 64, 64), 3, 0.2, 2.5)
+    a = np.zeros((26, 66, 66), np.uint32)
+    b = np.zeros_like(a)
+    ows.segment_output_image(fm, out=a.ravel())
+    ows.segment_output_image(fm, out=b.ravel(), threads=4)
+    assert np.array_equal(a, b) and a.max() > 3
