@@ -155,13 +155,13 @@ def other_precision_leg(u, other, vol, fm, labels, chunk, margin, args, n_chunks
             "roofline": conv_roofline(other, mfma_flops, n_chunks, args.steps, ms_mfma, n_mfma, args.batch)}
 
 
-def train_step_leg(sd, patch=(10, 256, 256), steps=5):
+def train_step_leg(sd, patch=(10, 256, 256), steps=5, precision="fp32"):
     """The other entry point of the path (train_unet, train.py:25-183): one training step on one (10,256,256) patch --
     forward, BCE loss, backward, the reference's two Adam updates per sample -- in fp32 (training never uses the split
     arithmetic).  Reported beside the headline, never as `value`."""
     from iterseg_amd.train import Trainer
     from tests.synth import positive_volume
-    t = Trainer(sd, 5, patch)
+    t = Trainer(sd, 5, patch, precision=precision)
     x = torch.from_numpy(positive_volume(patch, 1)).cuda()
     y = torch.from_numpy((np.random.default_rng(1).random((5,) + patch) < 0.5).astype(np.float32)).cuda()
     for _ in range(2):
@@ -175,7 +175,10 @@ def train_step_leg(sd, patch=(10, 256, 256), steps=5):
     fwd, direct = conv_flops_per_chunk(patch)
     return {"patch": list(patch), "ms_per_step": 1e3 * dt, "voxels_per_s": float(np.prod(patch)) / dt, "loss": float(loss),
             "tflops_of_3x_forward": 3.0 * (fwd + direct) / dt / 1e12, "peak_tflops_fp32_matrix": PEAK_MFMA_F32,
-            "note": "forward + BCE + backward (dgrad, wgrad, BatchNorm) + the reference's double Adam update, batch 1"}
+            "precision": precision,
+            "note": "forward + BCE + backward (dgrad, wgrad, BatchNorm) + the reference's double Adam update, batch 1"
+                    + ("; bf16 = forward and data-gradient convolutions of the wide layers on the bf16 matrix cores, fp32 master "
+                       "weights / weight gradients / BatchNorm / Adam (BASELINE config 4's arithmetic)" if precision == "bf16" else "")}
 
 
 def structured_watershed_leg(u, n=512, volume_fraction=0.12, t_unet_ms=None):
@@ -454,6 +457,7 @@ def main():
             out["config2"] = config2_leg(u, 0, chunk, margin, args.batch)
             out["watershed_structured"] = structured_watershed_leg(u, t_unet_ms=t_unet if shape == (512, 512, 512) else None)
             out["train_step"] = train_step_leg(sd)
+            out["train_step_bf16"] = train_step_leg(sd, precision="bf16")
         if extra and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, chunk, margin)
     # N > 1, default mode: the two jobs with a collective in the timed region ride along (one step each, all ranks)

@@ -118,10 +118,19 @@ int isx_unet_set_batch(isx_ctx *ctx, int batch);
  * two halves (hi + lo/2^11), three v_mfma_f32_32x32x16_f16 per K block with separate fp32 accumulators -- fp32-class
  * results (about 2^-21 per product, below the fp32 accumulation noise; measured error against a float64 oracle at or
  * below the fp32 kernel's) at the f16 matrix rate; layers whose operands could leave the f16 range run the fp32 kernel.
- * ISX_PRECISION_FP32: v_mfma_f32_32x32x2_f32, exact fp32 products.  Training always runs fp32.  Same reference
- * operator either way: nn.Conv3d in ConvModule.forward (unet.py:63-79,91-106). */
+ * ISX_PRECISION_FP32: v_mfma_f32_32x32x2_f32, exact fp32 products.
+ * Reduced-precision side modes (never the default; stated tolerances in tests/test_gpu_unet.py, test_gpu_train.py):
+ * ISX_PRECISION_F16: plain f16 operands (round to nearest), one MFMA per product, fp32 accumulate -- the "fp16 U-Net" of
+ * BASELINE config 5; same f16 range fallback as the split mode.  ISX_PRECISION_BF16: plain bf16 operands
+ * (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fp32 BatchNorm statistics.
+ * Training runs fp32 except in ISX_PRECISION_BF16, where the wide convolutions of the forward pass and their data
+ * gradients run on the bf16 matrix cores from bf16 copies of the fp32 master weights (weight gradients, BatchNorm,
+ * the loss and Adam stay fp32): the mixed-precision mode of BASELINE config 4.  Same reference operator in every
+ * mode: nn.Conv3d in ConvModule.forward (unet.py:63-79,91-106). */
 #define ISX_PRECISION_FP32 0
 #define ISX_PRECISION_SPLIT_F16 1
+#define ISX_PRECISION_F16 2
+#define ISX_PRECISION_BF16 3
 int isx_unet_set_precision(isx_ctx *ctx, int mode);
 
 /* ---------------------------------------------------------------------------------- *

@@ -12,6 +12,12 @@
 // about 2^-21 per product -- below the rounding noise of the fp32 accumulation over K >= 864 terms.  The epilogue
 // returns HI + LO * 2^-11 + bias.  Operands are clamped to +-65504 (post-BatchNorm activations are nowhere near).
 //
+// Precision modes (template parameter PM; isx_unet_set_precision): 0 = the split arithmetic above (the default, fp32-class);
+// 1 = plain f16 operands (round to nearest, one MFMA per product, ~5e-4 relative per operand: the "fp16 U-Net" of BASELINE
+// config 5); 2 = plain bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 range, ~4e-3 per operand: the mixed-precision mode of
+// BASELINE config 4's training).  The single-product modes use only the hi half of each weight stage and of the halo tile
+// (half the LDS traffic and a third of the MFMAs); accumulation, bias and the BatchNorm statistics stay fp32 in every mode.
+//
 // Structure: as conv_mfma_kernel (128 voxels x BN columns per work-group, halo tile of the input in LDS reused by
 // all 27 taps, register prefetch of the next stage, BN+ReLU of the producer and zero padding applied at the LDS
 // store, XCD-aware 1-D grid), with a K stage of 8 input channels: v_mfma_f32_32x32x16_f16 takes k = 8*(lane/32)+j,
@@ -30,6 +36,7 @@ namespace isx {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 static constexpr float H2_SCALE = 2048.f, H2_MIN = 6.103515625e-05f, H2_MAX = 65504.f;
 
@@ -66,24 +73,59 @@ __device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &
     split2(b.z, b.w, hi.w, lo.w);
 }
 
+// 8 fp32 -> 8 f16 (round to nearest even, clamped) / 8 bf16 (round to nearest even), packed in a uint4
+__device__ __forceinline__ uint32_t pack_f16_rn(float x, float y)
+{
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    union { h2v v; uint32_t u; } H;
+    H.v[0] = (_Float16)__builtin_amdgcn_fmed3f(x, -H2_MAX, H2_MAX);
+    H.v[1] = (_Float16)__builtin_amdgcn_fmed3f(y, -H2_MAX, H2_MAX);
+    return H.u;
+}
+__host__ __device__ inline uint16_t bf16_rne_bits(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16_rn(float x, float y)
+{
+    uint32_t a = __float_as_uint(x), b = __float_as_uint(y);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+template <int PM>
+__device__ __forceinline__ void round8(const float4 &a, const float4 &b, uint4 &hi)
+{
+    if constexpr (PM == 1) {
+        hi.x = pack_f16_rn(a.x, a.y); hi.y = pack_f16_rn(a.z, a.w); hi.z = pack_f16_rn(b.x, b.y); hi.w = pack_f16_rn(b.z, b.w);
+    } else {
+        hi.x = pack_bf16_rn(a.x, a.y); hi.y = pack_bf16_rn(a.z, a.w); hi.z = pack_bf16_rn(b.x, b.y); hi.w = pack_bf16_rn(b.z, b.w);
+    }
+}
+
 // TX = 3: all 27 taps (14 pairs).  TX = 1: the 9 taps with dx = 0 (5 pairs) -- the folded tail layer, whose three
 // x-taps live in the output columns (see conv_mfma_kernel / tail_combine_kernel).
 // MT = 32-row tiles per wave (1: 128 voxels per work-group, 2: 256).  With 32 columns, MT = 2 gives the wave a
 // 64 x 32 tile whose six fragment reads feed six MFMAs, like the 32 x 64 tile of the 64-column variant.
-template <int BN, int TX, int MT>
+template <int BN, int TX, int MT, int PM>
 __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 {
+    constexpr bool SPLIT = PM == 0;
     constexpr int ROWS = 128 * MT, TXW = 8 * MT;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     constexpr int NT = BN / 32;
     constexpr int NTAPS = 9 * TX, NPAIR = (NTAPS + 1) / 2;
     constexpr int BU = 2 * NPAIR * BN;                    // uint4 per half of the weight slab (hi | lo)
-    constexpr int NB = (2 * BU + 255) / 256;              // uint4 of weights per thread per stage (14 / 7 / 3)
-    constexpr bool BEXACT = (2 * BU) % 256 == 0;
+    constexpr int SLAB = SPLIT ? 2 * BU : BU;             // uint4 of weights staged per K step (single-product modes: hi only)
+    constexpr int NB = (SLAB + 255) / 256;                // uint4 of weights per thread per stage (14 / 7 / 3; halved without lo)
+    constexpr bool BEXACT = SLAB % 256 == 0;
     uint4 *Bs = smem4;                                    // [hi: 28][BN] | [lo: 28][BN]
-    uint4 *AsH = smem4 + 2 * BU;
-    uint4 *AsL = AsH + a.slots_max;
-    int *rowinfo = (int *)(AsL + a.slots_max);
+    uint4 *AsH = smem4 + SLAB;
+    uint4 *AsL = AsH + a.slots_max;                       // (SPLIT only)
+    int *rowinfo = (int *)(AsH + (SPLIT ? 2 : 1) * a.slots_max);
     float *red = (float *)(rowinfo + ROWS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
@@ -165,13 +207,13 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
               gv4 = MT > 1 ? slot_voxel(tid + 1024) : -2;
 
     const int nsteps = (a.CA + a.CB) >> 3;
-    f32x16 acc_hi[MT][NT], acc_lo[MT][NT];
+    f32x16 acc_hi[MT][NT], acc_lo[SPLIT ? MT : 1][SPLIT ? NT : 1];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc_hi[m][j][i] = 0.f; acc_lo[m][j][i] = 0.f; }
+            for (int i = 0; i < 16; ++i) { acc_hi[m][j][i] = 0.f; if constexpr (SPLIT) acc_lo[m][j][i] = 0.f; }
 
     // named prefetch registers (arrays that live across the K loop end up in scratch)
     float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
@@ -183,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }
-#define H2_LOAD_B(k) if constexpr (NB > k) { if (BEXACT || tid + 256 * k < 2 * BU) rb##k = wsrc[tid + 256 * k]; }
+#define H2_LOAD_B(k) if constexpr (NB > k) { if (BEXACT || tid + 256 * k < SLAB) rb##k = wsrc[tid + 256 * k]; }
 #define H2_LOAD_STAGE(step_)                                                                      \
     {                                                                                             \
         const int c0 = (step_) << 3;                                                              \
@@ -197,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         vs0 = *(const float4 *)&scp[so]; vs1 = *(const float4 *)&scp[so + 4];                     \
         vh0 = *(const float4 *)&shp[so]; vh1 = *(const float4 *)&shp[so + 4];                     \
         H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4)                          \
-        const uint4 *wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  \
+        const uint4 *wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  /* packs keep the hi|lo stride in every mode */ \
         H2_LOAD_B(0) H2_LOAD_B(1) H2_LOAD_B(2) H2_LOAD_B(3) H2_LOAD_B(4) H2_LOAD_B(5) H2_LOAD_B(6) \
         H2_LOAD_B(7) H2_LOAD_B(8) H2_LOAD_B(9) H2_LOAD_B(10) H2_LOAD_B(11) H2_LOAD_B(12) H2_LOAD_B(13) \
     }
@@ -210,11 +252,11 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         if (has_affine) { H2_AFF(v, vs0, vh0) H2_AFF(w, vs1, vh1) }                               \
         if (gv##k < 0) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }                            \
         uint4 hi, lo;                                                                             \
-        split8(v, w, hi, lo);                                                                     \
+        if constexpr (SPLIT) { split8(v, w, hi, lo); AsL[tid + 256 * k] = lo; }                   \
+        else round8<PM>(v, w, hi);                                                                \
         AsH[tid + 256 * k] = hi;                                                                  \
-        AsL[tid + 256 * k] = lo;                                                                  \
     }
-#define H2_STORE_B(k) if constexpr (NB > k) { if (BEXACT || tid + 256 * k < 2 * BU) Bs[tid + 256 * k] = rb##k; }
+#define H2_STORE_B(k) if constexpr (NB > k) { if (BEXACT || tid + 256 * k < SLAB) Bs[tid + 256 * k] = rb##k; }
 
     // LDS offset of tap t relative to the output voxel's slot (tap 27 = padding pair of tap 26: zero weights)
     auto tap_off = [&](int t) __attribute__((always_inline)) -> int {
@@ -236,24 +278,34 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) {
             const int to = hh ? tap_off(2 * p + 1) : tap_off(2 * p);
-            union FR { uint4 u; f16x8 v; };
+            union FR { uint4 u; f16x8 v; bf16x8 w; };
             FR ah[MT], al[MT];
             ah[0].u = AsH[aslot0 + to];
-            al[0].u = AsL[aslot0 + to];
-            if constexpr (MT > 1) { ah[1].u = AsH[aslot1 + to]; al[1].u = AsL[aslot1 + to]; }
+            if constexpr (SPLIT) al[0].u = AsL[aslot0 + to];
+            if constexpr (MT > 1) { ah[1].u = AsH[aslot1 + to]; if constexpr (SPLIT) al[1].u = AsL[aslot1 + to]; }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 FR bh, bl;
                 bh.u = bph[(2 * p) * BN + 32 * j];
-                bl.u = bpl[(2 * p) * BN + 32 * j];
+                if constexpr (SPLIT) {
+                    bl.u = bpl[(2 * p) * BN + 32 * j];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc_hi[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bh.v, acc_hi[m][j], 0, 0, 0);
-                    acc_lo[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bl.v, acc_lo[m][j], 0, 0, 0);
+                    for (int m = 0; m < MT; ++m) {
+                        acc_hi[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bh.v, acc_hi[m][j], 0, 0, 0);
+                        acc_lo[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bl.v, acc_lo[m][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc_lo[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m].v, bh.v, acc_lo[m][j], 0, 0, 0);
+                } else if constexpr (PM == 1) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc_hi[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bh.v, acc_hi[m][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc_hi[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].w, bh.w, acc_hi[m][j], 0, 0, 0);
                 }
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc_lo[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m].v, bh.v, acc_lo[m][j], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -278,7 +330,9 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
                 const int row = (wave * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
                 const int g = rowinfo[row];
                 if (g >= 0) {
-                    const float v = fmaf(acc_lo[m][j][i], 1.f / H2_SCALE, acc_hi[m][j][i]) + bsv;
+                    float v;
+                    if constexpr (SPLIT) v = fmaf(acc_lo[m][j][i], 1.f / H2_SCALE, acc_hi[m][j][i]) + bsv;
+                    else v = acc_hi[m][j][i] + bsv;
                     if (ch < a.store_cols) a.out[((int64_t)b * M + g) * a.store_cols + ch] = v;
                     s += v;
                     q += v * v;
@@ -317,7 +371,8 @@ int conv_h2_bn(const isx_tune &tune, int slots, int cout)
 }
 
 // w: reference layout [Cout][Cin][27] fp32 -> [Cout/BN][Cin/8][hi|lo][28 taps][BN][8 channels] halves
-void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out)
+// pm = 0: split halves (hi | lo); 1: f16 round-to-nearest in hi; 2: bf16 round-to-nearest in hi (lo stays zero, unused)
+void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out, int pm)
 {
     const int ntiles = cout / bn, nsteps = cin / 8;
     const size_t half_slab = (size_t)28 * bn * 8;
@@ -332,13 +387,14 @@ void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint
                 uint16_t hb, lb;
                 memcpy(&hb, &h, 2);
                 memcpy(&lb, &l, 2);
+                if (pm == 2) { hb = bf16_rne_bits(w[((size_t)co * cin + ci) * 27 + t]); lb = 0; }
                 out[base + e] = hb;
                 out[base + half_slab + e] = lb;
             }
 }
 
 // folded tail layer (cout <= 5): [Cin/8][hi|lo][10 (dz,dy) taps][32 columns = dx*cout + o][8 channels] halves
-void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out)
+void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out, int pm)
 {
     const int nsteps = cin / 8;
     const size_t half_slab = (size_t)10 * 32 * 8;
@@ -354,14 +410,46 @@ void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_
                 uint16_t hb, lb;
                 memcpy(&hb, &h, 2);
                 memcpy(&lb, &l, 2);
+                if (pm == 2) { hb = bf16_rne_bits(w[((size_t)co * cin + ci) * 27 + t]); lb = 0; }
                 out[base + e] = hb;
                 out[base + half_slab + e] = lb;
             }
 }
 
+// Device version of pack_h2_weights for training (the weights change every step): wref = [Cout][Cin][27] fp32.
+// transpose != 0: the dgrad operator (Cin <-> Cout, taps mirrored), packed as a convolution with `cin_p` = Cout input
+// channels (zero-padded to a multiple of 8) and `cout_p` = Cin output channels.  bf16 in the hi half, lo left zero.
+__global__ void repack_bf16_kernel(const float *__restrict__ wref, int cout, int cin, int transpose, int bn, int cout_p, int cin_p,
+                                   uint16_t *__restrict__ dst)
+{
+    const int nsteps = cin_p / 8;
+    const size_t half_slab = (size_t)28 * bn * 8;
+    const int64_t n = (int64_t)cout_p * cin_p * 27;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % 27), ci = (int)((i / 27) % cin_p), co = (int)(i / (27 * (int64_t)cin_p));
+        float v = 0.f;
+        if (!transpose) { if (co < cout && ci < cin) v = wref[((size_t)co * cin + ci) * 27 + t]; }
+        else if (ci < cout && co < cin) v = wref[((size_t)ci * cin + co) * 27 + (26 - t)];
+        const size_t base = ((size_t)(co / bn) * nsteps + ci / 8) * 2 * half_slab;
+        dst[base + ((size_t)t * bn + co % bn) * 8 + ci % 8] = bf16_rne_bits(v);
+    }
+}
+
+int repack_bf16(isx_ctx *ctx, const float *wref, int cout, int cin, int transpose, int bn, int cout_p, int cin_p, void *dst)
+{
+    const int64_t n = (int64_t)cout_p * cin_p * 27;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    repack_bf16_kernel<<<grid, 256, 0, ctx->stream>>>(wref, cout, cin, transpose, bn, cout_p, cin_p, (uint16_t *)dst);
+    ISX_CHECK_LAUNCH();
+    return ISX_OK;
+}
+
+size_t h2_pack_halves(int cout_p, int cin_p, int bn) { return (size_t)(cout_p / bn) * (cin_p / 8) * 2 * 28 * bn * 8 + 4096; }
+
 // fold != 0: the folded tail layer (TX = 1, 32 columns of which store_cols = 16 are stored, no statistics)
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used)
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used, int pm)
 {
     ConvArgs a;
     a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
@@ -389,24 +477,30 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     ISX_REQUIRE(a.slots_max <= (mt == 2 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     a.ntiles = fold ? 1 : cout / BN;
     const int npair = fold ? 5 : 14;
-    const size_t lds = (size_t)(2 * 2 * npair * BN + 2 * a.slots_max) * 16 + (128 * mt + 4 * BN * 2) * sizeof(float);
+    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * (2 * npair * BN + a.slots_max)) * 16 + (128 * mt + 4 * BN * 2) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
     bool &attr_done = ctx->h2_attr_done;                  // per context (setting it again from another context is harmless)
+#define ISX_H2_ATTR(BN_, TX_, MT_) \
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<BN_, TX_, MT_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<BN_, TX_, MT_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<BN_, TX_, MT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (!attr_done) {
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<32, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_H2_ATTR(64, 3, 1) ISX_H2_ATTR(32, 3, 1) ISX_H2_ATTR(32, 3, 2) ISX_H2_ATTR(32, 1, 1) ISX_H2_ATTR(32, 1, 2)
         attr_done = true;
     }
-    if (fold && mt == 2) conv_h2_kernel<32, 1, 2><<<grid, 256, lds, ctx->stream>>>(a);
-    else if (fold) conv_h2_kernel<32, 1, 1><<<grid, 256, lds, ctx->stream>>>(a);
-    else if (BN == 64) conv_h2_kernel<64, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
-    else if (mt == 2) conv_h2_kernel<32, 3, 2><<<grid, 256, lds, ctx->stream>>>(a);
-    else conv_h2_kernel<32, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
+#undef ISX_H2_ATTR
+#define ISX_H2_GO(BN_, TX_, MT_) \
+    do { if (pm == 0) conv_h2_kernel<BN_, TX_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
+         else if (pm == 1) conv_h2_kernel<BN_, TX_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
+         else conv_h2_kernel<BN_, TX_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
+    if (fold && mt == 2) ISX_H2_GO(32, 1, 2);
+    else if (fold) ISX_H2_GO(32, 1, 1);
+    else if (BN == 64) ISX_H2_GO(64, 3, 1);
+    else if (mt == 2) ISX_H2_GO(32, 3, 2);
+    else ISX_H2_GO(32, 3, 1);
+#undef ISX_H2_GO
     ISX_CHECK_LAUNCH();
     return ISX_OK;
 }

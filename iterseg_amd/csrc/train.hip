@@ -37,6 +37,10 @@ struct TrainState {
     int dstride[18];                 // channel stride of draw[li] (cout, or 8 for a thin layer whose dgrad runs on MFMA)
     std::vector<void *> blocks;
     float *draw[18] = {nullptr}, *gact[18] = {nullptr}, *w_dgrad[18] = {nullptr};
+    // bf16 mixed precision (ISX_PRECISION_BF16): device-refreshed packs of the forward (both tile widths) and dgrad operators
+    void *wbf_fwd64[18] = {nullptr}, *wbf_fwd32[18] = {nullptr}, *wbf_dg[18] = {nullptr};
+    int wbf_dg_bn[18] = {0};
+    bool bf_fresh = false;           // the bf16 packs match P
     float *dcat[4] = {nullptr}, *dpool[4] = {nullptr};
     float *part = nullptr, *coef = nullptr, *wpart = nullptr, *lossbuf = nullptr, *zeros = nullptr;
     size_t part_floats = 0, wpart_floats = 0;
@@ -700,6 +704,7 @@ static int repack_all(isx_ctx *ctx)
 {
     UNetState *u = ctx->unet;
     TrainState *t = u->train;
+    t->bf_fresh = u->precision == ISX_PRECISION_BF16;
     for (int li = 0; li < 18; ++li) {
         ConvBN &L = u->cv[li];
         const float *wref = t->P + t->off_w[li];
@@ -709,6 +714,11 @@ static int repack_all(isx_ctx *ctx)
         if (use_mfma(L.cin, L.cout)) {
             repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 0, L.w, 0);
             if (t->w_dgrad[li]) repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 1, t->w_dgrad[li], 0);
+            if (u->precision == ISX_PRECISION_BF16) {
+                if (t->wbf_fwd64[li]) ISX_TRY(repack_bf16(ctx, wref, L.cout, L.cin, 0, 64, L.cout, L.cin, t->wbf_fwd64[li]));
+                if (t->wbf_fwd32[li]) ISX_TRY(repack_bf16(ctx, wref, L.cout, L.cin, 0, 32, L.cout, L.cin, t->wbf_fwd32[li]));
+                if (t->wbf_dg[li]) ISX_TRY(repack_bf16(ctx, wref, L.cout, L.cin, 1, t->wbf_dg_bn[li], L.cin, L.cout, t->wbf_dg[li]));
+            }
         } else if (use_fold(L.cin, L.cout)) {
             repack_fold_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, L.w);
             if (t->w_dgrad[li]) repack_mfma_kernel<<<grid, 256, 0, ctx->stream>>>(wref, L.cout, L.cin, 1, t->w_dgrad[li], 8);
@@ -801,6 +811,11 @@ static int dgrad(isx_ctx *ctx, int li, float *dst)
     TrainState *t = u->train;
     const ConvBN &L = u->cv[li];
     const Level &l = u->lv[MOD_LEVEL[li / 2]];
+    if (u->precision == ISX_PRECISION_BF16 && t->wbf_dg[li] && t->dstride[li] == L.cout && conv_mt(ctx->tune, l, u->wbatch, L.cin) == 1) {
+        // bf16 mixed precision: the same operator on the bf16 matrix cores (d(raw) is rounded to bf16 at the LDS store)
+        return launch_conv_h2(ctx, l, 1, Src{t->draw[li], nullptr, nullptr, L.cout}, Src{nullptr, nullptr, nullptr, 0}, t->wbf_dg[li],
+                              t->zeros, L.cin, dst, nullptr, nullptr, 1, ctx->tune.xcd_remap, 0, nullptr, 2);
+    }
     if (t->w_dgrad[li]) {
         // the forward kernel with Cin <-> Cout: "input" = d(raw) (Cout channels), "output" = dX (Cin channels)
         return launch_conv_mfma(ctx, l, 1, Src{t->draw[li], nullptr, nullptr, t->dstride[li]}, Src{nullptr, nullptr, nullptr, 0},
@@ -954,6 +969,32 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
         ISX_TRY(talloc(t, (size_t)u->lv[3 - k].M * 2 * u->up[k].C, &t->dcat[k]));
         ISX_TRY(talloc(t, (size_t)u->lv[k + 1].M * MOD_COUT[k], &t->dpool[k]));
     }
+    // bf16 packs (refreshed on the device after every optimiser step while the context is in ISX_PRECISION_BF16)
+    for (int li = 0; li < 18; ++li) {
+        ConvBN &L = u->cv[li];
+        if (!use_mfma(L.cin, L.cout) || L.cin % 8) continue;
+        const Level &l = u->lv[MOD_LEVEL[li / 2]];
+        int t0, t1, t2, slots;
+        conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
+        for (int bn = 32; bn <= 64; bn += 32) {
+            if (L.cout % bn) continue;
+            float *p = nullptr;
+            const size_t halves = h2_pack_halves(L.cout, L.cin, bn);
+            ISX_TRY(talloc(t, (halves + 1) / 2, &p));
+            ISX_HIP(hipMemsetAsync(p, 0, halves * 2, ctx->stream));
+            (bn == 64 ? t->wbf_fwd64[li] : t->wbf_fwd32[li]) = p;
+            (bn == 64 ? L.w_bf_64 : L.w_bf_32) = p;              // the forward reads the refreshed packs from now on
+        }
+        if (li != 0 && L.cin % 32 == 0 && L.cout % 8 == 0) {     // dgrad operator: Cout -> Cin
+            const int bn = conv_h2_bn(ctx->tune, slots, L.cin);
+            float *p = nullptr;
+            const size_t halves = h2_pack_halves(L.cin, L.cout, bn);
+            ISX_TRY(talloc(t, (halves + 1) / 2, &p));
+            ISX_HIP(hipMemsetAsync(p, 0, halves * 2, ctx->stream));
+            t->wbf_dg[li] = p;
+            t->wbf_dg_bn[li] = bn;
+        }
+    }
     t->part_floats = (size_t)4 << 20;
     ISX_TRY(talloc(t, t->part_floats, &t->part));
     ISX_TRY(talloc(t, 1024, &t->coef));
@@ -989,6 +1030,7 @@ static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dic
     // last step (the trained UNet object is handed back to the caller): the backward buffers are sized for the patch
     // bound at isx_train_bind, so the forward workspace is brought back to it first (a no-op when nothing changed)
     ISX_TRY(prepare_workspace(ctx, t->cz, t->cy, t->cx, 1));
+    if (u->precision == ISX_PRECISION_BF16 && !t->bf_fresh) ISX_TRY(repack_all(ctx));      // precision switched since the last update
     const Level &l0 = u->lv[0];
     const int C = u->out_channels;
     ISX_REQUIRE(C <= 8, "at most 8 output channels");

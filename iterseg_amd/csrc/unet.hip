@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
     float4 ra0, ra1, ra2, ra3, ra4, rb0, rb1, rb2, rb3, rb4, rb5, rb6, vs, vh;
     bool has_affine = false;
 #define ISX_LOAD_A(k) if constexpr (k < 4 || MT > 1) ra##k = *(const float4 *)&src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];
-#define ISX_LOAD_B(k) if constexpr (NB > k) rb##k = wsrc[tid + 256 * k];
+// (guarded: the slab is not a multiple of 256 float4 -- 864 / 1728 -- and the last stage of the last tile ends the
+// allocation; the unguarded tail read 2.5 KB past it, harmless only while the next page happens to be mapped)
+#define ISX_LOAD_B(k) if constexpr (NB > k) { if (B4 % 256 == 0 || tid + 256 * k < B4) rb##k = wsrc[tid + 256 * k]; }
 #define ISX_LOAD_STAGE(step_)                                                                     \
     {                                                                                             \
         const int c0 = (step_) << 2;                                                              \
@@ -915,23 +917,28 @@ static int commit_weights(isx_ctx *ctx, int out_channels)
             const bool w_in_range = wabs < 6.0e4f;              // otherwise this layer stays on the fp32 kernel
             if (use_fold(L.cin, cout) && L.cin % 8 == 0 && w_in_range) {
                 std::vector<uint16_t> hp;
-                pack_h2_fold_weights(w->f.data(), cout, L.cin, hp);
-                void *d = nullptr;
-                ISX_HIP(hipMalloc(&d, hp.size() * 2));
-                u->wblocks.push_back(d);
-                ISX_HIP(hipMemcpy(d, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
-                L.w_h2_32 = d;
+                for (int pm = 0; pm <= 2; pm += 2) {              // split halves (their hi half serves plain f16), bf16
+                    pack_h2_fold_weights(w->f.data(), cout, L.cin, hp, pm);
+                    void *d = nullptr;
+                    ISX_HIP(hipMalloc(&d, hp.size() * 2));
+                    u->wblocks.push_back(d);
+                    ISX_HIP(hipMemcpy(d, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+                    (pm == 0 ? L.w_h2_32 : L.w_bf_32) = d;
+                }
             }
             if (use_mfma(L.cin, cout) && L.cin % 8 == 0 && w_in_range) {       // split-f16 packs (both tile widths: the tile
                 std::vector<uint16_t> hp;                       // geometry is only known once a chunk arrives)
                 for (int bn = 32; bn <= 64; bn += 32) {
                     if (cout % bn) continue;
-                    pack_h2_weights(w->f.data(), cout, L.cin, bn, hp);
-                    void *d = nullptr;
-                    ISX_HIP(hipMalloc(&d, hp.size() * 2));
-                    u->wblocks.push_back(d);
-                    ISX_HIP(hipMemcpy(d, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
-                    (bn == 64 ? L.w_h2_64 : L.w_h2_32) = d;
+                    for (int pm = 0; pm <= 2; pm += 2) {
+                        pack_h2_weights(w->f.data(), cout, L.cin, bn, hp, pm);
+                        void *d = nullptr;
+                        ISX_HIP(hipMalloc(&d, hp.size() * 2));
+                        u->wblocks.push_back(d);
+                        ISX_HIP(hipMemcpy(d, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+                        if (pm == 0) (bn == 64 ? L.w_h2_64 : L.w_h2_32) = d;
+                        else (bn == 64 ? L.w_bf_64 : L.w_bf_32) = d;
+                    }
                 }
             }
             std::vector<float> b8(std::max(cout, 8), 0.f);
@@ -1108,19 +1115,27 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
         ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
         int t0, t1, t2, slots;
         conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
-        const void *wh = conv_h2_bn(ctx->tune, slots, L.cout) == 64 ? L.w_h2_64 : L.w_h2_32;
-        const bool in_range = std::max(sa.bound, sb.bound) < 6.0e4f;          // else operands could leave the f16 range
-        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && wh && in_range && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1)
-            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, 0, &stat_tiles));
+        const bool bf = u->precision == ISX_PRECISION_BF16;
+        const bool b64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64;
+        const void *wh = bf ? (b64 ? L.w_bf_64 : L.w_bf_32) : (b64 ? L.w_h2_64 : L.w_h2_32);
+        const bool in_range = bf || std::max(sa.bound, sb.bound) < 6.0e4f;    // else operands could leave the f16 range
+        // training keeps fp32 products except in the bf16 mixed-precision mode (its packs are refreshed every step)
+        const bool reduced = u->precision != ISX_PRECISION_FP32 && (!u->train || bf);
+        const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
+        if (reduced && wh && in_range && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1)
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, 0, &stat_tiles, pm));
         else
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
     } else if (use_fold(L.cin, L.cout)) {
         // pass 1 on the matrix cores: 9 (dz,dy) taps, x-taps folded into 3*cout <= 16 output columns
-        if (u->precision == ISX_PRECISION_SPLIT_F16 && !u->train && L.w_h2_32 && std::max(sa.bound, sb.bound) < 6.0e4f &&
+        const bool bf = u->precision == ISX_PRECISION_BF16;
+        const void *wf = bf ? L.w_bf_32 : L.w_h2_32;
+        const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
+        if (u->precision != ISX_PRECISION_FP32 && !u->train && wf && (bf || std::max(sa.bound, sb.bound) < 6.0e4f) &&
             conv_mt(ctx->tune, l, u->wbatch, 32) == 1) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
-            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, L.w_h2_32, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
-                                   ctx->tune.xcd_remap, 1, nullptr));
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wf, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
+                                   ctx->tune.xcd_remap, 1, nullptr, pm));
         } else {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ConvArgs a;
@@ -1372,7 +1387,7 @@ int isx_get_weight_host(isx_ctx *ctx, const char *key, void *data, int64_t nbyte
 
 int isx_unet_set_precision(isx_ctx *ctx, int mode)
 {
-    ISX_REQUIRE(ctx && (mode == ISX_PRECISION_FP32 || mode == ISX_PRECISION_SPLIT_F16), "precision mode %d", mode);
+    ISX_REQUIRE(ctx && mode >= ISX_PRECISION_FP32 && mode <= ISX_PRECISION_BF16, "precision mode %d", mode);
     if (!ctx->unet) { ctx->unet = new UNetState(); ctx->unet->tune = ctx->tune; }
     ctx->unet->precision = mode;
     return ISX_OK;

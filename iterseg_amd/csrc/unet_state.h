@@ -23,7 +23,8 @@ struct ConvBN {                 // one Conv3d followed by its BatchNorm3d
     std::string conv, bn;       // state-dict prefixes, e.g. "c0.conv0", "c0.batch0"
     int cin = 0, cout = 0;
     float *w = nullptr;         // packed weights (layout depends on the kernel that reads them)
-    void *w_h2_64 = nullptr, *w_h2_32 = nullptr;   // split-f16 packs for 64- / 32-column tiles (conv_h2.hip)
+    void *w_h2_64 = nullptr, *w_h2_32 = nullptr;   // split-f16 packs for 64- / 32-column tiles (conv_h2.hip); their hi halves serve the plain-f16 mode
+    void *w_bf_64 = nullptr, *w_bf_32 = nullptr;   // bf16 packs, same layout (hi half bf16, lo unused)
     float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *rmean = nullptr, *rvar = nullptr;
     int64_t nbt = 0;
     float *scale = nullptr, *shift = nullptr;       // [B][cout], valid after bn_finalize
@@ -109,10 +110,12 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
 // split-f16 convolution (conv_h2.hip)
 int conv_h2_bn(const isx_tune &tune, int slots, int cout);
 int h2_mt(const isx_tune &tune, const Level &l, int batch);
-void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out);
-void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out);
+void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out, int pm);
+void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out, int pm);
+int repack_bf16(isx_ctx *ctx, const float *wref, int cout, int cin, int transpose, int bn, int cout_p, int cin_p, void *dst);
+size_t h2_pack_halves(int cout_p, int cin_p, int bn);
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used);
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used, int pm = 0);
 int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch);
 int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3]);
 int dev_alloc(UNetState *u, size_t floats, float **out);

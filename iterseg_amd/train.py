@@ -77,8 +77,14 @@ class Trainer:
     """One U-Net replica being trained on this rank's GPU."""
 
     def __init__(self, state_dict=None, out_channels=5, patch=(10, 256, 256), device=None, seed=0,
-                 chan_final_activations=None):
-        self.unet = UNet(1, out_channels, device=device, batch=1, chan_final_activations=chan_final_activations)
+                 chan_final_activations=None, precision="fp32"):
+        """``precision``: ``"fp32"`` (the reference's arithmetic) or ``"bf16"`` (mixed precision, BASELINE config 4: the wide
+        convolutions of the forward pass and their data gradients on the bf16 matrix cores, everything else fp32)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("training precision must be 'fp32' or 'bf16'")
+        self.unet = UNet(1, out_channels, device=device, batch=1, chan_final_activations=chan_final_activations,
+                         precision=precision)
+        self.precision = precision
         if state_dict is None:
             state_dict = _weights.generate_state_dict(seed, 1, out_channels)
         self.unet.load_state_dict(state_dict)
@@ -97,7 +103,10 @@ class Trainer:
         _lib.check(lib.isx_train_bind(h, _lib._dims(self.patch), C.c_void_p(self.params.data_ptr()),
                                       C.c_void_p(self.grads.data_ptr()), C.c_void_p(self.adam_m.data_ptr()),
                                       C.c_void_p(self.adam_v.data_ptr()), n))
-        self.unet.trainer = self                  # UNet.state_dict() reads the live parameters from here
+        # UNet.state_dict() reads the live parameters from here.  The UNet holds the parameter TENSOR, not the Trainer: no
+        # reference cycle (contexts are destroyed promptly, in creation order), and the buffer the library's bias / BatchNorm
+        # pointers alias stays alive as long as the context does -- also for the UNet that train_unet hands back
+        self.unet._train_params = (self.layout, self.params, self.grads, self.adam_m, self.adam_v)
 
     # ------------------------------------------------------------------ steps
     def _call(self, x, y, loss, chan_weights, lr, n_adam, backward, channelwise=None):
@@ -173,7 +182,7 @@ def _load(i, xs):
 def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', channels=None, validate=True,
                log=True, epochs=3, lr=0.01, loss_function='BCELoss', chan_weights=None, weights=None,
                update_every=20, losses=None, chan_losses=None, fork_channels=None, chan_final_activations=None,
-               double_step=True, **kwargs):
+               double_step=True, precision="fp32", **kwargs):
     """Train the affinity U-Net on lists of patches ``x[i]`` (Z,Y,X) / ``y[i]`` (C,Z,Y,X).  Returns
     ``(unet, unet_path)`` like the reference; ``unet_path`` is None when ``out_dir`` is None (the reference
     leaves it unbound there, train.py:177-183)."""
@@ -197,7 +206,7 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
     if weights is not None:
         sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in weights.items()}
     trainer = Trainer(sd, out_channels=n_out, patch=patch, seed=kwargs.get('seed', 0),
-                      chan_final_activations=chan_final_activations)
+                      chan_final_activations=chan_final_activations, precision=precision)
     cwise = channelwise_spec(losses, chan_losses, n_out) if loss_function == 'Channelwise' else None
     loss_dict = {'epoch': [], 'batch_num': [], 'loss': [], 'data_id': []}
     for c in channels:

@@ -45,7 +45,7 @@ class UNet:
         self._batch = int(batch)
         self._loaded = False
         self._sd = None
-        self.trainer = None
+        self._train_params = None          # (layout, flat parameter tensor) once a Trainer is bound to this context
         self.precision = "fp32"
         self.set_precision(precision if precision is not None else os.environ.get("ISX_CONV_PRECISION", DEFAULT_PRECISION))
 
@@ -89,17 +89,19 @@ class UNet:
         # a U-Net that is (or was) being trained: the live parameters are the trainer's flat buffer, not the arrays
         # this object was loaded from (``unet, _ = train_unet(...); torch.save(unet.state_dict(), ...)`` is the
         # reference idiom, train.py:183)
-        tr = getattr(self, "trainer", None)
-        if tr is not None:
-            for k, shape, off in tr.layout:
-                out[k] = tr.params[off:off + int(np.prod(shape))].view(shape).detach().cpu().clone()
+        if self._train_params is not None:
+            layout, params = self._train_params[:2]
+            for k, shape, off in layout:
+                out[k] = params[off:off + int(np.prod(shape))].view(shape).detach().cpu().clone()
         return out
 
     def set_precision(self, precision):
-        """Arithmetic of the wide inference convolutions: ``"fp32"`` (exact fp32 products) or ``"split-f16"``
-        (fp32 operands split into two halves each, f16 matrix cores, fp32 accumulation: fp32-class results;
-        see include/itersegx.h).  Training always runs fp32."""
-        modes = {"fp32": 0, "split-f16": 1}
+        """Arithmetic of the wide convolutions: ``"fp32"`` (exact fp32 products), ``"split-f16"`` (fp32 operands split
+        into two halves each, f16 matrix cores, fp32 accumulation: fp32-class results, the default), or the reduced-
+        precision side modes ``"f16"`` / ``"bf16"`` (plain operands, one MFMA per product; see include/itersegx.h).
+        Training runs fp32 except in ``"bf16"`` (mixed precision: bf16 forward / data-gradient convolutions, fp32
+        master weights, weight gradients, BatchNorm and Adam)."""
+        modes = {"fp32": 0, "split-f16": 1, "f16": 2, "bf16": 3}
         if precision not in modes:
             raise ValueError(f"precision must be one of {sorted(modes)}")
         _lib.check(self.ctx.lib.isx_unet_set_precision(self.ctx.handle, modes[precision]))
