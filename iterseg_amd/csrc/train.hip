@@ -487,9 +487,11 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int split
     const int64_t n = (int64_t)Cout * Cin * 27;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int t = (int)(i % 27), ci = (int)((i / 27) % Cin), co = (int)(i / (27 * (int64_t)Cin));
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[(((int64_t)k * 27 + t) * CoP + co) * CiP + ci];
-        dw[i] = s;
+        // the split-K partials (fp32 MFMA accumulations over one K block each) are of either sign and cancel: the final
+        // sum runs in double, in a fixed order, so that it adds no rounding of its own
+        double s = 0.0;
+        for (int k = 0; k < splits; ++k) s += (double)partial[(((int64_t)k * 27 + t) * CoP + co) * CiP + ci];
+        dw[i] = (float)s;
     }
 }
 

@@ -134,8 +134,10 @@ def test_full_size_patch_against_oracle():
         mine = np.abs(got - ref).max()
         theirs = np.abs(g32[k].astype(np.float64) - ref).max()
         scale = np.abs(ref).max()
-        # measured (scratch/dbg_train.py): both fp32 implementations sit at 0.001 % .. 7 % of max|grad| from float64
-        assert mine <= max(10.0 * theirs, 3e-2 * scale) + 1e-9, (k, mine, theirs, scale)
+        print(f"{k}: ours {mine:.3e} torch-fp32 {theirs:.3e} (x{mine / max(theirs, 1e-30):.1f}) max|g| {scale:.3e}")
+        # measured with the split-K partials of wgrad reduced in double: 0.9x .. 5x torch-fp32's own error on the
+        # convolution weights; the folded tail layer and up3 (other summation trees) sit at 0.2 % of max|grad|
+        assert mine <= max(6.0 * theirs, 5e-3 * scale) + 1e-9, (k, mine, theirs, scale)
 
 
 @pytest.mark.parametrize("tag,name,arg", [
