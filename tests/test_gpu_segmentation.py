@@ -172,3 +172,35 @@ def test_plugin_call_from_worker_threads_two_contexts():
     for k in range(2):
         for t in range(3):
             assert got[k][t] is not None and np.array_equal(got[k][t], expected[k][t]) and expected[k][t].max() > 0
+
+
+def test_segment_stack_with_the_hip_path(unet):
+    """SURVEY.md 8(e), frames of a (t,z,y,x) stack: distributed.segment_stack drives the HIP compute (not the injected
+    oracle of the gloo CPU test) -- single process here, two gloo ranks in tests/_stack_worker.py; per-frame labels equal
+    the per-frame plugin calls."""
+    from iterseg_amd import segmentation as seg
+    from iterseg_amd.distributed import segment_stack
+    from tests.synth import positive_volume
+    data = np.stack([positive_volume((8, 40, 48), s) for s in (21, 22, 23)])
+
+    def frame(vol):
+        vol = vol / vol.max()
+        cur = np.zeros(tuple(s + 2 for s in vol.shape), np.uint32)
+        seg.affinity_watershed_for_chunks(vol.astype(np.float32), cur, CHUNK, MARGIN, unet=unet,
+                                          output_volume=np.zeros((5,) + vol.shape, np.float32))
+        return cur[1:-1, 1:-1, 1:-1].astype(np.int32)
+
+    out = segment_stack(data, frame)
+    assert tuple(out.shape) == data.shape and out.dtype == torch.int32
+    for t in range(3):
+        assert np.array_equal(out[t].cpu().numpy(), frame(data[t])) and int(out[t].max()) > 0
+    # two ranks (gloo, both on cuda:0): frame t on rank t mod 2, all-gather of the label tiles
+    import os, socket, subprocess, sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_stack_worker.py")]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
