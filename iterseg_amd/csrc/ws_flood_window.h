@@ -638,8 +638,10 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             if (sp < nw) squash_from(sp);
         }
         WTICK(4);
-        // ---- E: commit the idle episodes at the front, in order -----------------------------------------------------------
-        {
+        // ---- E: commit the idle episodes at the front, in order (up to three bursts of 64 per sub-round: on tie plateaus
+        //         every episode is a single pop and the whole window turns over) ---------------------------------------------
+        for (int burst = 0; burst < 3 && nw > 0 && !serial; ++burst) {
+            const unsigned long long qh = burst == 0 ? qhead : (scount > 0 ? srun[shead].key : ~0ull);   // enqueues moved the run
             const int j = lane;
             const bool valid = j < nw;
             const int s = valid ? slot_of(j) : 0;
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             bool idle = st && q1.x == WIN_NONE;
             // the front episode with a full list commits what it has done: the element it was about to pop goes back to
             // the queue like any other residual
-            const bool forced = front_forced && j == 0 && st && q1.x != WIN_NONE && np + 6 > tcap;
+            const bool forced = burst == 0 && front_forced && j == 0 && st && q1.x != WIN_NONE && np + 6 > tcap;
             if (forced) { pval[pl * WIN_T + (int)(q1.y >> 24)] = q1.w; idle = true; }
             WIN_FENCE();
             const unsigned long long nb_ = ~__ballot(idle);
@@ -673,9 +675,13 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             // residuals of the episodes committing before me must all sort after everything I popped (they are older
             // than my discoveries: strict for those; my root is older than any residual: ties go to the root)
             uint32_t F = wave_shr1(wave_prefix_min(j < m ? resmin : 0xFFFFFFFFu), 0xFFFFFFFFu);
-            const uint32_t qv = (uint32_t)(qhead >> 32);
+            const uint32_t qv = (uint32_t)(qh >> 32);
             if (qv < F) F = qv;
-            const bool ok = j < m && q0.y <= F && (maxnew == 0u || maxnew < F);
+            // ... and after the root behind me, which may be a residual that an earlier burst of this sub-round put there
+            // (the bound check at the top of the sub-round has not seen it yet)
+            uint32_t succv = 0xFFFFFFFFu;
+            if (valid && j + 1 < nw) succv = winq0[slot_of(j + 1)].y;
+            const bool ok = j < m && q0.y <= F && (maxnew == 0u || (maxnew < F && maxnew < succv));
             const unsigned long long nok = ~__ballot(ok);
             int ncommit = nok ? __ffsll((long long)nok) - 1 : 64;
             WTICK(5);
@@ -735,6 +741,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                     enqueue64(has, r.key, r.idx, r.pad);
                 }
             }
+            if (ncommit < 64) break;
         }
         WTICK(7);
         if (serial) break;
