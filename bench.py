@@ -183,13 +183,14 @@ def train_step_leg(sd, patch=(10, 256, 256), steps=5, precision="fp32"):
 
 def structured_watershed_leg(u, n=512, volume_fraction=0.12, t_unet_ms=None):
     """the watershed stage alone on a *structured* feature map -- blobs / distance-transform centroid
-    channel / gradient affinities as in the reference's own demo (watershed.py:256-262; tests/synth.blob_feature_map,
-    mirror-tiled to n^3) -- where the mask falls into many components of every size, which is what a trained network
-    produces.  `end_to_end_voxels_per_s` prices a whole frame with this watershed behind the measured U-Net stage."""
+    channel / gradient affinities as in the reference's own demo (watershed.py:256-262; tests/synth.blob_feature_map) --
+    where the mask falls into many components of every size, which is what a trained network produces.  The n^3 input is
+    eight independently seeded (n/2)^3 demo volumes side by side (tests/synth.blob_feature_map_tiled).
+    `end_to_end_voxels_per_s` prices a whole frame with this watershed behind the measured U-Net stage."""
     from iterseg_amd import watershed as ws
-    from tests.synth import blob_feature_map_mirrored
+    from tests.synth import blob_feature_map_tiled
     shape = (n, n, n)
-    fm = torch.from_numpy(blob_feature_map_mirrored(n, 0, volume_fraction, 3.0)).cuda()
+    fm = torch.from_numpy(blob_feature_map_tiled(n, 0, volume_fraction, 3.0)).cuda()
     lab = torch.zeros(tuple(s + 2 for s in shape), dtype=torch.int32, device=fm.device)
     best, stages = None, None
     for _ in range(2):
@@ -210,7 +211,7 @@ def structured_watershed_leg(u, n=512, volume_fraction=0.12, t_unet_ms=None):
     sz = torch.as_tensor(sizes).flatten()
     sz = torch.sort(sz[sz > 0], descending=True).values
     n_lab = int((lab > 0).sum().item())
-    out = {"shape": list(shape), "volume_fraction": volume_fraction, "ms": 1e3 * best, "voxels_per_s": nvox / best,
+    out = {"shape": list(shape), "volume_fraction": volume_fraction, "construction": "8 independently seeded (n/2)^3 demo volumes", "ms": 1e3 * best, "voxels_per_s": nvox / best,
            "stages_ms": stages, "instances": int(lab.max().item()), "labelled_voxels": n_lab,
            "components": int(sz.numel()), "largest_components": [int(v) for v in sz[:4].tolist()],
            "flood_pops_per_s": n_lab / max(stages["ws_flood"], 1e-9) * 1e3,

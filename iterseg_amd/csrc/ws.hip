@@ -1836,8 +1836,10 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     int wcap = WIN_W, tcap = WIN_T;
     if (const char *e = getenv("ISX_FLOOD_WIN")) wcap = atoi(e);                      // tests: tiny windows / lists
     if (const char *e = getenv("ISX_FLOOD_LIST")) tcap = atoi(e);
+    int max_bursts = 3;
+    if (const char *e = getenv("ISX_FLOOD_BURSTS")) max_bursts = atoi(e);
     ISX_REQUIRE(wcap >= 1 && wcap <= WIN_W && tcap >= 6 && tcap <= WIN_T, "ISX_FLOOD_WIN / ISX_FLOOD_LIST out of range");
-    Scratch<uint32_t> claim(ctx, window_mode ? 1 : (size_t)PN);
+    Scratch<uint32_t> claim(ctx, (window_mode && !getenv("ISX_FLOOD_TRACE")) ? 1 : (size_t)std::max<unsigned long long>((unsigned long long)PN, 3 * (total + 1)));
     Scratch<unsigned long long> vstate(ctx, window_mode ? (size_t)PN : 1);
     Scratch<unsigned long long> stats(ctx, 48);
     if (!pool.ok() || !claim.ok() || !arena.ok() || !stats.ok() || !vstate.ok()) return ISX_ERR_NOMEM;
@@ -1879,9 +1881,25 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         ISX_CHECK_LAUNCH();
         flood_window_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                             comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
-                                                            pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, wcap, tcap,
-                                                            bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world);
+                                                            pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, wcap, tcap, max_bursts,
+                                                            bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world,
+                                                            getenv("ISX_FLOOD_TRACE") ? claim.p : nullptr);
         ISX_CHECK_LAUNCH();
+        if (const char *tp = getenv("ISX_FLOOD_TRACE")) {      // development: commit order of every component's roots
+            ISX_HIP(hipStreamSynchronize(ctx->stream));
+            std::vector<uint32_t> hl(3 * ((size_t)total + 1)), hf(n_comp);
+            std::vector<unsigned long long> ho(n_comp + 1), hk(n_seeds);
+            ISX_HIP(hipMemcpy(hl.data(), claim.p, 3 * ((size_t)total + 1) * 4, hipMemcpyDeviceToHost));
+            ISX_HIP(hipMemcpy(hf.data(), comp_first.p, (size_t)n_comp * 4, hipMemcpyDeviceToHost));
+            ISX_HIP(hipMemcpy(ho.data(), comp_off.p, (size_t)(n_comp + 1) * 8, hipMemcpyDeviceToHost));
+            ISX_HIP(hipMemcpy(hk.data(), keys_sorted.p, (size_t)n_seeds * 8, hipMemcpyDeviceToHost));
+            FILE *f = fopen(tp, "wb");
+            if (f) {
+                unsigned long long hdr[3] = {n_comp, n_seeds, total};
+                fwrite(hdr, 8, 3, f); fwrite(ho.data(), 8, n_comp + 1, f); fwrite(hf.data(), 4, n_comp, f); fwrite(hk.data(), 8, n_seeds, f);
+                fwrite(hl.data(), 4, 3 * ((size_t)total + 1), f); fclose(f);
+            }
+        }
     } else {
         ISX_HIP(hipMemsetAsync(claim.p, 0, (size_t)PN * sizeof(uint32_t), ctx->stream));
         flood_wave_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, claim.p, keys_sorted.p, n_seeds, comp_first.p,
@@ -1894,6 +1912,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         unsigned long long hs[48];
         ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         ISX_HIP(hipStreamSynchronize(ctx->stream));
+        if (hs[40]) fprintf(stderr, "[isx flood/window] ORDER CHECK failed first at tag %llu sub-round %llu nw %llu run %llu: key %016llx !< next %016llx at p %llu (1 window, 2 window/run, 3 run: %llu)\n   window tail (last first): %016llx %016llx %016llx %016llx | run head: %016llx %016llx %016llx %016llx | cold %llu fifo drains %llu seeds %llu staged %llu\n   [tier check] last hot insert key %016llx hot_max then %016llx reason %llu (1 below hot max, 2 cold free) nw %llu run %llu\n", hs[40], hs[41], hs[42], hs[43], hs[44], hs[45], hs[46], hs[47], hs[20], hs[21], hs[22], hs[23], hs[24], hs[25], hs[26], hs[27], hs[28], hs[29], hs[30], hs[31], hs[20], hs[21], hs[22], hs[23], hs[24]);
         if (hs[9]) {
             fprintf(stderr, "[isx flood/window] WATCHDOG: %llu component(s) exceeded the sub-round limit; front: nw %llu run %llu cold %llu cur|meta %016llx key %016llx "
                             "qhead %016llx maxnew|nstage %016llx pops %llu | pos1 key %016llx cur|meta %016llx wh %llu npfree %llu\n", hs[9], hs[24], hs[25], hs[26], hs[27], hs[28], hs[29], hs[30], hs[31], hs[20], hs[21], hs[22], hs[23]);

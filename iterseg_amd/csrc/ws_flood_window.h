@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
     HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
     int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long coop_min_size, int run_limit,
-    int drain_n, int wcap, int tcap, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world)
+    int drain_n, int wcap, int tcap, int max_bursts, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world,
+    uint32_t *dbg_log)
 {
     __shared__ HeapEnt srun[WIN_RCAP];            // .pad carries the element's label
     __shared__ HeapEnt stage[WIN_STAGE];
@@ -81,6 +82,9 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     __shared__ HeapEnt ovl[6 * 64];               // take-overs of this row (at most one per lane and direction): key = old holder, idx = voxel
     __shared__ int hist[64];
     __shared__ uint32_t lstat[16];
+#ifdef ISX_FLOOD_CHECK
+    __shared__ int dbg_seen[WIN_W];
+#endif
     const uint32_t c = blockIdx.x;
     const int lane = threadIdx.x;
     if (c >= n_comp) return;
@@ -132,7 +136,10 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     uint32_t agebase = ns - 1;                    // seeds carry ages 0..ns-1 in index order; pushes continue
     uint32_t nspill = 0;                          // elements that could not be queued (kept for the serial continuation)
     bool serial = false, started_any = false;
-    bool dirty = false;                           // a key landed right behind an episode since the last bound check
+    bool dirty = false;
+#ifdef ISX_FLOOD_CHECK
+    unsigned long long dbg_key = 0, dbg_hmax = 0; int dbg_reason = 0, dbg_nw = 0, dbg_sc = 0; uint32_t dbg_count = 0, dbg_ecount = 0;
+#endif                           // a key landed right behind an episode since the last bound check
     // statistics (ISX_FLOOD_STATS) live in LDS, bumped by lane 0: every live scalar costs SGPRs this kernel is short of
     enum { ST_SUB, ST_POPS, ST_EXEC, ST_HOT, ST_COLD, ST_DRAIN, ST_EVICT, ST_MID, ST_SQ_EV, ST_SQ_EPS, ST_ROWS, ST_OVER, ST_FORCED, ST_SLOW, ST_N };
     for (int i = lane; i < ST_N; i += 64) lstat[i] = 0u;
@@ -341,16 +348,120 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         WIN_FENCE();
     };
 
+#ifdef ISX_FLOOD_CHECK
+    // development build: window sorted, window <= run head, run sorted
+    auto check_order = [&](int tag) {
+        bool bad = false;
+        unsigned long long bk = 0, bnk = 0; int bp = -1, where = 0;
+        for (int base = 0; base < nw; base += 64) {
+            const int p = base + lane;
+            if (p < nw) {
+                const unsigned long long k = key_at(slot_of(p));
+                const unsigned long long nk = p + 1 < nw ? key_at(slot_of(p + 1)) : (scount > 0 ? srun[shead].key : ~0ull);
+                if (!(k < nk) && !bad) { bad = true; bk = k; bnk = nk; bp = p; where = p + 1 < nw ? 1 : 2; }
+            }
+        }
+        for (int base = 0; base + 1 < scount; base += 64) {
+            const int p = base + lane;
+            if (p + 1 < scount && !(srun[(shead + p) & SMASK].key < srun[(shead + p + 1) & SMASK].key) && !bad) {
+                bad = true; bk = srun[(shead + p) & SMASK].key; bnk = srun[(shead + p + 1) & SMASK].key; bp = p; where = 3;
+            }
+        }
+        // every window episode owns its own discovery list; free list and owned lists partition the ids
+        for (int i = lane; i < WIN_W; i += 64) dbg_seen[i] = 0;
+        WIN_FENCE();
+        for (int base = 0; base < nw; base += 64) {
+            const int p = base + lane;
+            if (p < nw) atomicAdd(&dbg_seen[(winq1[slot_of(p)].y >> 16) & 0xFFu], 1);
+        }
+        for (int i = lane; i < npfree; i += 64) atomicAdd(&dbg_seen[pfree[i]], 1);
+        WIN_FENCE();
+        for (int i = lane; i < WIN_W; i += 64)
+            if (dbg_seen[i] != 1 && !bad) { bad = true; bk = (unsigned long long)i; bnk = (unsigned long long)dbg_seen[i]; bp = npfree; where = 5; }
+        const unsigned long long bb = __ballot(bad);
+        if (bb) serial = true;             // stop here: the serial continuation finishes the component
+        if (bb && stats && lane == __ffsll((long long)bb) - 1 && stats[40] == 0ull) {
+            stats[40] = (unsigned long long)tag; stats[41] = (unsigned long long)st_sub; stats[42] = (unsigned long long)nw; stats[43] = (unsigned long long)scount;
+            stats[44] = bk; stats[45] = bnk; stats[46] = (unsigned long long)bp; stats[47] = (unsigned long long)where;
+            for (int q = 0; q < 6; ++q) stats[10 + q] = 0;
+            for (int q = 0; q < 4 && q < nw; ++q) stats[20 + q] = key_at(slot_of(nw - 1 - q));
+            for (int q = 0; q < 4 && q < scount; ++q) stats[24 + q] = srun[(shead + q) & SMASK].key;
+            stats[28] = (unsigned long long)cold.count; stats[29] = (unsigned long long)cold.fifo_drains; stats[30] = (unsigned long long)ns; stats[31] = (unsigned long long)nstage;
+        }
+    };
+    // every cold element (arena's lowest bucket, staged) must sort after every hot element
+    auto check_tiers = [&](int tag) {
+        if (!cold.on) return;
+        unsigned long long cmin = ~0ull;
+        for (int i = lane; i < nstage; i += 64) { const unsigned long long k = stage[i].key; if (k < cmin) cmin = k; }
+        if (cold.count > 0) {
+            const uint32_t b = cold_lowest(cold, lane);
+            uint32_t seg = cld32(&cold.bhead()[b]);
+            uint32_t off = cld32(&cold.bmeta()[b]) & ~COLD_UNSORTED;
+            while (seg != COLD_NONE) {
+                const HeapEnt h = cld_ent(&cold.pool()[seg]);
+                const uint32_t n = (uint32_t)(h.key >> 32);
+                for (uint32_t j = off + lane; j < n; j += 64) { const unsigned long long k = cld64(&cold.pool()[seg + 1u + j].key); if (k < cmin) cmin = k; }
+                off = 0;
+                seg = (uint32_t)h.key;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = shfl64(cmin, lane ^ o); if (t < cmin) cmin = t; }
+        unsigned long long hmax = 0ull;
+        if (scount > 0) hmax = srun[(shead + scount - 1) & SMASK].key;
+        else if (nw > 0) hmax = key_at(slot_of(nw - 1));
+        if (cmin < hmax) {
+            serial = true;
+            if (stats && lane == 0 && stats[40] == 0ull) {
+                stats[40] = (unsigned long long)tag; stats[41] = (unsigned long long)st_sub; stats[42] = (unsigned long long)nw; stats[43] = (unsigned long long)scount;
+                stats[44] = hmax; stats[45] = cmin; stats[46] = (unsigned long long)cold.low; stats[47] = 7ull;
+                stats[28] = (unsigned long long)cold.count; stats[29] = (unsigned long long)cold.fifo_drains; stats[30] = (unsigned long long)ns; stats[31] = (unsigned long long)nstage;
+                stats[20] = dbg_key; stats[21] = dbg_hmax; stats[22] = (unsigned long long)dbg_reason; stats[23] = (unsigned long long)dbg_nw; stats[24] = (unsigned long long)dbg_sc;
+            }
+        }
+    };
+#define WCHECK(tag) do { check_order(tag); if (!serial) check_tiers(100 + (tag)); } while (0)
+#else
+#define WCHECK(tag) do { } while (0)
+#endif
     // One (wave-uniform) element that the tier rule keeps hot: window if it sorts into it, else the run.
     auto hot_insert = [&](unsigned long long ek, uint32_t ei, uint32_t el) {
         WSTAT(ST_HOT, 1);
+#ifdef ISX_FLOOD_CHECK
+        if (cold.on && cold.count > 0) {
+            const uint32_t truth = cold_lowest(cold, lane);
+            if (truth != cold.low && stats && lane == 0 && stats[40] == 0ull) {
+                stats[40] = 99ull; stats[41] = (unsigned long long)st_sub; stats[42] = (unsigned long long)truth; stats[43] = (unsigned long long)cold.low;
+                stats[44] = ek; stats[45] = (unsigned long long)cold.count; stats[46] = (unsigned long long)nstage; stats[47] = (unsigned long long)cold_bucket(cold, ek);
+            }
+        }
+#endif
         if (nw > 0 && ek < key_at(slot_of(nw - 1))) {
             if ((nw == wcap || npfree == 0) && scount >= WIN_RCAP - 2) { run_evict(); if (serial) { spill64(lane == 0, ek, ei); return; } }
             win_insert(ek, ei, el);
             return;
         }
         if (scount == 0 && nw < wcap && npfree > 0) { win_insert(ek, ei, el); return; }
-        if (scount >= WIN_RCAP - 2) { run_evict(); if (serial) { spill64(lane == 0, ek, ei); return; } }
+        if (scount >= WIN_RCAP - 2) {
+            run_evict();
+            if (serial) { spill64(lane == 0, ek, ei); return; }
+            // the eviction lowered the hot maximum (and possibly cold.low): the element was judged against the old tiers
+            // and may belong to the cold tier now (found by the tier check of the development build: a full run in the
+            // middle of a commit burst put 0.44 behind zeros that had just been evicted)
+            bool below_hot_max = false;
+            if (scount > 0) below_hot_max = ek < srun[(shead + scount - 1) & SMASK].key;
+            else if (nw > 0) below_hot_max = ek < key_at(slot_of(nw - 1));
+            const bool cold_free = (cold.count == 0 && nstage == 0) || cold_bucket(cold, ek) < cold.low;
+            if (!below_hot_max && !cold_free) {
+                if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; stage[nstage] = e; }
+                ++nstage;
+                WSTAT(ST_COLD, 1);
+                WIN_FENCE();
+                if (nstage >= WIN_STAGE - 64) flush_stage(64);
+                return;
+            }
+        }
         run_insert(ek, ei, el);
     };
 
@@ -391,7 +502,14 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 if (nstage >= WIN_STAGE - 64) flush_stage(64);
                 continue;
             }
+#ifdef ISX_FLOOD_CHECK
+            dbg_key = ek; dbg_reason = (below_hot_max ? 1 : 0) | (cold_free ? 2 : 0); dbg_nw = nw; dbg_sc = scount;
+            dbg_hmax = scount > 0 ? srun[(shead + scount - 1) & SMASK].key : (nw > 0 ? key_at(slot_of(nw - 1)) : 0ull);
+#endif
             hot_insert(ek, ei, el);
+#ifdef ISX_FLOOD_CHECK
+            if (!serial) check_tiers(700);
+#endif
         }
         if (nstage >= 64 && !serial) flush_stage(64);
     };
@@ -459,11 +577,13 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             break;
         }
         WTICK(0);
+        WCHECK(1);
         if (scount > run_limit) { run_evict(); if (serial) break; }
+        WCHECK(2);
         // ---- A: an episode that popped past its bound (bound = value of the next larger queued key) is wrong.  A bound
         //         only ever drops when a new key lands right behind an episode, so the scan runs after such insertions only
         const unsigned long long qhead = scount > 0 ? srun[shead].key : ~0ull;
-        if (dirty) {
+        if (dirty || (max_bursts & 0x100)) {
             dirty = false;
             int sp = -1;
             for (int base = 0; base < nw && sp < 0; base += 64) {
@@ -505,6 +625,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         // ---- C: one pop per active episode, 64 episodes per row -----------------------------------------------------
         unsigned long long squash_key = ~0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // label stores / releases of earlier sub-rounds are performed
+        if ((max_bursts & 0x600) && nact > 64 * ((max_bursts >> 9) & 3)) nact = 64 * ((max_bursts >> 9) & 3);      // debug knob: rows per sub-round
         for (int r0 = 0; r0 < nact; r0 += 64) {
             WSTAT(ST_ROWS, 1);
             const bool act = r0 + lane < nact;
@@ -637,10 +758,11 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             }
             if (sp < nw) squash_from(sp);
         }
+        WCHECK(4);
         WTICK(4);
         // ---- E: commit the idle episodes at the front, in order (up to three bursts of 64 per sub-round: on tie plateaus
         //         every episode is a single pop and the whole window turns over) ---------------------------------------------
-        for (int burst = 0; burst < 3 && nw > 0 && !serial; ++burst) {
+        for (int burst = 0; burst < (max_bursts & 0xFF) && nw > 0 && !serial; ++burst) {
             const unsigned long long qh = burst == 0 ? qhead : (scount > 0 ? srun[shead].key : ~0ull);   // enqueues moved the run
             const int j = lane;
             const bool valid = j < nw;
@@ -704,6 +826,23 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 agebase += tot;
                 WSTAT(ST_POPS, tot - ptotal + (uint32_t)ncommit);           // popped discoveries + the roots
                 const uint32_t lab = q0.w;
+#ifdef ISX_FLOOD_CHECK
+                if (dbg_log) {      // commit order of the roots of this component (development build)
+                    uint32_t *dl = dbg_log + comp_off[c];
+                    const unsigned long long tot_ = comp_off[n_comp] + 1ull;
+                    if (cm && dbg_count + (uint32_t)j + 1u < (uint32_t)csize) {
+                        dl[dbg_count + (uint32_t)j] = q0.z;
+                        dl[2ull * tot_ + dbg_count + (uint32_t)j] = (uint32_t)np | ((uint32_t)st_sub << 8);
+                        for (int i = 0; i < np; ++i) {
+                            const uint32_t o_ = dbg_ecount + np_incl - (uint32_t)np + (uint32_t)i;
+                            if (o_ < (uint32_t)csize) dl[tot_ + o_] = pidx[pl * WIN_T + i] | (pval[pl * WIN_T + i] == WIN_POPPED ? 0x80000000u : 0u);
+                        }
+                    }
+                    dbg_ecount += tot;
+                    dbg_count += (uint32_t)ncommit;
+                    if (lane == 0) dl[csize - 1ull] = dbg_count;
+                }
+#endif
                 {
                     const u32x4 *pi4 = (const u32x4 *)&pidx[pl * WIN_T], *pv4 = (const u32x4 *)&pval[pl * WIN_T];
                     for (int i4 = 0; __any(cm && 4 * i4 < np); ++i4) {
@@ -714,6 +853,16 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                             for (int e = 0; e < 4; ++e) {
                                 const int i = 4 * i4 + e;
                                 if (i < np) {
+#ifdef ISX_FLOOD_CHECK
+                                    {   // a committing episode must still hold every voxel it discovered
+                                        const unsigned long long mykey_ = ((unsigned long long)q0.y << 32) | q0.x;
+                                        const unsigned long long cur_ = __hip_atomic_load(&state[vv[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if (cur_ != mykey_ && stats && stats[40] == 0ull) {
+                                            stats[40] = 200ull; stats[41] = (unsigned long long)st_sub; stats[42] = (unsigned long long)nw; stats[43] = (unsigned long long)j;
+                                            stats[44] = mykey_; stats[45] = cur_; stats[46] = (unsigned long long)vv[e]; stats[47] = (unsigned long long)i;
+                                        }
+                                    }
+#endif
                                     __hip_atomic_store(&state[vv[e]], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     out[vv[e]] = lab;                    // label at discovery (watershed.py:153)
                                     if (ff[e] != WIN_POPPED) {
@@ -738,9 +887,12 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                     const bool has = b0 + (uint32_t)lane < ptotal;
                     HeapEnt r; r.key = 0; r.idx = 0; r.pad = 0;
                     if (has) r = pend[b0 + lane];
-                    enqueue64(has, r.key, r.idx, r.pad);
+                    enqueue64(has, r.key, r.idx, r.pad);         // once `serial` is set this spills: every residual must survive
+                    if (!serial) WCHECK(50 + burst);
                 }
             }
+            WCHECK(10 + burst);
+            if (serial) break;
             if (ncommit < 64) break;
         }
         WTICK(7);
@@ -750,7 +902,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         {
             if (scount == 0 && cold.on && (cold.count > 0 || nstage > 0)) {
                 if (nstage > 0) { flush_stage(nstage); if (serial) break; }
-                if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; WSTAT(ST_DRAIN, 1); }
+                if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; WSTAT(ST_DRAIN, 1); WCHECK(40); }
             }
             while (nw < wcap && scount > 0) {
                 int take = wcap - nw;
@@ -772,11 +924,12 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 WIN_FENCE();
                 if (scount == 0 && cold.on && (cold.count > 0 || nstage > 0)) {
                     if (nstage > 0) { flush_stage(nstage); if (serial) break; }
-                    if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; WSTAT(ST_DRAIN, 1); }
+                    if (cold.count > 0) { scount = cold_drain(cold, srun, hist, lane, drain_n); shead = 0; WSTAT(ST_DRAIN, 1); WCHECK(41); }
                 }
             }
             if (serial) break;
         }
+        WCHECK(30);
         WTICK(8);
     }
 

@@ -313,6 +313,10 @@ static inline int elem_less(const orc_elem_t *a, const orc_elem_t *b)
 }
 
 /* the heap loop (watershed.py:127-158) over the given seeds, whose labels are already in `out` */
+static int64_t *g_trace = NULL; static int64_t g_trace_cap = 0, g_trace_n = 0;
+void orc_set_trace(int64_t *buf, int64_t cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
+int64_t orc_trace_count(void) { return g_trace_n; }
+
 static int64_t flood_core(const float *aff, const int64_t *seeds, int64_t nseeds,
                           const uint8_t *mask, uint32_t *out, const int64_t dims[3])
 {
@@ -355,6 +359,7 @@ static int64_t flood_core(const float *aff, const int64_t *seeds, int64_t nseeds
             heap[c] = last;
         }
         ++pops;
+        if (g_trace && g_trace_n < g_trace_cap) g_trace[g_trace_n++] = top.idx;      /* test hook: pop order (single-threaded runs only) */
         for (int k = 0; k < 6; ++k) {
             int64_t nb = top.idx + noff[k];
             if (!mask[nb] || out[nb]) continue;

@@ -51,3 +51,44 @@ def blob_feature_map_mirrored(n, seed, volume_fraction=0.3, blob_sigma=3.0):
     for ax in (1, 2, 3):
         h = np.concatenate([h, np.flip(h, axis=ax)], axis=ax)
     return np.ascontiguousarray(h, np.float32)
+
+
+def blob_feature_map_tiled(n, seed, volume_fraction=0.3, blob_sigma=3.0, workers=8):
+    """An ``(n, n, n)`` structured input made of eight independently seeded ``(n/2)^3`` demo volumes side by side (seeds
+    ``8*seed .. 8*seed+7``; each one is the reference's construction, watershed.py:256-262).  Components keep the size
+    distribution of the demo volume (they only merge where two tiles happen to have foreground on both sides of a
+    shared face), unlike ``blob_feature_map_mirrored`` whose mirror planes glue every touching component to its image.
+    The tiles are built by child interpreters (scipy's distance transform is single-threaded; plain subprocesses, so it
+    does not matter whether the caller holds a GPU context or has a ``__main__`` guard)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    assert n % 2 == 0
+    h = n // 2
+    out = np.empty((5, n, n, n), np.float32)
+
+    def place(k, t):
+        z, y, x = (k >> 2) & 1, (k >> 1) & 1, k & 1
+        out[:, z * h:(z + 1) * h, y * h:(y + 1) * h, x * h:(x + 1) * h] = t
+
+    if workers <= 1:
+        for k in range(8):
+            place(k, blob_feature_map((h, h, h), 8 * seed + k, volume_fraction, blob_sigma))
+        return out
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tmp = tempfile.mkdtemp(prefix="isx_tiles_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from tests.synth import blob_feature_map; "
+            "np.save(sys.argv[1], blob_feature_map((%d, %d, %d), int(sys.argv[2]), %r, %r))" % (root, h, h, h, volume_fraction, blob_sigma))
+    try:
+        procs = [subprocess.Popen([sys.executable, "-c", code, os.path.join(tmp, f"t{k}.npy"), str(8 * seed + k)])
+                 for k in range(8)]
+        for k, p in enumerate(procs):
+            if p.wait() != 0:
+                raise RuntimeError("tile generator failed")
+            place(k, np.load(os.path.join(tmp, f"t{k}.npy")))
+            os.remove(os.path.join(tmp, f"t{k}.npy"))
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out

@@ -110,3 +110,28 @@ def test_large_volume_properties_and_flood_path_agreement(unet, n, monkeypatch):
     ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=lab_b)
     assert torch.equal(lab_a, lab_b)
     unet.set_batch(32)
+
+
+@pytest.mark.parametrize("cold_min", [None, "200000"])
+def test_structured_512_labels_against_oracle(cold_min, monkeypatch):
+    """The structured 512^3 volume of bench.py's `watershed_structured` leg (eight independently seeded blob tiles, ~10 M
+    mask voxels in ~5000 components): whole-volume labels against the C oracle, bit for bit.  This input is the
+    reproducer of a lost-residual bug: with three commit bursts per sub-round a component WITHOUT a cold arena can
+    overflow its LDS run in the middle of an enqueue and hand over to the serial heap there -- every residual gathered
+    for that burst has to reach the heap (two voxels were mislabelled when the rest of the batch was dropped).  The
+    second case raises the arena threshold so that many more components take that hand-over."""
+    from iterseg_amd import watershed as ws
+    from oracle import watershed as ows
+    from tests.synth import blob_feature_map_tiled
+    if cold_min:
+        monkeypatch.setenv("ISX_FLOOD_COLD_MIN", cold_min)
+    n = 512
+    fm = blob_feature_map_tiled(n, 0, 0.12, 3.0)
+    pshape = (n + 2,) * 3
+    ref = np.zeros(pshape, np.uint32)
+    ows.segment_output_image(fm, out=ref.ravel(), threads=16)
+    lab = torch.zeros(pshape, dtype=torch.int32, device="cuda")
+    ws.segment_output_image(torch.from_numpy(fm).cuda(), (0, 1, 2), 4, 3, out=lab)
+    got = lab.cpu().numpy().astype(np.uint32)
+    assert int((ref > 0).sum()) > 5_000_000
+    assert int((got != ref).sum()) == 0
