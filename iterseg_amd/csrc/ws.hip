@@ -805,7 +805,8 @@ __global__ void flood_kernel(const float *__restrict__ aff, const uint8_t *__res
 // ------------------------------------------------------------------------------------------------
 static constexpr int COOP_SCAP = 2048;                      // LDS run capacity (entries of 16 B)
 static constexpr unsigned long long COOP_MIN_SIZE = 512;    // components below this stay on flood_kernel
-static constexpr unsigned long long COLD_MIN_SIZE = 32768;  // components from this size get a cold arena
+static constexpr unsigned long long COLD_MIN_SIZE = 4096;   // components from this size get a cold arena (raised by the host until the arenas fit COLD_ARENA_BUDGET)
+static constexpr unsigned long long COLD_ARENA_BUDGET = 8ull << 30;   // bytes; one arena is >= 7.4 MB (bucket tables), ISX_FLOOD_ARENA_MB overrides
 static constexpr uint32_t COLD_UNSORTED = 0x80000000u;
 static constexpr int COLD_NBK = 65536;                      // buckets: top 16 bits of the order-preserving key
 static constexpr int COLD_DRAIN = 1024;                     // elements moved from a bucket to the LDS run at once
@@ -1821,12 +1822,23 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     if (const char *e = getenv("ISX_FLOOD_DRAIN")) drain_n = atoi(e);
     ISX_REQUIRE(run_limit >= 8 && run_limit <= COOP_SCAP - 6 * 64 && drain_n >= 4 && drain_n <= COLD_DRAIN && drain_n <= run_limit,
                 "ISX_FLOOD_RUN_LIMIT / ISX_FLOOD_DRAIN out of range");
-    arena_need_kernel<<<cdiv(n_comp + 1, TPB), TPB, 0, ctx->stream>>>(comp_cap.p, n_comp, coop_min, cold_min, arena_need.p);
-    ISX_CHECK_LAUNCH();
-    ISX_TRY(exclusive_scan_u64(ctx, (const uint64_t *)arena_need.p, (uint64_t *)arena_off.p, n_comp + 1));
+    // A component without an arena whose LDS run overflows finishes on the one-lane heap; on structured volumes those
+    // mid-size components were the critical path (tiled 512^3 blobs: 263 ms with arenas from 32 768 voxels, 103 ms from
+    // 4 096).  An arena costs 7.4 MB of bucket tables whatever the component's size, so the threshold doubles until the
+    // arenas fit the budget (a volume of many thousand mid-size components keeps the larger ones only).
+    unsigned long long arena_budget = COLD_ARENA_BUDGET;
+    if (const char *e = getenv("ISX_FLOOD_ARENA_MB")) arena_budget = strtoull(e, nullptr, 10) << 20;
     unsigned long long arena_total = 0;
-    ISX_HIP(hipMemcpyAsync(&arena_total, arena_off.p + n_comp, 8, hipMemcpyDeviceToHost, ctx->stream));
-    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    for (;;) {
+        arena_need_kernel<<<cdiv(n_comp + 1, TPB), TPB, 0, ctx->stream>>>(comp_cap.p, n_comp, coop_min, cold_min, arena_need.p);
+        ISX_CHECK_LAUNCH();
+        ISX_TRY(exclusive_scan_u64(ctx, (const uint64_t *)arena_need.p, (uint64_t *)arena_off.p, n_comp + 1));
+        ISX_HIP(hipMemcpyAsync(&arena_total, arena_off.p + n_comp, 8, hipMemcpyDeviceToHost, ctx->stream));
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        // never above the round-1 threshold: the large components keep their arenas whatever they cost
+        if (arena_total * sizeof(HeapEnt) <= arena_budget || getenv("ISX_FLOOD_COLD_MIN") || cold_min >= 32768ull) break;
+        cold_min *= 2;
+    }
     Scratch<HeapEnt> pool(ctx, (size_t)total + 1);
     Scratch<HeapEnt> arena(ctx, (size_t)arena_total + 1);
     // large components: ISX_FLOOD_MODE=wave selects the round-based kernel of round 1 (kept for A/B runs), default is the
