@@ -1924,7 +1924,9 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         unsigned long long hs[48];
         ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         ISX_HIP(hipStreamSynchronize(ctx->stream));
+#ifdef ISX_FLOOD_CHECK          // these slots carry the phase timers in the ISX_FLOOD_PROF build
         if (hs[40]) fprintf(stderr, "[isx flood/window] ORDER CHECK failed first at tag %llu sub-round %llu nw %llu run %llu: key %016llx !< next %016llx at p %llu (1 window, 2 window/run, 3 run: %llu)\n   window tail (last first): %016llx %016llx %016llx %016llx | run head: %016llx %016llx %016llx %016llx | cold %llu fifo drains %llu seeds %llu staged %llu\n   [tier check] last hot insert key %016llx hot_max then %016llx reason %llu (1 below hot max, 2 cold free) nw %llu run %llu\n", hs[40], hs[41], hs[42], hs[43], hs[44], hs[45], hs[46], hs[47], hs[20], hs[21], hs[22], hs[23], hs[24], hs[25], hs[26], hs[27], hs[28], hs[29], hs[30], hs[31], hs[20], hs[21], hs[22], hs[23], hs[24]);
+#endif
         if (hs[9]) {
             fprintf(stderr, "[isx flood/window] WATCHDOG: %llu component(s) exceeded the sub-round limit; front: nw %llu run %llu cold %llu cur|meta %016llx key %016llx "
                             "qhead %016llx maxnew|nstage %016llx pops %llu | pos1 key %016llx cur|meta %016llx wh %llu npfree %llu\n", hs[9], hs[24], hs[25], hs[26], hs[27], hs[28], hs[29], hs[30], hs[31], hs[20], hs[21], hs[22], hs[23]);

@@ -638,6 +638,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             const int pl = (int)((q1.y >> 16) & 0xFFu);
             const bool was_started = (q1.y >> 8) & 1u;
             int np = was_started ? (int)(q1.y & 0xFFu) : 0;
+            uint32_t npop = was_started ? ((q1.y >> 9) & 0x7Fu) : 0u;       // discoveries popped so far (marked WIN_POPPED)
             uint32_t mx = q1.z;
             if (was_started && q1.w > mx) mx = q1.w;              // the popped element joins "everything this episode popped"
             unsigned long long old[6];
@@ -731,15 +732,17 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             if (act) {
                 const unsigned long long nk = p + 1 < nw ? key_at(slot_of(p + 1)) : qhead;
                 const uint32_t bound = (uint32_t)(nk >> 32);
-                uint32_t cur = WIN_NONE, curi = 0xFFu, curv = 0u;
+                // an episode that goes idle keeps the smallest of its residuals in .w (no element in hand any more): the
+                // commit rule needs it every sub-round until the episode commits, and the list does not change any more
+                uint32_t cur = WIN_NONE, curi = 0xFFu, curv = bf;
                 if (bi >= 0 && bf < bound) {
                     cur = pidx[pl * WIN_T + bi];
                     curi = (uint32_t)bi;
-                    curv = bf;
                     pval[pl * WIN_T + bi] = WIN_POPPED;
+                    ++npop;
                 }
                 q1.x = cur;
-                q1.y = (uint32_t)np | (1u << 8) | ((uint32_t)pl << 16) | (curi << 24);
+                q1.y = (uint32_t)np | (1u << 8) | (npop << 9) | ((uint32_t)pl << 16) | (curi << 24);
                 q1.z = mx;
                 q1.w = curv;
                 winq1[s] = q1;
@@ -779,11 +782,21 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             WIN_FENCE();
             const unsigned long long nb_ = ~__ballot(idle);
             const int m = nb_ ? __ffsll((long long)nb_) - 1 : 64;       // leading idle episodes
-            uint32_t resmin = 0xFFFFFFFFu, pc = 0u;                     // smallest residual, number of residuals
+            // smallest residual, number of residuals: cached when the episode went idle (C); only the forced front episode,
+            // whose element in hand went back into its list, is scanned
+            uint32_t resmin = 0xFFFFFFFFu, pc = 0u;
+            if (j < m && !forced) { resmin = q1.w; pc = (uint32_t)np - ((q1.y >> 9) & 0x7Fu); }
+#ifdef ISX_FLOOD_CHECK
+            const uint32_t c_resmin = resmin, c_pc = pc;
+            resmin = 0xFFFFFFFFu; pc = 0u;
+            const bool scan_me = j < m;
+#else
+            const bool scan_me = j < m && forced;
+#endif
             {
                 const u32x4 *pv4 = (const u32x4 *)&pval[pl * WIN_T];
-                for (int i4 = 0; __any(j < m && 4 * i4 < np); ++i4) {
-                    if (j < m && 4 * i4 < np) {
+                for (int i4 = 0; __any(scan_me && 4 * i4 < np); ++i4) {
+                    if (scan_me && 4 * i4 < np) {
                         const u32x4 v4 = pv4[i4];
                         const int i = 4 * i4;
                         if (v4.x != WIN_POPPED) { ++pc; if (v4.x < resmin) resmin = v4.x; }
@@ -793,6 +806,12 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                     }
                 }
             }
+#ifdef ISX_FLOOD_CHECK
+            if (j < m && !forced && (c_resmin != resmin || c_pc != pc) && stats && stats[40] == 0ull) {
+                stats[40] = 300ull; stats[41] = (unsigned long long)st_sub; stats[42] = (unsigned long long)nw; stats[43] = (unsigned long long)j;
+                stats[44] = c_resmin; stats[45] = resmin; stats[46] = c_pc; stats[47] = pc;
+            }
+#endif
             const uint32_t maxnew = q1.z;                               // an idle episode has no element in hand; forced: excluded
             // residuals of the episodes committing before me must all sort after everything I popped (they are older
             // than my discoveries: strict for those; my root is older than any residual: ties go to the root)
