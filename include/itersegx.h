@@ -92,6 +92,11 @@ int isx_load_weight_host(isx_ctx *ctx, const char *key, const void *data, const 
 /* Call after the last isx_load_weight_host: checks the schema strictly (like
  * load_state_dict(strict=True)) and repacks into kernel layouts on the device. */
 int isx_weights_commit(isx_ctx *ctx, int out_channels);
+/* The forked network of the reference -- UNet(out_channels=(a, b)) (unet.py:152-157,192-210) as train_unet builds it for
+ * fork_channels (train.py:139-141): one encoder, shared transposed convolutions, one decoder c5_i..c8_i per fork, outputs
+ * concatenated (unet.py:313-325).  nforks = 1 or 2 (the reference's decoder() serves forks 0 and 1), at most 8 channels
+ * in total; state-dict keys "c5_1.conv0.weight" ... for the second decoder.  nforks = 1 is isx_weights_commit. */
+int isx_weights_commit_forked(isx_ctx *ctx, const int32_t *fork_channels, int nforks);
 /* Read back a state_dict entry (running statistics are updated by forward passes, U2). */
 int isx_get_weight_host(isx_ctx *ctx, const char *key, void *data, int64_t nbytes);
 

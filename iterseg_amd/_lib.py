@@ -41,6 +41,7 @@ SIGNATURES = {
     "isx_make_chunks": (_i64, [_i64p, _i64p, _i64p, _i32p, _i64]),
     "isx_load_weight_host": (C.c_int, [_vp, C.c_char_p, _vp, _i64p, C.c_int]),
     "isx_weights_commit": (C.c_int, [_vp, C.c_int]),
+    "isx_weights_commit_forked": (C.c_int, [_vp, _i32p, C.c_int]),
     "isx_get_weight_host": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
     "isx_unet_forward_chunks": (C.c_int, [_vp, _vp, _i64p, _i32p, _i64, _i64p, _vp]),
     "isx_predict_volume": (C.c_int, [_vp, _vp, _i64p, _i32p, _i64, _i64, _i64p, _vp]),

@@ -33,15 +33,15 @@ struct TrainState {
     int cz = 0, cy = 0, cx = 0;
     float *P = nullptr, *G = nullptr, *Mo = nullptr, *Vo = nullptr;
     int64_t nparam = 0, adam_t = 0;
-    int64_t off_w[18], off_b[18], off_gamma[18], off_beta[18], off_upw[4], off_upb[4];
-    int dstride[18];                 // channel stride of draw[li] (cout, or 8 for a thin layer whose dgrad runs on MFMA)
+    int64_t off_w[ISX_MAX_LAYERS], off_b[ISX_MAX_LAYERS], off_gamma[ISX_MAX_LAYERS], off_beta[ISX_MAX_LAYERS], off_upw[4], off_upb[4];
+    int dstride[ISX_MAX_LAYERS];                 // channel stride of draw[li] (cout, or 8 for a thin layer whose dgrad runs on MFMA)
     std::vector<void *> blocks;
-    float *draw[18] = {nullptr}, *gact[18] = {nullptr}, *w_dgrad[18] = {nullptr};
+    float *draw[ISX_MAX_LAYERS] = {nullptr}, *gact[ISX_MAX_LAYERS] = {nullptr}, *w_dgrad[ISX_MAX_LAYERS] = {nullptr};
     // bf16 mixed precision (ISX_PRECISION_BF16): device-refreshed packs of the forward (both tile widths) and dgrad operators
-    void *wbf_fwd64[18] = {nullptr}, *wbf_fwd32[18] = {nullptr}, *wbf_dg[18] = {nullptr};
-    int wbf_dg_bn[18] = {0};
+    void *wbf_fwd64[ISX_MAX_LAYERS] = {nullptr}, *wbf_fwd32[ISX_MAX_LAYERS] = {nullptr}, *wbf_dg[ISX_MAX_LAYERS] = {nullptr};
+    int wbf_dg_bn[ISX_MAX_LAYERS] = {0};
     bool bf_fresh = false;           // the bf16 packs match P
-    float *dcat[4] = {nullptr}, *dpool[4] = {nullptr};
+    float *dcat[ISX_MAX_FORKS][4] = {{nullptr}}, *dpool[4] = {nullptr};      // dcat[fork][k]: gradient of cat(up_k, skip) of that decoder
     float *part = nullptr, *coef = nullptr, *wpart = nullptr, *lossbuf = nullptr, *zeros = nullptr;
     size_t part_floats = 0, wpart_floats = 0;
 };
@@ -649,15 +649,25 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
 
 // up-conv parameter gradients: reference layout dW[c][kidx], db[c]
 __global__ void up_grad_finalize_kernel(const float *__restrict__ part, int blocks, int C, int kt,
-                                        float *__restrict__ dw, float *__restrict__ db)
+                                        float *__restrict__ dw, float *__restrict__ db, int accumulate)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (kt + 1) * C) return;
     const int r = i / C, c = i % C;
     double s = 0.0;
     for (int b = 0; b < blocks; ++b) s += (double)part[(int64_t)b * (kt + 1) * C + i];
-    if (r < kt) dw[(int64_t)c * kt + r] = (float)s;
-    else db[c] = (float)s;
+    // accumulate: the transposed convolutions are shared by the decoders of a forked network (unet.py:213-242)
+    if (r < kt) dw[(int64_t)c * kt + r] = (float)s + (accumulate ? dw[(int64_t)c * kt + r] : 0.f);
+    else db[c] = (float)s + (accumulate ? db[c] : 0.f);
+}
+
+// dst[m][c0 + c] += src[m][c0 + c] for c < n (row stride `stride`): gradients that two decoders send to the same tensor
+__global__ void add_cols_kernel(float *__restrict__ dst, const float *__restrict__ src, int stride, int c0, int n, int64_t M)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * n) return;
+    const int64_t o = (i / n) * stride + c0 + (int)(i % n);
+    dst[o] += src[o];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -683,16 +693,16 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
 static int64_t param_layout(UNetState *u, TrainState *t)
 {
     int64_t off = 0;
-    for (int mi = 0; mi < 9; ++mi) {
+    for (int l0 = 0; l0 < u->nlayers; l0 += 2) {          // module by module: c0..c4, c5_0..c8_0, then c5_1..c8_1 of a second fork
         for (int j = 0; j < 2; ++j) {
-            const ConvBN &L = u->cv[2 * mi + j];
-            t->off_w[2 * mi + j] = off; off += (int64_t)L.cout * L.cin * 27;
-            t->off_b[2 * mi + j] = off; off += L.cout;
+            const ConvBN &L = u->cv[l0 + j];
+            t->off_w[l0 + j] = off; off += (int64_t)L.cout * L.cin * 27;
+            t->off_b[l0 + j] = off; off += L.cout;
         }
         for (int j = 0; j < 2; ++j) {
-            const ConvBN &L = u->cv[2 * mi + j];
-            t->off_gamma[2 * mi + j] = off; off += L.cout;
-            t->off_beta[2 * mi + j] = off; off += L.cout;
+            const ConvBN &L = u->cv[l0 + j];
+            t->off_gamma[l0 + j] = off; off += L.cout;
+            t->off_beta[l0 + j] = off; off += L.cout;
         }
     }
     for (int k = 0; k < 4; ++k) {
@@ -707,7 +717,7 @@ static int repack_all(isx_ctx *ctx)
     UNetState *u = ctx->unet;
     TrainState *t = u->train;
     t->bf_fresh = u->precision == ISX_PRECISION_BF16;
-    for (int li = 0; li < 18; ++li) {
+    for (int li = 0; li < u->nlayers; ++li) {
         ConvBN &L = u->cv[li];
         const float *wref = t->P + t->off_w[li];
         const int64_t n = (int64_t)L.cout * L.cin * 27;
@@ -746,7 +756,7 @@ static int bn_backward(isx_ctx *ctx, int li, const float *g, int gstride, int ac
     UNetState *u = ctx->unet;
     TrainState *t = u->train;
     const ConvBN &L = u->cv[li];
-    const Level &l = u->lv[MOD_LEVEL[li / 2]];
+    const Level &l = u->lv[MOD_LEVEL[layer_module(li)]];
     const int C = L.cout;
     const int rows = 512;
     const int blocks = (int)((l.M + rows - 1) / rows);
@@ -771,7 +781,7 @@ static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
     UNetState *u = ctx->unet;
     TrainState *t = u->train;
     const ConvBN &L = u->cv[li];
-    const Level &l = u->lv[MOD_LEVEL[li / 2]];
+    const Level &l = u->lv[MOD_LEVEL[layer_module(li)]];
     WgradArgs a;
     a.dy = t->draw[li];
     a.dy_stride = t->dstride[li];
@@ -812,7 +822,7 @@ static int dgrad(isx_ctx *ctx, int li, float *dst)
     UNetState *u = ctx->unet;
     TrainState *t = u->train;
     const ConvBN &L = u->cv[li];
-    const Level &l = u->lv[MOD_LEVEL[li / 2]];
+    const Level &l = u->lv[MOD_LEVEL[layer_module(li)]];
     if (u->precision == ISX_PRECISION_BF16 && t->wbf_dg[li] && t->dstride[li] == L.cout && conv_mt(ctx->tune, l, u->wbatch, L.cin) == 1) {
         // bf16 mixed precision: the same operator on the bf16 matrix cores (d(raw) is rounded to bf16 at the LDS store)
         return launch_conv_h2(ctx, l, 1, Src{t->draw[li], nullptr, nullptr, L.cout}, Src{nullptr, nullptr, nullptr, 0}, t->wbf_dg[li],
@@ -837,35 +847,46 @@ static int backward(isx_ctx *ctx)
     const Level *lv = u->lv;
     const Src none{nullptr, nullptr, nullptr, 0};
     auto act = [&](int li) { const ConvBN &L = u->cv[li]; return Src{u->raw[li], L.scale, L.shift, L.cout}; };
-    // ---- decoder, last module first --------------------------------------------------------------
-    for (int k = 3; k >= 0; --k) {
-        const int mi = 5 + k, l1 = 2 * mi + 1, l0 = 2 * mi;
-        const int skip_li = 2 * (3 - k) + 1;
-        const UpConv &U = u->up[k];
-        const Level &lo = lv[3 - k];
-        // conv1 of the module: g arrives in gact[l1] (the loss wrote it for the last module)
-        ISX_TRY(bn_backward(ctx, l1, t->gact[l1], u->cv[l1].cout, mi == 8 ? 1 : 0));
-        ISX_TRY(wgrad(ctx, l1, act(l0), none));
-        ISX_TRY(dgrad(ctx, l1, t->gact[l0]));
-        // conv0 of the module: input = cat(up_k, act(skip))
-        ISX_TRY(bn_backward(ctx, l0, t->gact[l0], u->cv[l0].cout, 0));
-        ISX_TRY(wgrad(ctx, l0, Src{u->ups[k], nullptr, nullptr, U.C}, act(skip_li)));
-        ISX_TRY(dgrad(ctx, l0, t->dcat[k]));                       // [M][2C]: first C -> up_k, last C -> skip
-        // transposed conv backward -> gradient of the module that fed it (c4, c5, c6, c7 second conv)
-        const int mi_in = (k == 0) ? 4 : 4 + k, li_in = 2 * mi_in + 1;
-        const Level &ls = lv[MOD_LEVEL[mi_in]];
-        const ConvBN &Lin = u->cv[li_in];
-        const int kt = U.kz * 4;
-        const int vpb = 1024;
-        const int blocks = (int)((ls.M + vpb - 1) / vpb);
-        ISX_REQUIRE((size_t)blocks * (kt + 1) * U.C <= t->part_floats, "internal: partial buffer too small");
-        upsample_bwd_kernel<<<blocks, 256, (size_t)(256 / (U.C / 4)) * (kt + 1) * U.C * sizeof(float), ctx->stream>>>(
-            u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, t->dcat[k], 2 * U.C, lo.D, lo.H,
-            lo.W, t->gact[li_in], t->part, vpb);
-        ISX_CHECK_LAUNCH();
-        up_grad_finalize_kernel<<<cdiv((kt + 1) * U.C, 256), 256, 0, ctx->stream>>>(t->part, blocks, U.C, kt, t->G + t->off_upw[k],
-                                                                                 t->G + t->off_upb[k]);
-        ISX_CHECK_LAUNCH();
+    // ---- decoder(s), last module first.  A forked network (unet.py:313-325) sends two gradients to every skip tensor, to
+    //      up0's output and to the shared transposed-convolution weights: fork 1 runs first, fork 0 adds its share. -----
+    for (int f = u->nforks - 1; f >= 0; --f) {
+        for (int k = 3; k >= 0; --k) {
+            const int l1 = dec_layer(f, k, 1), l0 = dec_layer(f, k, 0);
+            const int skip_li = 2 * (3 - k) + 1;
+            const UpConv &U = u->up[k];
+            const Level &lo = lv[3 - k];
+            // conv1 of the module: g arrives in gact[l1] (the loss wrote it for the last module)
+            ISX_TRY(bn_backward(ctx, l1, t->gact[l1], u->cv[l1].cout, k == 3 ? 1 : 0));
+            ISX_TRY(wgrad(ctx, l1, act(l0), none));
+            ISX_TRY(dgrad(ctx, l1, t->gact[l0]));
+            // conv0 of the module: input = cat(up_k, act(skip))
+            ISX_TRY(bn_backward(ctx, l0, t->gact[l0], u->cv[l0].cout, 0));
+            ISX_TRY(wgrad(ctx, l0, Src{u->ups[ups_index(f, k)], nullptr, nullptr, U.C}, act(skip_li)));
+            ISX_TRY(dgrad(ctx, l0, t->dcat[f][k]));                    // [M][2C]: first C -> up_k, last C -> skip
+            if (u->nforks > 1 && f == 0) {
+                // the other decoder's share: the skip half always; for k = 0 also the up half (up0(c4) is one tensor)
+                const int c0 = k == 0 ? 0 : U.C, n = k == 0 ? 2 * U.C : U.C;
+                add_cols_kernel<<<cdiv(lo.M * n, 256), 256, 0, ctx->stream>>>(t->dcat[0][k], t->dcat[1][k], 2 * U.C, c0, n, lo.M);
+                ISX_CHECK_LAUNCH();
+            }
+            if (k == 0 && f > 0) continue;                           // up0's backward runs once, on the summed gradient
+            // transposed conv backward -> gradient of the module that fed it (c4, c5, c6, c7 second conv)
+            const int li_in = (k == 0) ? 9 : dec_layer(f, k - 1, 1);
+            const Level &ls = lv[MOD_LEVEL[layer_module(li_in)]];
+            const ConvBN &Lin = u->cv[li_in];
+            const int kt = U.kz * 4;
+            const int vpb = 1024;
+            const int blocks = (int)((ls.M + vpb - 1) / vpb);
+            ISX_REQUIRE((size_t)blocks * (kt + 1) * U.C <= t->part_floats, "internal: partial buffer too small");
+            upsample_bwd_kernel<<<blocks, 256, (size_t)(256 / (U.C / 4)) * (kt + 1) * U.C * sizeof(float), ctx->stream>>>(
+                u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, t->dcat[f][k], 2 * U.C, lo.D, lo.H,
+                lo.W, t->gact[li_in], t->part, vpb);
+            ISX_CHECK_LAUNCH();
+            up_grad_finalize_kernel<<<cdiv((kt + 1) * U.C, 256), 256, 0, ctx->stream>>>(t->part, blocks, U.C, kt, t->G + t->off_upw[k],
+                                                                                     t->G + t->off_upb[k],
+                                                                                     (u->nforks > 1 && f == 0 && k > 0) ? 1 : 0);
+            ISX_CHECK_LAUNCH();
+        }
     }
     // ---- encoder, bottom first ---------------------------------------------------------------------
     for (int mi = 4; mi >= 0; --mi) {
@@ -888,7 +909,7 @@ static int backward(isx_ctx *ctx)
         const int kdec = 3 - (mi - 1);                              // decoder stage that consumed this skip
         const int64_t total = l.M * (Lp.cout / 4);
         pool_bwd_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[lp], Lp.scale, Lp.shift, Lp.cout, lprev.D, lprev.H, lprev.W,
-                                                                mi == 4 ? 2 : 1, l.D, l.H, l.W, t->dpool[mi - 1], t->dcat[kdec],
+                                                                mi == 4 ? 2 : 1, l.D, l.H, l.W, t->dpool[mi - 1], t->dcat[0][kdec],
                                                                 2 * Lp.cout, Lp.cout, t->gact[lp], total);
         ISX_CHECK_LAUNCH();
     }
@@ -927,7 +948,7 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
     u->wz = 0;                                        // force a B = 1 workspace
     ISX_TRY(prepare_workspace(ctx, t->cz, t->cy, t->cx, 1));
     // current weights (host copies in reference layout) -> P; BN / bias pointers now alias P
-    for (int li = 0; li < 18; ++li) {
+    for (int li = 0; li < u->nlayers; ++li) {
         ConvBN &L = u->cv[li];
         const HostTensor &w = u->host[L.conv + ".weight"], &b = u->host[L.conv + ".bias"];
         const HostTensor &g = u->host[L.bn + ".weight"], &be = u->host[L.bn + ".bias"];
@@ -948,9 +969,9 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
     }
     // backward buffers
     size_t max_rawc = 0;
-    for (int li = 0; li < 18; ++li) {
+    for (int li = 0; li < u->nlayers; ++li) {
         const ConvBN &L = u->cv[li];
-        const Level &l = u->lv[MOD_LEVEL[li / 2]];
+        const Level &l = u->lv[MOD_LEVEL[layer_module(li)]];
         t->dstride[li] = L.cout;
         if (use_fold(L.cin, L.cout) && L.cin % 32 == 0) {
             // thin layer fed by a wide one: its d(raw) is stored 8 channels wide (zeros after cout) so that the
@@ -968,14 +989,14 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
         max_rawc = std::max(max_rawc, (size_t)L.cout);
     }
     for (int k = 0; k < 4; ++k) {
-        ISX_TRY(talloc(t, (size_t)u->lv[3 - k].M * 2 * u->up[k].C, &t->dcat[k]));
+        for (int f = 0; f < u->nforks; ++f) ISX_TRY(talloc(t, (size_t)u->lv[3 - k].M * 2 * u->up[k].C, &t->dcat[f][k]));
         ISX_TRY(talloc(t, (size_t)u->lv[k + 1].M * MOD_COUT[k], &t->dpool[k]));
     }
     // bf16 packs (refreshed on the device after every optimiser step while the context is in ISX_PRECISION_BF16)
-    for (int li = 0; li < 18; ++li) {
+    for (int li = 0; li < u->nlayers; ++li) {
         ConvBN &L = u->cv[li];
         if (!use_mfma(L.cin, L.cout) || L.cin % 8) continue;
-        const Level &l = u->lv[MOD_LEVEL[li / 2]];
+        const Level &l = u->lv[MOD_LEVEL[layer_module(li)]];
         int t0, t1, t2, slots;
         conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
         for (int bn = 32; bn <= 64; bn += 32) {
@@ -1004,7 +1025,7 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
     ISX_TRY(talloc(t, 1024, &t->zeros));
     ISX_HIP(hipMemsetAsync(t->zeros, 0, 1024 * 4, ctx->stream));
     size_t wp = 0;
-    for (int li = 0; li < 18; ++li) {
+    for (int li = 0; li < u->nlayers; ++li) {
         const ConvBN &L = u->cv[li];
         const size_t tco = L.cout <= 32 ? 32 : 64, tci = L.cin <= 32 ? 32 : 64;       // as in wgrad()
         size_t tiles = ((L.cout + tco - 1) / tco) * ((L.cin + tci - 1) / tci);
@@ -1050,12 +1071,24 @@ static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dic
     double total = 0.0;
     if (!dice) {
         ISX_REQUIRE((size_t)blocks * C <= t->part_floats, "internal: partial buffer too small");
-        loss_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[17], LL.scale, LL.shift, y, C, l0.M, spec, t->gact[17], t->part);
-        ISX_CHECK_LAUNCH();
-        colsum_kernel<<<C, 256, 0, ctx->stream>>>(t->part, blocks, C, t->lossbuf);
-        ISX_CHECK_LAUNCH();
+        // every decoder's channels against their slice of the target (the reference concatenates the forks' outputs and
+        // applies one loss to the whole tensor, unet.py:322 + train.py:344-363: the means in spec.w are over all channels)
+        int c_off = 0;
+        for (int f = 0; f < u->nforks; ++f) {
+            const int lf = dec_layer(f, 3, 1);
+            const ConvBN &Lf = u->cv[lf];
+            LossSpec sp;
+            for (int c = 0; c < 8; ++c) { sp.kind[c] = c_off + c < 8 ? spec.kind[c_off + c] : 0; sp.w[c] = c_off + c < 8 ? spec.w[c_off + c] : 0.f; }
+            loss_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[lf], Lf.scale, Lf.shift, y + (int64_t)c_off * l0.M, Lf.cout, l0.M, sp,
+                                                         t->gact[lf], t->part);
+            ISX_CHECK_LAUNCH();
+            colsum_kernel<<<Lf.cout, 256, 0, ctx->stream>>>(t->part, blocks, Lf.cout, t->lossbuf + c_off);
+            ISX_CHECK_LAUNCH();
+            c_off += Lf.cout;
+        }
         ISX_HIP(hipMemcpyAsync(hs, t->lossbuf, C * 4, hipMemcpyDeviceToHost, ctx->stream));
     } else {
+        ISX_REQUIRE(u->nforks == 1, "DiceLoss on a forked network is not built (BCE / MSE / channel-wise losses are)");
         const int64_t plane = (int64_t)l0.H * l0.W;
         ISX_REQUIRE(plane % 256 == 0 && l0.D * 3 * C <= 2048, "internal: DiceLoss needs H*W %% 256 == 0");
         ISX_REQUIRE((size_t)blocks * C * 3 <= t->part_floats, "internal: partial buffer too small");

@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void tail_combine_kernel(const float *__restri
 // crop into the (C, Z, Y, X) feature map (process_chunks, predict.py:82-95).
 // ------------------------------------------------------------------------------------------
 __global__ void final_kernel(const float *__restrict__ raw, const float *__restrict__ scale,
-                             const float *__restrict__ shift, int nout, int cz, int cy, int cx,
+                             const float *__restrict__ shift, int nout, int c_off, int c_total, int cz, int cy, int cx,
                              const int32_t *__restrict__ table, float *__restrict__ out_ncdhw,
                              float *__restrict__ fm, int64_t Z, int64_t Y, int64_t X, int64_t total)
 {
@@ -773,8 +773,8 @@ __global__ void final_kernel(const float *__restrict__ raw, const float *__restr
     for (int c = 0; c < nout; ++c) {
         float v = fmaf(raw[i * nout + c], scale[b * nout + c], shift[b * nout + c]);
         v = 1.f / (1.f + expf(-v));
-        if (out_ncdhw) out_ncdhw[((int64_t)b * nout + c) * M + m] = v;
-        if (in_crop) fm[(((int64_t)c * Z + (r[0] + z)) * Y + (r[1] + y)) * X + (r[2] + x)] = v;
+        if (out_ncdhw) out_ncdhw[((int64_t)b * c_total + c_off + c) * M + m] = v;        // forks are concatenated (unet.py:322)
+        if (in_crop) fm[(((int64_t)(c_off + c) * Z + (r[0] + z)) * Y + (r[1] + y)) * X + (r[2] + x)] = v;
     }
 }
 
@@ -852,18 +852,29 @@ bool use_mfma(int cin, int cout) { return cin >= 32 && (cin % 4) == 0 && (cout %
 // thin layer with many inputs: x-taps folded into the MFMA N tile (3 * cout <= 16 columns)
 bool use_fold(int cin, int cout) { return cin >= 32 && (cin % 4) == 0 && cout <= 5; }
 
-static int commit_weights(isx_ctx *ctx, int out_channels)
+static int commit_weights(isx_ctx *ctx, const int *fork_channels, int nforks)
 {
     UNetState *u = ctx->unet;
-    ISX_REQUIRE(out_channels >= 1 && out_channels <= 8, "out_channels must be 1..8 (single decoder)");
+    ISX_REQUIRE(nforks >= 1 && nforks <= ISX_MAX_FORKS, "1 or 2 decoders (the reference's decoder() handles forks 0 and 1, unet.py:330-362)");
+    int out_channels = 0;
+    for (int f = 0; f < nforks; ++f) {
+        ISX_REQUIRE(fork_channels[f] >= 1 && fork_channels[f] <= 8, "decoder %d: out_channels must be 1..8", f);
+        u->fork_channels[f] = fork_channels[f];
+        out_channels += fork_channels[f];
+    }
+    ISX_REQUIRE(out_channels <= 8, "at most 8 output channels over all decoders");
     u->out_channels = out_channels;
+    u->nforks = nforks;
+    u->nlayers = 18 + 8 * (nforks - 1);
     size_t expected = 0;
-    for (int mi = 0; mi < 9; ++mi) {
-        int cin = MOD_CIN[mi], cout = MOD_COUT[mi] < 0 ? out_channels : MOD_COUT[mi];
+    for (int mx = 0; mx < 9 + 4 * (nforks - 1); ++mx) {
+        const int fork = mx < 9 ? 0 : 1, mi = mx < 9 ? mx : mx - 4;              // mi: table index (c0..c8)
+        const std::string mname = mi < 5 ? std::string(MODS[mi]) : std::string(MODS[mi]).substr(0, 2) + "_" + std::to_string(fork);
+        int cin = MOD_CIN[mi], cout = MOD_COUT[mi] < 0 ? fork_channels[fork] : MOD_COUT[mi];
         for (int j = 0; j < 2; ++j) {
-            ConvBN &L = u->cv[2 * mi + j];
-            L.conv = std::string(MODS[mi]) + ".conv" + std::to_string(j);
-            L.bn = std::string(MODS[mi]) + ".batch" + std::to_string(j);
+            ConvBN &L = u->cv[(mx < 9 ? 2 * mx : 18 + 2 * (mx - 9)) + j];
+            L.conv = mname + ".conv" + std::to_string(j);
+            L.bn = mname + ".batch" + std::to_string(j);
             L.cin = j == 0 ? cin : cout;
             L.cout = cout;
             const HostTensor *w = need(u, L.conv + ".weight", {cout, L.cin, 3, 3, 3});
@@ -1053,9 +1064,9 @@ int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
     for (int k = 0; k <= 4; ++k) lv[k].M = (int64_t)lv[k].D * lv[k].H * lv[k].W;
     const int B = batch;
     ISX_TRY(dev_alloc(u, (size_t)B * lv[0].M, &u->x0));
-    for (int li = 0; li < 18; ++li) {
+    for (int li = 0; li < u->nlayers; ++li) {
         ConvBN &L = u->cv[li];
-        const Level &l = lv[MOD_LEVEL[li / 2]];
+        const Level &l = lv[MOD_LEVEL[layer_module(li)]];
         ISX_TRY(dev_alloc(u, (size_t)B * l.M * L.cout, &u->raw[li]));
         L.tiles = layer_tiles(u, li, l, B);
         ISX_TRY(dev_alloc(u, (size_t)B * L.tiles * L.cout, &L.psum));
@@ -1070,6 +1081,7 @@ int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
     for (int k = 0; k < 4; ++k) {
         ISX_TRY(dev_alloc(u, (size_t)B * lv[k + 1].M * MOD_COUT[k], &u->pool[k]));       // pooled module k output
         ISX_TRY(dev_alloc(u, (size_t)B * lv[3 - k].M * UP_C[k], &u->ups[k]));            // up_k output at level 3-k
+        if (u->nforks > 1 && k > 0) ISX_TRY(dev_alloc(u, (size_t)B * lv[3 - k].M * UP_C[k], &u->ups[ups_index(1, k)]));
     }
     u->wz = cz; u->wy = cy; u->wx = cx; u->wbatch = B;
     return ISX_OK;
@@ -1219,7 +1231,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
     const Src none{nullptr, nullptr, nullptr, 0};
     // |relu(BN(x))| <= |gamma| * sqrt(M - 1) + |beta| for batch statistics over M values: the range check of the
     // split-f16 convolution (run_conv) uses these bounds, pooling keeps them, the up-convolution scales them
-    auto bn_bound = [&](int li) { const ConvBN &L = u->cv[li]; return L.gmax * sqrtf((float)lv[MOD_LEVEL[li / 2]].M) + L.bmax; };
+    auto bn_bound = [&](int li) { const ConvBN &L = u->cv[li]; return L.gmax * sqrtf((float)lv[MOD_LEVEL[layer_module(li)]].M) + L.bmax; };
     auto act = [&](int li) { const ConvBN &L = u->cv[li]; return Src{u->raw[li], L.scale, L.shift, L.cout, bn_bound(li)}; };
     // ---- encoder ----------------------------------------------------------------------------
     for (int mi = 0; mi <= 4; ++mi) {
@@ -1240,37 +1252,43 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             ISX_CHECK_LAUNCH();
         }
     }
-    // ---- decoder ------------------------------------------------------------------------------
-    for (int k = 0; k < 4; ++k) {
-        const int mi_in = (k == 0) ? 4 : 4 + k;               // module feeding up_k: c4, c5, c6, c7
-        const int li_in = 2 * mi_in + 1;
-        const Level &ls = lv[MOD_LEVEL[mi_in]];               // source level
-        const Level &lo = lv[3 - k];                          // output level (after crop)
-        const UpConv &U = u->up[k];
-        const ConvBN &Lin = u->cv[li_in];
+    // ---- decoder(s): every fork runs c5..c8 of its own on the shared encoder outputs and transposed convolutions; up0 of
+    //      the bottleneck is the same tensor for both, the outputs are concatenated (unet.py:313-325) ---------------------
+    int c_off = 0;
+    for (int f = 0; f < u->nforks; ++f) {
+        for (int k = 0; k < 4; ++k) {
+            const int li_in = (k == 0) ? 9 : dec_layer(f, k - 1, 1);   // layer feeding up_k: c4, c5, c6, c7 (second conv)
+            const Level &ls = lv[MOD_LEVEL[layer_module(li_in)]];   // source level
+            const Level &lo = lv[3 - k];                          // output level (after crop)
+            const UpConv &U = u->up[k];
+            const ConvBN &Lin = u->cv[li_in];
+            float *upo = u->ups[ups_index(f, k)];
+            if (!(f > 0 && k == 0)) {
+                ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
+                int64_t total = (int64_t)B * lo.M * (U.C / 4);
+                ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
+                upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D,
+                                                                        ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, U.bias, lo.D,
+                                                                        lo.H, lo.W, upo, total, 1 /* streaming stores: the 5.4 GB output is far larger than L2 */);
+                ISX_CHECK_LAUNCH();
+            }
+            const int l0 = dec_layer(f, k, 0), l1 = dec_layer(f, k, 1);   // c5..c8 of this fork
+            const int skip_li = 2 * (3 - k) + 1;                   // c3, c2, c1, c0 second conv
+            ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, bn_bound(li_in) * U.wmax + U.bmax}, act(skip_li)));
+            ISX_TRY(run_conv(ctx, l1, lo, B, act(l0), none));
+        }
         {
             ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
-            int64_t total = (int64_t)B * lo.M * (U.C / 4);
+            const int lf = dec_layer(f, 3, 1);
+            const ConvBN &L = u->cv[lf];
+            int64_t total = (int64_t)B * lv[0].M;
             ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
-            upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D,
-                                                                    ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, U.bias, lo.D,
-                                                                    lo.H, lo.W, u->ups[k], total, 1 /* streaming stores: the 5.4 GB output is far larger than L2 */);
+            final_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[lf], L.scale, L.shift, L.cout, c_off, u->out_channels,
+                                                                 lv[0].D, lv[0].H, lv[0].W, u->d_table, out_ncdhw, fm,
+                                                                 shape ? shape[0] : 0, shape ? shape[1] : 0, shape ? shape[2] : 0, total);
             ISX_CHECK_LAUNCH();
+            c_off += L.cout;
         }
-        const int mi = 5 + k;                                  // c5..c8
-        const int skip_li = 2 * (3 - k) + 1;                   // c3, c2, c1, c0 second conv
-        ISX_TRY(run_conv(ctx, 2 * mi, lo, B, Src{u->ups[k], nullptr, nullptr, U.C, bn_bound(li_in) * U.wmax + U.bmax}, act(skip_li)));
-        ISX_TRY(run_conv(ctx, 2 * mi + 1, lo, B, act(2 * mi), none));
-    }
-    {
-        ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
-        const ConvBN &L = u->cv[17];
-        int64_t total = (int64_t)B * lv[0].M;
-        ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
-        final_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[17], L.scale, L.shift, L.cout, lv[0].D, lv[0].H,
-                                                             lv[0].W, u->d_table, out_ncdhw, fm, shape ? shape[0] : 0,
-                                                             shape ? shape[1] : 0, shape ? shape[2] : 0, total);
-        ISX_CHECK_LAUNCH();
     }
     u->last_n = B;
     return ISX_OK;
@@ -1350,7 +1368,18 @@ int isx_weights_commit(isx_ctx *ctx, int out_channels)
     ISX_REQUIRE(ctx, "null context");
     if (!ctx->unet) { set_error("no weights loaded"); return ISX_ERR_STATE; }
     ISX_HIP(hipSetDevice(ctx->device));
-    return commit_weights(ctx, out_channels);
+    return commit_weights(ctx, &out_channels, 1);
+}
+
+int isx_weights_commit_forked(isx_ctx *ctx, const int32_t *fork_channels, int nforks)
+{
+    ISX_REQUIRE(ctx && fork_channels, "null argument");
+    if (!ctx->unet) { set_error("no weights loaded"); return ISX_ERR_STATE; }
+    ISX_REQUIRE(nforks >= 1 && nforks <= ISX_MAX_FORKS, "1 or 2 decoders");
+    ISX_HIP(hipSetDevice(ctx->device));
+    int fc[ISX_MAX_FORKS] = {0, 0};
+    for (int f = 0; f < nforks; ++f) fc[f] = fork_channels[f];
+    return commit_weights(ctx, fc, nforks);
 }
 
 int isx_get_weight_host(isx_ctx *ctx, const char *key, void *data, int64_t nbytes)
@@ -1362,7 +1391,7 @@ int isx_get_weight_host(isx_ctx *ctx, const char *key, void *data, int64_t nbyte
     std::string k(key);
     auto it = u->host.find(k);
     ISX_REQUIRE(it != u->host.end(), "unknown key %s", key);
-    for (int li = 0; li < 18; ++li) {
+    for (int li = 0; li < u->nlayers; ++li) {
         ConvBN &L = u->cv[li];
         const float *src = nullptr;
         if (k == L.bn + ".running_mean") src = L.rmean;
@@ -1434,16 +1463,17 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
     std::string nm(name);
     const float *src = nullptr, *sc = nullptr, *sh = nullptr;
     int C = 0, mode = 0, level = 0;
-    for (int mi = 0; mi < 9 && !src; ++mi) {
-        std::string m(MODS[mi]);
+    for (int li = 0; li < u->nlayers && !src; li += 2) {        // module names follow the state dict: c0..c4, c5_0..c8_0, c5_1..c8_1
+        const int mi = layer_module(li);
+        const std::string m = u->cv[li].conv.substr(0, u->cv[li].conv.find('.'));
         for (int j = 0; j < 2; ++j) {
-            const ConvBN &L = u->cv[2 * mi + j];
-            if (nm == L.conv) { src = u->raw[2 * mi + j]; C = L.cout; mode = 0; level = MOD_LEVEL[mi]; }
-            else if (nm == L.bn) { src = u->raw[2 * mi + j]; sc = L.scale; sh = L.shift; C = L.cout; mode = 1; level = MOD_LEVEL[mi]; }
+            const ConvBN &L = u->cv[li + j];
+            if (nm == L.conv) { src = u->raw[li + j]; C = L.cout; mode = 0; level = MOD_LEVEL[mi]; }
+            else if (nm == L.bn) { src = u->raw[li + j]; sc = L.scale; sh = L.shift; C = L.cout; mode = 1; level = MOD_LEVEL[mi]; }
         }
         if (nm == m) {
-            const ConvBN &L = u->cv[2 * mi + 1];
-            src = u->raw[2 * mi + 1]; sc = L.scale; sh = L.shift; C = L.cout; mode = (mi == 8) ? 3 : 2; level = MOD_LEVEL[mi];
+            const ConvBN &L = u->cv[li + 1];
+            src = u->raw[li + 1]; sc = L.scale; sh = L.shift; C = L.cout; mode = (mi == 8) ? 3 : 2; level = MOD_LEVEL[mi];
         }
     }
     for (int k = 0; k < 4 && !src; ++k) {

@@ -45,15 +45,25 @@ struct UpConv {
 
 struct Level { int D = 0, H = 0, W = 0; int64_t M = 0; };
 
+// Layer numbering.  0..9: encoder (c0.conv0 .. c4.conv1); 10..17: decoder of fork 0 (c5_0.conv0 .. c8_0.conv1); 18..25: decoder
+// of fork 1 (c5_1 .. c8_1) when the network is forked (reference: unet.py:152-157,192-210,313-325 -- the forks share
+// the encoder and the transposed convolutions, each has its own c5..c8; the reference's decoder() handles i = 0, 1 only).
+static constexpr int ISX_MAX_LAYERS = 26, ISX_MAX_MODULES = 13, ISX_MAX_UPS = 7, ISX_MAX_FORKS = 2;
+inline int layer_module(int li) { return li < 18 ? li / 2 : 5 + (li - 18) / 2; }       // 0..8: c0..c8 (table index of MOD_*)
+inline int dec_layer(int fork, int k, int j) { return (fork == 0 ? 10 : 18) + 2 * k + j; }     // k = 0..3: c5..c8
+inline int ups_index(int fork, int k) { return (k == 0 || fork == 0) ? k : 3 + k; }        // up0's output is shared by the forks
+
 struct UNetState {
     isx_tune tune;                   // copy of the owning context's knobs (isx_ctx_create)
     std::map<std::string, HostTensor> host;
     bool committed = false;
-    int out_channels = 5;
+    int out_channels = 5;            // all forks together (the channel count of the output tensor)
+    int nforks = 1, fork_channels[ISX_MAX_FORKS] = {5, 0};
+    int nlayers = 18;                // 18, or 26 with two forks
     int batch = 4;
     int precision = ISX_PRECISION_SPLIT_F16;     // arithmetic of the wide inference convolutions (isx_unet_set_precision)
     // layers: index 0..17 = c0.conv0, c0.conv1, c1.conv0, ... c4.conv1, c5.conv0 ... c8.conv1
-    ConvBN cv[18];
+    ConvBN cv[ISX_MAX_LAYERS];
     UpConv up[4];
     // workspace for (cz, cy, cx) x batch
     int wz = 0, wy = 0, wx = 0, wbatch = 0;
@@ -61,9 +71,9 @@ struct UNetState {
     std::vector<void *> blocks;      // workspace (re-allocated when the chunk geometry changes)
     std::vector<void *> wblocks;     // weights
     float *x0 = nullptr;
-    float *raw[18] = {nullptr};
+    float *raw[ISX_MAX_LAYERS] = {nullptr};
     float *pool[4] = {nullptr};
-    float *ups[4] = {nullptr};
+    float *ups[ISX_MAX_UPS] = {nullptr};      // ups_index(fork, k)
     float *ptail = nullptr;           // [B][M0][16] partial sums of the folded tail layer
     float *wtail = nullptr, *zeros32 = nullptr;
     const int32_t *d_table = nullptr;   // device rows of the launch set in flight

@@ -58,7 +58,8 @@ def trainable_layout(out_channels=5):
     module as conv0.{weight,bias}, conv1.{weight,bias}, batch0.{weight,bias}, batch1.{weight,bias}, then the
     transposed convolutions (the order ``isx_train_bind`` documents)."""
     schema = _weights.unet_schema(1, out_channels)
-    mods = ["c0", "c1", "c2", "c3", "c4", "c5_0", "c6_0", "c7_0", "c8_0"]
+    nforks = len(out_channels) if isinstance(out_channels, (tuple, list)) else 1
+    mods = ["c0", "c1", "c2", "c3", "c4"] + [f"c{n}_{i}" for i in range(nforks) for n in (5, 6, 7, 8)]
     keys = []
     for m in mods:
         keys += [f"{m}.conv0.weight", f"{m}.conv0.bias", f"{m}.conv1.weight", f"{m}.conv1.bias",
@@ -85,10 +86,12 @@ class Trainer:
         self.unet = UNet(1, out_channels, device=device, batch=1, chan_final_activations=chan_final_activations,
                          precision=precision)
         self.precision = precision
+        if isinstance(out_channels, list):
+            out_channels = tuple(out_channels)
         if state_dict is None:
             state_dict = _weights.generate_state_dict(seed, 1, out_channels)
         self.unet.load_state_dict(state_dict)
-        self.out_channels = out_channels
+        self.out_channels = self.unet.out_channels            # all decoders together (a tuple = the forked network)
         self.patch = tuple(int(p) for p in patch)
         dev = torch.device("cuda", self.unet.device)
         lib, h = self.unet.ctx.lib, self.unet.ctx.handle
@@ -187,10 +190,9 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
     ``(unet, unet_path)`` like the reference; ``unet_path`` is None when ``out_dir`` is None (the reference
     leaves it unbound there, train.py:177-183)."""
     import pandas as pd
-    if fork_channels is not None:
-        raise NotImplementedError("forked decoders (train.py:139-141, unet.py:313-325) are not on the accelerated path")
-    if chan_final_activations is not None and list(chan_final_activations) != ['sigmoid']:
-        # never accepted-and-ignored: the reference hands it to UNet (train.py:135-137) where it changes the arithmetic
+    nforks = len(fork_channels) if fork_channels is not None else 1
+    if chan_final_activations is not None and list(chan_final_activations) != ['sigmoid'] * nforks:
+        # never accepted-and-ignored: the reference hands it to UNet (train.py:135-141) where it changes the arithmetic
         raise NotImplementedError(f"chan_final_activations={chan_final_activations!r}: only the default 'sigmoid' is built")
     save_output = out_dir is not None
     print('Output will be saved: ', save_output)
@@ -205,8 +207,15 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
     sd = None
     if weights is not None:
         sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in weights.items()}
-    trainer = Trainer(sd, out_channels=n_out, patch=patch, seed=kwargs.get('seed', 0),
-                      chan_final_activations=chan_final_activations, precision=precision)
+    if fork_channels is not None:
+        # train.py:139-141: UNet(out_channels=fork_channels) -- one decoder per entry, outputs concatenated in channel order
+        fork_channels = tuple(int(c) for c in fork_channels)
+        if sum(fork_channels) != n_out:
+            raise ValueError(f"fork_channels {fork_channels} do not add up to the {n_out} target channels")
+        if loss_function == 'DiceLoss':
+            raise NotImplementedError("DiceLoss on a forked network is not built (BCELoss, WeightedBCE, Channelwise are)")
+    trainer = Trainer(sd, out_channels=fork_channels if fork_channels is not None else n_out, patch=patch,
+                      seed=kwargs.get('seed', 0), chan_final_activations=chan_final_activations, precision=precision)
     cwise = channelwise_spec(losses, chan_losses, n_out) if loss_function == 'Channelwise' else None
     loss_dict = {'epoch': [], 'batch_num': [], 'loss': [], 'data_id': []}
     for c in channels:
@@ -239,6 +248,8 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
         _write_log(f'Epochs: {epochs}; learning rate: {lr}; patches: {len(x)} training / {len(vx)} validation', out_dir)
         _write_log('Initial weights: ' + ('supplied state dict' if weights is not None else 'seeded generator'), out_dir)
         _write_log(f'Channels: {channels}', out_dir)
+        if fork_channels is not None:
+            _write_log(f'Channels per fork (according to channel order): {fork_channels}', out_dir)
     unet_path = None
     for e in range(epochs):
         if validate and e == 0:

@@ -30,15 +30,22 @@ class UNet:
     def __init__(self, in_channels=1, out_channels=5, down_factors=(1, 2, 2), up='convolution',
                  downsample_1_at_bottom=True, chan_final_activations=None, device=None, batch=32,
                  precision=None):
-        if isinstance(out_channels, tuple):
-            raise NotImplementedError("forked decoders (out_channels tuple) are not on the accelerated path")
+        # a tuple = the forked network (unet.py:152-157): one decoder c5_i..c8_i per entry on a shared encoder, outputs
+        # concatenated (unet.py:313-325); the reference's decoder() serves forks 0 and 1 (unet.py:330-362)
+        self.forked = isinstance(out_channels, (tuple, list))
+        self.fork_channels = tuple(int(c) for c in out_channels) if self.forked else (int(out_channels),)
+        if len(self.fork_channels) > 2:
+            raise NotImplementedError("more than two decoders: the reference's decoder() only handles forks 0 and 1")
+        if sum(self.fork_channels) > 8:
+            raise NotImplementedError("at most 8 output channels over all decoders")
         if in_channels != 1 or tuple(down_factors) != (1, 2, 2) or up != 'convolution' or not downsample_1_at_bottom:
             raise NotImplementedError("only the configuration iterseg ships (in=1, (1,2,2), transposed conv) is built")
-        if chan_final_activations is not None and list(chan_final_activations) != ['sigmoid']:
+        if chan_final_activations is not None and list(chan_final_activations) != ['sigmoid'] * len(self.fork_channels):
             # unet.py:205-209: one entry per decoder, handed to ConvModule(final=...); only the default is built
             raise NotImplementedError(f"chan_final_activations={chan_final_activations!r}: only the reference's default "
-                                      "final activation ('sigmoid', single decoder) is on the accelerated path")
-        self.in_channels, self.out_channels = in_channels, int(out_channels)
+                                      "final activation ('sigmoid' for every decoder) is on the accelerated path")
+        self.in_channels, self.out_channels = in_channels, int(sum(self.fork_channels))
+        self._schema_out = self.fork_channels if self.forked else self.out_channels
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.ctx = _lib.Context(self.device)
         _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch)))
@@ -55,7 +62,7 @@ class UNet:
         sd = OrderedDict()
         for k, v in state_dict.items():
             sd[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
-        _weights.check_state_dict(sd, self.in_channels, self.out_channels)     # strict key/shape check
+        _weights.check_state_dict(sd, self.in_channels, self._schema_out)      # strict key/shape check
         if self._loaded:                          # a committed context cannot be re-loaded: start a new one
             self.ctx.close()
             self.ctx = _lib.Context(self.device)
@@ -70,7 +77,11 @@ class UNet:
                 a = np.ascontiguousarray(v, np.float32)
                 shp = (C.c_int64 * a.ndim)(*a.shape)
                 _lib.check(lib.isx_load_weight_host(h, k.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim))
-        _lib.check(lib.isx_weights_commit(h, self.out_channels))
+        if self.forked:
+            fc = (C.c_int32 * len(self.fork_channels))(*self.fork_channels)
+            _lib.check(lib.isx_weights_commit_forked(h, fc, len(self.fork_channels)))
+        else:
+            _lib.check(lib.isx_weights_commit(h, self.out_channels))
         self._sd = sd
         self._loaded = True
         return self

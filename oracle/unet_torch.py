@@ -89,7 +89,9 @@ def conv_module(p, name, x, final="relu", taps=None):
 
 
 def unet_forward(p, x, taps=None, final="sigmoid"):
-    """x: (1,1,D,H,W) float32 tensor -> (1,5,D,H,W).  Single (non-forked) decoder."""
+    """x: (1,1,D,H,W) float32 tensor -> (1,C,D,H,W).  One decoder, or -- when the parameters hold ``c5_1...`` -- the forked
+    network (unet.py:313-325): every fork runs its own c5_i..c8_i on the shared encoder outputs and transposed convolutions,
+    the outputs are concatenated in fork order."""
     c0 = conv_module(p, "c0", x, taps=taps)
     x = F.max_pool3d(c0, (1, 2, 2), (1, 2, 2), padding=(0, 1, 1))
     if taps is not None:
@@ -102,27 +104,33 @@ def unet_forward(p, x, taps=None, final="sigmoid"):
     x = F.max_pool3d(c3, (2, 2, 2), (2, 2, 2), padding=(0, 1, 1))
     if taps is not None:
         taps["d3"] = x
-    x = conv_module(p, "c4", x, taps=taps)
-    x = F.conv_transpose3d(x, p["up0.weight"], p["up0.bias"], stride=(2, 2, 2), groups=256)
-    if taps is not None:
-        taps["up0"] = x
-    x = torch.cat([x[:, :, :, :-1, :-1], c3], 1)
-    if taps is not None:
-        taps["c5_0.in"] = x
-    x = conv_module(p, "c5_0", x, taps=taps)
-    x = F.conv_transpose3d(x, p["up1.weight"], p["up1.bias"], stride=(1, 2, 2), groups=128)
-    x = torch.cat([x[:, :, :, :-1, :-1], c2], 1)
-    x = conv_module(p, "c6_0", x, taps=taps)
-    x = F.conv_transpose3d(x, p["up2.weight"], p["up2.bias"], stride=(1, 2, 2), groups=64)
-    x = torch.cat([x[:, :, :, :-1, :-1], c1], 1)
-    x = conv_module(p, "c7_0", x, taps=taps)
-    x = F.conv_transpose3d(x, p["up3.weight"], p["up3.bias"], stride=(1, 2, 2), groups=32)
-    if taps is not None:
-        taps["up3"] = x
-    x = torch.cat([x[:, :, :, 1:-1, 1:-1], c0], 1)
-    if taps is not None:
-        taps["c8_0.in"] = x
-    return conv_module(p, "c8_0", x, final=final, taps=taps)
+    c4 = conv_module(p, "c4", x, taps=taps)
+    outs = []
+    i = 0
+    while f"c5_{i}.conv0.weight" in p:
+        ftaps = taps if i == 0 else None                       # the tap names of the fixtures are those of fork 0
+        x = F.conv_transpose3d(c4, p["up0.weight"], p["up0.bias"], stride=(2, 2, 2), groups=256)
+        if ftaps is not None:
+            ftaps["up0"] = x
+        x = torch.cat([x[:, :, :, :-1, :-1], c3], 1)
+        if ftaps is not None:
+            ftaps["c5_0.in"] = x
+        x = conv_module(p, f"c5_{i}", x, taps=ftaps)
+        x = F.conv_transpose3d(x, p["up1.weight"], p["up1.bias"], stride=(1, 2, 2), groups=128)
+        x = torch.cat([x[:, :, :, :-1, :-1], c2], 1)
+        x = conv_module(p, f"c6_{i}", x, taps=ftaps)
+        x = F.conv_transpose3d(x, p["up2.weight"], p["up2.bias"], stride=(1, 2, 2), groups=64)
+        x = torch.cat([x[:, :, :, :-1, :-1], c1], 1)
+        x = conv_module(p, f"c7_{i}", x, taps=ftaps)
+        x = F.conv_transpose3d(x, p["up3.weight"], p["up3.bias"], stride=(1, 2, 2), groups=32)
+        if ftaps is not None:
+            ftaps["up3"] = x
+        x = torch.cat([x[:, :, :, 1:-1, 1:-1], c0], 1)
+        if ftaps is not None:
+            ftaps["c8_0.in"] = x
+        outs.append(conv_module(p, f"c8_{i}", x, final=final, taps=ftaps))
+        i += 1
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
 
 
 def predict_volume(sd, volume, chunk_size, margin, threads=None):

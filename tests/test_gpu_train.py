@@ -237,8 +237,10 @@ def test_unsupported_final_activation_is_rejected_not_ignored():
     ys = [np.zeros((5, 4, 32, 32), np.float32)]
     with pytest.raises(NotImplementedError):
         train.train_unet(xs, xs, ys, ys, epochs=1, chan_final_activations=['tanh'])
+    with pytest.raises(NotImplementedError):                     # one entry per decoder, each must be the default
+        train.train_unet(xs, xs, ys, ys, epochs=1, fork_channels=(3, 2), chan_final_activations=['sigmoid', 'tanh'])
     with pytest.raises(NotImplementedError):
-        train.train_unet(xs, xs, ys, ys, epochs=1, fork_channels=(3, 2))
+        train.train_unet(xs, xs, ys, ys, epochs=1, fork_channels=(3, 2), loss_function='DiceLoss')
     train.train_unet(xs, xs, ys, ys, epochs=1, chan_final_activations=['sigmoid'], validate=False)
 
 
@@ -298,3 +300,105 @@ def test_bf16_mixed_precision_training_step():
     # the state dict it returns is fp32 (master weights) and loads for inference
     sd2 = b.state_dict()
     assert all(v.dtype == torch.float32 for k, v in sd2.items() if not k.endswith("num_batches_tracked"))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the forked network: UNet(out_channels=(3, 2)) as train_unet builds it for fork_channels (train.py:139-141)
+# ------------------------------------------------------------------------------------------------------------------
+def _forked_trainer(d, patch=(4, 32, 32)):
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from iterseg_amd import weights
+    from iterseg_amd.train import Trainer
+    forks = tuple(int(c) for c in d["forks"])
+    return Trainer(weights.generate_state_dict(3, 1, forks), out_channels=forks, patch=patch)
+
+
+def test_forked_forward_loss_and_gradients_match_reference(golden):
+    """Two decoders on one encoder: outputs concatenated, one BCE over all channels; the encoder, up0's output and the
+    shared transposed-convolution weights receive the sum of both decoders' gradients.  Same tolerances as the
+    single-decoder test above."""
+    d = golden("forked_step_4x32x32")
+    t = _forked_trainer(d)
+    assert t.out_channels == 5 and t.unet.forked and t.unet.fork_channels == (3, 2)
+    loss, chan = t._call(d["x"], d["y"], "BCELoss", None, 0.01, 0, True)     # backward, no update
+    assert abs(loss - float(d["loss_bce"])) < 1e-5
+    assert np.allclose(chan, d["loss_bce_per_channel"], atol=1e-5)
+    for k in [f[5:] for f in d.files if f.startswith("grad.")]:
+        ref = d["grad." + k]
+        got = _slice(t.grad(k), k)
+        tol = 2e-3 * np.abs(ref).max() + 1e-6
+        assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())
+    # the inference entry of the same object: (1, 1, D, H, W) -> (1, 5, D, H, W), channels in fork order
+    y = t.unet(d["x"][None, None])
+    assert tuple(y.shape) == (1, 5, 4, 32, 32)
+    y = y.cpu().numpy() if isinstance(y, torch.Tensor) else np.asarray(y)
+    assert np.abs(y - d["y_hat"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("double", [False, True])
+def test_forked_adam_update_and_state_dict(golden, double):
+    d = golden("forked_step_4x32x32")
+    t = _forked_trainer(d)
+    t.train_step(d["x"], d["y"], lr=0.01, loss="BCELoss", double_step=double)
+    tag = "double" if double else "single"
+    sd = t.state_dict()
+    assert list(sd.keys()) == [str(k) for k in d["keys"]]                  # c5_1 ... c8_1 included, reference order
+    for k in [f[5:] for f in d.files if f.startswith("grad.")]:
+        ref, g = d[f"param_{tag}." + k], d["grad." + k]
+        got = _slice(t.param(k), k)
+        sig = np.abs(g) > 1e-5
+        assert np.abs(got - ref)[sig].max(initial=0) < 2e-4, k
+        assert np.abs(_slice(sd[k], k) - got).max() == 0.0               # state_dict reads the live parameters
+    for k in ("c4.batch1.running_mean", "c8_1.batch1.running_var"):
+        assert np.abs(sd[k].numpy() - d[f"post_{tag}." + k]).max() < 1e-5, k
+    assert int(sd["c8_1.batch1.num_batches_tracked"]) == int(d[f"post_{tag}.c8_1.batch1.num_batches_tracked"])
+
+
+def test_forked_against_oracle_float64_and_channelwise_loss():
+    """A second geometry and loss: (6, 48, 32) patch, forks (2, 4), Channelwise (BCE on the first fork's channels, MSE on
+    the second's) -- gradients of every parameter tensor against the float64 autograd of the torch-CPU oracle."""
+    from iterseg_amd import weights
+    from iterseg_amd.train import Trainer, channelwise_spec
+    from oracle import unet_torch as ou
+    from tests.synth import positive_volume
+    forks, patch = (2, 4), (6, 48, 32)
+    sd = weights.generate_state_dict(5, 1, forks)
+    rng = np.random.default_rng(2)
+    x = positive_volume(patch, 9)
+    y = (rng.random((6,) + patch) < 0.4).astype(np.float32)
+    losses, chan_losses = ["BCELoss", "MSELoss"], [slice(0, 2), slice(2, 6)]
+    t = Trainer(sd, out_channels=forks, patch=patch)
+    loss, _ = t._call(x, y, "Channelwise", None, 0.01, 0, True, channelwise=channelwise_spec(losses, chan_losses, 6))
+    p = ou._as_params(sd, requires_grad=True, dtype=torch.float64)
+    yh = ou.unet_forward(p, torch.from_numpy(x)[None, None].double())
+    yy = torch.from_numpy(y)[None].double()
+    # ChannelwiseLoss (custom_loss.py:131-159): every entry is a mean over its own elements, the result the mean over entries
+    ref_loss = 0.5 * (torch.nn.functional.binary_cross_entropy(yh[:, 0:2], yy[:, 0:2]) + torch.nn.functional.mse_loss(yh[:, 2:6], yy[:, 2:6]))
+    ref_loss.backward()
+    assert abs(loss - float(ref_loss)) < 1e-5
+    for k, shape, off in t.layout:
+        ref = p[k].grad.numpy()
+        got = t.grad(k).detach().cpu().numpy().astype(np.float64)
+        assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, (k, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_train_unet_with_fork_channels(tmp_path):
+    from iterseg_amd import train
+    from iterseg_amd.unet import UNet
+    from tests.synth import positive_volume
+    rng = np.random.default_rng(3)
+    xs = [positive_volume((4, 32, 32), s) for s in range(3)]
+    ys = [(rng.random((5, 4, 32, 32)) < 0.3).astype(np.float32) for _ in range(3)]
+    unet, path = train.train_unet(xs, xs[:1], ys, ys[:1], out_dir=str(tmp_path), name="f", channels=tuple("abcde"),
+                                  epochs=2, lr=0.01, update_every=2, fork_channels=(3, 2))
+    assert unet.forked and unet.fork_channels == (3, 2) and path is not None
+    sd = torch.load(path)
+    assert "c8_1.conv1.weight" in sd and tuple(sd["c8_1.conv1.weight"].shape) == (2, 2, 3, 3, 3)
+    u2 = UNet(1, (3, 2), batch=1)
+    u2.load_state_dict(sd)                                                  # the checkpoint loads into a fresh forked net
+    assert tuple(np.asarray(u2(xs[0][None, None])).shape) == (1, 5, 4, 32, 32)
+    assert "Channels per fork" in open(tmp_path / "log.txt").read()
+    with pytest.raises(ValueError):
+        train.train_unet(xs, xs[:1], ys, ys[:1], out_dir=None, channels=tuple("abcde"), epochs=1, fork_channels=(3, 3))
+    with pytest.raises(NotImplementedError):
+        UNet(1, (2, 2, 2))

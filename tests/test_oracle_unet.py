@@ -152,3 +152,26 @@ def test_dice_and_channelwise_losses_match_reference_classes(golden):
         assert np.abs(yh.grad.numpy() - g[f"{tag}.grad"]).max() <= 1e-9 + 1e-5 * np.abs(g[f"{tag}.grad"]).max(), tag
     log = ou.channel_log("DiceLoss", torch.from_numpy(d["y_hat"]), yy)
     assert np.allclose(log, g["dice.per_channel_log"], atol=1e-6)
+
+
+def test_forked_network_matches_reference(golden):
+    """UNet(out_channels=(3, 2)) (unet.py:152-157,313-362): forward, loss, gradients (also of the shared encoder and
+    transposed convolutions, which receive both decoders' contributions) and the Adam update against the fixture
+    captured from the reference (tests/golden/gen_stage1c_forked.py)."""
+    from iterseg_amd import weights
+    d = golden("forked_step_4x32x32")
+    forks = tuple(int(c) for c in d["forks"])
+    sd = weights.generate_state_dict(3, 1, forks)
+    assert list(sd.keys()) == [str(k) for k in d["keys"]]
+    for double in (False, True):
+        loss, y_hat, grads, new = ou.train_step(sd, d["x"], d["y"], lr=0.01, double_step=double)
+        tag = "double" if double else "single"
+        assert abs(loss - float(d["loss_bce"])) < 1e-6
+        assert np.abs(y_hat - d["y_hat"]).max() < FWD_TOL
+        for k in [f[5:] for f in d.files if f.startswith("grad.")]:
+            g = grads[k].reshape(grads[k].shape[0], -1)[:, :64]
+            ref = d["grad." + k]
+            assert np.abs(g - ref).max() <= 1e-5 + 1e-3 * np.abs(ref).max(), k
+            w = new[k].reshape(new[k].shape[0], -1)[:, :64]
+            sig = np.abs(ref) > 1e-5
+            assert np.abs(w - d[f"param_{tag}." + k])[sig].max(initial=0) < 1e-4, k
