@@ -222,6 +222,28 @@ int isx_label_contingency(isx_ctx *ctx, const int32_t *gt, const int32_t *mr, in
  * rank).  The caller combines the label volumes with an element-wise max (RCCL all-reduce).  Applies to
  * isx_affinity_watershed / isx_segment_output_image / isx_segment_volume*; (0, 1) restores the default. */
 int isx_ws_set_shard(isx_ctx *ctx, int rank, int world);
+
+/* ---------------------------------------------------------------------------------- *
+ * Collectives on RCCL (xGMI), one process per GPU -- for hosts that do not already hold a communicator (the Python host
+ * of this repository uses torch.distributed, which is the same RCCL).  They are the three exchanges of the sharded path:
+ *   isx_allreduce_grads       data-parallel training: the reference's step (train.py:344-363) on every rank, gradients
+ *                             averaged between isx_train_step(..., n_adam = 0) and isx_adam_step
+ *   isx_gather_tiles          all-gather of equal-sized per-rank tiles: feature-map z-slabs of ONE volume predicted
+ *                             chunk-sharded (predict.py:64-126), or the label tiles of a stack segmented frame-sharded
+ *                             (segmentation.py:873-882)
+ *   isx_allreduce_max_labels  merges label volumes flooded component-sharded (isx_ws_set_shard): disjoint supports
+ * RCCL is loaded (dlopen) by the first isx_comm_* call; all calls are enqueued on the context's stream.
+ * ---------------------------------------------------------------------------------- */
+#define ISX_COMM_ID_BYTES 128
+/* Rank 0 creates the id and the host distributes it (MPI, a socket, a file); then every rank calls isx_comm_init. */
+int isx_comm_unique_id(uint8_t *id /* [ISX_COMM_ID_BYTES] */);
+int isx_comm_init(isx_ctx *ctx, const uint8_t *id, int rank, int world);
+int isx_comm_destroy(isx_ctx *ctx);
+/* grads (device, n floats): sum over the ranks, then divided by the world size, in place. */
+int isx_allreduce_grads(isx_ctx *ctx, float *grads, int64_t n);
+/* recv (device) = the ranks' send buffers (device, bytes_per_rank each) in rank order. */
+int isx_gather_tiles(isx_ctx *ctx, const void *send, void *recv, int64_t bytes_per_rank);
+int isx_allreduce_max_labels(isx_ctx *ctx, int32_t *labels, int64_t n);
 /* skimage.filters.gaussian as used at watershed.py:227 / :234: float32 in/out, per-axis
  * sigma in {0,1,2}, border 'nearest', truncate 4, double accumulation per pass. */
 int isx_ws_gaussian(isx_ctx *ctx, const float *img, float *out, const int64_t shape[3],

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libitersegx.so")
 
-SOURCES = ["isx_ctx.hip", "prims.hip", "ws.hip", "unet.hip", "conv_h2.hip", "train.hip", "labels.hip", "metrics.hip"]
+SOURCES = ["isx_ctx.hip", "prims.hip", "ws.hip", "unet.hip", "conv_h2.hip", "train.hip", "labels.hip", "metrics.hip", "comm.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"]
@@ -68,7 +68,7 @@ def build(force=False, verbose=False, jobs=4):
                 if verbose and warn.strip():
                     print(warn)
     if todo or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]      # dlopen: RCCL is loaded lazily (comm.hip)
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -57,6 +57,12 @@ SIGNATURES = {
     "isx_training_labels": (C.c_int, [_vp, _vp, _i64p, C.c_int, _i32p, _i32p, _i32p, C.POINTER(C.c_double), _vp]),
     "isx_label_contingency": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64p]),
     "isx_ws_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "isx_comm_unique_id": (C.c_int, [_vp]),
+    "isx_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "isx_comm_destroy": (C.c_int, [_vp]),
+    "isx_allreduce_grads": (C.c_int, [_vp, _vp, _i64]),
+    "isx_gather_tiles": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "isx_allreduce_max_labels": (C.c_int, [_vp, _vp, _i64]),
     "isx_ws_gaussian": (C.c_int, [_vp, _vp, _vp, _i64p, _i32p]),
     "isx_ws_threshold_otsu": (C.c_int, [_vp, _vp, _i64, _f32p]),
     "isx_ws_mask": (C.c_int, [_vp, _vp, _i64p, _vp, _f32p]),

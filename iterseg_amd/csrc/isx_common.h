@@ -85,6 +85,8 @@ struct isx_ctx {
     int64_t prof_n[ISX_PROF_NCLASS] = {0};
     isx::UNetState *unet = nullptr;
     int ws_shard_rank = 0, ws_shard_world = 1;     // W4 component sharding (isx_ws_set_shard)
+    void *comm = nullptr;                          // RCCL communicator (isx_comm_init), ncclComm_t
+    int comm_rank = 0, comm_world = 1;
 
     void *alloc(size_t bytes);
     void release(void *p);
@@ -125,5 +127,6 @@ struct ProfScope {
 inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 void unet_destroy(UNetState *);
+void comm_release(isx_ctx *c);            // comm.hip
 
 }  // namespace isx

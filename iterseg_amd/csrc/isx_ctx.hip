@@ -160,6 +160,7 @@ void isx_ctx_destroy(isx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm) isx::comm_release(c);
     if (c->unet) isx::unet_destroy(c->unet);
     for (auto &kv : c->live_blocks) (void)hipFree(kv.first);
     c->live_blocks.clear();
