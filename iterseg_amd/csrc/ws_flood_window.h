@@ -35,7 +35,11 @@ static constexpr uint32_t WIN_NONE = 0xFFFFFFFFu;
 static constexpr unsigned long long ST_FREE = ~0ull;
 static constexpr uint32_t WIN_POPPED = 0xFFFFFFFFu;     // ford() of no real value
 
-#define WIN_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// One wave works on a component and the LDS executes a wave's DS instructions in issue order: a word written by one lane is
+// seen by every later read of the same wave without waiting for the write to retire.  The fence therefore only has to stop
+// the COMPILER from moving LDS accesses across it; the compiler inserts the waits that loaded values need on its own.
+// (It used to be an `s_waitcnt lgkmcnt(0)`: SQ counters showed half of the kernel's cycles in waits, most of them here.)
+#define WIN_FENCE() asm volatile("" ::: "memory")
 
 __global__ void flood_state_init_kernel(const uint8_t *__restrict__ mask, const uint32_t *__restrict__ out,
                                         unsigned long long *__restrict__ state, int64_t PN)
