@@ -1760,6 +1760,18 @@ __global__ void arena_need_kernel(const unsigned long long *comp_cap, uint32_t n
     need[c] = (sz >= coop_min && sz >= cold_min) ? (unsigned long long)COLD_META_ENTS + 4ull * sz + 5ull * COLD_NBK + 4096ull : 0ull;
 }
 
+// launch order of the window kernel: largest component first (work-groups are dispatched in block order and a big component
+// keeps its CU for the whole flood -- started last, the largest one alone set the time of a structured volume)
+__global__ void comp_order_key_kernel(const unsigned long long *comp_off, uint32_t n_comp, unsigned long long coop_min,
+                                      unsigned long long *keys)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_comp) return;
+    const unsigned long long sz = comp_off[c + 1] - comp_off[c];
+    const unsigned long long inv = 0xFFFFFFFFull - (sz < 0xFFFFFFFFull ? sz : 0xFFFFFFFFull);
+    keys[c] = sz >= coop_min ? (inv << 32) | c : ~0ull;            // components of the one-lane kernel sort last and are skipped
+}
+
 #include "ws_flood_window.h"
 
 // Flood given raveled seed indices (device u32) in list order (label = position + 1).
@@ -1891,7 +1903,12 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     if (window_mode) {
         flood_state_init_kernel<<<cdiv(PN, TPB), TPB, 0, ctx->stream>>>(mask, out, vstate.p, PN);
         ISX_CHECK_LAUNCH();
-        flood_window_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
+        Scratch<unsigned long long> okeys(ctx, n_comp), order(ctx, n_comp);
+        if (!okeys.ok() || !order.ok()) return ISX_ERR_NOMEM;
+        comp_order_key_kernel<<<cdiv(n_comp, TPB), TPB, 0, ctx->stream>>>(comp_off.p, n_comp, coop_min, okeys.p);
+        ISX_CHECK_LAUNCH();
+        ISX_TRY(sort_u64(ctx, (const uint64_t *)okeys.p, (uint64_t *)order.p, n_comp));
+        flood_window_kernel<<<n_comp, 64, 0, ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                             comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
                                                             pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, wcap, tcap, max_bursts,
                                                             bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world,

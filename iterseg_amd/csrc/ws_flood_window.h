@@ -66,6 +66,7 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
 }
 
 __global__ __launch_bounds__(64) void flood_window_kernel(
+    const unsigned long long *__restrict__ order,
     const float *__restrict__ aff, const uint8_t *__restrict__ mask, uint32_t *__restrict__ out,
     unsigned long long *__restrict__ state, const unsigned long long *__restrict__ keys, uint32_t n_seeds,
     const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
@@ -89,9 +90,11 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
 #ifdef ISX_FLOOD_CHECK
     __shared__ int dbg_seen[WIN_W];
 #endif
-    const uint32_t c = blockIdx.x;
     const int lane = threadIdx.x;
-    if (c >= n_comp) return;
+    if (blockIdx.x >= n_comp) return;
+    const unsigned long long okey = order[blockIdx.x];         // components by decreasing size (comp_order_key_kernel)
+    if (okey == ~0ull) return;
+    const uint32_t c = (uint32_t)okey;
     if (!comp_owned(comp_off, c, n_comp, shard_rank, shard_world)) return;
     const uint32_t first = comp_first[c];
     const uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
