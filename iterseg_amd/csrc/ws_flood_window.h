@@ -772,7 +772,14 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         WTICK(4);
         // ---- E: commit the idle episodes at the front, in order (up to three bursts of 64 per sub-round: on tie plateaus
         //         every episode is a single pop and the whole window turns over) ---------------------------------------------
-        for (int burst = 0; burst < (max_bursts & 0xFF) && nw > 0 && !serial; ++burst) {
+        // Three sub-rounds in four (config 2) have a front episode that is still descending: nothing can commit, and the
+        // whole commit phase is skipped on the strength of one word of the front slot.
+        bool front_ready = front_forced;
+        if (!front_ready && nw > 0) {
+            const u32x4 f1 = winq1[slot_of(0)];
+            front_ready = rdlane((uint32_t)(((f1.y >> 8) & 1u) != 0u && f1.x == WIN_NONE), 0) != 0u;
+        }
+        for (int burst = 0; front_ready && burst < (max_bursts & 0xFF) && nw > 0 && !serial; ++burst) {
             const unsigned long long qh = burst == 0 ? qhead : (scount > 0 ? srun[shead].key : ~0ull);   // enqueues moved the run
             const int j = lane;
             const bool valid = j < nw;
