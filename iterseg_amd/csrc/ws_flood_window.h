@@ -144,6 +144,8 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     uint32_t nspill = 0;                          // elements that could not be queued (kept for the serial continuation)
     bool serial = false, started_any = false;
     bool dirty = false;
+    bool list_valid = false;                      // actpos[0, nact_carry) is the active list of the coming sub-round (window untouched since)
+    int nact_carry = 0;
 #ifdef ISX_FLOOD_CHECK
     unsigned long long dbg_key = 0, dbg_hmax = 0; int dbg_reason = 0, dbg_nw = 0, dbg_sc = 0; uint32_t dbg_count = 0, dbg_ecount = 0;
 #endif                           // a key landed right behind an episode since the last bound check
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     // squash every episode from window position sp on: claims released, back to "root not popped yet"
     auto squash_from = [&](int sp) {
         WSTAT(ST_SQ_EV, 1);
+        list_valid = false;
         for (int base = sp; base < nw; base += 64) {
             const int p = base + lane;
             const bool valid = p < nw;
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     // a new root at its sorted position in the window (wave-uniform element, ek sorts below the last root or the
     // window has room at its end)
     auto win_insert = [&](unsigned long long ek, uint32_t ei, uint32_t el) {
+        list_valid = false;
         int pos = 0;
         for (int base = 0; base < nw; base += 64) {
             const int p = base + lane;
@@ -611,6 +615,14 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         // ---- B: episodes that want to pop ------------------------------------------------------------------------
         int nact = 0;
         bool front_forced = false;
+        if (list_valid) {
+            // nothing touched the window since the last sub-round (no commit, insertion, refill or squash -- three sub-rounds
+            // in four while a long descent sits at the front): the episodes that still want to pop were compacted by C
+            nact = nact_carry;
+            const u32x4 f1 = winq1[slot_of(0)];
+            const bool st0 = (f1.y >> 8) & 1u;
+            front_forced = rdlane((uint32_t)(f1.x != WIN_NONE && st0 && (int)(f1.y & 0xFFu) + 6 > tcap), 0) != 0u;
+        } else
         for (int base = 0; base < nw; base += 64) {
             const int p = base + lane;
             bool act = false, stalled = false;
@@ -632,7 +644,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         // ---- C: one pop per active episode, 64 episodes per row -----------------------------------------------------
         unsigned long long squash_key = ~0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // label stores / releases of earlier sub-rounds are performed
-        if ((max_bursts & 0x600) && nact > 64 * ((max_bursts >> 9) & 3)) nact = 64 * ((max_bursts >> 9) & 3);      // debug knob: rows per sub-round
+        int nnext = 0;                                            // active list of the next sub-round, compacted in place
         for (int r0 = 0; r0 < nact; r0 += 64) {
             WSTAT(ST_ROWS, 1);
             const bool act = r0 + lane < nact;
@@ -724,15 +736,20 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             uint32_t bf = WIN_POPPED;
             int bi = -1;
             {
+                // sixteen entries per trip: the four reads of a group are issued together (the kernel is bound by dependent
+                // LDS trips, not by LDS bandwidth); entries past `np` are stale but in bounds (WIN_T = 48) and masked
                 const u32x4 *pv4 = (const u32x4 *)&pval[pl * WIN_T];
-                for (int i4 = 0; __any(act && 4 * i4 < np); ++i4) {
-                    if (act && 4 * i4 < np) {
-                        const u32x4 v4 = pv4[i4];
-                        const int i = 4 * i4;
-                        if (v4.x < bf) { bf = v4.x; bi = i; }
-                        if (i + 1 < np && v4.y < bf) { bf = v4.y; bi = i + 1; }
-                        if (i + 2 < np && v4.z < bf) { bf = v4.z; bi = i + 2; }
-                        if (i + 3 < np && v4.w < bf) { bf = v4.w; bi = i + 3; }
+                for (int i4 = 0; __any(act && 4 * i4 < np); i4 += 4) {
+                    u32x4 g[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k] = pv4[i4 + k < WIN_T / 4 ? i4 + k : WIN_T / 4 - 1];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = 4 * (i4 + k);
+                        if (act && i < np && g[k].x < bf) { bf = g[k].x; bi = i; }
+                        if (act && i + 1 < np && g[k].y < bf) { bf = g[k].y; bi = i + 1; }
+                        if (act && i + 2 < np && g[k].z < bf) { bf = g[k].z; bi = i + 2; }
+                        if (act && i + 3 < np && g[k].w < bf) { bf = g[k].w; bi = i + 3; }
                     }
                 }
             }
@@ -754,10 +771,20 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 q1.w = curv;
                 winq1[s] = q1;
             }
+            {
+                // still wants to pop and has room for six more discoveries (B's rule): stays in the list; positions keep
+                // their order, and the write index never passes the row being read
+                const bool keep = act && q1.x != WIN_NONE && np + 6 <= tcap;
+                const unsigned long long kb = __ballot(keep);
+                if (keep) actpos[nnext + __popcll(kb & lt_mask)] = (unsigned short)p;
+                nnext += __popcll(kb);
+            }
             WSTAT(ST_EXEC, (uint32_t)__popcll(__ballot(act)));
             WIN_FENCE();
             WTICK(3);
         }
+        nact_carry = nnext;
+        list_valid = true;                                       // until something below touches the window
         // ---- D: squash from the first episode that lost a discovery it had already used --------------------------------
         if (squash_key != ~0ull) {
             int sp = 0;
@@ -910,6 +937,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                         }
                     }
                 }
+                list_valid = false;
                 if (cm) pfree[npfree + j] = (unsigned short)pl;
                 npfree += ncommit;
                 wh = slot_of(ncommit);
@@ -950,6 +978,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                     winq0[s] = e;
                     winq1[s] = fresh_q1(e.z, pl);
                 }
+                list_valid = false;
                 npfree -= take;
                 nw += take;
                 shead = (shead + take) & SMASK;
