@@ -402,3 +402,30 @@ def test_train_unet_with_fork_channels(tmp_path):
         train.train_unet(xs, xs[:1], ys, ys[:1], out_dir=None, channels=tuple("abcde"), epochs=1, fork_channels=(3, 3))
     with pytest.raises(NotImplementedError):
         UNet(1, (2, 2, 2))
+
+
+def test_forked_network_in_bf16_mixed_precision():
+    """The forked network through the bf16 mixed-precision mode (the layers of the second decoder get their refreshed bf16
+    packs like every other wide layer): loss close to the fp32 step on the same patch, gradients of both decoders and of
+    the shared encoder point the same way, and training reduces the loss."""
+    from iterseg_amd import weights
+    from iterseg_amd.train import Trainer
+    from tests.synth import positive_volume
+    forks, patch = (3, 2), (10, 64, 64)
+    sd = weights.generate_state_dict(4, 1, forks)
+    x = positive_volume(patch, 6)
+    y = (np.random.default_rng(6).random((5,) + patch) < 0.4).astype(np.float32)
+    a = Trainer(sd, out_channels=forks, patch=patch, precision="fp32")
+    b = Trainer(sd, out_channels=forks, patch=patch, precision="bf16")
+    la, _ = a._call(x, y, "BCELoss", None, 0.01, 0, True)
+    lb, _ = b._call(x, y, "BCELoss", None, 0.01, 0, True)
+    assert abs(la - lb) < 2e-3 and la != lb
+    for k in ("c0.conv1.weight", "c4.conv0.weight", "c5_0.conv0.weight", "c5_1.conv0.weight", "c7_1.conv1.weight", "c8_0.conv0.weight",
+              "c8_1.conv0.weight", "up1.weight"):
+        ga, gb = a.grad(k).double(), b.grad(k).double()
+        cos = float((ga * gb).sum() / (ga.norm() * gb.norm() + 1e-30))
+        assert cos > 0.9, (k, cos)
+    first = b.train_step(x, y, lr=0.01)[0]
+    for _ in range(5):
+        last = b.train_step(x, y, lr=0.01)[0]
+    assert last < first
