@@ -363,17 +363,22 @@ struct WgradArgs {
 // 64 voxels of a K block between them (KG groups) and their accumulators are summed through LDS at the end, so a
 // 32-channel layer no longer computes a zero-padded 64x64 tile.  The next block is prefetched into registers
 // while the matrix cores work on the current one.
+// One work-group computes the THREE x-taps (dx = -1, 0, +1) of one (dz, dy): the x-shift of a tap is a shift by one row of
+// the staged input tile (66 rows for 64 voxels), so dY and the input are fetched once for three taps instead of once per tap
+// (round 2: the kernel was bound by L2 traffic at 16 FLOP per byte, 0.29 of the fp32 matrix peak).  A voxel at the end of an
+// x-row has no +1 neighbour (the next linear voxel belongs to the next row): its dY value is zeroed for that tap.
 template <int TCO, int TCI>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
 {
     constexpr int NSUB = (TCO / 32) * (TCI / 32), KG = 4 / NSUB, KSTEPS = 32 / KG;
-    constexpr int NY = TCO / 16, NX = TCI / 16;             // float4 per thread per block (64 voxels x TC / 4 / 256)
+    constexpr int NY = TCO / 16;                             // float4 of dY per thread per block (64 voxels x TCO / 4 / 256)
+    constexpr int XROWS = 66, XQ = TCI / 4, NX = (XROWS * XQ + 255) / 256;      // input rows u = v0 - 1 .. v0 + 64
     __shared__ __attribute__((aligned(16))) float Ys[64 * TCO];
-    __shared__ __attribute__((aligned(16))) float Xs[64 * TCI];
+    __shared__ __attribute__((aligned(16))) float Xs[XROWS * TCI];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
     const int co_t = blockIdx.x / a.ci_tiles, ci_t = blockIdx.x % a.ci_tiles;
-    const int tap = blockIdx.y, split = blockIdx.z;
-    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    const int tap9 = blockIdx.y, split = blockIdx.z;
+    const int dz = tap9 / 3 - 1, dy = tap9 % 3 - 1;
     const int D = a.D, H = a.H, W = a.W, Cin = a.CA + a.CB;
     const int64_t M = (int64_t)D * H * W;
     const int64_t v_begin = (int64_t)split * a.vox_per_split;
@@ -381,13 +386,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
     if (v_end > M) v_end = M;
     const int sub = wave % NSUB, kg = wave / NSUB;
     const int wr = sub / (TCI / 32), wc = sub % (TCI / 32);
-    f32x16 acc;
+    f32x16 acc[3];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     const int co0 = co_t * TCO, ci0 = ci_t * TCI;
     // staging roles: TCO/4 (TCI/4) lanes cover the channels of one voxel with a float4 each
-    constexpr int YQ = TCO / 4, XQ = TCI / 4, YV = 256 / YQ, XV = 256 / XQ;     // voxels per pass
-    const int yq = tid % YQ, yv = tid / YQ, xq = tid % XQ, xv = tid / XQ;
+    constexpr int YQ = TCO / 4, YV = 256 / YQ;               // voxels per pass
+    const int yq = tid % YQ, yv = tid / YQ;
     float4 ry[NY], rx[NX];
 
     auto load_block = [&](int64_t v0) __attribute__((always_inline)) {
@@ -406,12 +413,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
         }
 #pragma unroll
         for (int p = 0; p < NX; ++p) {
-            const int64_t v = v0 + xv + XV * p;
+            const int idx = tid + 256 * p;
+            const int row = idx / XQ, xq = idx % XQ;
+            const int64_t u = v0 - 1 + row;                  // the voxel whose (dz, dy)-shifted input sits in this row
             float4 xvv = make_float4(0.f, 0.f, 0.f, 0.f);
             const int ci = ci0 + 4 * xq;
-            if (v < v_end && ci < Cin) {
-                const int x = (int)(v % W) + dx, y = (int)((v / W) % H) + dy, z = (int)(v / ((int64_t)W * H)) + dz;
-                if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
+            if (row < XROWS && u >= 0 && u < M && ci < Cin) {
+                const int x = (int)(u % W), y = (int)((u / W) % H) + dy, z = (int)(u / ((int64_t)W * H)) + dz;
+                if (z >= 0 && z < D && y >= 0 && y < H) {
                     const int64_t g = ((int64_t)z * H + y) * W + x;
                     const bool fromB = ci >= a.CA;
                     const float *src = fromB ? a.srcB : a.srcA, *sc = fromB ? a.scaleB : a.scaleA, *sh = fromB ? a.shiftB : a.shiftA;
@@ -445,37 +454,55 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
 #pragma unroll
         for (int p = 0; p < NY; ++p) *(float4 *)&Ys[(yv + YV * p) * TCO + 4 * yq] = ry[p];
 #pragma unroll
-        for (int p = 0; p < NX; ++p) *(float4 *)&Xs[(xv + XV * p) * TCI + 4 * xq] = rx[p];
+        for (int p = 0; p < NX; ++p) {
+            const int idx = tid + 256 * p;
+            if (idx < XROWS * XQ) *(float4 *)&Xs[(idx / XQ) * TCI + 4 * (idx % XQ)] = rx[p];
+        }
         __syncthreads();
         if (v0 + 64 < v_end) load_block(v0 + 64);          // in flight while the matrix cores run
-        const float *yp = Ys + (kg * 2 * KSTEPS + hh) * TCO + wr * 32 + nn;
-        const float *xp = Xs + (kg * 2 * KSTEPS + hh) * TCI + wc * 32 + nn;
+        const int kk0 = kg * 2 * KSTEPS + hh;               // this lane's first voxel row of the block
+        const float *yp = Ys + kk0 * TCO + wr * 32 + nn;
+        const float *xp = Xs + kk0 * TCI + wc * 32 + nn;   // row kk + t holds the input of voxel v + (t - 1)
+        int xm = (int)((v0 + kk0) % W);                     // x coordinate of that voxel; rows advance by 2
 #pragma unroll
-        for (int k = 0; k < KSTEPS; ++k)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[k * 2 * TCO], xp[k * 2 * TCI], acc, 0, 0, 0);
+        for (int k = 0; k < KSTEPS; ++k) {
+            const float yv_ = yp[k * 2 * TCO];
+            const float y0 = xm > 0 ? yv_ : 0.f, y2 = xm < W - 1 ? yv_ : 0.f;      // no -1 / +1 neighbour in this x-row
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, xp[(k * 2) * TCI], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv_, xp[(k * 2 + 1) * TCI], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(y2, xp[(k * 2 + 2) * TCI], acc[2], 0, 0, 0);
+            xm += 2;
+            if (xm >= W) xm -= W;
+        }
     }
     // sum the K groups (fixed order), then store.  D layout: column (ci) = lane & 31,
     // row (co) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
     if (KG > 1) {
-        __shared__ float red[(KG > 1 ? (KG - 1) * NSUB : 1) * 1024];       // [KG-1][NSUB][16][64]
-        __syncthreads();
-        if (kg > 0)
+        __shared__ float red[(KG > 1 ? (KG - 1) * NSUB : 1) * 1024];       // [KG-1][NSUB][16][64], one tap at a time
 #pragma unroll
-            for (int i = 0; i < 16; ++i) red[(((kg - 1) * NSUB + sub) * 16 + i) * 64 + lane] = acc[i];
-        __syncthreads();
-        if (kg == 0)
-            for (int g = 1; g < KG; ++g)
+        for (int t = 0; t < 3; ++t) {
+            __syncthreads();
+            if (kg > 0)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] += red[(((g - 1) * NSUB + sub) * 16 + i) * 64 + lane];
+                for (int i = 0; i < 16; ++i) red[(((kg - 1) * NSUB + sub) * 16 + i) * 64 + lane] = acc[t][i];
+            __syncthreads();
+            if (kg == 0)
+                for (int g = 1; g < KG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] += red[(((g - 1) * NSUB + sub) * 16 + i) * 64 + lane];
+        }
     }
     if (kg == 0) {
         const int CoP = a.co_tiles * TCO, CiP = a.ci_tiles * TCI;
-        float *dst = a.partial + (((int64_t)split * 27 + tap) * CoP) * CiP;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int co = co0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const int ci = ci0 + wc * 32 + nn;
-            dst[(int64_t)co * CiP + ci] = acc[i];
+        for (int t = 0; t < 3; ++t) {
+            float *dst = a.partial + (((int64_t)split * 27 + (tap9 * 3 + t)) * CoP) * CiP;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const int ci = ci0 + wc * 32 + nn;
+                dst[(int64_t)co * CiP + ci] = acc[t][i];
+            }
         }
     }
 }
@@ -793,7 +820,7 @@ static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
     a.co_tiles = (L.cout + tco - 1) / tco;
     a.ci_tiles = (L.cin + tci - 1) / tci;
     const int64_t chunks = (l.M + 63) / 64;
-    int want = 4096 / (a.co_tiles * a.ci_tiles * 27) + 1;          // enough work-groups to fill the chip
+    int want = 4096 / (a.co_tiles * a.ci_tiles * 18) + 1;          // enough work-groups to fill the chip (9 per tile, three x-taps each; twice the K range of round 1's split: the partials are 3x larger per work-group)
     if (want > chunks / 4) want = (int)std::max<int64_t>(1, chunks / 4);     // at least 4 K blocks per work-group
     if (want > 256) want = 256;
     a.vox_per_split = ((chunks + want - 1) / want) * 64;
@@ -801,7 +828,7 @@ static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
     a.partial = t->wpart;
     const size_t need = (size_t)a.splits * 27 * a.co_tiles * tco * a.ci_tiles * tci;
     ISX_REQUIRE(need <= t->wpart_floats, "internal: wgrad partial buffer too small (%zu > %zu)", need, t->wpart_floats);
-    const dim3 wgrid(a.co_tiles * a.ci_tiles, 27, a.splits);
+    const dim3 wgrid(a.co_tiles * a.ci_tiles, 9, a.splits);
     if (tco == 64 && tci == 64) wgrad_mfma_kernel<64, 64><<<wgrid, 256, 0, ctx->stream>>>(a);
     else if (tco == 32 && tci == 64) wgrad_mfma_kernel<32, 64><<<wgrid, 256, 0, ctx->stream>>>(a);
     else if (tco == 64 && tci == 32) wgrad_mfma_kernel<64, 32><<<wgrid, 256, 0, ctx->stream>>>(a);
@@ -1029,7 +1056,7 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
         const ConvBN &L = u->cv[li];
         const size_t tco = L.cout <= 32 ? 32 : 64, tci = L.cin <= 32 ? 32 : 64;       // as in wgrad()
         size_t tiles = ((L.cout + tco - 1) / tco) * ((L.cin + tci - 1) / tci);
-        size_t splits = 4096 / (tiles * 27) + 1;
+        size_t splits = 4096 / (tiles * 18) + 1;
         if (splits > 256) splits = 256;
         wp = std::max(wp, (splits + 1) * 27 * tiles * tco * tci);
     }
