@@ -1131,16 +1131,29 @@ __device__ __forceinline__ void lds_sort(HeapEnt *srun, int n, int lane)
     while (np < n) np <<= 1;
     for (int j = n + lane; j < np; j += 64) { HeapEnt e; e.key = ~0ull; e.idx = 0; e.pad = 0; srun[j] = e; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // j is a power of two: the pair index is shifts and masks (the division by a run-time j cost most of the 59 k cycles a
+    // 256-element sort took -- 12 % of the config-2 flood); all pairs of a pass are read before the first is written back
     for (int k = 2; k <= np; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < np / 2; t += 64) {
-                const int i = ((t / j) * 2 * j) + (t % j);        // lower index of the pair
-                const int p = i + j;
-                const bool up = ((i & k) == 0);
-                const HeapEnt a = srun[i], bb = srun[p];
-                if ((a.key > bb.key) == up) { srun[i] = bb; srun[p] = a; }
+        for (int j = k >> 1, lj = 31 - __clz(j); j > 0; j >>= 1, --lj) {
+            for (int t0 = 0; t0 < np / 2; t0 += 128) {
+                HeapEnt a[2], bb[2];
+                int ii[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t0 + 64 * u + lane;
+                    ii[u] = ((t >> lj) << (lj + 1)) | (t & (j - 1));         // lower index of the pair
+                    if (t < np / 2) { a[u] = srun[ii[u]]; bb[u] = srun[ii[u] + j]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t0 + 64 * u + lane;
+                    if (t < np / 2) {
+                        const bool up = ((ii[u] & k) == 0);
+                        if ((a[u].key > bb[u].key) == up) { srun[ii[u]] = bb[u]; srun[ii[u] + j] = a[u]; }
+                    }
+                }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");          // one wave: LDS operations execute in order, the next pass sees these stores
         }
 }
 
