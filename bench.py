@@ -124,7 +124,8 @@ def conv_roofline(precision, mfma_flops, n_chunks, steps, ms_mfma, n_mfma, batch
     elif precision != "fp32":
         r["note"] = ("achieved = algorithmic (fp32-equivalent) FLOPs; the split executes 3 f16 MFMAs per product (x 28/27 tap "
                      "padding), so the f16 pipe runs at about 3.1x this fraction; against the fp32 matrix peak (157.3) the same "
-                     "work rate is %.2f" % (ach / PEAK_MFMA_F32))
+                     "work rate is %.2f; measured with rocm-smi (profiles/r02_clock_power_during_bench.txt): the kernel runs at the "
+                     "package power cap (~1300 W, shader clock 2.05-2.1 GHz instead of 2.4)" % (ach / PEAK_MFMA_F32))
     return r
 
 
