@@ -264,6 +264,62 @@ def config2_leg(u, sd_seed_rank, chunk, margin, batch):
             "flood_pops_per_s": n_lab / max(prof["ws_flood"], 1e-9) * 1e3}
 
 
+def plugin_path_leg(u, chunk, margin, device_ms_per_frame, shape=(512, 512, 512), frames=4):
+    """The call the reference actually makes (segmentation.py:833-900): HOST float32 frames in, HOST labels out.
+    `single_frame`: segment_single_volume(frame, ..., affinity_watershed_for_chunks) on one 512^3 host array -- the
+    plugin's processing function behind the reference's own per-frame host code (min / max / divide / padded zeros),
+    with the share of the time spent outside the device work.  `stack`: segmentation_loop over a (4,512,512,512) host
+    stack into an int32 label store, frames pipelined through isx_pipe_* (upload of t+1 and download of t-1 under the
+    compute of t); `vs_device_resident` compares its per-frame time with the headline's."""
+    from iterseg_amd import segmentation
+    from iterseg_amd._lib import NoSeedsError
+    from tests.synth import positive_volume
+    nvox = float(np.prod(shape))
+    stack = np.stack([positive_volume(shape, seed=t) for t in range(frames)])
+    config = {"unet": u, "output_volume": segmentation.a_w_output_volume(stack, 5)}
+    out = {}
+    # one frame through the plugin pair, as segment_single_volume calls it
+    best = None
+    for _ in range(2):
+        frame = stack[0].copy()                               # segmentation_loop's astype copy (segmentation.py:877)
+        u.ctx.prof_enable(False)
+        u.ctx.prof_enable(True)
+        t0 = time.perf_counter()
+        try:
+            labels = segmentation.segment_single_volume(frame, chunk, config, margin, segmentation.affinity_watershed_for_chunks)
+        except NoSeedsError:
+            labels = None
+        dt = time.perf_counter() - t0
+        dev_ms = sum(u.ctx.prof_get(k)[0] for k in ("conv_mfma", "conv_direct", "elementwise", "ws_filters", "ws_ccl", "ws_flood"))
+        if best is None or dt < best[0]:
+            best = (dt, dev_ms)
+    u.ctx.prof_enable(False)
+    out["single_frame"] = {"value": nvox / best[0], "unit": "voxels/s", "ms": 1e3 * best[0], "device_kernels_ms": best[1],
+                           "host_and_pcie_share": 1.0 - best[1] * 1e-3 / best[0],
+                           "labelled_voxels": int((labels > 0).sum()) if labels is not None else 0}
+    # the stack through segmentation_loop (pipelined)
+    store = np.zeros((frames,) + shape, np.int32)
+    t0 = time.perf_counter()
+    done = [t for t in segmentation.segmentation_loop(None, stack, chunk, margin, store, segmentation.affinity_watershed_for_chunks, config)]
+    dt = time.perf_counter() - t0
+    assert done == list(range(frames))
+    assert np.array_equal(store[0], labels.view(np.int32)) if labels is not None else True
+    out["stack"] = {"frames": frames, "value": frames * nvox / dt, "unit": "voxels/s", "ms_per_frame": 1e3 * dt / frames,
+                    "vs_device_resident": (1e3 * dt / frames) / device_ms_per_frame if device_ms_per_frame else None,
+                    "labelled_voxels": int((store > 0).sum())}
+    os.environ["ISX_FRAME_PIPE"] = "0"
+    store[:] = 0
+    t0 = time.perf_counter()
+    for _ in segmentation.segmentation_loop(None, stack, chunk, margin, store, segmentation.affinity_watershed_for_chunks, config):
+        pass
+    dt0 = time.perf_counter() - t0
+    os.environ["ISX_FRAME_PIPE"] = "1"
+    out["stack_unpipelined_ms_per_frame"] = 1e3 * dt0 / frames
+    out["workload"] = (f"host float32 frames {shape} -> host labels through the plugin pair; device-resident headline "
+                       f"{device_ms_per_frame:.1f} ms/frame")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -464,6 +520,7 @@ def main():
                                                                  mfma_flops)}
         if extra:
             del vol, fm, labels
+            out["plugin_path"] = plugin_path_leg(u, chunk, margin, 1e3 * elapsed / args.steps)
             out["config2"] = config2_leg(u, 0, chunk, margin, args.batch)
             out["watershed_structured"] = structured_watershed_leg(u, t_unet_ms=t_unet if shape == (512, 512, 512) else None)
             out["train_step"] = train_step_leg(sd)

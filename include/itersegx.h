@@ -137,6 +137,15 @@ int isx_unet_set_batch(isx_ctx *ctx, int batch);
 #define ISX_PRECISION_F16 2
 #define ISX_PRECISION_BF16 3
 int isx_unet_set_precision(isx_ctx *ctx, int mode);
+/* How each convolution of the LAST forward actually ran (layer order: c0.conv0, c0.conv1, c1.conv0 ... c4.conv1,
+ * c5_0.conv0 ... c8_0.conv1, then c5_1 ... c8_1 of a second fork): the reduced modes send a layer whose operands could
+ * leave the f16 range (bounds from the BatchNorm affine parameters of its producer) to the fp32 kernel, at about half the
+ * throughput -- this makes that decision visible.  Returns the number of layers (modes may be NULL);
+ * *n_fallback = layers that ran ISX_ARITH_FP32_RANGE_FALLBACK.  Same operator as above (unet.py:63-79,91-106). */
+#define ISX_ARITH_FP32 0                  /* fp32 kernel: the mode asked for it, the layer is a thin (direct) one, or training */
+#define ISX_ARITH_REDUCED 1               /* the split-f16 / f16 / bf16 kernel                                                 */
+#define ISX_ARITH_FP32_RANGE_FALLBACK 2   /* a reduced mode was asked for but the range check sent the layer to fp32          */
+int isx_unet_precision_report(isx_ctx *ctx, int32_t *modes, int cap, int32_t *n_fallback);
 
 /* ---------------------------------------------------------------------------------- *
  * Training -- replaces _train_step + the duplicated optimiser.step() (src/iterseg/train.py:344-353,
@@ -173,6 +182,12 @@ int isx_train_step_channelwise(isx_ctx *ctx, const float *x, const float *y, con
 int isx_adam_step(isx_ctx *ctx, float lr, int n_steps);
 /* Re-derive the kernel-layout weights after the caller changed the bound parameter buffer. */
 int isx_train_refresh_weights(isx_ctx *ctx);
+/* Gradient tensors of the last backward pass of isx_train_step, channels-last [M][C] float32, to HOST memory (the
+ * counterpart of isx_unet_tap_host for loss.backward(), train.py:351; tests pin the bf16 data-gradient convolutions layer
+ * by layer with it).  name: "draw:<layer>" d loss / d raw convolution output, "gact:<layer>" d loss / d activation,
+ * "dpool:<k>", "dcat:<k>" gradients of the pooled / concatenated inputs; layer numbering as isx_unet_precision_report.
+ * shape_out = {M, C}. */
+int isx_train_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_elems, int64_t shape_out[2]);
 
 /* ---------------------------------------------------------------------------------- *
  * Training targets -- src/iterseg/labels.py (the producer side of train_unet). *
@@ -289,6 +304,12 @@ int isx_segment_output_image(isx_ctx *ctx, const float *feature_map, const int64
                              uint32_t *labels, int64_t min_area, int64_t max_area,
                              const float *abs_thresh, int64_t *seeds_out, int64_t seeds_cap,
                              int64_t *n_seeds, uint8_t *mask_out, float *thresh);
+/* The same with segment_output_image's `scale=` argument (watershed.py:170,217-219 -> affinity_watershed :23-24):
+ * scale (host, 3 floats, may be NULL): |scale[a]| multiplies the normalised, padded affinity channel a before the flood. */
+int isx_segment_output_image_scaled(isx_ctx *ctx, const float *feature_map, const int64_t shape[3],
+                                    uint32_t *labels, int64_t min_area, int64_t max_area,
+                                    const float *abs_thresh, int64_t *seeds_out, int64_t seeds_cap,
+                                    int64_t *n_seeds, uint8_t *mask_out, float *thresh, const float *scale);
 
 /* ---------------------------------------------------------------------------------- *
  * End to end -- replaces segment_single_volume + affinity_watershed_for_chunks          *
@@ -307,6 +328,30 @@ int isx_segment_volume(isx_ctx *ctx, const float *volume, const int64_t shape[3]
 int isx_segment_volume_host(isx_ctx *ctx, const float *input_volume, const int64_t shape[3],
                             const int64_t chunk[3], const int64_t margin[3],
                             uint32_t *current_output);
+
+/* ---------------------------------------------------------------------------------- *
+ * Frame pipeline for host-resident (t,z,y,x) stacks -- replaces the per-frame host<->device traffic of
+ * segmentation_loop (src/iterseg/segmentation.py:833-882: for every t, segment_single_volume(frame) ->
+ * output_labels[t] = labels).  Frames of a stack are independent there, so while frame t computes, frame t+1 is
+ * staged into pinned memory and uploaded and the labels of frame t-1 are downloaded, on a copy stream and library
+ * threads.  Between isx_pipe_create and isx_pipe_destroy the pipe's compute thread is the only user of the context.
+ *   isx_pipe_submit  queues one float32 (Z,Y,X) HOST frame (it must stay valid until its isx_pipe_wait); at most
+ *                    `depth` frames are in flight.  ISX_PIPE_NORMALISE: frame /= max(frame) on the device
+ *                    (segmentation.py:889) instead of on the host.
+ *   isx_pipe_wait    blocks until the OLDEST frame in flight is done and writes its labels to HOST memory:
+ *                    uint32 (Z+2,Y+2,X+2) like current_output (segmentation.py:890-899), or with ISX_PIPE_CROPPED the
+ *                    (Z,Y,X) interior that segment_single_volume returns (:900) -- 32-bit either way, so an int32
+ *                    label store row (segmentation.py:881) can be the destination.  Returns the frame's status
+ *                    (ISX_ERR_NO_SEEDS: labels are all zero, the reference raises for such a frame).
+ * ---------------------------------------------------------------------------------- */
+typedef struct isx_pipe isx_pipe;
+#define ISX_PIPE_NORMALISE 1
+#define ISX_PIPE_CROPPED 2
+int isx_pipe_create(isx_ctx *ctx, const int64_t shape[3], const int64_t chunk[3], const int64_t margin[3],
+                    int depth, isx_pipe **pipe);
+int isx_pipe_submit(isx_pipe *pipe, const float *frame, int flags);
+int isx_pipe_wait(isx_pipe *pipe, void *labels, int flags);
+void isx_pipe_destroy(isx_pipe *pipe);
 
 #ifdef __cplusplus
 }

@@ -48,12 +48,14 @@ SIGNATURES = {
     "isx_unet_tap_host": (C.c_int, [_vp, C.c_char_p, _vp, _i64, _i64p]),
     "isx_unet_set_batch": (C.c_int, [_vp, C.c_int]),
     "isx_unet_set_precision": (C.c_int, [_vp, C.c_int]),
+    "isx_unet_precision_report": (C.c_int, [_vp, _i32p, C.c_int, _i32p]),
     "isx_train_param_count": (_i64, [_vp]),
     "isx_train_bind": (C.c_int, [_vp, _i64p, _vp, _vp, _vp, _vp, _i64]),
     "isx_train_step": (C.c_int, [_vp, _vp, _vp, C.c_int, _f32p, _f32, C.c_int, C.c_int, _f32p]),
     "isx_train_step_channelwise": (C.c_int, [_vp, _vp, _vp, _i32p, _f32p, _f32, C.c_int, C.c_int, _f32p]),
     "isx_adam_step": (C.c_int, [_vp, _f32, C.c_int]),
     "isx_train_refresh_weights": (C.c_int, [_vp]),
+    "isx_train_tap_host": (C.c_int, [_vp, C.c_char_p, _vp, _i64, _i64p]),
     "isx_training_labels": (C.c_int, [_vp, _vp, _i64p, C.c_int, _i32p, _i32p, _i32p, C.POINTER(C.c_double), _vp]),
     "isx_label_contingency": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64p]),
     "isx_ws_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -71,9 +73,14 @@ SIGNATURES = {
     "isx_ws_components": (C.c_int, [_vp, _vp, _i64p, _vp, _vp]),
     "isx_affinity_watershed": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64p, _f32p]),
     "isx_segment_output_image": (C.c_int, [_vp, _vp, _i64p, _vp, _i64, _i64, _f32p, _vp, _i64, _i64p, _vp, _f32p]),
+    "isx_segment_output_image_scaled": (C.c_int, [_vp, _vp, _i64p, _vp, _i64, _i64, _f32p, _vp, _i64, _i64p, _vp, _f32p, _f32p]),
     "isx_normalise_volume": (C.c_int, [_vp, _vp, _i64]),
     "isx_segment_volume": (C.c_int, [_vp, _vp, _i64p, _i64p, _i64p, _vp, _vp]),
     "isx_segment_volume_host": (C.c_int, [_vp, _vp, _i64p, _i64p, _i64p, _vp]),
+    "isx_pipe_create": (C.c_int, [_vp, _i64p, _i64p, _i64p, C.c_int, C.POINTER(_vp)]),
+    "isx_pipe_submit": (C.c_int, [_vp, _vp, C.c_int]),
+    "isx_pipe_wait": (C.c_int, [_vp, _vp, C.c_int]),
+    "isx_pipe_destroy": (None, [_vp]),
 }
 
 _LIB = None

@@ -46,7 +46,14 @@ static Rccl *rccl()
     return ok ? &r : nullptr;
 }
 
-#define ISX_NCCL(call)                                                                            \
+// dlerror() is NULL when dlopen succeeded and only a dlsym came back empty (or when it was already consumed)
+static const char *dl_reason()
+{
+    const char *e = dlerror();
+    return e ? e : "a required nccl* symbol is missing from the library";
+}
+
+#define ISX_NCCL(call)                                                                           \
     do {                                                                                          \
         ncclResult_t r_ = (call);                                                                 \
         if (r_ != ncclSuccess) { set_error("%s failed: %s", #call, rccl()->GetErrorString(r_)); return ISX_ERR_HIP; } \
@@ -75,7 +82,7 @@ int isx_comm_unique_id(uint8_t *id)
 {
     ISX_REQUIRE(id, "null argument");
     static_assert(sizeof(ncclUniqueId) == ISX_COMM_ID_BYTES, "ncclUniqueId size");
-    if (!rccl()) { set_error("RCCL (librccl.so) could not be loaded: %s", dlerror()); return ISX_ERR_STATE; }
+    if (!rccl()) { set_error("RCCL (librccl.so) could not be loaded: %s", dl_reason()); return ISX_ERR_STATE; }
     ncclUniqueId u;
     ISX_NCCL(rccl()->GetUniqueId(&u));
     memcpy(id, &u, sizeof(u));
@@ -87,7 +94,7 @@ int isx_comm_init(isx_ctx *ctx, const uint8_t *id, int rank, int world)
     ISX_REQUIRE(ctx && id, "null argument");
     ISX_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank %d of %d", rank, world);
     ISX_REQUIRE(!ctx->comm, "this context already has a communicator");
-    if (!rccl()) { set_error("RCCL (librccl.so) could not be loaded: %s", dlerror()); return ISX_ERR_STATE; }
+    if (!rccl()) { set_error("RCCL (librccl.so) could not be loaded: %s", dl_reason()); return ISX_ERR_STATE; }
     ISX_HIP(hipSetDevice(ctx->device));
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));

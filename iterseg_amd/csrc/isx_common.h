@@ -87,10 +87,14 @@ struct isx_ctx {
     int ws_shard_rank = 0, ws_shard_world = 1;     // W4 component sharding (isx_ws_set_shard)
     void *comm = nullptr;                          // RCCL communicator (isx_comm_init), ncclComm_t
     int comm_rank = 0, comm_world = 1;
+    void *pinned_buf[2] = {nullptr, nullptr};      // host staging of isx_segment_volume_host (0: frame in, 1: labels out)
+    size_t pinned_bytes[2] = {0, 0};
 
     void *alloc(size_t bytes);
     void release(void *p);
     void trim();
+    void *pinned(int which, size_t bytes);
+    void pinned_free();
     void prof_begin(int cls);
     void prof_end();
     void prof_collect();

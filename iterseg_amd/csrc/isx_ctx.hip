@@ -165,6 +165,7 @@ void isx_ctx_destroy(isx_ctx *c)
     for (auto &kv : c->live_blocks) (void)hipFree(kv.first);
     c->live_blocks.clear();
     c->trim();
+    c->pinned_free();
     for (auto &s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

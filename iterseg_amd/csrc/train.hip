@@ -776,6 +776,13 @@ static int repack_all(isx_ctx *ctx)
     return ISX_OK;
 }
 
+int train_ensure_bf16_packs(isx_ctx *ctx)
+{
+    UNetState *u = ctx->unet;
+    if (!u || !u->train || u->precision != ISX_PRECISION_BF16 || u->train->bf_fresh) return ISX_OK;
+    return repack_all(ctx);
+}
+
 // gradient of the loss w.r.t. the post-activation output of layer li arrives in g (channel stride gstride);
 // produces draw[li] and the BN / bias gradients.
 static int bn_backward(isx_ctx *ctx, int li, const float *g, int gstride, int act)
@@ -1080,7 +1087,7 @@ static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dic
     // last step (the trained UNet object is handed back to the caller): the backward buffers are sized for the patch
     // bound at isx_train_bind, so the forward workspace is brought back to it first (a no-op when nothing changed)
     ISX_TRY(prepare_workspace(ctx, t->cz, t->cy, t->cx, 1));
-    if (u->precision == ISX_PRECISION_BF16 && !t->bf_fresh) ISX_TRY(repack_all(ctx));      // precision switched since the last update
+    ISX_TRY(train_ensure_bf16_packs(ctx));      // precision switched since the last update
     const Level &l0 = u->lv[0];
     const int C = u->out_channels;
     ISX_REQUIRE(C <= 8, "at most 8 output channels");
@@ -1204,6 +1211,43 @@ int isx_train_step_channelwise(isx_ctx *ctx, const float *x, const float *y, con
         }
     }
     return train_step_impl(ctx, x, y, 0, spec, lr, n_adam, do_backward, loss_out);
+}
+
+// Gradient tensors of the LAST backward pass, channels-last [M][C] float32, copied to the host (tests: the per-layer pins
+// of the bf16 data-gradient convolutions).  name: "draw:<li>" = d(loss)/d(raw conv output) of layer li (C = its stored
+// channel stride), "gact:<li>" = d(loss)/d(activation output of layer li) as the layer above delivered it,
+// "dpool:<k>" = gradient of the pooled input of encoder module k + 1, "dcat:<k>" = gradient of decoder stage k's
+// concatenated input (fork 0).  shape_out = {M, C}.
+int isx_train_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_elems, int64_t shape_out[2])
+{
+    if (!ctx || !ctx->unet || !ctx->unet->train) { set_error("call isx_train_bind first"); return ISX_ERR_STATE; }
+    ISX_REQUIRE(name && out && shape_out, "null argument");
+    ISX_HIP(hipSetDevice(ctx->device));
+    UNetState *u = ctx->unet;
+    TrainState *t = u->train;
+    const std::string nm(name);
+    const size_t colon = nm.find(':');
+    ISX_REQUIRE(colon != std::string::npos, "tap name '%s': expected <kind>:<index>", name);
+    const std::string kind = nm.substr(0, colon);
+    const int idx = atoi(nm.c_str() + colon + 1);
+    const float *src = nullptr;
+    int64_t M = 0, C = 0;
+    if ((kind == "draw" || kind == "gact") && idx >= 0 && idx < u->nlayers) {
+        const Level &l = u->lv[MOD_LEVEL[layer_module(idx)]];
+        M = l.M;
+        C = kind == "draw" ? t->dstride[idx] : u->cv[idx].cout;
+        src = kind == "draw" ? t->draw[idx] : t->gact[idx];
+    } else if (kind == "dpool" && idx >= 0 && idx < 4) {
+        M = u->lv[idx + 1].M; C = MOD_COUT[idx]; src = t->dpool[idx];
+    } else if (kind == "dcat" && idx >= 0 && idx < 4) {
+        M = u->lv[3 - idx].M; C = 2 * u->up[idx].C; src = t->dcat[0][idx];
+    }
+    ISX_REQUIRE(src, "unknown gradient tap '%s'", name);
+    ISX_REQUIRE(cap_elems >= M * C, "tap buffer too small: need %ld floats", (long)(M * C));
+    ISX_HIP(hipMemcpyAsync(out, src, (size_t)(M * C) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ISX_HIP(hipStreamSynchronize(ctx->stream));
+    shape_out[0] = M; shape_out[1] = C;
+    return ISX_OK;
 }
 
 // after an external update of the bound parameter buffer (e.g. an all-reduce + optimiser step done elsewhere)

@@ -1134,7 +1134,9 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
         // training keeps fp32 products except in the bf16 mixed-precision mode (its packs are refreshed every step)
         const bool reduced = u->precision != ISX_PRECISION_FP32 && (!u->train || bf);
         const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
-        if (reduced && wh && in_range && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1)
+        const bool h2 = reduced && wh && in_range && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1;
+        u->arith[li] = h2 ? ISX_ARITH_REDUCED : (reduced && wh && !in_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
+        if (h2)
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, 0, &stat_tiles, pm));
         else
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
@@ -1143,8 +1145,11 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
         const bool bf = u->precision == ISX_PRECISION_BF16;
         const void *wf = bf ? L.w_bf_32 : L.w_h2_32;
         const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
-        if (u->precision != ISX_PRECISION_FP32 && !u->train && wf && (bf || std::max(sa.bound, sb.bound) < 6.0e4f) &&
-            conv_mt(ctx->tune, l, u->wbatch, 32) == 1) {
+        const bool fold_range = bf || std::max(sa.bound, sb.bound) < 6.0e4f;
+        const bool fold_h2 = u->precision != ISX_PRECISION_FP32 && !u->train && wf && fold_range && conv_mt(ctx->tune, l, u->wbatch, 32) == 1;
+        u->arith[li] = fold_h2 ? ISX_ARITH_REDUCED
+                               : (u->precision != ISX_PRECISION_FP32 && !u->train && wf && !fold_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
+        if (fold_h2) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wf, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
                                    ctx->tune.xcd_remap, 1, nullptr, pm));
@@ -1316,6 +1321,7 @@ static int run_chunks(isx_ctx *ctx, const float *volume, const int64_t shape[3],
                         r[2] + cx <= shape[2],
                     "chunk %ld starts at (%d,%d,%d): outside the volume", (long)i, r[0], r[1], r[2]);
     }
+    if (u->train && u->precision == ISX_PRECISION_BF16) ISX_TRY(train_ensure_bf16_packs(ctx));
     // workspace for min(batch, n) chunks: ~0.6 GB per (10,256,256) chunk, grown on demand
     ISX_TRY(prepare_workspace(ctx, cz, cy, cx, (int)std::min<int64_t>(u->batch, n)));
     const int64_t M0 = u->lv[0].M;
@@ -1422,6 +1428,20 @@ int isx_unet_set_precision(isx_ctx *ctx, int mode)
     return ISX_OK;
 }
 
+int isx_unet_precision_report(isx_ctx *ctx, int32_t *modes, int cap, int32_t *n_fallback)
+{
+    ISX_TRY(check_ready(ctx));
+    UNetState *u = ctx->unet;
+    ISX_REQUIRE(u->last_n >= 1, "no forward has run yet");
+    int nf = 0;
+    for (int li = 0; li < u->nlayers; ++li) {
+        if (modes && li < cap) modes[li] = u->arith[li];
+        if (u->arith[li] == ISX_ARITH_FP32_RANGE_FALLBACK) ++nf;
+    }
+    if (n_fallback) *n_fallback = nf;
+    return u->nlayers;
+}
+
 int isx_unet_set_batch(isx_ctx *ctx, int batch)
 {
     ISX_REQUIRE(ctx && batch >= 1 && batch <= 64, "batch must be 1..64");
@@ -1524,26 +1544,6 @@ int isx_segment_volume(isx_ctx *ctx, const float *volume, const int64_t shape[3]
                                       nullptr, nullptr);
     // output_volume[:] = 0 (segmentation.py:195)
     ISX_HIP(hipMemsetAsync(feature_map, 0, (size_t)ctx->unet->out_channels * shape[0] * shape[1] * shape[2] * 4, ctx->stream));
-    return rc;
-}
-
-int isx_segment_volume_host(isx_ctx *ctx, const float *input_volume, const int64_t shape[3], const int64_t chunk[3],
-                            const int64_t margin[3], uint32_t *current_output)
-{
-    ISX_TRY(check_ready(ctx));
-    ISX_REQUIRE(input_volume && shape && chunk && margin && current_output, "null argument");
-    ISX_HIP(hipSetDevice(ctx->device));
-    const int64_t n = shape[0] * shape[1] * shape[2];
-    const int64_t pn = (shape[0] + 2) * (shape[1] + 2) * (shape[2] + 2);
-    Scratch<float> vol(ctx, n), fm(ctx, (size_t)ctx->unet->out_channels * n);
-    Scratch<uint32_t> lab(ctx, pn);
-    if (!vol.ok() || !fm.ok() || !lab.ok()) return ISX_ERR_NOMEM;
-    ISX_HIP(hipMemcpyAsync(vol.p, input_volume, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    ISX_HIP(hipMemcpyAsync(lab.p, current_output, pn * 4, hipMemcpyHostToDevice, ctx->stream));
-    int rc = isx_segment_volume(ctx, vol.p, shape, chunk, margin, fm.p, lab.p);
-    if (rc != ISX_OK && rc != ISX_ERR_NO_SEEDS) return rc;
-    ISX_HIP(hipMemcpyAsync(current_output, lab.p, pn * 4, hipMemcpyDeviceToHost, ctx->stream));
-    ISX_HIP(hipStreamSynchronize(ctx->stream));
     return rc;
 }
 

@@ -78,11 +78,16 @@ struct UNetState {
     float *wtail = nullptr, *zeros32 = nullptr;
     const int32_t *d_table = nullptr;   // device rows of the launch set in flight
     int last_n = 0;
+    int arith[ISX_MAX_LAYERS] = {0};  // how each convolution ran in the last forward (ISX_ARITH_*, isx_unet_precision_report)
     struct TrainState *train = nullptr;
 };
 
 
 struct TrainState;
+// train.hip: on a context with a bound trainer the bf16 weight packs are derived from the trainer's fp32 master weights
+// and only refreshed while the precision is BF16; every bf16 forward (training or inference) calls this first so that a
+// precision switch after fp32 steps never convolves with stale or zero packs.
+int train_ensure_bf16_packs(isx_ctx *ctx);
 
 struct Src { const float *p; const float *scale; const float *shift; int C; float bound = 0.f; };   // bound: max |activation| (split-f16 range check)
 

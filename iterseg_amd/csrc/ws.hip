@@ -2192,6 +2192,15 @@ int isx_segment_output_image(isx_ctx *ctx, const float *fm, const int64_t shape[
                              int64_t *seeds_out, int64_t seeds_cap, int64_t *n_seeds_out,
                              uint8_t *mask_out, float *thresh_out)
 {
+    return isx_segment_output_image_scaled(ctx, fm, shape, labels, min_area, max_area, abs_thresh, seeds_out, seeds_cap,
+                                           n_seeds_out, mask_out, thresh_out, nullptr);
+}
+
+int isx_segment_output_image_scaled(isx_ctx *ctx, const float *fm, const int64_t shape[3], uint32_t *labels,
+                                    int64_t min_area, int64_t max_area, const float *abs_thresh,
+                                    int64_t *seeds_out, int64_t seeds_cap, int64_t *n_seeds_out,
+                                    uint8_t *mask_out, float *thresh_out, const float *scale)
+{
     ISX_REQUIRE(ctx && fm && shape && labels, "null argument");
     ISX_HIP(hipSetDevice(ctx->device));
     const int64_t Z = shape[0], Y = shape[1], X = shape[2], n = Z * Y * X;
@@ -2306,7 +2315,7 @@ int isx_segment_output_image(isx_ctx *ctx, const float *fm, const int64_t shape[
         ISX_CHECK_LAUNCH();
     }
     // the filtered mask's components are a subset of the raw mask's: reuse roots and sizes
-    ISX_TRY(flood_impl(ctx, aff.p, ridx_keep.p, n_keep, mask_f, labels, pshape, parent.p, sizes.p, nullptr));
+    ISX_TRY(flood_impl(ctx, aff.p, ridx_keep.p, n_keep, mask_f, labels, pshape, parent.p, sizes.p, scale));
     return ISX_OK;
 }
 

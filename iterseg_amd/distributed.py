@@ -141,6 +141,8 @@ def combine_labels(labels, group=None):
     """Union of component-sharded label volumes: element-wise max all-reduce (int32, 0 = not mine; label ids are
     seed positions + 1 < 2^31, so the signed maximum is the unsigned one)."""
     assert labels.dtype == torch.int32
+    # label ids are 1..n_seeds and there are fewer seeds than voxels, so this bounds them below 2^31
+    assert labels.numel() < 2 ** 31, "label ids could reach 2^31: the signed max would not be the unsigned one"
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world > 1:
         dist.all_reduce(labels, op=dist.ReduceOp.MAX, group=group)

@@ -13,10 +13,12 @@ given) works as the image layer, and without zarr the label store is a numpy arr
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import json
 import os
 import pathlib
+import weakref
 
 import numpy as np
 import torch
@@ -78,8 +80,30 @@ def affinity_watershed_prep_config(input_volume_layer, unet_or_config_file, refe
     return {'unet': unet, 'output_volume': output_volume}
 
 
+# Feature-map buffers handed out by a_w_output_volume that nothing has written yet.  The reference's processing function
+# fills `output_volume` chunk by chunk and zeroes it when the frame is done (segmentation.py:183-195); here the feature map
+# lives in HBM, the host array is never written, and re-zeroing 2.7 GB of untouched host memory per 512^3 frame would only
+# commit its pages.  The arrays are handed out read-only, so "still all zero" holds as long as they are registered here; the
+# generic branch (a foreign model object) makes its array writable again and drops it from the registry.
+_PRISTINE_ZEROS = {}
+
+
 def a_w_output_volume(data, num_pred_channels, **kwargs):
-    return np.zeros((num_pred_channels,) + tuple(data.shape[-3:]), dtype=np.float32)
+    out = np.zeros((num_pred_channels,) + tuple(data.shape[-3:]), dtype=np.float32)
+    out.flags.writeable = False
+    key = id(out)
+    _PRISTINE_ZEROS[key] = weakref.ref(out, lambda _r, k=key: _PRISTINE_ZEROS.pop(k, None))
+    return out
+
+
+def _is_pristine_zeros(a):
+    r = _PRISTINE_ZEROS.get(id(a))
+    return r is not None and r() is a and not a.flags.writeable
+
+
+def _make_writable(a):
+    if _PRISTINE_ZEROS.pop(id(a), None) is not None:
+        a.flags.writeable = True
 
 
 def affinity_watershed_for_chunks(input_volume, current_output, chunk_size, margin, unet=None,
@@ -92,6 +116,7 @@ def affinity_watershed_for_chunks(input_volume, current_output, chunk_size, marg
         raise ValueError('unet must not be none. Please ensure a unet was loaded and added to the config dict in the config function')
     if not isinstance(unet, unet_mod.UNet):
         # a foreign model object: keep the reference's generic control flow
+        _make_writable(output_volume)
         config = {'unet': unet, 'output_volume': output_volume}
         process_chunks(input_volume, chunk_size, output_volume, margin, predict_chunk_feature_map, config=config)
         ws.segment_output_image(output_volume, affinities_channels=(0, 1, 2), thresholding_channel=3,
@@ -108,8 +133,56 @@ def affinity_watershed_for_chunks(input_volume, current_output, chunk_size, marg
         out.view(np.uint32).ctypes.data_as(C.c_void_p))
     if out is not current_output:
         current_output[...] = out
-    output_volume[:] = 0
+    if not _is_pristine_zeros(output_volume):      # post-condition of segmentation.py:195: all zeros
+        output_volume[:] = 0
     _lib.check(rc)
+
+
+class FramePipe:
+    """Two-deep frame pipeline over ``isx_pipe_*`` for host-resident stacks: ``submit(frame)`` stages and uploads a
+    float32 (Z,Y,X) frame while earlier frames compute, ``wait(out)`` returns the labels of the oldest frame in flight
+    (the (Z,Y,X) interior, 32-bit).  Used by :func:`segmentation_loop`; the U-Net's context belongs to the pipe until
+    ``close()``."""
+
+    def __init__(self, unet, shape, chunk_size, margin, depth=2):
+        self.unet, self.shape, self.depth = unet, tuple(int(s) for s in shape), int(depth)
+        self._h = C.c_void_p()
+        self._keep = collections.deque()
+        unet._bind_stream()
+        _lib.check(unet.ctx.lib.isx_pipe_create(unet.ctx.handle, _lib._dims(self.shape), _lib._dims(chunk_size),
+                                                _lib._dims(margin if not isinstance(margin, int) else (margin,) * 3),
+                                                self.depth, C.byref(self._h)))
+
+    @property
+    def in_flight(self):
+        return len(self._keep)
+
+    def submit(self, frame, normalise=False):
+        assert frame.dtype == np.float32 and frame.flags.c_contiguous and tuple(frame.shape) == self.shape
+        _lib.check(self.unet.ctx.lib.isx_pipe_submit(self._h, frame.ctypes.data_as(C.c_void_p), 1 if normalise else 0))
+        self._keep.append(frame)                   # the library reads the frame until its wait()
+
+    def wait(self, out=None):
+        """-> labels (Z,Y,X); ``out``: C-contiguous 32-bit array of that shape (e.g. a row of the int32 label store)."""
+        if out is None:
+            out = np.empty(self.shape, np.uint32)
+        assert out.flags.c_contiguous and out.itemsize == 4 and tuple(out.shape) == self.shape
+        rc = self.unet.ctx.lib.isx_pipe_wait(self._h, out.ctypes.data_as(C.c_void_p), 2)
+        self._keep.popleft()
+        _lib.check(rc)
+        return out
+
+    def close(self):
+        if self._h:
+            self.unet.ctx.lib.isx_pipe_destroy(self._h)
+            self._h = C.c_void_p()
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def segment_volume_device(unet, volume, chunk_size, margin, feature_map=None, labels=None):
@@ -179,6 +252,11 @@ def segmentation_loop(viewer, data, chunk_size, margin, output_labels, processin
         output_labels[...] = output
         yield 0
         return
+    u = config.get('unet') if isinstance(config, dict) else None
+    if (processing_function is affinity_watershed_for_chunks and isinstance(u, unet_mod.UNet) and data.shape[0] > 1
+            and os.environ.get("ISX_FRAME_PIPE", "1") != "0"):
+        yield from _pipelined_frames(data, chunk_size, margin, output_labels, config)
+        return
     for t in range(data.shape[0]):
         if np.any(output_labels[t]):          # warm restart: frames that already have labels are skipped
             continue
@@ -188,11 +266,60 @@ def segmentation_loop(viewer, data, chunk_size, margin, output_labels, processin
         yield t
 
 
+def _pipelined_frames(data, chunk_size, margin, output_labels, config):
+    """segmentation_loop over the accelerated processing function with frame t+1 crossing PCIe while frame t computes
+    (``isx_pipe_*``): same frames, same per-frame results, same yield order.  ``frame /= max`` (segmentation.py:889) is the
+    same IEEE float32 division on the device; the zero-slice branch (:887-888) is evaluated on the host while the frame is
+    already in flight, and a frame whose shape it changes is redone through the one-frame path."""
+    u = config['unet']
+    shape = tuple(int(v) for v in data.shape[-3:])
+    pipe = FramePipe(u, shape, chunk_size, margin, depth=2)
+    direct = isinstance(output_labels, np.ndarray) and output_labels.dtype.itemsize == 4
+    pending = collections.deque()                 # (t, reduced frame or None)
+
+    def finish():
+        t0, redo = pending.popleft()
+        if redo is not None:                      # rare: the frame lost all-zero planes, its pipelined result is void
+            pipe.wait()
+            output_labels[t0, ...] = segment_single_volume(redo, chunk_size, config, margin, affinity_watershed_for_chunks)
+        elif direct and output_labels[t0].flags.c_contiguous:
+            pipe.wait(out=output_labels[t0])      # uint32 labels < 2^31: the bits are the int32 values
+        else:
+            output_labels[t0, ...] = pipe.wait()
+        return t0
+
+    try:
+        for t in range(data.shape[0]):
+            if np.any(output_labels[t]):          # warm restart
+                continue
+            frame = np.asarray(data[t])
+            if frame.dtype != np.float32 or not frame.flags.c_contiguous:
+                frame = np.ascontiguousarray(frame, dtype=np.float32)
+            pipe.submit(frame, normalise=True)
+            redo = None
+            if frame.min() == 0:
+                reduced = remove_sum_zero_slices(frame)
+                if reduced.shape != frame.shape:
+                    redo = reduced.astype(np.float32)
+            pending.append((t, redo))
+            if redo is not None:
+                # the one-frame path needs the context: everything in flight is finished first, in order
+                while pending:
+                    yield finish()
+            elif len(pending) == pipe.depth:
+                yield finish()
+        while pending:
+            yield finish()
+    finally:
+        pipe.close()
+
+
 def segment_single_volume(input_volume, chunk_size, config, margin, processing_function):
     if input_volume.min() == 0:
         input_volume = remove_sum_zero_slices(input_volume)
     input_volume /= np.max(input_volume)
-    current_output = np.pad(np.zeros(input_volume.shape, dtype=np.uint32), 1, mode='constant', constant_values=0)
+    # np.pad(np.zeros(shape, uint32), 1) upstream (segmentation.py:890): the same zeros, without writing them once
+    current_output = np.zeros(tuple(s + 2 for s in input_volume.shape), dtype=np.uint32)
     crop = (slice(1, -1),) * current_output.ndim
     processing_function(input_volume, current_output, chunk_size, margin, **config)
     return current_output[crop]

@@ -114,6 +114,9 @@ class Trainer:
     # ------------------------------------------------------------------ steps
     def _call(self, x, y, loss, chan_weights, lr, n_adam, backward, channelwise=None):
         dev = self.params.device
+        if self.unet._train_params is None or self.unet._train_params[1] is not self.params:
+            raise RuntimeError("this Trainer's U-Net was re-loaded (load_state_dict opens a new context): build a new "
+                               "Trainer from the new state dict")
         x = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.float32).to(dev).contiguous()
         y = torch.as_tensor(np.asarray(y) if not isinstance(y, torch.Tensor) else y, dtype=torch.float32).to(dev).contiguous()
         assert tuple(x.shape) == self.patch and tuple(y.shape) == (self.out_channels,) + self.patch, (x.shape, y.shape)
@@ -158,6 +161,17 @@ class Trainer:
         return self._call(x, y, loss, chan_weights, 0.0, 0, False, channelwise)
 
     # ------------------------------------------------------------------ state
+    def grad_tap(self, name):
+        """A gradient tensor of the last backward pass as an (M, C) numpy array (``isx_train_tap_host``):
+        ``"draw:<layer>"``, ``"gact:<layer>"``, ``"dpool:<k>"``, ``"dcat:<k>"``."""
+        cap = 1 << 26
+        buf = np.empty(cap, np.float32)
+        shp = (C.c_int64 * 2)()
+        self.unet._bind_stream()
+        _lib.check(self.unet.ctx.lib.isx_train_tap_host(self.unet.ctx.handle, name.encode(), buf.ctypes.data_as(C.c_void_p),
+                                                        cap, shp))
+        return buf[:shp[0] * shp[1]].reshape(shp[0], shp[1]).copy()
+
     def grad(self, key):
         for k, shape, off in self.layout:
             if k == key:
@@ -277,8 +291,10 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
         pd.DataFrame(loss_dict).to_csv(os.path.join(out_dir, 'loss_' + name + '.csv'))
         if validate:
             # _save_output (train.py:425-432): the last validation predictions, one file per validation patch
+            requested = trainer.unet.precision
             trainer.unet.set_precision("fp32")
             v_y_hats = [trainer.unet(np.asarray(_load(i, vx), np.float32)[None, None])[0] for i in range(len(vx))]
+            trainer.unet.set_precision(requested)           # the network handed back keeps the arithmetic it was trained in
             _save_output(v_y_hats, vids, out_dir, name='_validation')
             pd.DataFrame(validation_dict).to_csv(os.path.join(out_dir, 'validation-loss_' + name + '.csv'))
     return trainer.unet, unet_path

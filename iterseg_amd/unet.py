@@ -65,6 +65,8 @@ class UNet:
         _weights.check_state_dict(sd, self.in_channels, self._schema_out)      # strict key/shape check
         if self._loaded:                          # a committed context cannot be re-loaded: start a new one
             self.ctx.close()
+            # the trainer bound to the old context (if any) is gone with it: state_dict() must not read its buffers
+            self._train_params = None
             self.ctx = _lib.Context(self.device)
             _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, self._batch))
             self.set_precision(self.precision)
@@ -117,6 +119,20 @@ class UNet:
             raise ValueError(f"precision must be one of {sorted(modes)}")
         _lib.check(self.ctx.lib.isx_unet_set_precision(self.ctx.handle, modes[precision]))
         self.precision = precision
+
+    def precision_report(self):
+        """How each convolution of the last forward ran: ``{"c0.conv0": "fp32" | "reduced" | "fp32-range-fallback", ...}``
+        (``isx_unet_precision_report``).  A trained network with large BatchNorm weights can push layers of the split-f16 /
+        f16 modes back to the fp32 kernel; this is where that shows."""
+        modes = (C.c_int32 * 26)()
+        nf = C.c_int32(0)
+        n = self.ctx.lib.isx_unet_precision_report(self.ctx.handle, modes, 26, C.byref(nf))
+        if n < 0:
+            _lib.check(n)
+        mods = ["c0", "c1", "c2", "c3", "c4", "c5_0", "c6_0", "c7_0", "c8_0", "c5_1", "c6_1", "c7_1", "c8_1"]
+        names = [f"{m}.conv{j}" for m in mods for j in (0, 1)]
+        kind = {0: "fp32", 1: "reduced", 2: "fp32-range-fallback"}
+        return {names[i]: kind[modes[i]] for i in range(n)}
 
     def set_batch(self, batch):
         _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch)))

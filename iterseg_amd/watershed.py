@@ -210,40 +210,29 @@ def segment_output_image(unet_output, affinities_channels, centroids_channel, th
     else:
         out_host = out
         lab = torch.from_numpy(np.ascontiguousarray(out).view(np.int32).reshape(pshape)).to(dev)
-    if scale is not None:
-        seg, seeds, mask = _segment_piecewise(ctx, fm, lab, scale, absolute_thresh)
-    else:
-        cap = max(1024, fm[0].numel() // 8)
-        at = C.byref(C.c_float(absolute_thresh)) if absolute_thresh is not None else None
-        while True:
-            seeds = torch.empty((cap, 3), dtype=torch.int64, device=dev)
-            mask = torch.empty(pshape, dtype=torch.uint8, device=dev)
-            ns = C.c_int64(0)
-            _lib.check(ctx.lib.isx_segment_output_image(ctx.handle, _ptr(fm), _lib._dims(shape), _ptr(lab), 10,
-                                                        10000000, at, _ptr(seeds), cap, C.byref(ns), _ptr(mask),
-                                                        None))
-            if ns.value <= cap:
-                break
-            # more seeds than the report buffer (large plateaus keep every voxel as a seed): run again with room for all of
-            # them, on a clean label buffer, as _get_centroids does
-            cap = int(ns.value)
-            lab.zero_()
-        seeds = seeds[:ns.value]
+    sc = None
+    if scale is not None:                # |scale| multiplies the affinities inside the library (watershed.py:23-24)
+        sv = np.abs(np.asarray(scale, np.float32)).reshape(-1)
+        sc = (C.c_float * 3)(*(list(sv) if sv.size == 3 else [float(sv[0])] * 3))
+    cap = max(1024, fm[0].numel() // 8)
+    at = C.byref(C.c_float(absolute_thresh)) if absolute_thresh is not None else None
+    while True:
+        seeds = torch.empty((cap, 3), dtype=torch.int64, device=dev)
+        mask = torch.empty(pshape, dtype=torch.uint8, device=dev)
+        ns = C.c_int64(0)
+        _lib.check(ctx.lib.isx_segment_output_image_scaled(ctx.handle, _ptr(fm), _lib._dims(shape), _ptr(lab), 10,
+                                                           10000000, at, _ptr(seeds), cap, C.byref(ns), _ptr(mask),
+                                                           None, sc))
+        if ns.value <= cap:
+            break
+        # more seeds than the report buffer (large plateaus keep every voxel as a seed): run again with room for all of
+        # them, on a clean label buffer, as _get_centroids does
+        cap = int(ns.value)
+        lab.zero_()
+    seeds = seeds[:ns.value]
     seg_dev = lab.reshape(pshape)[1:-1, 1:-1, 1:-1]
     if out_host is not None:
         out_host.reshape(-1).view(np.int32)[:] = lab.reshape(-1).cpu().numpy()
         seg = out_host.reshape(pshape)[1:-1, 1:-1, 1:-1]
         return seg, seeds.cpu().numpy(), mask.cpu().numpy().astype(bool)
     return seg_dev, seeds, mask.bool()
-
-
-def _segment_piecewise(ctx, fm, lab, scale, absolute_thresh):
-    """General form (``scale=`` given): the same stages through the per-stage entry points."""
-    aff = fm[:3] / fm[:3].amax(dim=(1, 2, 3), keepdim=True)
-    aff = torch.nn.functional.pad(aff, (1, 1, 1, 1, 1, 1))
-    cents = _get_centroids(fm[4]) + 1
-    mask = (fm[3] > absolute_thresh) if absolute_thresh is not None else _get_mask(fm[3])
-    mask = torch.nn.functional.pad(mask.to(torch.uint8), (1, 1, 1, 1, 1, 1))
-    mask, cents = _remove_unwanted_objects(mask, cents, min_area=10, max_area=10000000)
-    affinity_watershed(aff.contiguous(), cents, mask, scale=scale, out=lab)
-    return lab, cents - 1, mask.to(torch.uint8)

@@ -64,9 +64,71 @@ def _as_params(sd, requires_grad=False, dtype=None):
     return p
 
 
+# ---- bf16 mixed-precision emulation (BASELINE config 4's arithmetic; iterseg_amd/csrc/train.hip, conv_h2.hip PM = 2) ------
+# The HIP training step in precision "bf16" rounds exactly these operands to bfloat16 (round to nearest even) and nothing
+# else: in the FORWARD pass the input activations (after the producer's BatchNorm + ReLU, pooling, up-convolution and
+# concatenation) and the weights of every wide convolution (Cin >= 32, Cout a multiple of 32: `use_mfma`), and in the DATA
+# gradient of those layers (except c0.conv1... see _bf16_dgrad) the incoming gradient d(raw) and the weights.  Products are
+# exact, accumulation, bias, BatchNorm (statistics and backward), weight gradients (from the UNROUNDED activations and
+# gradients), the thin layers, the loss and Adam stay in the working precision.  With `bf16_emulation(True)` the convolutions
+# below do the same, so the HIP step can be compared with this oracle at the fp32 tolerance instead of with its own fp32 run.
+_BF16 = {"on": False}
+
+
+class bf16_emulation:
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = _BF16["on"]
+        _BF16["on"] = self.on
+
+    def __exit__(self, *a):
+        _BF16["on"] = self.prev
+
+
+def _rb(t):
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)     # the kernels round fp32 values
+
+
+def _bf16_forward(cin, cout):
+    return cin >= 32 and cin % 4 == 0 and cout % 32 == 0            # use_mfma (unet.hip)
+
+
+def _bf16_dgrad(name, cin, cout):
+    # train.hip isx_train_bind: a bf16 dgrad operator exists for wide layers with Cin % 32 == 0 and Cout % 8 == 0,
+    # never for layer 0 (c0.conv0 has no data gradient at all)
+    return _bf16_forward(cin, cout) and cin % 32 == 0 and cout % 8 == 0
+
+
+class _ConvMixed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, rf, rd):
+        ctx.save_for_backward(x, w)
+        ctx.rd = rd
+        return F.conv3d(_rb(x) if rf else x, _rb(w) if rf else w, b, padding=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.nn.grad.conv3d_input(x.shape, _rb(w) if ctx.rd else w, _rb(g) if ctx.rd else g, padding=1)
+        gw = torch.nn.grad.conv3d_weight(x, w.shape, g, padding=1)          # fp32 operands, unrounded
+        return gx, gw, g.sum((0, 2, 3, 4)), None, None
+
+
+def _conv(p, key, x):
+    w, b = p[f"{key}.weight"], p[f"{key}.bias"]
+    if not _BF16["on"]:
+        return F.conv3d(x, w, b, padding=1)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    return _ConvMixed.apply(x, w, b, _bf16_forward(cin, cout), _bf16_dgrad(key, cin, cout))
+
+
 def conv_module(p, name, x, final="relu", taps=None):
     for j in (0, 1):
-        x = F.conv3d(x, p[f"{name}.conv{j}.weight"], p[f"{name}.conv{j}.bias"], padding=1)
+        x = _conv(p, f"{name}.conv{j}", x)
         if taps is not None:
             taps[f"{name}.conv{j}"] = x
         # train-mode BN: batch statistics, biased variance; running stats updated in place
@@ -182,8 +244,9 @@ def channel_log(name, y_hat, y, chan_weights=None):
     return [float(loss_fn(name, y_hat[:, i].detach(), y[:, i].detach(), chan_weights)) for i in range(y_hat.shape[1])]
 
 
-def train_step(sd, x, y, lr=0.01, loss="BCELoss", double_step=True, chan_weights=None, dtype=torch.float32):
-    """One ``_train_step`` (+ the duplicated ``optimiser.step()`` of train.py:310).
+def train_step(sd, x, y, lr=0.01, loss="BCELoss", double_step=True, chan_weights=None, dtype=torch.float32, bf16=False):
+    """One ``_train_step`` (+ the duplicated ``optimiser.step()`` of train.py:310).  ``bf16``: the mixed-precision
+    arithmetic of the HIP step in precision "bf16" (see ``bf16_emulation``).
 
     Returns ``(loss, y_hat, grads, new_params)`` with numpy payloads.
     """
@@ -191,9 +254,10 @@ def train_step(sd, x, y, lr=0.01, loss="BCELoss", double_step=True, chan_weights
     leaves = [t for t in p.values() if t.requires_grad]
     opt = torch.optim.Adam(leaves, lr=lr)
     opt.zero_grad()
-    y_hat = unet_forward(p, torch.from_numpy(x)[None, None].to(dtype))
-    l = loss_fn(loss, y_hat, torch.from_numpy(y)[None].to(dtype), chan_weights)
-    l.backward()
+    with bf16_emulation(bool(bf16)):
+        y_hat = unet_forward(p, torch.from_numpy(x)[None, None].to(dtype))
+        l = loss_fn(loss, y_hat, torch.from_numpy(y)[None].to(dtype), chan_weights)
+        l.backward()
     grads = {k: t.grad.detach().numpy().copy() for k, t in p.items() if t.requires_grad}
     opt.step()
     if double_step:

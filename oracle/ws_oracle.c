@@ -403,10 +403,17 @@ int64_t orc_affinity_watershed_mt(const float *aff, const int64_t *seeds, int64_
                                   const uint8_t *mask, uint32_t *out, const int64_t dims[3], int nthreads)
 {
     if (nseeds <= 0) return -1;
+    /* A seed OFF the mask is still popped by the reference loop and labels its in-mask neighbours (watershed.py:139-153),
+     * and it can join two components: such marker lists do not decompose, they take the single heap.  (The plugin path
+     * never produces one: _remove_unwanted_objects keeps only seeds inside surviving components, watershed.py:247-250.) */
+    for (int64_t i = 0; i < nseeds; ++i)
+        if (!mask[seeds[i]]) return orc_affinity_watershed(aff, seeds, nseeds, mask, out, dims);
     int64_t N = dims[0] * dims[1] * dims[2];
     int64_t SZ = dims[1] * dims[2], SY = dims[2];
     const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
     for (int64_t i = 0; i < nseeds; ++i) out[seeds[i]] = (uint32_t)(i + 1);
+    int64_t *saved_trace = g_trace;
+    g_trace = NULL;                      /* the trace hook is a process-global: not from inside the parallel region */
     /* component id of every seed: flood fill of the mask from each not yet visited seed */
     int32_t *comp = (int32_t *)calloc((size_t)N, sizeof(int32_t));
     int64_t *stack = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
@@ -414,7 +421,6 @@ int64_t orc_affinity_watershed_mt(const float *aff, const int64_t *seeds, int64_
     int32_t ncomp = 0;
     for (int64_t i = 0; i < nseeds; ++i) {
         int64_t s0 = seeds[i];
-        if (!mask[s0]) { keys[i].comp = -1 - i; keys[i].order = i; continue; }   /* off-mask seed: never spreads */
         if (!comp[s0]) {
             ++ncomp;
             int64_t sp = 0;
@@ -450,10 +456,10 @@ int64_t orc_affinity_watershed_mt(const float *aff, const int64_t *seeds, int64_
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : pops)
 #endif
     for (int64_t r = 0; r < nrun; ++r) {
-        if (keys[first[r]].comp < 0) continue;
         pops += flood_core(aff, sorted + first[r], first[r + 1] - first[r], mask, out, dims);
     }
     (void)nthreads;
+    g_trace = saved_trace;
     free(first);
     free(sorted);
     free(keys);

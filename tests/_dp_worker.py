@@ -26,10 +26,11 @@ def main():
     xs = [positive_volume(patch, 100 + r) for r in range(world)]
     ys = [(np.random.default_rng(200 + r).random((5,) + patch) < 0.4).astype(np.float32) for r in range(world)]
     ok = True
-    for double_step in (True, False):
-        t = Trainer(sd, out_channels=5, patch=patch)
+    # fp32 with and without the duplicated optimiser step, then BASELINE config 4 itself: bf16 mixed precision AND data parallel
+    for double_step, precision in ((True, "fp32"), (False, "fp32"), (True, "bf16")):
+        t = Trainer(sd, out_channels=5, patch=patch, precision=precision)
         loss, _ = t.train_step(xs[rank], ys[rank], lr=0.01, double_step=double_step)       # world size 2 branch
-        ref = Trainer(sd, out_channels=5, patch=patch)
+        ref = Trainer(sd, out_channels=5, patch=patch, precision=precision)
         g = torch.zeros_like(ref.grads)
         losses = []
         for r in range(world):
@@ -41,7 +42,7 @@ def main():
         _lib.check(ref.unet.ctx.lib.isx_adam_step(ref.unet.ctx.handle, C.c_float(0.01), 2 if double_step else 1))
         torch.cuda.synchronize()
         ok = ok and abs(loss - losses[rank]) < 1e-7 and torch.equal(t.params, ref.params)
-        ok = ok and not torch.equal(t.params, Trainer(sd, out_channels=5, patch=patch).params)       # it did move
+        ok = ok and not torch.equal(t.params, Trainer(sd, out_channels=5, patch=patch, precision=precision).params)       # it did move
         # replicas stay in lock step: every rank holds the same parameters after the step
         both = [torch.empty_like(t.params) for _ in range(world)]
         dist.all_gather(both, t.params)

@@ -135,3 +135,82 @@ def test_structured_512_labels_against_oracle(cold_min, monkeypatch):
     got = lab.cpu().numpy().astype(np.uint32)
     assert int((ref > 0).sum()) > 5_000_000
     assert int((got != ref).sum()) == 0
+
+
+def test_mirrored_512_one_giant_component_against_oracle():
+    """One 256^3 demo volume mirrored to 512^3 (tests/synth.blob_feature_map_mirrored): the components that touch a mirror
+    plane merge with their images into ONE ~7 M-voxel blob component next to ~10 k small ones.  This is the input that
+    tripped the flood's sub-round watchdog in round 2 (a window key sorting above the run head after a mid-insert run
+    eviction -- the tier rule is now re-evaluated after every eviction and checked at every eviction, DESIGN.md 5);
+    whole-volume labels against the C oracle, bit for bit, and no invariant report."""
+    from iterseg_amd import watershed as ws
+    from oracle import watershed as ows
+    from tests.synth import blob_feature_map_mirrored
+    n = 512
+    fm = blob_feature_map_mirrored(n, 0, 0.12, 3.0)
+    pshape = (n + 2,) * 3
+    ref = np.zeros(pshape, np.uint32)
+    ows.segment_output_image(fm, out=ref.ravel(), threads=16)
+    lab = torch.zeros(pshape, dtype=torch.int32, device="cuda")
+    _, _, mask = ws.segment_output_image(torch.from_numpy(fm).cuda(), (0, 1, 2), 4, 3, out=lab)
+    got = lab.cpu().numpy().astype(np.uint32)
+    _, sizes = ws.connected_components(mask)
+    assert int(torch.as_tensor(sizes).max()) > 3_000_000          # the giant component is there
+    assert int((got != ref).sum()) == 0
+
+
+def test_config3_two_frames_at_stated_size(unet):
+    """BASELINE configs[2] at its stated frame size: two frames of 32x512x512 (36 chunks each) through the device-resident
+    call that bench.py's stack_step makes, through the pipelined host loop (segmentation_loop -> isx_pipe_*) and through
+    the plugin's processing function frame by frame: identical labels, structural properties."""
+    from iterseg_amd import segmentation as seg
+    from tests.synth import positive_volume
+    shape = (32, 512, 512)
+    data = np.stack([positive_volume(shape, t) for t in (0, 1)])
+    store = np.zeros(data.shape, np.int32)
+    config = {"unet": unet, "output_volume": seg.a_w_output_volume(data, 5)}
+    done = list(seg.segmentation_loop(None, data, CHUNK, MARGIN, store, seg.affinity_watershed_for_chunks, config))
+    assert done == [0, 1]
+    for t in (0, 1):
+        dev = seg.segment_volume_device(unet, torch.from_numpy(data[t]).cuda(), CHUNK, MARGIN)
+        assert np.array_equal(dev[1:-1, 1:-1, 1:-1].cpu().numpy(), store[t]), t
+        cur = np.zeros(tuple(s + 2 for s in shape), np.uint32)
+        seg.affinity_watershed_for_chunks(data[t].copy(), cur, CHUNK, MARGIN, **config)
+        assert np.array_equal(cur[1:-1, 1:-1, 1:-1].view(np.int32), store[t]), t
+        assert store[t].max() > 0 and not cur[0].any() and not cur[:, 0].any() and not cur[:, :, 0].any()
+    assert not np.array_equal(store[0], store[1])                  # the frames differ
+
+
+def test_config5_1024_cubed_f16(unet):
+    """BASELINE configs[4]: 1024^3 with the fp16 U-Net (precision="f16": plain f16 operands, fp32 accumulate) + the
+    int32 watershed -- all 6272 chunks in the reduced mode (no layer falls back to fp32 with these weights), structural
+    properties of the labels, and the f16 feature map within its stated tolerance (4e-3) of the split-f16 one on the
+    first launch set."""
+    from iterseg_amd import watershed as ws
+    n = 1024
+    shape = (n, n, n)
+    rng = np.random.default_rng(0)
+    dvol = torch.empty(shape, dtype=torch.float32, device="cuda")
+    for z0 in range(0, n, 64):
+        dvol[z0:z0 + 64] = torch.from_numpy(1.0 - rng.random((64, n, n), dtype=np.float32)).cuda()
+    dvol /= dvol.max()
+    unet.set_batch(64)
+    main = unet.precision
+    try:
+        ref_head = unet.predict_volume(dvol[:10].contiguous(), CHUNK, MARGIN).clone()
+        unet.set_precision("f16")
+        fm = unet.predict_volume(dvol, CHUNK, MARGIN)
+        rep = unet.precision_report()
+        assert "fp32-range-fallback" not in rep.values()
+        assert sum(v == "reduced" for v in rep.values()) == 16      # the 15 wide layers + the folded tail layer
+        head = unet.predict_volume(dvol[:10].contiguous(), CHUNK, MARGIN)
+        assert float((head - ref_head).abs().max()) <= 4e-3
+    finally:
+        unet.set_precision(main)
+        unet.set_batch(32)
+    del dvol, ref_head, head
+    pshape = tuple(s + 2 for s in shape)
+    lab = torch.zeros(pshape, dtype=torch.int32, device="cuda")
+    seg, seeds, mask = ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=lab)
+    assert len(seeds) > 0
+    _properties(lab, torch.as_tensor(mask, device="cuda"), seeds)

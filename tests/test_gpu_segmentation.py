@@ -204,3 +204,63 @@ def test_segment_stack_with_the_hip_path(unet):
            "--master-port", str(port), os.path.join(root, "tests", "_stack_worker.py")]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_frame_pipeline_equals_frame_by_frame_loop(unet, monkeypatch):
+    """segmentation_loop over a host stack: the pipelined route (isx_pipe_*: upload of t+1 / download of t-1 under the
+    compute of t, normalisation on the device) gives the labels of the frame-by-frame route bit for bit -- including a
+    frame that loses an all-zero plane (min() == 0 -> remove_sum_zero_slices changes its shape upstream; here such a frame
+    cannot be stored in a fixed-shape stack, so the loop must fail the same way on both routes), a frame with zeros that
+    keeps its shape, a frame scaled by 9 (normalisation), and the warm restart."""
+    from iterseg_amd import segmentation as seg
+    from tests.synth import positive_volume
+    data = np.stack([positive_volume((8, 40, 48), s) for s in (1, 2, 3, 4, 5)])
+    data[1] *= 9.0
+    data[2][3, 5, 7] = 0.0                                       # min() == 0 but no empty plane: shape kept
+    layer = types.SimpleNamespace(data=data)
+    config = seg.affinity_watershed_prep_config(layer, unet, None)
+    assert not config['output_volume'].flags.writeable           # pristine zeros: never written, never re-zeroed
+    outs = {}
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("ISX_FRAME_PIPE", pipe)
+        store = np.zeros(data.shape, np.int32)
+        store[3, 0, 0, 0] = 7                                    # warm restart: frame 3 counts as done
+        order = list(seg.segmentation_loop(None, data, CHUNK, MARGIN, store, seg.affinity_watershed_for_chunks, config))
+        assert order == [0, 1, 2, 4]
+        outs[pipe] = store
+    assert np.array_equal(outs["1"], outs["0"]) and outs["1"][0].max() > 0
+    assert not outs["1"][3].ravel()[1:].any()
+    assert not config['output_volume'].any()
+    for t in (1, 2):
+        ref = _oracle_labels(unet, (data[t] / data[t].max()).astype(np.float32))
+        assert np.array_equal(outs["1"][t].astype(np.uint32), ref[1:-1, 1:-1, 1:-1]), t
+
+
+def test_frame_pipe_direct_use_and_errors(unet):
+    """isx_pipe_*: more submits than `depth` are refused, wait without a frame is refused, padded and cropped outputs
+    agree with the one-frame host entry, a non-zero current_output is kept by isx_segment_volume_host."""
+    from iterseg_amd import segmentation as seg
+    from tests.synth import positive_volume
+    vols = [positive_volume((8, 40, 48), s) for s in (11, 12, 13)]
+    pipe = seg.FramePipe(unet, vols[0].shape, CHUNK, MARGIN, depth=2)
+    with pytest.raises(ValueError):
+        pipe.wait()
+    pipe.submit(vols[0])
+    pipe.submit(vols[1])
+    with pytest.raises(ValueError):
+        pipe.submit(vols[2])
+    a = pipe.wait()
+    pipe.submit(vols[2])
+    b, c = pipe.wait(), pipe.wait()
+    pipe.close()
+    for v, got in zip(vols, (a, b, c)):
+        cur = np.zeros(tuple(s + 2 for s in v.shape), np.uint32)
+        seg.affinity_watershed_for_chunks(v, cur, CHUNK, MARGIN, unet=unet, output_volume=np.zeros((5,) + v.shape, np.float32))
+        assert np.array_equal(got, cur[1:-1, 1:-1, 1:-1]) and got.max() > 0
+    # labels a caller left in current_output survive (the flood keeps pre-labelled voxels: isx_affinity_watershed)
+    cur2 = np.zeros_like(cur)
+    cur2[0, 0, 0] = 12345                                        # on the border: outside the mask, nothing floods it
+    seg.affinity_watershed_for_chunks(vols[2], cur2, CHUNK, MARGIN, unet=unet, output_volume=np.zeros((5,) + v.shape, np.float32))
+    assert cur2[0, 0, 0] == 12345
+    cur2[0, 0, 0] = 0
+    assert np.array_equal(cur2, cur)

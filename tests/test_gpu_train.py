@@ -302,6 +302,124 @@ def test_bf16_mixed_precision_training_step():
     assert all(v.dtype == torch.float32 for k, v in sd2.items() if not k.endswith("num_batches_tracked"))
 
 
+def test_bf16_convolutions_pinned_layer_by_layer_against_the_rounding_oracle():
+    """BASELINE config 4's arithmetic against an ORACLE instead of against this build's own fp32 step.  oracle/unet_torch.py
+    restates which operands the bf16 mode rounds (`bf16_emulation`: inputs + weights of the wide convolutions in the
+    forward pass, d(raw) + weights in their data gradients; everything else fp32).  An end-to-end comparison cannot be
+    tight: with train-mode BatchNorm and random weights this network amplifies a 1e-6 input perturbation into 7-20 % of a
+    weight gradient once operands are rounded to 8 bits (measured with the oracle against itself, float32 vs float64
+    working precision: the 1-ulp differences decide roundings), so the end-to-end check below stays a diagnostic.  What
+    pins the packing (tap order, channel order, the transposed / mirrored dgrad operator, the PM = 2 path of conv_h2) is
+    the same comparison LAYER BY LAYER on identical inputs: every bf16 convolution launch of one training step is
+    recomputed by the oracle from the HIP step's own input tensor (taps) and must agree to 1e-3 of the output's
+    maximum -- exact products and fp32 accumulation on both sides leave only the summation order and a rare rounding tie;
+    one wrong tap or channel is an O(1) error."""
+    import torch.nn.functional as F
+    from iterseg_amd import weights
+    from iterseg_amd.train import Trainer
+    from oracle import unet_torch as ou
+    from tests.synth import positive_volume
+    sd = weights.generate_state_dict(0)
+    patch = (10, 64, 64)
+    x = positive_volume(patch, 5)
+    y = (np.random.default_rng(5).random((5,) + patch) < 0.4).astype(np.float32)
+    t = Trainer(sd, out_channels=5, patch=patch, precision="bf16")
+    loss, _ = t._call(x, y, "BCELoss", None, 0.01, 0, True)
+    u = t.unet
+    tap = lambda n: torch.from_numpy(u.tap(n))
+    act = lambda m, j: torch.relu(tap(f"{m}.batch{j}"))
+    mods = ["c0", "c1", "c2", "c3", "c4", "c5_0", "c6_0", "c7_0", "c8_0"]
+    skip = {"c5_0": "c3", "c6_0": "c2", "c7_0": "c1", "c8_0": "c0"}
+    inputs = {}
+    for mi, m in enumerate(mods):
+        if mi == 0:
+            inputs[(m, 0)] = torch.from_numpy(x)[None]
+        elif mi <= 4:
+            inputs[(m, 0)] = tap(f"d{mi - 1}")
+        else:
+            inputs[(m, 0)] = torch.cat([tap(f"up{mi - 5}.cropped"), tap(skip[m])], 0)
+        inputs[(m, 1)] = act(m, 0)
+    rb = ou._rb
+    n_fwd = n_dg = 0
+    worst = 0.0
+    for mi, m in enumerate(mods):
+        for j in (0, 1):
+            li = 2 * mi + j
+            w = torch.from_numpy(sd[f"{m}.conv{j}.weight"])
+            b = torch.from_numpy(sd[f"{m}.conv{j}.bias"])
+            cout, cin = int(w.shape[0]), int(w.shape[1])
+            if ou._bf16_forward(cin, cout):
+                ref = F.conv3d(rb(inputs[(m, j)])[None], rb(w), b, padding=1)[0]
+                got = tap(f"{m}.conv{j}")
+                err = float((got - ref).abs().max() / ref.abs().max())
+                worst = max(worst, err)
+                assert err <= 1e-3, ("forward", m, j, err)
+                # and it IS the rounded arithmetic, not fp32: the unrounded convolution is measurably further away
+                plain = F.conv3d(inputs[(m, j)][None], w, b, padding=1)[0]
+                assert float((got - plain).abs().max()) > 3 * float((got - ref).abs().max()), (m, j)
+                n_fwd += 1
+            if li > 0 and ou._bf16_dgrad(f"{m}.conv{j}", cin, cout):
+                D, H, W = inputs[(m, j)].shape[1:]
+                g = torch.from_numpy(t.grad_tap(f"draw:{li}")).reshape(D, H, W, cout).permute(3, 0, 1, 2).contiguous()
+                ref = torch.nn.grad.conv3d_input((1, cin, D, H, W), rb(w), rb(g)[None], padding=1)[0]
+                if j == 1:
+                    got = t.grad_tap(f"gact:{li - 1}")
+                elif mi <= 4:
+                    got = t.grad_tap(f"dpool:{mi - 1}")
+                else:
+                    got = t.grad_tap(f"dcat:{mi - 5}")
+                got = torch.from_numpy(got).reshape(D, H, W, cin).permute(3, 0, 1, 2)
+                err = float((got - ref).abs().max() / ref.abs().max())
+                worst = max(worst, err)
+                assert err <= 1e-3, ("dgrad", m, j, err)
+                n_dg += 1
+    assert n_fwd == 15 and n_dg == 15, (n_fwd, n_dg)
+    # diagnostic only (see above): the whole step against the rounding oracle and against the fp32 oracle
+    lo, _, go, _ = ou.train_step(sd, x, y, bf16=True)
+    lf, _, gf, _ = ou.train_step(sd, x, y)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+    ks = ["c0.conv1.weight", "c2.conv1.weight", "c4.conv0.weight", "c8_0.conv0.weight"]
+    print(f"per-layer worst relative error {worst:.2e}; loss hip-bf16 {loss:.6f}, oracle-bf16 {lo:.6f}, oracle-fp32 {lf:.6f}")
+    print("end-to-end gradient distance (relative L2) hip-bf16 vs oracle-bf16 | oracle-bf16 vs oracle-fp32: " +
+          ", ".join(f"{k} {rel(t.grad(k).cpu().numpy(), go[k]):.3f}|{rel(go[k], gf[k]):.3f}" for k in ks))
+    assert abs(loss - lo) < 2e-3
+
+
+def test_bf16_inference_on_a_trained_context_never_uses_stale_packs():
+    """on a train-bound context the bf16 weight packs are trainer buffers that only a bf16-mode update
+    refreshed, so `Trainer(precision="fp32")` -> steps -> `set_precision("bf16")` -> inference convolved with zero packs,
+    and a bf16 trainer that took fp32 steps kept stale ones.  Every bf16 forward now refreshes them first."""
+    from iterseg_amd import weights
+    from iterseg_amd.train import Trainer
+    from tests.synth import positive_volume
+    patch = (4, 32, 32)
+    x = positive_volume(patch, 1)
+    y = (np.random.default_rng(3).random((5,) + patch) < 0.4).astype(np.float32)
+    a = Trainer(weights.generate_state_dict(0), out_channels=5, patch=patch, precision="fp32")
+    a.train_step(x, y)
+    ref = a.unet(x[None, None])[0]                                   # fp32 inference with the trained weights
+    a.unet.set_precision("bf16")
+    got = a.unet(x[None, None])[0]
+    assert np.isfinite(got).all() and np.abs(got - ref).max() < 0.1       # bf16 rounding on a tiny patch; zero packs give O(0.5)
+    # a bf16 trainer that steps in fp32 for a while and returns to bf16
+    b = Trainer(weights.generate_state_dict(0), out_channels=5, patch=patch, precision="bf16")
+    b.train_step(x, y)
+    b.unet.set_precision("fp32")
+    for _ in range(3):
+        b.train_step(x, y, lr=0.05)
+    ref = b.unet(x[None, None])[0]
+    b.unet.set_precision("bf16")
+    got = b.unet(x[None, None])[0]
+    assert np.abs(got - ref).max() < 0.1
+    # load_state_dict on a trained U-Net drops the old trainer's buffers (ADVICE r2, low)
+    u = a.unet
+    u.load_state_dict(weights.generate_state_dict(7))
+    sd7 = u.state_dict()
+    assert np.array_equal(sd7["c0.conv0.weight"].numpy(), weights.generate_state_dict(7)["c0.conv0.weight"])
+    with pytest.raises(RuntimeError):
+        a.train_step(x, y)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # the forked network: UNet(out_channels=(3, 2)) as train_unet builds it for fork_channels (train.py:139-141)
 # ------------------------------------------------------------------------------------------------------------------

@@ -247,3 +247,23 @@ def test_connected_components_helper(ws):
     for c in range(1, min(n, 20) + 1):
         idx = np.flatnonzero(lab.ravel() == c)
         assert (roots.ravel()[idx] == idx.min()).all() and sizes.ravel()[idx.min()] == idx.size
+
+
+@pytest.mark.parametrize("scale,abs_thresh", [((2.0, -1.0, 0.5), None), (0.25, 0.5)])
+def test_segment_output_image_scale_and_absolute_thresh(ws, scale, abs_thresh):
+    """segment_output_image's general form (watershed.py:165-223 with `scale=` / `absolute_thresh=`): one library call
+    (isx_segment_output_image_scaled), checked against the oracle's stages composed the way the reference composes them."""
+    from oracle import watershed as ows
+    from tests.synth import smooth_feature_map
+    fm = smooth_feature_map((12, 40, 36), 21)
+    seg, seeds, mask = ws.segment_output_image(fm, (0, 1, 2), 4, 3, scale=scale, absolute_thresh=abs_thresh)
+    aff = fm[:3] / fm[:3].max(axis=(1, 2, 3)).reshape(-1, 1, 1, 1)
+    aff = np.pad(aff, ((0, 0), (1, 1), (1, 1), (1, 1)))
+    cents = ows._get_centroids(fm[4]) + 1
+    m = ows._get_mask(fm[3]) if abs_thresh is None else fm[3] > np.float32(abs_thresh)
+    m, cents = ows._remove_unwanted_objects(np.pad(m, 1), cents, min_area=10, max_area=10000000)
+    sc = np.asarray(scale, np.float32).reshape(-1, 1) if np.ndim(scale) else scale
+    ref = ows.affinity_watershed(np.ascontiguousarray(aff, np.float32), cents, m, scale=sc)
+    assert np.array_equal(mask, m)
+    assert np.array_equal(np.asarray(seg).astype(np.int64), ref.reshape(m.shape)[1:-1, 1:-1, 1:-1].astype(np.int64))
+    assert np.asarray(seg).max() > 0

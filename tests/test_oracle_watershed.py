@@ -159,3 +159,19 @@ def test_component_parallel_segment_output_image():
     ows.segment_output_image(fm, out=a.ravel())
     ows.segment_output_image(fm, out=b.ravel(), threads=4)
     assert np.array_equal(a, b) and a.max() > 3
+
+
+def test_threaded_flood_with_off_mask_seed_equals_single_heap():
+    """A marker OFF the mask is still popped by the reference loop and labels its in-mask neighbours (watershed.py:139-153);
+    such a list does not decompose over components, so the threaded oracle must take the single heap for it."""
+    from oracle import watershed as ows
+    rng = np.random.default_rng(5)
+    shape = (8, 12, 12)
+    aff = np.pad(rng.random((3,) + tuple(s - 2 for s in shape), dtype=np.float32), ((0, 0), (1, 1), (1, 1), (1, 1)))
+    mask = np.zeros(shape, bool)
+    mask[1:-1, 1:-1, 1:5] = True
+    mask[1:-1, 1:-1, 6:-1] = True                     # two components separated by the plane x = 5
+    seeds = np.array([[3, 3, 2], [4, 6, 5], [3, 8, 8]])          # the middle one sits on the separating plane (off-mask)
+    a = ows.affinity_watershed(aff, seeds, mask, threads=0)
+    b = ows.affinity_watershed(aff, seeds, mask, threads=4)
+    assert np.array_equal(a, b) and (a == 2).sum() > 1          # the off-mask seed labelled neighbours on both sides
