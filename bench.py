@@ -299,6 +299,10 @@ def plugin_path_leg(u, chunk, margin, device_ms_per_frame, shape=(512, 512, 512)
                            "labelled_voxels": int((labels > 0).sum()) if labels is not None else 0}
     # the stack through segmentation_loop (pipelined)
     store = np.zeros((frames,) + shape, np.int32)
+    # warm-up like the headline's: one 2-frame pass allocates the pipe's slots (kept by the U-Net) and touches the store
+    for _ in segmentation.segmentation_loop(None, stack[:2], chunk, margin, store[:2], segmentation.affinity_watershed_for_chunks, config):
+        pass
+    store[:] = 0
     t0 = time.perf_counter()
     done = [t for t in segmentation.segmentation_loop(None, stack, chunk, margin, store, segmentation.affinity_watershed_for_chunks, config)]
     dt = time.perf_counter() - t0

@@ -87,6 +87,10 @@ struct isx_ctx {
     int ws_shard_rank = 0, ws_shard_world = 1;     // W4 component sharding (isx_ws_set_shard)
     void *comm = nullptr;                          // RCCL communicator (isx_comm_init), ncclComm_t
     int comm_rank = 0, comm_world = 1;
+    hipStream_t aux_stream = nullptr;               // side stream of the flood's work-group kernel (forked from / joined to `stream`)
+    hipEvent_t aux_ev[2] = {nullptr, nullptr};
+    int aux_fork();
+    int aux_join();
     void *pinned_buf[2] = {nullptr, nullptr};      // host staging of isx_segment_volume_host (0: frame in, 1: labels out)
     size_t pinned_bytes[2] = {0, 0};
 

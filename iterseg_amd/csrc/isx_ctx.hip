@@ -67,6 +67,25 @@ void isx_ctx::trim()
     free_blocks.clear();
 }
 
+int isx_ctx::aux_fork()
+{
+    if (!aux_stream) {
+        ISX_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+        ISX_HIP(hipEventCreateWithFlags(&aux_ev[0], hipEventDisableTiming));
+        ISX_HIP(hipEventCreateWithFlags(&aux_ev[1], hipEventDisableTiming));
+    }
+    ISX_HIP(hipEventRecord(aux_ev[0], stream));
+    ISX_HIP(hipStreamWaitEvent(aux_stream, aux_ev[0], 0));
+    return ISX_OK;
+}
+
+int isx_ctx::aux_join()
+{
+    ISX_HIP(hipEventRecord(aux_ev[1], aux_stream));
+    ISX_HIP(hipStreamWaitEvent(stream, aux_ev[1], 0));
+    return ISX_OK;
+}
+
 void isx_ctx::prof_begin(int cls)
 {
     auto get = [&]() {
@@ -166,6 +185,8 @@ void isx_ctx_destroy(isx_ctx *c)
     c->live_blocks.clear();
     c->trim();
     c->pinned_free();
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    for (auto e : c->aux_ev) if (e) (void)hipEventDestroy(e);
     for (auto &s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -1793,6 +1793,7 @@ __global__ void comp_order_key_kernel(const unsigned long long *comp_off, uint32
 }
 
 #include "ws_flood_window.h"
+#include "ws_flood_group.h"
 
 // Flood given raveled seed indices (device u32) in list order (label = position + 1).
 // parent/sizes: CCL of `mask` if the caller already has it, else nullptr.
@@ -1882,7 +1883,20 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     if (const char *e = getenv("ISX_FLOOD_LIST")) tcap = atoi(e);
     int max_bursts = 3;
     if (const char *e = getenv("ISX_FLOOD_BURSTS")) max_bursts = atoi(e);
+    int group_bursts = max_bursts & 0x7FF;       // + (ISX_FLOOD_GWATCHDOG << 16): sub-round limit of the work-group kernel (tests of its hand-over)
+    if (const char *e = getenv("ISX_FLOOD_GWATCHDOG")) group_bursts |= (atoi(e) & 0x7FFF) << 16;
+    // the largest components: one WORK-GROUP each (ws_flood_group.h; window of 512 episodes, lists of up to 192 discoveries).
+    // ISX_FLOOD_GROUP_MIN: smallest component for it (0 = never: everything >= coop_min on the single-wave window kernel);
+    // ISX_FLOOD_GWIN / ISX_FLOOD_GLIST shrink its window / lists (tests)
+    unsigned long long group_min = GROUP_MIN_SIZE;
+    if (const char *e = getenv("ISX_FLOOD_GROUP_MIN")) group_min = strtoull(e, nullptr, 10);
+    if (group_min == 0 || !window_mode) group_min = ~0ull;
+    if (group_min != ~0ull && group_min < coop_min) group_min = coop_min;
+    int gwcap = GRP_W, gtcap = GRP_T;
+    if (const char *e = getenv("ISX_FLOOD_GWIN")) gwcap = atoi(e);
+    if (const char *e = getenv("ISX_FLOOD_GLIST")) gtcap = atoi(e);
     ISX_REQUIRE(wcap >= 1 && wcap <= WIN_W && tcap >= 6 && tcap <= WIN_T, "ISX_FLOOD_WIN / ISX_FLOOD_LIST out of range");
+    ISX_REQUIRE(gwcap >= 1 && gwcap <= GRP_W && gtcap >= 6 && gtcap <= GRP_T, "ISX_FLOOD_GWIN / ISX_FLOOD_GLIST out of range");
     Scratch<uint32_t> claim(ctx, (window_mode && !getenv("ISX_FLOOD_TRACE")) ? 1 : (size_t)std::max<unsigned long long>((unsigned long long)PN, 3 * (total + 1)));
     Scratch<unsigned long long> vstate(ctx, window_mode ? (size_t)PN : 1);
     Scratch<unsigned long long> stats(ctx, 48);
@@ -1928,12 +1942,24 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         comp_order_key_kernel<<<cdiv(n_comp, TPB), TPB, 0, ctx->stream>>>(comp_off.p, n_comp, coop_min, okeys.p);
         ISX_CHECK_LAUNCH();
         ISX_TRY(sort_u64(ctx, (const uint64_t *)okeys.p, (uint64_t *)order.p, n_comp));
+        if (group_min != ~0ull) {
+            // the giants run beside the mid-size components (other CUs): a side stream, joined below
+            const bool side = getenv("ISX_FLOOD_GROUP_STREAM") && atoi(getenv("ISX_FLOOD_GROUP_STREAM")) != 0;
+            if (side) ISX_TRY(ctx->aux_fork());
+            flood_group_kernel<<<n_comp, GRP_W, 0, side ? ctx->aux_stream : ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
+                                                                   comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1], pshape[2], PN,
+                                                                   s[0], s[1], s[2], group_min, run_limit, drain_n, gwcap, gtcap, group_bursts,
+                                                                   bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world);
+            ISX_CHECK_LAUNCH();
+        }
         flood_window_kernel<<<n_comp, 64, 0, ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                             comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
                                                             pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, wcap, tcap, max_bursts,
                                                             bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world,
-                                                            getenv("ISX_FLOOD_TRACE") ? claim.p : nullptr);
+                                                            getenv("ISX_FLOOD_TRACE") ? claim.p : nullptr, group_min);
         ISX_CHECK_LAUNCH();
+        if (group_min != ~0ull && getenv("ISX_FLOOD_GROUP_STREAM") && atoi(getenv("ISX_FLOOD_GROUP_STREAM")) != 0) ISX_TRY(ctx->aux_join());
+
         if (const char *tp = getenv("ISX_FLOOD_TRACE")) {      // development: commit order of every component's roots
             ISX_HIP(hipStreamSynchronize(ctx->stream));
             std::vector<uint32_t> hl(3 * ((size_t)total + 1)), hf(n_comp);
@@ -1964,6 +1990,26 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
 #ifdef ISX_FLOOD_CHECK          // these slots carry the phase timers in the ISX_FLOOD_PROF build
         if (hs[40]) fprintf(stderr, "[isx flood/window] ORDER CHECK failed first at tag %llu sub-round %llu nw %llu run %llu: key %016llx !< next %016llx at p %llu (1 window, 2 window/run, 3 run: %llu)\n   window tail (last first): %016llx %016llx %016llx %016llx | run head: %016llx %016llx %016llx %016llx | cold %llu fifo drains %llu seeds %llu staged %llu\n   [tier check] last hot insert key %016llx hot_max then %016llx reason %llu (1 below hot max, 2 cold free) nw %llu run %llu\n", hs[40], hs[41], hs[42], hs[43], hs[44], hs[45], hs[46], hs[47], hs[20], hs[21], hs[22], hs[23], hs[24], hs[25], hs[26], hs[27], hs[28], hs[29], hs[30], hs[31], hs[20], hs[21], hs[22], hs[23], hs[24]);
 #endif
+        if (hs[22]) fprintf(stderr, "[isx flood/group] serial continuation requested %llu time(s) and SKIPPED (development flag); last: mode %llu sub-round %llu component size %llu\n",
+                            hs[22], hs[23] & 0xFF, (hs[23] >> 8) & 0xFFFFFF, hs[23] >> 32);
+        if (hs[20]) {
+            fprintf(stderr, "[isx flood/group] GUARD: %llu report(s), site %llu (1-3: voxel index outside the volume, 100+: hand-over sanity, 200: run empty with cold elements, 3xx: order check tag) "
+                            "sub-round %llu where %llu lane %llu keys %016llx %016llx nw|run %016llx\n", hs[20], hs[21], hs[10] & 0xFFFFFFFF, (hs[10] >> 32) & 0xFF, hs[10] >> 40, hs[40], hs[41], hs[42]);
+            set_error("flood group kernel produced an invalid voxel index (internal error)");
+            return ISX_ERR_INTERNAL;
+        }
+        if (hs[16]) {
+            fprintf(stderr, "[isx flood] TIER INVARIANT: %llu run eviction(s) left the hot maximum above the lowest cold bucket\n", hs[16]);
+            set_error("flood tier invariant violated (internal error)");
+            return ISX_ERR_INTERNAL;
+        }
+        if (hs[9] && group_min != ~0ull)
+            fprintf(stderr, "[isx flood/group] watchdog state (if it was the work-group kernel): nw %llu run %llu | free chunks %llu reserve %llu free slots %llu dirty %llu forced %llu | front: info %08llx (np %llu npop %llu started %llu idle %llu) mx %08llx resmin %08llx slot %llu key %016llx | next key %016llx qhead %016llx | episodes %llu started %llu idle %llu with-spare %llu chunks-held %llu entries %llu | pops %llu cold %llu\n",
+                    hs[24], hs[25], hs[26] & 0xFFFF, (hs[26] >> 16) & 0xFFFF, (hs[26] >> 32) & 0xFFFF, (hs[26] >> 48) & 0xFF, hs[26] >> 56, hs[27] & 0xFFFFFFFF,
+                    hs[27] & 0xFF, (hs[27] >> 8) & 0xFF, (hs[27] >> 16) & 1, (hs[27] >> 17) & 1, hs[27] >> 32, hs[10] & 0xFFFFFFFF, (hs[10] >> 32) & 0xFFF, hs[28], hs[23], hs[29],
+                    hs[30] & 0xFFFF, (hs[30] >> 16) & 0xFFFF, (hs[30] >> 32) & 0xFFFF, hs[30] >> 48, (hs[31] >> 32) & 0xFFFF, hs[31] >> 48, hs[31] & 0xFFFFFFFF, hs[10] >> 44);
+        if (hs[9] && group_min != ~0ull)
+            fprintf(stderr, "[isx flood/group] window head keys %016llx %016llx %016llx %016llx | run head keys %016llx %016llx %016llx %016llx\n", hs[40], hs[41], hs[42], hs[43], hs[44], hs[45], hs[46], hs[47]);
         if (hs[9]) {
             fprintf(stderr, "[isx flood/window] WATCHDOG: %llu component(s) exceeded the sub-round limit; front: nw %llu run %llu cold %llu cur|meta %016llx key %016llx "
                             "qhead %016llx maxnew|nstage %016llx pops %llu | pos1 key %016llx cur|meta %016llx wh %llu npfree %llu\n", hs[9], hs[24], hs[25], hs[26], hs[27], hs[28], hs[29], hs[30], hs[31], hs[20], hs[21], hs[22], hs[23]);
@@ -1977,7 +2023,14 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                         "evicted %llu squashes %llu (bound %llu) squashed eps %llu forced %llu serial_handover %llu\n",
                 hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[2] ? (double)hs[1] / hs[2] : 0.0, hs[13], hs[3], hs[7], hs[4], hs[5], hs[10],
                 hs[6], hs[11], hs[14], hs[12], hs[15], hs[8]);
+        if (group_min != ~0ull)
+            fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu take-over matchings %llu\n", hs[17], hs[18], hs[19]);
 #ifdef ISX_FLOOD_PROF
+        if (group_min != ~0ull)
+            fprintf(stderr, "[isx flood/group] cycles/sub-round of lane 0: (S0)->claims %.0f | claims issued+returned %.0f | wait (S3) %.0f | take-over block %.0f | lists+next pop %.0f | wait (S5) %.0f | "
+                            "squash+publish %.0f | decide %.0f | labels %.0f | enqueue %.0f | refill+drain %.0f | loop end %.0f\n",
+                    (double)hs[32] / hs[0], (double)hs[41] / hs[0], (double)hs[33] / hs[0], (double)hs[42] / hs[0], (double)hs[43] / hs[0], (double)hs[34] / hs[0],
+                    (double)hs[35] / hs[0], (double)hs[36] / hs[0], (double)hs[37] / hs[0], (double)hs[38] / hs[0], (double)hs[39] / hs[0], (double)hs[40] / hs[0]);
         fprintf(stderr, "[isx flood/window] cycles/sub-round: loop+evict %.0f | scan %.0f | trip %.0f | lists %.0f | squash %.0f | commit: decide %.0f labels %.0f enqueue %.0f | refill %.0f\n",
                 (double)hs[32] / hs[0], (double)hs[33] / hs[0], (double)hs[34] / hs[0], (double)hs[35] / hs[0], (double)hs[36] / hs[0],
                 (double)hs[37] / hs[0], (double)hs[38] / hs[0], (double)hs[39] / hs[0], (double)hs[40] / hs[0]);

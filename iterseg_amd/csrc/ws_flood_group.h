@@ -1,0 +1,1046 @@
+// ws_flood_group.h -- the flood of one LARGE mask component by one WORK-GROUP of eight waves (512 lanes).
+// Included by ws.hip inside namespace isx, after ws_flood_window.h (same rules, same queue tiers; scratch/group_sim.c is
+// the CPU model of exactly these phases and is checked against the sequential oracle by scratch/group_sim.py).
+//
+// Replaces raveled_affinity_watershed (watershed.py:95-159) for components of >= group_min voxels, bit-exactly.
+//
+// The single-wave window kernel keeps 192 episodes in LDS and walks them with one wave: every sub-round it compacts an
+// active list, loads and stores the episode words, scans the discovery lists for the next pop, and one lane at a time
+// inserts residuals into the window / the run; the wave owns a whole CU's LDS while three of its four SIMDs idle.  Here
+//   * ONE EPISODE PER LANE: slot = thread id, the episode's words live in registers, no active list, no slot loads;
+//   * the window is 512 episodes wide and a discovery list may grow to 192 entries (chunk pool in LDS, 8 entries per chunk):
+//     the model gives 36.8 committed pops per sub-round on the random-weight U-Net output against 17.3 (W = 192, T = 48),
+//     and a tenth of the window insertions / evictions, which were mostly forced commits of long episodes;
+//   * the unpopped discoveries BELOW the bound ("candidates") sit in six registers -- the next pop is a register minimum,
+//     the list is append-only (commit, squash and the rare overflow re-read it);
+//   * a squash is "every episode with key >= K" -- each lane compares its own key;
+//   * a commit burst is as wide as the window (prefix minimum / prefix sums over 512 lanes), the committing lanes write
+//     their own labels and residuals, and the residuals of a burst enter the run in ONE ranked merge;
+//   * the cold tier (HBM buckets: cold_append / cold_drain of ws.hip) is driven by wave 0.
+// Phases are separated by work-group barriers; wave-uniform queue state lives in LDS (`sh`).
+//
+// Correctness argument: as ws_flood_window.h (induction over window positions; the front episode is never wrong).  What is
+// new is only WHO does the work.  Claims of one sub-round arrive in any order from the eight waves: after the barrier that
+// ends the claim phase the holder of a voxel is the smallest claiming key, every lane reads its claims back, and a
+// take-over that hit a claim of an EARLIER sub-round (take-overs != fresh losses, then matched entry by entry) squashes
+// from the victim's key.
+
+static constexpr int GRP_W = 256;                 // lanes = episode slots
+static constexpr int GRP_NWV = GRP_W / 64;        // waves
+static constexpr int GRP_T = 192;                 // discoveries one episode may hold
+static constexpr int GRP_CH = 8;                  // entries per chunk
+static constexpr int GRP_NCH = GRP_W + GRP_W / 2; // chunks in the pool
+static constexpr int GRP_CMAX = 6;                // register candidates
+static constexpr int GRP_PEND = GRP_W;            // residuals of one commit burst (one per lane in the enqueue)
+static constexpr int GRP_STAGE = GRP_PEND + 64;   // staged cold-bound elements
+static constexpr int GRP_TL = 256;                // take-over / fresh-loss records of one sub-round
+static constexpr uint32_t GRP_NONE = 0xFFFFFFFFu;
+static constexpr unsigned long long GROUP_MIN_SIZE = 0;        // 0: off by default (ISX_FLOOD_GROUP_MIN enables it) until it beats the single-wave kernel
+
+enum { GI_OH, GI_NW, GI_SHEAD, GI_SCOUNT, GI_NSTAGE, GI_NFREECH, GI_NFREESLOT, GI_SERIAL, GI_FORCED, GI_NTOOK, GI_NLOST, GI_NT, GI_NL,
+       GI_DIRTY, GI_COLD_COUNT, GI_COLD_LOW, GI_M, GI_NCOMMIT, GI_PENDN, GI_NHOT, GI_NWB, GI_AGEBASE, GI_NPTOT, GI_ANY, GI_TAKE, GI_POS,
+       GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_N };
+enum { GQ_KSQ, GQ_TMIN, GQ_N };
+enum { GS_SUB, GS_POPS, GS_EXEC, GS_SQ_EPS, GS_SQ_BOUND, GS_SQ_LOST, GS_SLOW, GS_FORCED, GS_RELOAD, GS_RUNINS, GS_WININS, GS_WINEV, GS_COLD,
+       GS_DRAIN, GS_BURST, GS_N };
+
+// ---- the cold tier, driven by wave 0, OUT OF LINE: cold_append / cold_drain are large, and inlined into the kernel their
+// registers pushed the episode words of the hot loop into scratch memory (a scratch round trip per phase).  The tier's
+// state (`Cold`) lives in LDS between calls; count / low are published in shI for the other waves. --------------------------------
+__device__ __forceinline__ void grp_publish_cold(const Cold &cold, int *shI, int lane)
+{
+    if (lane == 0) { shI[GI_COLD_COUNT] = (int)cold.count; shI[GI_COLD_LOW] = (int)cold.low; }
+}
+
+// append stage[0, nstage) to the buckets, 64 at a time
+__device__ __noinline__ void grp_w0_flush_stage(Cold *cs, HeapEnt *stage, int *shI, uint32_t *lstat, int lane)
+{
+    Cold cold = *cs;
+    const int nstage = shI[GI_NSTAGE];
+    int done = 0;
+    while (done < nstage) {
+        const int m = nstage - done < 64 ? nstage - done : 64;
+        const bool hs = lane < m;
+        HeapEnt e; e.key = 0; e.idx = 0; e.pad = 0;
+        if (hs) e = stage[done + lane];
+        cold_append(cold, hs, e.key, e.idx, e.pad, lane);
+        if (cold.failed) break;                      // nothing of this batch was written
+        done += m;
+    }
+    if (lane == 0) atomicAdd(&lstat[GS_COLD], (uint32_t)done);
+    if (cold.failed) {
+        // keep what is left at the front of `stage` for the serial continuation
+        for (int j0 = done; j0 < nstage; j0 += 64) {
+            HeapEnt e; e.key = 0; e.idx = 0; e.pad = 0;
+            if (j0 + lane < nstage) e = stage[j0 + lane];
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (j0 + lane < nstage) stage[j0 + lane - done] = e;
+        }
+        if (lane == 0) { shI[GI_NSTAGE] = nstage - done; shI[GI_SERIAL] = 1; }
+    } else if (lane == 0) shI[GI_NSTAGE] = 0;
+    grp_publish_cold(cold, shI, lane);
+    *cs = cold;
+}
+
+// the largest run elements go to their buckets (ascending, so that a bucket's list stays FIFO)
+__device__ __noinline__ void grp_w0_run_evict(Cold *cs, HeapEnt *srun, int *shI, uint32_t *lstat, unsigned long long *stats, int keep, int lane)
+{
+    constexpr int SMASK = COOP_SCAP - 1;
+    const int shead = shI[GI_SHEAD], scount = shI[GI_SCOUNT];
+    if (scount <= keep) return;
+    Cold cold = *cs;
+    if (!cold.on) { if (lane == 0) shI[GI_SERIAL] = 1; return; }
+    const int ev = scount - keep;
+    int done = 0;
+    while (done < ev) {
+        const int m = ev - done < 64 ? ev - done : 64;
+        const bool hs = lane < m;
+        HeapEnt e; e.key = 0; e.idx = 0; e.pad = 0;
+        if (hs) e = srun[(shead + keep + done + lane) & SMASK];
+        cold_append(cold, hs, e.key, e.idx, e.pad, lane);
+        if (cold.failed) break;
+        done += m;
+    }
+    if (cold.failed) {
+        for (int j0 = keep + done; j0 < scount; j0 += 64) {      // close the gap
+            const bool mv = j0 + lane < scount;
+            HeapEnt e; e.key = 0; e.idx = 0; e.pad = 0;
+            if (mv) e = srun[(shead + j0 + lane) & SMASK];
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (mv) srun[(shead + j0 + lane - done) & SMASK] = e;
+        }
+        if (lane == 0) { shI[GI_SCOUNT] = scount - done; shI[GI_SERIAL] = 1; }
+    } else {
+        if (lane == 0) { shI[GI_SCOUNT] = keep; atomicAdd(&lstat[GS_COLD], (uint32_t)ev); }
+        // always-on tier assertion (cheap form): the hot maximum may not lie in a bucket above the lowest cold one
+        if (lane == 0 && keep > 0 && stats) {
+            const unsigned long long hm = srun[(shead + keep - 1) & SMASK].key;
+            if (cold.count > 0 && cold_bucket(cold, hm) > cold.low) atomicAdd(&stats[16], 1ull);
+        }
+    }
+    grp_publish_cold(cold, shI, lane);
+    *cs = cold;
+}
+
+// the run is empty: staged elements to their buckets, then the lowest bucket into the run
+__device__ __noinline__ void grp_w0_drain(Cold *cs, HeapEnt *srun, HeapEnt *stage, int *hist, int *shI, uint32_t *lstat, int drain_n, int lane)
+{
+    if (shI[GI_NSTAGE] > 0) grp_w0_flush_stage(cs, stage, shI, lstat, lane);
+    Cold cold = *cs;
+    if (!cold.failed && cold.count > 0) {
+        const int got = cold_drain(cold, srun, hist, lane, drain_n);
+        if (lane == 0) { shI[GI_SCOUNT] = got; shI[GI_SHEAD] = 0; atomicAdd(&lstat[GS_DRAIN], 1u); }
+    }
+    grp_publish_cold(cold, shI, lane);
+    *cs = cold;
+}
+
+// seeds beyond the hot tiers start cold
+__device__ __noinline__ void grp_w0_seed_append(Cold *cs, const unsigned long long *keys, uint32_t first, uint32_t from, uint32_t ns,
+                                                const uint32_t *out, int *shI, int lane)
+{
+    Cold cold = *cs;
+    const unsigned long long ZKEY = (unsigned long long)0x80000000u << 32;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t j0 = from; j0 < ns; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool hs = j < ns;
+        const uint32_t vi = hs ? (uint32_t)(keys[first + j] & 0xFFFFFFFFull) : 0u;
+        cold_append(cold, hs, ZKEY | (unsigned long long)j, vi, hs ? out[vi] : 0u, lane);
+        if (cold.failed) { if (lane == 0) shI[GI_SERIAL] = 2; break; }
+    }
+    grp_publish_cold(cold, shI, lane);
+    *cs = cold;
+}
+
+// serial continuation: every bucket's elements into the heap
+__device__ __noinline__ uint32_t grp_w0_collect_cold(Cold *cs, HeapEnt *heap, uint32_t hn, int lane)
+{
+    Cold cold = *cs;
+    if (cold.on) {
+        while (cold.count > 0) {
+            const uint32_t b = cold_lowest(cold, lane);
+            uint32_t seg = cld32(&cold.bhead()[b]);
+            uint32_t off = cld32(&cold.bmeta()[b]) & ~COLD_UNSORTED;
+            uint32_t got = 0;
+            while (seg != COLD_NONE) {
+                const HeapEnt h = cld_ent(&cold.pool()[seg]);
+                const uint32_t n = (uint32_t)(h.key >> 32);
+                if (lane == 0)
+                    for (uint32_t j = off; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool()[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
+                got += n - off;
+                off = 0;
+                seg = (uint32_t)h.key;
+            }
+            cold_mark_empty(cold, b, lane);
+            cold.count -= got;
+        }
+    }
+    *cs = cold;
+    return hn;
+}
+
+__global__ __launch_bounds__(GRP_W) void flood_group_kernel(
+    const unsigned long long *__restrict__ order,
+    const float *__restrict__ aff, const uint8_t *__restrict__ mask, uint32_t *__restrict__ out,
+    unsigned long long *__restrict__ state, const unsigned long long *__restrict__ keys, uint32_t n_seeds,
+    const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
+    HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
+    int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long group_min, int run_limit,
+    int drain_n, int wcap, int tcap, int max_bursts, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world)
+{
+    __shared__ HeapEnt srun[COOP_SCAP];
+    __shared__ HeapEnt stage[GRP_STAGE];
+    __shared__ HeapEnt pend[GRP_PEND];
+    __shared__ HeapEnt hotb[GRP_PEND];
+    __shared__ uint32_t pvox[GRP_NCH * GRP_CH], pval[GRP_NCH * GRP_CH];
+    __shared__ unsigned short cnext[GRP_NCH], freech[GRP_NCH];
+    __shared__ unsigned short resch[GRP_T / GRP_CH + 2];                 // the front episode's reserve (one full list)
+    __shared__ unsigned long long okey[GRP_W], succ[GRP_W];
+    __shared__ unsigned short oslot[GRP_W], freeslot[GRP_W];
+    __shared__ uint32_t pub_res[GRP_W], pub_mx[GRP_W], pub_info[GRP_W];   // info: np | npop << 8 | started << 16 | idle << 17
+    __shared__ uint32_t ci_age[GRP_W], ci_off[GRP_W];                    // commit orders of a burst (ci_off: GRP_NONE = not committing)
+    __shared__ u32x4 newroot[GRP_W];                                     // {key.lo, key.hi, voxel, label}
+    __shared__ uint32_t newflag[GRP_W];
+    __shared__ unsigned long long tlk[2][GRP_TL];
+    __shared__ uint32_t tlv[2][GRP_TL];
+    __shared__ int wtmp[4][GRP_NWV];
+    __shared__ int hist[64];
+    __shared__ int shI[GI_N];
+    __shared__ unsigned long long shQ[GQ_N];
+    __shared__ uint32_t lstat[GS_N];
+    __shared__ Cold scold;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x >= n_comp) return;
+    const unsigned long long okey_comp = order[blockIdx.x];
+    if (okey_comp == ~0ull) return;
+    const uint32_t c = (uint32_t)okey_comp;
+    if (!comp_owned(comp_off, c, n_comp, shard_rank, shard_world)) return;
+    const uint32_t first = comp_first[c];
+    const uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
+    if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;
+    const unsigned long long csize = comp_off[c + 1] - comp_off[c];
+    if (csize < group_min) return;
+    HeapEnt *heap = heap_pool + comp_off[c];
+    const uint32_t ns = end - first;
+
+    const int noff32[6] = {-(int)(PY * PX), -(int)PX, -1, 1, (int)PX, (int)(PY * PX)};
+    const int ax[6] = {0, 1, 2, 2, 1, 0};
+    const float sc[3] = {s0, s1, s2};
+    const unsigned long long ZKEY = (unsigned long long)0x80000000u << 32;
+    constexpr int SMASK = COOP_SCAP - 1;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    if (wcap > GRP_W) wcap = GRP_W;
+    if (tcap > GRP_T) tcap = GRP_T;
+    const int reserve = (tcap + GRP_CH - 1) / GRP_CH + 1;
+
+    // ---- cold tier: owned by wave 0 (its lanes hold `cold`); count / low are published in shI for the others ---------------
+    Cold cold;
+    cold.on = arena_off && (arena_off[c + 1] > arena_off[c]);
+    cold.failed = false; cold.bump = 0; cold.count = 0; cold.low = COLD_NBK; cold.fifo_drains = 0;
+#ifdef ISX_FLOOD_PROF
+    for (int i = 0; i < 8; ++i) cold.tk[i] = 0;
+    cold.n_groups = 0;
+#endif
+    cold.cb = COLD_NONE; cold.pool_cap = 0; cold.vlo = bk_lo; cold.vinv = bk_inv; cold.base = nullptr;
+    if (cold.on) {
+        HeapEnt *base = arena + arena_off[c];
+        cold.base = (uint32_t *)base;
+        cold.pool_cap = (uint32_t)(arena_off[c + 1] - arena_off[c] - COLD_META_ENTS);
+        for (int i = tid; i < COLD_NBK; i += GRP_W) { cold.bhead()[i] = COLD_NONE; cold.btail()[i] = COLD_NONE; cold.bcount()[i] = 0; cold.bmeta()[i] = 0; }
+        for (int i = tid; i < COLD_NBK / 64; i += GRP_W) cold.bm0()[i] = 0ull;
+        if (tid < COLD_NBK / 4096) cold.bm1()[tid] = 0ull;
+    }
+    if (tid == 0) scold = cold;
+    const bool cold_on = cold.on;
+    for (int i = tid; i < GI_N; i += GRP_W) shI[i] = i == GI_COLD_LOW ? COLD_NBK : 0;
+    if (tid < GQ_N) shQ[tid] = ~0ull;
+    for (int i = tid; i < GS_N; i += GRP_W) lstat[i] = 0u;
+    for (int i = tid; i < GRP_NCH; i += GRP_W) freech[i] = (unsigned short)(GRP_NCH - 1 - i);
+    freeslot[tid] = (unsigned short)(GRP_W - 1 - tid);
+    newflag[tid] = 0u;
+    ci_off[tid] = GRP_NONE;
+    __syncthreads();
+
+    // ---- episode of this lane (slot = tid) -----------------------------------------------------------------------------------------
+    bool has = false, started = false;
+    unsigned long long key = 0ull;
+    uint32_t root = 0, lab = 0, cur = GRP_NONE, curv = 0;
+    int cur_addr = -1, cur_li = -1, np = 0, npop = 0;
+    uint32_t mx = 0, resmin = 0xFFFFFFFFu;
+    int ncand = 0, ndef = 0;
+    uint32_t cv[GRP_CMAX], cx[GRP_CMAX], cla[GRP_CMAX];           // cla: list index << 16 | pool address
+    int chfirst = -1, chlast = -1, spare = -1;
+#pragma unroll
+    for (int k = 0; k < GRP_CMAX; ++k) { cv[k] = 0; cx[k] = 0; cla[k] = 0; }
+
+    auto ep_fresh = [&]() {
+        started = false; cur = root; curv = 0; cur_addr = -1; cur_li = -1; np = 0; npop = 0; mx = 0; resmin = 0xFFFFFFFFu;
+        ncand = 0; ndef = 0; chfirst = -1; chlast = -1; spare = -1;
+    };
+    auto free_chunks = [&]() {                       // pushes only: never in a phase that allocates
+        for (int ch = chfirst; ch >= 0;) { const int n = cnext[ch] == 0xFFFFu ? -1 : (int)cnext[ch]; freech[atomicAdd(&shI[GI_NFREECH], 1)] = (unsigned short)ch; ch = n; }
+        if (spare >= 0) freech[atomicAdd(&shI[GI_NFREECH], 1)] = (unsigned short)spare;
+        chfirst = chlast = spare = -1;
+    };
+    auto squash_me = [&]() {
+        if (started) {
+            atomicAdd(&lstat[GS_SQ_EPS], 1u);
+            int ch = chfirst;
+            for (int i = 0; i < np; ++i) {
+                if (i && (i % GRP_CH) == 0) ch = (int)cnext[ch];
+                const uint32_t vq = pvox[ch * GRP_CH + i % GRP_CH];
+                if (vq < (uint32_t)PN) atomicCAS(&state[vq], key, ST_FREE);
+                else if (stats) { atomicAdd(&stats[20], 1ull); stats[21] = 1ull; }
+            }
+        }
+        free_chunks();
+        ep_fresh();
+    };
+    // candidate order: (value, discovery index); every deferred entry sorts after every register candidate
+    auto cand_add = [&](uint32_t v, uint32_t x, int li, int ad) {
+        const uint32_t la = ((uint32_t)li << 16) | (uint32_t)ad;
+        int mk = -1; uint32_t mv = 0, ml = 0;
+#pragma unroll
+        for (int k = 0; k < GRP_CMAX; ++k)
+            if (k < ncand && (mk < 0 || mv < cv[k] || (mv == cv[k] && ml < (cla[k] >> 16)))) { mk = k; mv = cv[k]; ml = cla[k] >> 16; }
+        const bool below_max = mk >= 0 && (v < mv || (v == mv && (uint32_t)li < ml));
+        if (ncand < GRP_CMAX && (ndef == 0 || below_max)) {
+#pragma unroll
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) { cv[k] = v; cx[k] = x; cla[k] = la; }
+            ++ncand;
+            return;
+        }
+        if (ncand == GRP_CMAX && below_max) {
+#pragma unroll
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) { cv[k] = v; cx[k] = x; cla[k] = la; }
+        }
+        ++ndef;
+    };
+    auto reload = [&](uint32_t bound) {             // candidates / deferred count / resmin from the list
+        ncand = 0; ndef = 0; resmin = 0xFFFFFFFFu;
+        atomicAdd(&lstat[GS_RELOAD], 1u);
+        int ch = chfirst;
+        for (int i = 0; i < np; ++i) {
+            if (i && (i % GRP_CH) == 0) ch = (int)cnext[ch];
+            const int a = ch * GRP_CH + i % GRP_CH;
+            const uint32_t v = pval[a];
+            if (v == WIN_POPPED) continue;
+            if (cur != GRP_NONE && a == cur_addr) continue;
+            if (v < bound) cand_add(v, pvox[a], i, a);
+            else if (v < resmin) resmin = v;
+        }
+    };
+    auto select_next = [&](uint32_t bound) {
+        if (ncand == 0 && ndef > 0) reload(bound);
+        int mk = -1; uint32_t mv = 0, ml = 0;
+#pragma unroll
+        for (int k = 0; k < GRP_CMAX; ++k)
+            if (k < ncand && (mk < 0 || cv[k] < mv || (cv[k] == mv && (cla[k] >> 16) < ml))) { mk = k; mv = cv[k]; ml = cla[k] >> 16; }
+        if (mk >= 0 && mv < bound) {
+            uint32_t lx = 0, ll = 0, lv = 0;
+#pragma unroll
+            for (int k = 0; k < GRP_CMAX; ++k) {
+                if (k == mk) { cur = cx[k]; curv = cv[k]; cur_addr = (int)(cla[k] & 0xFFFFu); cur_li = (int)(cla[k] >> 16); }
+                if (k == ncand - 1) { lx = cx[k]; ll = cla[k]; lv = cv[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) { cx[k] = lx; cla[k] = ll; cv[k] = lv; }
+            --ncand;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand && cv[k] < resmin) resmin = cv[k];
+        ncand = 0;
+        if (ndef > 0) reload(bound);                 // the deferred ones sort after every candidate, i.e. at or above the bound
+        ncand = 0; ndef = 0;
+        cur = GRP_NONE;
+    };
+    auto adopt = [&]() {
+        if (newflag[tid]) {
+            const u32x4 r = newroot[tid];
+            newflag[tid] = 0u;
+            has = true; key = ((unsigned long long)r.y << 32) | r.x; root = r.z; lab = r.w;
+            ep_fresh();
+            // what the slot's previous episode published is void: a later burst of this sub-round must see "not started"
+            pub_info[tid] = 0u; pub_res[tid] = 0xFFFFFFFFu; pub_mx[tid] = 0u;
+        }
+    };
+    uint32_t st_sub = 0;
+    auto ord_at = [&](int p) -> int { return (shI[GI_OH] + p) & (GRP_W - 1); };
+    // development (ISX_FLOOD_BURSTS bit 0x400): window sorted, window <= run head, run sorted -- the first violation is
+    // reported with its tag and the component stops (all lanes call it, between barriers)
+    auto check_order = [&](int tag) {
+        if (!(max_bursts & 0x400)) return;
+        __syncthreads();
+        const int nwc = shI[GI_NW], scc = shI[GI_SCOUNT], shc = shI[GI_SHEAD];
+        bool bad = false; unsigned long long a_ = 0, b_ = 0; int where = 0;
+        if (tid < nwc) {
+            a_ = okey[ord_at(tid)];
+            b_ = tid + 1 < nwc ? okey[ord_at(tid + 1)] : (scc > 0 ? srun[shc].key : ~0ull);
+            if (!(a_ < b_)) { bad = true; where = tid + 1 < nwc ? 1 : 2; }
+        }
+        for (int p0 = tid; p0 + 1 < scc && !bad; p0 += GRP_W) {
+            a_ = srun[(shc + p0) & SMASK].key; b_ = srun[(shc + p0 + 1) & SMASK].key;
+            if (!(a_ < b_)) { bad = true; where = 3; }
+        }
+        if (bad && stats && atomicAdd(&stats[20], 1ull) == 0ull) {
+            stats[21] = 300ull + (unsigned long long)tag; stats[10] = (unsigned long long)st_sub | ((unsigned long long)where << 32) | ((unsigned long long)tid << 40);
+            stats[40] = a_; stats[41] = b_; stats[42] = (unsigned long long)nwc | ((unsigned long long)scc << 32);
+            shI[GI_SERIAL] = 1;
+        }
+        __syncthreads();
+    };
+
+    // ---- wave-0 helpers on the queue tiers (the other waves wait at the next barrier) -----------------------------------------------
+    auto publish_cold = [&]() { };                   // (the out-of-line routines publish count / low themselves)
+    auto flush_stage_w0 = [&]() { grp_w0_flush_stage(&scold, stage, shI, lstat, lane); };
+    auto run_evict_w0 = [&](int keep) { grp_w0_run_evict(&scold, srun, shI, lstat, stats, keep, lane); };
+
+    // ---- start: seeds (value 0, age = rank in index order) ---------------------------------------------------------------------------------
+    {
+        const uint32_t in_win = ns < (uint32_t)wcap ? ns : (uint32_t)wcap;
+        if ((uint32_t)tid < in_win) {
+            const uint32_t vi = (uint32_t)(keys[first + tid] & 0xFFFFFFFFull);
+            const unsigned long long k = ZKEY | (unsigned long long)tid;
+            okey[tid] = k; oslot[tid] = (unsigned short)tid;
+            succ[tid] = (uint32_t)tid + 1u < in_win ? (ZKEY | (unsigned long long)(tid + 1)) : ~0ull;
+            has = true; key = k; root = vi; lab = out[vi];
+            ep_fresh();
+        }
+        // slots [0, in_win) are taken: the free list holds the others (top of the stack = lowest free slot)
+        if (tid == 0) {
+            shI[GI_NW] = (int)in_win; shI[GI_NFREESLOT] = GRP_W - (int)in_win; shI[GI_AGEBASE] = (int)(ns - 1u);
+            int nf = GRP_NCH;
+            for (int i = 0; i < reserve; ++i) resch[i] = freech[--nf];
+            shI[GI_NRES] = reserve; shI[GI_NFREECH] = nf;
+        }
+        const uint32_t hot_cap = in_win + (uint32_t)run_limit;
+        const uint32_t in_hot = ns > hot_cap ? hot_cap : ns;
+        for (uint32_t j = in_win + (uint32_t)tid; j < in_hot; j += GRP_W) {
+            HeapEnt e;
+            e.key = ZKEY | (unsigned long long)j;
+            e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull);
+            e.pad = out[e.idx];
+            srun[j - in_win] = e;
+        }
+        if (tid == 0) shI[GI_SCOUNT] = in_hot > in_win ? (int)(in_hot - in_win) : 0;
+        __syncthreads();
+        if (ns > in_hot) {
+            if (!cold_on) { if (tid == 0) shI[GI_SERIAL] = 2; }            // 2: restart from the seeds on the serial heap
+            else if (wave == 0) grp_w0_seed_append(&scold, keys, first, in_hot, ns, out, shI, lane);
+        }
+        __syncthreads();
+    }
+
+#ifdef ISX_FLOOD_PROF
+    unsigned long long tk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_prev = __builtin_readcyclecounter();
+#define GTICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tk_acc[i] += t_ - tk_prev; tk_prev = t_; } while (0)
+#else
+#define GTICK(i) do { } while (0)
+#endif
+    // ================================================= sub-rounds ==================================================================
+    // watchdog: sub-rounds (never expected to be reached; ISX_FLOOD_GWATCHDOG sets a tiny limit to test the hand-over it leads to)
+    const uint32_t sub_limit = (max_bursts >> 16) ? (uint32_t)(max_bursts >> 16) : (csize > 60000000ull ? 0xFFFFFFFFu : 4096u + 64u * (uint32_t)csize);
+    for (;;) {
+        __syncthreads();                                                        // (S0) the previous sub-round is complete
+        GTICK(8);
+        if (shI[GI_SERIAL] || shI[GI_NW] == 0) break;
+        if (++st_sub > sub_limit) {                                             // watchdog (never expected): finish on the serial heap
+            if (tid < 8) wtmp[tid >> 2][tid & 3] = 0;
+            __syncthreads();
+            if (has) {
+                atomicAdd(&wtmp[0][0], 1);
+                if (started) atomicAdd(&wtmp[0][1], 1);
+                if (started && cur == GRP_NONE) atomicAdd(&wtmp[0][2], 1);
+                if (spare >= 0) atomicAdd(&wtmp[0][3], 1);
+                atomicAdd(&wtmp[1][0], (np + GRP_CH - 1) / GRP_CH);
+                atomicAdd(&wtmp[1][1], np);
+            }
+            __syncthreads();
+            if (tid == 0 && stats && !(max_bursts >> 16)) {
+                const int fs_ = (int)oslot[ord_at(0)];
+                atomicAdd(&stats[9], 1ull);
+                stats[24] = (unsigned long long)shI[GI_NW]; stats[25] = (unsigned long long)shI[GI_SCOUNT];
+                stats[26] = (unsigned long long)(uint32_t)shI[GI_NFREECH] | ((unsigned long long)(uint32_t)shI[GI_NRES] << 16) | ((unsigned long long)(uint32_t)shI[GI_NFREESLOT] << 32) | ((unsigned long long)(uint32_t)shI[GI_DIRTY] << 48) | ((unsigned long long)(uint32_t)shI[GI_FORCED] << 56);
+                stats[27] = (unsigned long long)pub_info[fs_] | ((unsigned long long)pub_mx[fs_] << 32);
+                stats[28] = okey[ord_at(0)];
+                stats[29] = shI[GI_SCOUNT] > 0 ? srun[shI[GI_SHEAD]].key : ~0ull;
+                stats[30] = (unsigned long long)(uint32_t)wtmp[0][0] | ((unsigned long long)(uint32_t)wtmp[0][1] << 16) | ((unsigned long long)(uint32_t)wtmp[0][2] << 32) | ((unsigned long long)(uint32_t)wtmp[0][3] << 48);
+                stats[31] = (unsigned long long)lstat[GS_POPS] | ((unsigned long long)(uint32_t)wtmp[1][0] << 32) | ((unsigned long long)(uint32_t)wtmp[1][1] << 48);
+                for (int q = 0; q < 4; ++q) {
+                    stats[40 + q] = q < shI[GI_NW] ? okey[ord_at(q)] : 0ull;
+                    stats[44 + q] = q < shI[GI_SCOUNT] ? srun[(shI[GI_SHEAD] + q) & SMASK].key : 0ull;
+                }
+                stats[10] = (unsigned long long)pub_res[fs_] | ((unsigned long long)fs_ << 32) | ((unsigned long long)shI[GI_COLD_COUNT] << 44);
+            }
+            __syncthreads();
+            if (tid == 0) shI[GI_SERIAL] = 1;
+            continue;
+        }
+        adopt();
+        if (shI[GI_SCOUNT] > run_limit) {                                       // uniform: the run outgrew its limit (tiny stress limits)
+            __syncthreads();
+            if (wave == 0) { run_evict_w0(run_limit / 2); publish_cold(); }
+            continue;
+        }
+        const int nw = shI[GI_NW];
+        // invariant of the bounds: the run is empty only if nothing at all is queued behind the window
+        if (tid == 0 && stats && shI[GI_SCOUNT] == 0 && cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0)) {
+            if (atomicAdd(&stats[20], 1ull) == 0ull) { stats[21] = 200ull; stats[10] = (unsigned long long)st_sub | ((unsigned long long)shI[GI_COLD_COUNT] << 32); }
+        }
+        const unsigned long long qhead = shI[GI_SCOUNT] > 0 ? srun[shI[GI_SHEAD]].key : ~0ull;
+        const int lastslot = (int)oslot[ord_at(nw - 1)], frontslot = (int)oslot[ord_at(0)];
+        const bool dirty = shI[GI_DIRTY] != 0;
+        // ---- A: an episode that popped (or holds) something at or above its bound is wrong; a bound only drops after an
+        //         insertion right behind the episode, so the check runs after insertions only -------------------------------------------
+        unsigned long long nk = ~0ull;
+        if (has) nk = tid == lastslot ? qhead : succ[tid];
+        uint32_t bound = (uint32_t)(nk >> 32);
+        if (dirty) {
+            if (has && started) {
+                uint32_t m2 = mx;
+                if (cur != GRP_NONE && cur_li >= 0 && curv > m2) m2 = curv;
+                if (m2 != 0u && m2 >= bound) atomicMin(&shQ[GQ_KSQ], key);
+                // candidates that the lower bound turned into residuals
+#pragma unroll
+                for (int k = GRP_CMAX - 1; k >= 0; --k) {
+                    if (k < ncand && cv[k] >= bound) {
+                        if (cv[k] < resmin) resmin = cv[k];
+                        uint32_t lx = 0, ll = 0, lv = 0;
+#pragma unroll
+                        for (int q = 0; q < GRP_CMAX; ++q) if (q == ncand - 1) { lx = cx[q]; ll = cla[q]; lv = cv[q]; }
+                        cx[k] = lx; cla[k] = ll; cv[k] = lv;
+                        --ncand;
+                    }
+                }
+            }
+            __syncthreads();                                                    // (S1)
+            const unsigned long long ksq = shQ[GQ_KSQ];
+            if (ksq != ~0ull) {
+                if (has && key >= ksq) squash_me();
+                if (tid == 0) atomicAdd(&lstat[GS_SQ_BOUND], 1u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();                                                    // (S2) releases performed, chunks back
+            if (tid == 0) { shQ[GQ_KSQ] = ~0ull; shI[GI_DIRTY] = 0; }
+        }
+        // ---- C: one pop per active episode ------------------------------------------------------------------------------------------
+        const int pool_base = shI[GI_NFREECH];                                  // stable: nothing is freed or granted before (S3)
+        bool active = false;
+        if (has && cur != GRP_NONE) {
+            bool room = true;
+            // Chunks: requests of one sub-round take RANKS (a monotonic counter); rank r is served from the stack top as it
+            // stood when the phase began iff r < that count -- a failed request changes nothing (a decrement that is undone
+            // lets another lane pop past a chunk that is still free: two episodes then share a chunk).  The front episode
+            // falls back on a reserve of one full list that only it may touch, so it can always finish or be forced to commit.
+            bool need = false;
+            if (started) {
+                room = np + 6 <= tcap;
+                const int used = np % GRP_CH, left = (np == 0 || used == 0) ? 0 : GRP_CH - used;
+                need = room && left < 6 && spare < 0;
+            } else need = spare < 0;
+            if (need) {
+                const int r = atomicAdd(&shI[GI_REQ], 1);
+                if (r < pool_base) spare = (int)freech[pool_base - 1 - r];
+                else if (tid == frontslot && shI[GI_NRES] > 0) spare = (int)resch[--shI[GI_NRES]];
+                else room = false;
+            }
+            active = room;
+            if (!room && tid == frontslot) {
+                if (started) shI[GI_FORCED] = 1;      // commits what it has done; that returns its chunks
+                // A front episode that has not even popped its root and finds pool AND reserve empty: every chunk is held by
+                // episodes behind it (a residual that became the new front took the place of the episode the reserve was
+                // serving).  Nothing can commit before the front, so everything behind it is squashed -- always legal --
+                // and its chunks come back for the next sub-round.
+                else atomicMin(&shQ[GQ_KSQ], tid == lastslot ? ~0ull : succ[tid]);
+            }
+        }
+        unsigned long long old[6];
+        float val[6];
+        uint32_t nbv[6];
+        uint32_t wonm = 0, tookmask = 0;
+        GTICK(0);
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                nbv[k] = cur + (uint32_t)noff32[k];
+                old[k] = 0ull; val[k] = 0.0f;
+                if (cur >= (uint32_t)PN && stats) { atomicAdd(&stats[20], 1ull); stats[21] = 3ull; }
+                if (nbv[k] < (uint32_t)PN && cur < (uint32_t)PN) {
+                    old[k] = __hip_atomic_fetch_min(&state[nbv[k]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    val[k] = (aff + (int64_t)ax[k] * PN)[k < 3 ? cur : nbv[k]];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (old[k] > key) { wonm |= 1u << k; if (old[k] != ST_FREE) tookmask |= 1u << k; }
+            if (tookmask) atomicAdd(&shI[GI_NTOOK], __popc(tookmask));
+        }
+        GTICK(9);
+        __syncthreads();                                                        // (S3) every claim of this sub-round is performed
+        GTICK(1);
+        if (tid == 0) { const int rq = shI[GI_REQ]; shI[GI_NFREECH] = pool_base - (rq < pool_base ? rq : pool_base); shI[GI_REQ] = 0; }
+        if (shI[GI_NTOOK] > 0) {                                                // uniform: somebody took a voxel over -> everybody reads back
+            uint32_t lost = 0;
+            if (active && wonm) {
+                unsigned long long now[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { now[k] = key; if (wonm & (1u << k)) now[k] = __hip_atomic_load(&state[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if ((wonm & (1u << k)) && now[k] != key) lost |= 1u << k;
+            }
+            if (lost) atomicAdd(&shI[GI_NLOST], __popc(lost));
+            // records for the matching (only looked at when the counts differ)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (tookmask & (1u << k)) {
+                    atomicMin(&shQ[GQ_TMIN], old[k]);
+                    const int i = atomicAdd(&shI[GI_NT], 1);
+                    if (i < GRP_TL) { tlk[0][i] = old[k]; tlv[0][i] = nbv[k]; }
+                }
+                if (lost & (1u << k)) {
+                    const int i = atomicAdd(&shI[GI_NL], 1);
+                    if (i < GRP_TL) { tlk[1][i] = key; tlv[1][i] = nbv[k]; }
+                }
+            }
+            wonm &= ~lost;
+            __syncthreads();                                                    // (S4)
+            if (shI[GI_NTOOK] != shI[GI_NLOST]) {
+                // a take-over hit a claim of an earlier sub-round: its holder (and everything behind it) is wrong
+                const int nT = shI[GI_NT], nL = shI[GI_NL];
+                if (nT > GRP_TL || nL > GRP_TL) { if (tid == 0) atomicMin(&shQ[GQ_KSQ], shQ[GQ_TMIN]); }     // record overflow: conservative
+                else {
+                    for (int t = tid; t < nT; t += GRP_W) {
+                        bool fresh = false;
+                        for (int l = 0; l < nL; ++l) if (tlk[1][l] == tlk[0][t] && tlv[1][l] == tlv[0][t]) fresh = true;
+                        if (!fresh) atomicMin(&shQ[GQ_KSQ], tlk[0][t]);
+                    }
+                }
+                if (tid == 0) atomicAdd(&lstat[GS_SLOW], 1u);
+            }
+        }
+        // discoveries (direction order = the reference's push order, watershed.py:146-158), next pop
+        GTICK(10);
+        if (active) {
+            if (started && cur_li >= 0) { pval[cur_addr] = WIN_POPPED; ++npop; if (curv > mx) mx = curv; }
+            started = true;
+            cur = GRP_NONE;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (wonm & (1u << k)) {
+                    const uint32_t v = ford(val[k] * sc[ax[k]] + 0.0f);
+                    if ((np % GRP_CH) == 0) {                                    // next chunk (reserved before the pop)
+                        const int ch = spare; spare = -1;
+                        cnext[ch] = (unsigned short)0xFFFFu;
+                        if (chfirst < 0) chfirst = ch; else cnext[chlast] = (unsigned short)ch;
+                        chlast = ch;
+                    }
+                    const int a = chlast * GRP_CH + np % GRP_CH;
+                    pvox[a] = nbv[k]; pval[a] = v;
+                    if (v < bound) cand_add(v, nbv[k], np, a); else if (v < resmin) resmin = v;
+                    ++np;
+                }
+            }
+            select_next(bound);
+            atomicAdd(&lstat[GS_EXEC], 1u);
+        }
+        GTICK(11);
+        __syncthreads();                                                        // (S5) lists written, take-over verdict in
+        GTICK(2);
+        {
+            const unsigned long long ksq = shQ[GQ_KSQ];
+            const bool any_sq = ksq != ~0ull;
+            if (any_sq) {
+                if (has && key >= ksq) squash_me();
+                if (tid == 0) atomicAdd(&lstat[GS_SQ_LOST], 1u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // an idle episode appends nothing more: its spare chunk goes back (frees only in this phase)
+            if (has && started && cur == GRP_NONE && spare >= 0) { freech[atomicAdd(&shI[GI_NFREECH], 1)] = (unsigned short)spare; spare = -1; }
+            if (has) { pub_res[tid] = resmin; pub_mx[tid] = mx; pub_info[tid] = (uint32_t)np | ((uint32_t)npop << 8) | ((started ? 1u : 0u) << 16) | ((started && cur == GRP_NONE ? 1u : 0u) << 17); }
+        }
+        __syncthreads();                                                        // (S6)
+        GTICK(3);
+        if (tid == 0) { shQ[GQ_KSQ] = ~0ull; shQ[GQ_TMIN] = ~0ull; shI[GI_NTOOK] = 0; shI[GI_NLOST] = 0; shI[GI_NT] = 0; shI[GI_NL] = 0; }
+        // ---- E: commit the idle episodes at the front, in order; bursts as wide as the window ------------------------------------------------
+        bool front_ready = shI[GI_FORCED] != 0 || ((pub_info[frontslot] >> 17) & 1u);
+        const bool forced_front = shI[GI_FORCED] != 0;
+        bool did_commit = false;
+        for (int burst = 0; front_ready && burst < (max_bursts & 0xFF) && shI[GI_NW] > 0 && !shI[GI_SERIAL]; ++burst) {
+            const int nwb = shI[GI_NW];
+            const unsigned long long qh = shI[GI_SCOUNT] > 0 ? srun[shI[GI_SHEAD]].key : ~0ull;
+            // the front episode with a full list (or an empty pool) commits what it has done: the element in hand and every
+            // candidate go back to the queue as residuals -- its owner rescans its list
+            const int fslot = (int)oslot[ord_at(0)];
+            if (burst == 0 && forced_front && tid == fslot && has && started && cur != GRP_NONE) {
+                uint32_t rm = 0xFFFFFFFFu;
+                int ch = chfirst;
+                for (int i = 0; i < np; ++i) {
+                    if (i && (i % GRP_CH) == 0) ch = (int)cnext[ch];
+                    const uint32_t v = pval[ch * GRP_CH + i % GRP_CH];
+                    if (v != WIN_POPPED && v < rm) rm = v;
+                }
+                cur = GRP_NONE; ncand = 0; ndef = 0; resmin = rm;
+                pub_res[tid] = rm; pub_info[tid] = (uint32_t)np | ((uint32_t)npop << 8) | (1u << 16) | (1u << 17);
+                atomicAdd(&lstat[GS_FORCED], 1u);
+            }
+            __syncthreads();                                                    // (E0)
+            // lane j = window position j
+            const int j = tid;
+            const bool valid = j < nwb;
+            const int s = valid ? (int)oslot[ord_at(j)] : 0;
+            const uint32_t info = valid ? pub_info[s] : 0u;
+            const bool idle = valid && ((info >> 17) & 1u);
+            const uint32_t e_np = info & 0xFFu, e_npop = (info >> 8) & 0xFFu;
+            const uint32_t e_res = valid ? pub_res[s] : 0xFFFFFFFFu, e_mx = valid ? pub_mx[s] : 0u;
+            const unsigned long long ek = valid ? okey[ord_at(j)] : ~0ull;
+            {
+                const unsigned long long nb_ = ~__ballot(idle);
+                if (lane == 0) wtmp[0][wave] = nb_ ? wave * 64 + __ffsll((long long)nb_) - 1 : (wave + 1) * 64;
+            }
+            __syncthreads();                                                    // (E1)
+            int m = GRP_W;
+#pragma unroll
+            for (int w = GRP_NWV - 1; w >= 0; --w) if (wtmp[0][w] < (w + 1) * 64) m = wtmp[0][w];
+            const bool inm = j < m;
+            const uint32_t pc = inm ? e_np - e_npop : 0u;
+            const uint32_t incl_min = wave_prefix_min(inm ? e_res : 0xFFFFFFFFu);
+            const uint32_t incl_pc = wave_incl_sum(pc), incl_np = wave_incl_sum(inm ? e_np : 0u);
+            if (lane == 63) { wtmp[1][wave] = (int)incl_min; wtmp[2][wave] = (int)incl_pc; wtmp[3][wave] = (int)incl_np; }
+            __syncthreads();                                                    // (E2)
+            uint32_t F = wave_shr1(incl_min, 0xFFFFFFFFu), poff = incl_pc - pc, nbase = incl_np - (inm ? e_np : 0u);
+#pragma unroll
+            for (int w = 0; w < GRP_NWV; ++w)
+                if (w < wave) { const uint32_t t = (uint32_t)wtmp[1][w]; F = t < F ? t : F; poff += (uint32_t)wtmp[2][w]; nbase += (uint32_t)wtmp[3][w]; }
+            const uint32_t qv = (uint32_t)(qh >> 32);
+            if (qv < F) F = qv;
+            uint32_t succv = 0xFFFFFFFFu;
+            if (valid && j + 1 < nwb) succv = (uint32_t)(okey[ord_at(j + 1)] >> 32);
+            const bool ok = inm && (uint32_t)(ek >> 32) <= F && (e_mx == 0u || (e_mx < F && e_mx < succv)) && poff + pc <= (uint32_t)GRP_PEND;
+            {
+                const unsigned long long nok = ~__ballot(ok);
+                if (lane == 0) wtmp[0][wave] = nok ? wave * 64 + __ffsll((long long)nok) - 1 : (wave + 1) * 64;
+            }
+            __syncthreads();                                                    // (E3)
+            int ncommit = GRP_W;
+#pragma unroll
+            for (int w = GRP_NWV - 1; w >= 0; --w) if (wtmp[0][w] < (w + 1) * 64) ncommit = wtmp[0][w];
+            if (ncommit > nwb) ncommit = nwb;
+            if (ncommit == 0) break;                                            // uniform
+            did_commit = true;
+            const uint32_t agebase = (uint32_t)shI[GI_AGEBASE];
+            if (j < ncommit) { ci_age[s] = agebase + nbase; ci_off[s] = poff; }
+            // cut only because `pend` is full?  then another burst of this sub-round takes the rest
+            if (j == ncommit && j < nwb)
+                shI[GI_ANY] = (inm && (uint32_t)(ek >> 32) <= F && (e_mx == 0u || (e_mx < F && e_mx < succv))) ? 1 : 0;
+            if (j == ncommit - 1) { shI[GI_NPTOT] = (int)(nbase + e_np); shI[GI_PENDN] = (int)(poff + pc); }
+            __syncthreads();                                                    // (E4) orders are out
+            GTICK(4);
+            // the committing lanes: labels (watershed.py:153), residuals in age order, chunks and slot back
+            if (has && ci_off[tid] != GRP_NONE) {
+                uint32_t po = ci_off[tid];
+                const uint32_t mybase = ci_age[tid];
+                int ch = chfirst;
+                for (int i = 0; i < np; ++i) {
+                    if (i && (i % GRP_CH) == 0) ch = (int)cnext[ch];
+                    const int a = ch * GRP_CH + i % GRP_CH;
+                    const uint32_t vx = pvox[a], f = pval[a];
+                    if (vx >= (uint32_t)PN) { if (stats) { atomicAdd(&stats[20], 1ull); stats[21] = 2ull; } continue; }
+                    __hip_atomic_store(&state[vx], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    out[vx] = lab;
+                    if (f != WIN_POPPED) {
+                        HeapEnt r;
+                        r.key = ((unsigned long long)f << 32) | (unsigned long long)(mybase + (uint32_t)i + 1u);
+                        r.idx = vx; r.pad = lab;
+                        pend[po++] = r;
+                    }
+                }
+                atomicAdd(&lstat[GS_POPS], (uint32_t)npop + 1u);
+                free_chunks();
+                has = false;
+                ci_off[tid] = GRP_NONE;
+                freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
+            }
+            __syncthreads();                                                    // (E5)
+            if (tid == 0) {
+                shI[GI_AGEBASE] = (int)(agebase + (uint32_t)shI[GI_NPTOT]);
+                shI[GI_OH] = (shI[GI_OH] + ncommit) & (GRP_W - 1);
+                shI[GI_NW] = nwb - ncommit;
+                atomicAdd(&lstat[GS_BURST], 1u);
+            }
+            __syncthreads();                                                    // (E6)
+            GTICK(5);
+            // ---- enqueue the burst's residuals --------------------------------------------------------------------------------------------
+            const int P = shI[GI_PENDN];
+            if (P > 0) {
+                // capacity first: an eviction moves the hot maximum, so the batch is judged against the tiers AFTER it
+                if (shI[GI_SCOUNT] + P > run_limit || shI[GI_SCOUNT] + P > COOP_SCAP - 8) {
+                    if (wave == 0) { int keep = run_limit / 2; if (keep > COOP_SCAP - GRP_PEND - 8) keep = COOP_SCAP - GRP_PEND - 8; run_evict_w0(keep); publish_cold(); }
+                    __syncthreads();
+                    if (shI[GI_SERIAL]) break;                                  // `pend` keeps the batch for the serial continuation
+                }
+                const int nw2 = shI[GI_NW], sc2 = shI[GI_SCOUNT], sh2 = shI[GI_SHEAD];
+                const bool hot_ne = nw2 > 0 || sc2 > 0;
+                const unsigned long long hot_max = sc2 > 0 ? srun[(sh2 + sc2 - 1) & SMASK].key : (nw2 > 0 ? okey[ord_at(nw2 - 1)] : 0ull);
+                const unsigned long long lastwin = nw2 > 0 ? okey[ord_at(nw2 - 1)] : 0ull;
+                const bool cold_ne = cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0);
+                HeapEnt r; r.key = 0; r.idx = 0; r.pad = 0;
+                const bool hasr = tid < P;
+                if (hasr) r = pend[tid];
+                const bool tocold = hasr && cold_ne && !(hot_ne && r.key < hot_max) && cold_bucket(cold, r.key) >= (uint32_t)shI[GI_COLD_LOW];
+                const bool towin = hasr && !tocold && nw2 > 0 && r.key < lastwin;
+                const bool torun = hasr && !tocold && !towin;
+                // three compactions (order inside a class is the age order of `pend`)
+                const unsigned long long bc = __ballot(tocold), bw = __ballot(towin), br = __ballot(torun);
+                if (lane == 0) { wtmp[0][wave] = __popcll(bc); wtmp[1][wave] = __popcll(bw); wtmp[2][wave] = __popcll(br); }
+                __syncthreads();
+                int oc = shI[GI_NSTAGE], ow = 0, orr = 0;
+#pragma unroll
+                for (int w = 0; w < GRP_NWV; ++w) if (w < wave) { oc += wtmp[0][w]; ow += wtmp[1][w]; orr += wtmp[2][w]; }
+                if (tocold) stage[oc + __popcll(bc & lt_mask)] = r;
+                // window-bound ones go back into `pend` (every lane has its element in a register by now), run-bound ones into
+                // `hotb`, which also takes the window-bound ones that turn out run-bound below: together at most P
+                if (towin) pend[ow + __popcll(bw & lt_mask)] = r;
+                if (torun) hotb[orr + __popcll(br & lt_mask)] = r;
+                __syncthreads();
+                if (tid == 0) {
+                    int tc = 0, tw = 0, tr = 0;
+                    for (int w = 0; w < GRP_NWV; ++w) { tc += wtmp[0][w]; tw += wtmp[1][w]; tr += wtmp[2][w]; }
+                    shI[GI_NSTAGE] += tc; shI[GI_NWB] = tw; shI[GI_NHOT] = tr; shI[GI_PENDN] = 0;
+                }
+                __syncthreads();
+                // window-bound residuals become roots at their sorted position, one at a time, each against the CURRENT last root
+                const int nwbnd = shI[GI_NWB];
+                for (int q = 0; q < nwbnd && !shI[GI_SERIAL]; ++q) {
+                    const HeapEnt e = pend[q];
+                    const int nw3 = shI[GI_NW];
+                    const bool into_win = nw3 > 0 && e.key < okey[ord_at(nw3 - 1)];
+                    if (!into_win) {                                           // an eviction moved the last root below it: run-bound after all
+                        __syncthreads();
+                        if (tid == 0) { hotb[shI[GI_NHOT]] = e; ++shI[GI_NHOT]; }
+                        __syncthreads();
+                        continue;
+                    }
+                    const bool full = nw3 == wcap || shI[GI_NFREESLOT] == 0;
+                    if (full && shI[GI_SCOUNT] >= COOP_SCAP - 2) {
+                        __syncthreads();
+                        if (wave == 0) { run_evict_w0(run_limit / 2); publish_cold(); }
+                        __syncthreads();
+                        if (shI[GI_SERIAL]) { if (tid == 0) { shI[GI_WB0] = q; } break; }     // [q, nwbnd) are still to be queued
+                    }
+                    // position
+                    {
+                        const bool lt = tid < nw3 && okey[ord_at(tid)] < e.key;
+                        const unsigned long long bl = __ballot(lt);
+                        if (lane == 0) wtmp[0][wave] = __popcll(bl);
+                    }
+                    const int ls3 = (int)oslot[ord_at(nw3 - 1)];
+                    __syncthreads();
+                    int pos = 0;
+#pragma unroll
+                    for (int w = 0; w < GRP_NWV; ++w) pos += wtmp[0][w];
+                    int nw4 = nw3;
+                    if (full) {
+                        // the last root goes back to the front of the run (it sorts below everything there)
+                        if (tid == ls3) {
+                            const int shn = (shI[GI_SHEAD] - 1) & SMASK;
+                            HeapEnt b; b.key = key; b.idx = root; b.pad = lab;
+                            srun[shn] = b;
+                            shI[GI_SHEAD] = shn; ++shI[GI_SCOUNT];
+                            squash_me();
+                            has = false;
+                            freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
+                            atomicAdd(&lstat[GS_WINEV], 1u);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                        --nw4;
+                        if (pos > nw4) pos = nw4;
+                    }
+                    // shift [pos, nw4) up by one
+                    unsigned long long mk_ = 0ull; unsigned short ms_ = 0;
+                    const bool mv = tid >= pos && tid < nw4;
+                    if (mv) { mk_ = okey[ord_at(tid)]; ms_ = oslot[ord_at(tid)]; }
+                    __syncthreads();
+                    if (mv) { okey[ord_at(tid + 1)] = mk_; oslot[ord_at(tid + 1)] = ms_; }
+                    if (tid == 0) {
+                        const int sl = (int)freeslot[--shI[GI_NFREESLOT]];
+                        okey[ord_at(pos)] = e.key; oslot[ord_at(pos)] = (unsigned short)sl;
+                        u32x4 nr = {(uint32_t)e.key, (uint32_t)(e.key >> 32), e.idx, e.pad};
+                        newroot[sl] = nr; newflag[sl] = 1u;
+                        shI[GI_NW] = nw4 + 1; shI[GI_DIRTY] = 1;
+                        shI[GI_POS] = pos;
+                        atomicAdd(&lstat[GS_WININS], 1u);
+                    }
+                    __syncthreads();
+                    if (tid == 0) {                                            // successor links of the new root and of its predecessor
+                        const int sl = (int)oslot[ord_at(pos)];
+                        succ[sl] = pos + 1 < nw4 + 1 ? okey[ord_at(pos + 1)] : ~0ull;
+                        if (pos > 0) succ[oslot[ord_at(pos - 1)]] = e.key;
+                        else { /* new front */ }
+                        if (full && pos < nw4) { /* last root changed: its successor is the run */ succ[oslot[ord_at(nw4)]] = ~0ull; }
+                        else if (full) succ[sl] = ~0ull;
+                    }
+                    __syncthreads();
+                    adopt();                                                    // the owner picks the root up at once (it may be evicted by the next insertion)
+                }
+                if (shI[GI_SERIAL]) break;
+                if (tid == 0) { shI[GI_NWB] = 0; shI[GI_WB0] = 0; }            // all of them are roots (or run-bound) now
+                // cold-bound ones: wave 0 appends them; the other waves merge the run-bound ones meanwhile
+                const int R = shI[GI_NHOT];
+                const int sc3 = shI[GI_SCOUNT], sh3 = shI[GI_SHEAD];
+                // a new element: rank among the new ones + number of run elements below it (against the run as it stands)
+                int mypos = -1; HeapEnt me; me.key = 0; me.idx = 0; me.pad = 0;
+                if (tid < R) {
+                    me = hotb[tid];
+                    int rk = 0;
+                    for (int q = 0; q < R; ++q) if (hotb[q].key < me.key) ++rk;
+                    int lo = 0, hi = sc3;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (srun[(sh3 + mid) & SMASK].key < me.key) lo = mid + 1; else hi = mid; }
+                    mypos = lo + rk;
+                }
+                // the run's own entries move up by the number of new keys below them, from the top of the run down, one entry
+                // per lane and round: an entry lands at or above its place, so a round never overwrites what a later round reads
+                if (R > 0 && sc3 > 0) {
+                    for (int base = ((sc3 - 1) / GRP_W) * GRP_W; base >= 0; base -= GRP_W) {
+                        const int pp = base + tid;
+                        const bool mv = pp < sc3;
+                        u32x4 e = {0u, 0u, 0u, 0u};
+                        int np2 = pp;
+                        if (mv) {
+                            e = run_ld(srun, (sh3 + pp) & SMASK);
+                            const unsigned long long k0 = ((unsigned long long)e.y << 32) | e.x;
+                            for (int q = 0; q < R; ++q) if (hotb[q].key < k0) ++np2;
+                        }
+                        __syncthreads();                                        // this round's entries (and, first round, the searches) are read
+                        if (mv && np2 != pp) run_st(srun, (sh3 + np2) & SMASK, e);
+                    }
+                } else __syncthreads();
+                if (mypos >= 0) srun[(sh3 + mypos) & SMASK] = me;
+                if (wave == 0 && shI[GI_NSTAGE] >= 64) { flush_stage_w0(); publish_cold(); }
+                if (tid == 0 && R > 0) { shI[GI_SCOUNT] = sc3 + R; shI[GI_NHOT] = 0; shI[GI_DIRTY] = 1; atomicAdd(&lstat[GS_RUNINS], (uint32_t)R); }
+                __syncthreads();
+                if (shI[GI_SERIAL]) break;
+            }
+            check_order(10 + burst);
+            if (ncommit < nwb && !shI[GI_ANY]) break;                           // uniform (GI_ANY: written before E4)
+            __syncthreads();
+            if (tid == 0) shI[GI_ANY] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) { shI[GI_FORCED] = 0; shI[GI_ANY] = 0; }
+        if (shI[GI_SERIAL]) continue;
+        GTICK(6);
+        // ---- G: refill the window from the run (from the buckets when the run is empty) ------------------------------------------------------
+        if (did_commit || shI[GI_NW] < wcap) {
+            for (;;) {
+                __syncthreads();
+                const bool need_drain = shI[GI_SCOUNT] == 0 && cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0);
+                if (need_drain) {
+                    if (wave == 0) grp_w0_drain(&scold, srun, stage, hist, shI, lstat, drain_n, lane);
+                    __syncthreads();
+                    if (shI[GI_SERIAL]) break;
+                }
+                const int nw5 = shI[GI_NW], sc5 = shI[GI_SCOUNT], sh5 = shI[GI_SHEAD], nf5 = shI[GI_NFREESLOT];
+                int take = wcap - nw5;
+                if (take > sc5) take = sc5;
+                if (take > nf5) take = nf5;
+                if (take <= 0) break;
+                if (tid < take) {
+                    const u32x4 e = run_ld(srun, (sh5 + tid) & SMASK);
+                    const int sl = (int)freeslot[nf5 - 1 - tid];
+                    okey[ord_at(nw5 + tid)] = ((unsigned long long)e.y << 32) | e.x;
+                    oslot[ord_at(nw5 + tid)] = (unsigned short)sl;
+                    newroot[sl] = e; newflag[sl] = 1u;
+                    unsigned long long nx = ~0ull;
+                    if (tid + 1 < take) { const u32x4 e2 = run_ld(srun, (sh5 + tid + 1) & SMASK); nx = ((unsigned long long)e2.y << 32) | e2.x; }
+                    succ[sl] = nx;
+                    if (tid == 0 && nw5 > 0) succ[oslot[ord_at(nw5 - 1)]] = ((unsigned long long)e.y << 32) | e.x;
+                }
+                __syncthreads();
+                if (tid == 0) { shI[GI_NW] = nw5 + take; shI[GI_SCOUNT] = sc5 - take; shI[GI_SHEAD] = (sh5 + take) & SMASK; shI[GI_NFREESLOT] = nf5 - take; }
+            }
+        }
+        GTICK(7);
+        check_order(30);
+        // the front's reserve is topped up from the pool (nobody allocates or frees between here and the next (S0))
+        if (tid == 0) { while (shI[GI_NRES] < reserve && shI[GI_NFREECH] > 0) resch[shI[GI_NRES]++] = freech[--shI[GI_NFREECH]]; }
+    }
+    __syncthreads();
+
+#ifdef ISX_FLOOD_PROF
+    // phase timers of the work-group's first lane: 0 bounds (A), 1 claims up to (S3), 2 read-back + lists + next pop, 3 squash + publish,
+    // 4 commit decision, 5 labels + residuals, 6 enqueue, 7 refill + drains, 8 loop end
+    if (stats && tid == 0) for (int i = 0; i < 12; ++i) atomicAdd(&stats[32 + i], tk_acc[i]);
+#endif
+#undef GTICK
+    if (stats && tid == 0) {
+        atomicAdd(&stats[0], (unsigned long long)st_sub);
+        atomicAdd(&stats[1], (unsigned long long)lstat[GS_POPS]);
+        atomicAdd(&stats[2], (unsigned long long)lstat[GS_EXEC]);
+        atomicAdd(&stats[3], (unsigned long long)lstat[GS_RUNINS]);
+        atomicAdd(&stats[4], (unsigned long long)lstat[GS_COLD]);
+        atomicAdd(&stats[5], (unsigned long long)lstat[GS_DRAIN]);
+        atomicAdd(&stats[6], (unsigned long long)lstat[GS_WINEV]);
+        atomicAdd(&stats[7], (unsigned long long)lstat[GS_WININS]);
+        atomicAdd(&stats[11], (unsigned long long)lstat[GS_SQ_LOST]);
+        atomicAdd(&stats[12], (unsigned long long)lstat[GS_SQ_EPS]);
+        atomicAdd(&stats[14], (unsigned long long)lstat[GS_SQ_BOUND]);
+        atomicAdd(&stats[15], (unsigned long long)lstat[GS_FORCED]);
+        atomicAdd(&stats[19], (unsigned long long)lstat[GS_SLOW]);
+        atomicAdd(&stats[17], (unsigned long long)lstat[GS_BURST]);
+        atomicAdd(&stats[18], (unsigned long long)lstat[GS_RELOAD]);
+        if (shI[GI_SERIAL]) atomicAdd(&stats[8], 1ull);
+    }
+    if (shI[GI_SERIAL]) {
+        // Exact continuation on one lane: every queued element (window roots -- their speculative work is dropped, `out`
+        // only ever holds committed labels --, run, staged, pending residuals, buckets) goes into the binary heap.
+        const int mode = shI[GI_SERIAL];
+        if (max_bursts & 0x200) {            // development: no continuation, only report that (and where) it was asked for
+            if (tid == 0 && stats) { atomicAdd(&stats[22], 1ull); stats[23] = (unsigned long long)mode | ((unsigned long long)st_sub << 8) | ((unsigned long long)csize << 32); }
+            return;
+        }
+        adopt();                                                                // a root handed to this slot but not picked up yet
+        if (has) { u32x4 r = {(uint32_t)key, (uint32_t)(key >> 32), root, lab}; newroot[tid] = r; }
+        newflag[tid] = has ? 1u : 0u;
+        __syncthreads();
+        if (wave != 0) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t hn = 0;
+        if (mode == 2) {
+            if (lane == 0)
+                for (uint32_t j = 0; j < ns; ++j) {
+                    HeapEnt e; e.key = ZKEY | (unsigned long long)j; e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull); e.pad = 0;
+                    heap_push(heap, hn, e);
+                }
+        } else {
+            if (lane == 0) {
+                for (int s = 0; s < GRP_W; ++s)
+                    if (newflag[s]) { const u32x4 r = newroot[s]; HeapEnt e; e.key = ((unsigned long long)r.y << 32) | r.x; e.idx = r.z; e.pad = 0; heap_push(heap, hn, e); }
+                const int sc = shI[GI_SCOUNT], sh_ = shI[GI_SHEAD];
+                for (int j = 0; j < sc; ++j) { HeapEnt e = srun[(sh_ + j) & SMASK]; e.pad = 0; heap_push(heap, hn, e); }
+                for (int j = 0; j < shI[GI_NSTAGE]; ++j) { HeapEnt e = stage[j]; e.pad = 0; heap_push(heap, hn, e); }
+                for (int j = 0; j < shI[GI_PENDN]; ++j) { HeapEnt e = pend[j]; e.pad = 0; heap_push(heap, hn, e); }
+                for (int j = 0; j < shI[GI_NHOT]; ++j) { HeapEnt e = hotb[j]; e.pad = 0; heap_push(heap, hn, e); }
+                for (int j = shI[GI_WB0]; j < shI[GI_NWB]; ++j) { HeapEnt e = pend[j]; e.pad = 0; heap_push(heap, hn, e); }
+            }
+            hn = grp_w0_collect_cold(&scold, heap, hn, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // sanity of what the continuation was handed (an element outside the volume or more elements than the component has
+        // voxels would take the heap or the flood out of bounds): reported, the component is left as it is
+        {
+            const uint32_t hn0 = rdlane(hn, 0);
+            bool bad = (unsigned long long)hn0 > csize;
+            for (uint32_t j = lane; j < hn0 && j < (uint32_t)csize; j += 64) if (cld_ent(&heap[j]).idx >= (uint32_t)PN) bad = true;
+            if (__any(bad)) {
+                if (lane == 0 && stats) { atomicAdd(&stats[20], 1ull); stats[21] = 100ull + (unsigned long long)mode; }
+                return;
+            }
+        }
+        if (lane == 0) serial_flood(heap, hn, (uint32_t)shI[GI_AGEBASE], aff, mask, out, PY, PX, PN, s0, s1, s2);
+    }
+}

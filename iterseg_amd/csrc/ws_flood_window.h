@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
     int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long coop_min_size, int run_limit,
     int drain_n, int wcap, int tcap, int max_bursts, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world,
-    uint32_t *dbg_log)
+    uint32_t *dbg_log, unsigned long long coop_max_size)
 {
     __shared__ HeapEnt srun[WIN_RCAP];            // .pad carries the element's label
     __shared__ HeapEnt stage[WIN_STAGE];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     const uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
     if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;
     const unsigned long long csize = comp_off[c + 1] - comp_off[c];
-    if (csize < coop_min_size) return;
+    if (csize < coop_min_size || csize >= coop_max_size) return;     // larger ones: flood_group_kernel (ws_flood_group.h)
     HeapEnt *heap = heap_pool + comp_off[c];
     const uint32_t ns = end - first;
 
@@ -228,6 +228,10 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             return;
         }
         scount = keep;
+        // always-on tier assertion (the cheap form of the development build's check_tiers): the hot maximum may not lie in a
+        // bucket above the lowest non-empty cold one; reported through stats[16] like the watchdog (host: ISX_ERR_INTERNAL)
+        if (stats && keep > 0 && cold.count > 0 && cold_bucket(cold, srun[(shead + keep - 1) & SMASK].key) > cold.low && lane == 0)
+            atomicAdd(&stats[16], 1ull);
     };
 
     // sorted insert of one (wave-uniform) element into the circular LDS run

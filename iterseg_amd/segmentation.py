@@ -167,10 +167,19 @@ class FramePipe:
         if out is None:
             out = np.empty(self.shape, np.uint32)
         assert out.flags.c_contiguous and out.itemsize == 4 and tuple(out.shape) == self.shape
+        if not self._keep:
+            raise ValueError("FramePipe.wait() without a frame in flight")
         rc = self.unet.ctx.lib.isx_pipe_wait(self._h, out.ctypes.data_as(C.c_void_p), 2)
         self._keep.popleft()
         _lib.check(rc)
         return out
+
+    def drain(self):
+        """Discard whatever is still in flight (after an error): the pipe is reusable afterwards."""
+        scratch = np.empty(self.shape, np.uint32)
+        while self._keep:
+            self.unet.ctx.lib.isx_pipe_wait(self._h, scratch.ctypes.data_as(C.c_void_p), 2)
+            self._keep.popleft()
 
     def close(self):
         if self._h:
@@ -273,7 +282,7 @@ def _pipelined_frames(data, chunk_size, margin, output_labels, config):
     already in flight, and a frame whose shape it changes is redone through the one-frame path."""
     u = config['unet']
     shape = tuple(int(v) for v in data.shape[-3:])
-    pipe = FramePipe(u, shape, chunk_size, margin, depth=2)
+    pipe = _pipe_for(u, shape, chunk_size, margin)
     direct = isinstance(output_labels, np.ndarray) and output_labels.dtype.itemsize == 4
     pending = collections.deque()                 # (t, reduced frame or None)
 
@@ -311,7 +320,22 @@ def _pipelined_frames(data, chunk_size, margin, output_labels, config):
         while pending:
             yield finish()
     finally:
-        pipe.close()
+        pipe.drain()          # only non-empty after an error; the pipe itself stays with the U-Net for the next stack
+
+
+def _pipe_for(unet, shape, chunk_size, margin):
+    """The U-Net's frame pipe for this geometry: its slots (two device frames + label blocks, the feature map, 2 x 2
+    pinned staging buffers -- 9 GB at 512^3) are allocated once and kept until the geometry changes or the U-Net's
+    context goes away (``UNet._drop_pipe``), like the context's own workspace cache."""
+    m = tuple(margin) if not isinstance(margin, int) else (margin,) * 3
+    key = (tuple(int(v) for v in shape), tuple(int(v) for v in chunk_size), tuple(int(v) for v in m))
+    cached = getattr(unet, "_frame_pipe", None)
+    if cached is not None and cached[0] == key and cached[1]._h:
+        return cached[1]
+    unet._drop_pipe()
+    pipe = FramePipe(unet, key[0], key[1], key[2], depth=2)
+    unet._frame_pipe = (key, pipe)
+    return pipe
 
 
 def segment_single_volume(input_volume, chunk_size, config, margin, processing_function):

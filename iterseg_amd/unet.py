@@ -64,6 +64,7 @@ class UNet:
             sd[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
         _weights.check_state_dict(sd, self.in_channels, self._schema_out)      # strict key/shape check
         if self._loaded:                          # a committed context cannot be re-loaded: start a new one
+            self._drop_pipe()
             self.ctx.close()
             # the trainer bound to the old context (if any) is gone with it: state_dict() must not read its buffers
             self._train_params = None
@@ -133,6 +134,19 @@ class UNet:
         names = [f"{m}.conv{j}" for m in mods for j in (0, 1)]
         kind = {0: "fp32", 1: "reduced", 2: "fp32-range-fallback"}
         return {names[i]: kind[modes[i]] for i in range(n)}
+
+    def _drop_pipe(self):
+        """Free the cached frame pipe (segmentation._pipe_for): it holds device and pinned memory of this context."""
+        cached = getattr(self, "_frame_pipe", None)
+        self._frame_pipe = None
+        if cached is not None:
+            cached[1].close()
+
+    def __del__(self):
+        try:
+            self._drop_pipe()        # before the context: isx_pipe_destroy synchronises on it
+        except Exception:
+            pass
 
     def set_batch(self, batch):
         _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch)))

@@ -162,6 +162,19 @@ FLOOD_ENVS = {
     "win-shortlist": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000", "ISX_FLOOD_LIST": "8"},
     "win-mid": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_WIN": "17", "ISX_FLOOD_LIST": "12",
                 "ISX_FLOOD_RUN_LIMIT": "40", "ISX_FLOOD_DRAIN": "16"},
+    # the work-group kernel (ws_flood_group.h: one episode per lane, 512-wide window, chunked lists) for EVERY component:
+    # defaults, LDS tiers only (overflow -> hand-over to the serial heap), a tiny hot tier, a window of one / three episodes
+    # with the shortest lists (forced commits of the front), short lists, a mid-size window, one commit burst per sub-round
+    "group-all": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1"},
+    "group-nocold": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000", "ISX_FLOOD_GROUP_MIN": "1"},
+    "group-cold-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "8",
+                        "ISX_FLOOD_DRAIN": "4"},
+    "group-win-one": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_GWIN": "1"},
+    "group-win-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_GWIN": "3",
+                       "ISX_FLOOD_GLIST": "6", "ISX_FLOOD_RUN_LIMIT": "8", "ISX_FLOOD_DRAIN": "4"},
+    "group-shortlist": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_GLIST": "8"},
+    "group-mid": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_GWIN": "17",
+                  "ISX_FLOOD_GLIST": "12", "ISX_FLOOD_RUN_LIMIT": "40", "ISX_FLOOD_DRAIN": "16", "ISX_FLOOD_BURSTS": "1"},
     # the round-based wave kernel of round 1 (kept selectable for A/B runs)
     "wave-legacy": {"ISX_FLOOD_MODE": "wave", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "96",
                     "ISX_FLOOD_DRAIN": "48"},
