@@ -25,11 +25,14 @@
 // take-over that hit a claim of an EARLIER sub-round (take-overs != fresh losses, then matched entry by entry) squashes
 // from the victim's key.
 
-static constexpr int GRP_W = 256;                 // lanes = episode slots
+#ifndef ISX_GRP_W
+#define ISX_GRP_W 256
+#endif
+static constexpr int GRP_W = ISX_GRP_W;           // lanes = episode slots
 static constexpr int GRP_NWV = GRP_W / 64;        // waves
-static constexpr int GRP_T = 192;                 // discoveries one episode may hold
+static constexpr int GRP_T = GRP_W > 256 ? 128 : 192;   // discoveries one episode may hold (LDS: the chunk table is GRP_W x GRP_T / 8)
 static constexpr int GRP_CH = 8;                  // entries per chunk
-static constexpr int GRP_NCH = GRP_W + GRP_W / 2; // chunks in the pool
+static constexpr int GRP_NCH = GRP_W > 256 ? 640 : GRP_W + GRP_W / 2;   // chunks in the pool
 static constexpr int GRP_CMAX = 6;                // register candidates
 static constexpr int GRP_PEND = GRP_W;            // residuals of one commit burst (one per lane in the enqueue)
 static constexpr int GRP_STAGE = GRP_PEND + 64;   // staged cold-bound elements
@@ -39,8 +42,8 @@ static constexpr unsigned long long GROUP_MIN_SIZE = 0;        // 0: off by defa
 
 enum { GI_OH, GI_NW, GI_SHEAD, GI_SCOUNT, GI_NSTAGE, GI_NFREECH, GI_NFREESLOT, GI_SERIAL, GI_FORCED, GI_NTOOK, GI_NLOST, GI_NT, GI_NL,
        GI_DIRTY, GI_COLD_COUNT, GI_COLD_LOW, GI_M, GI_NCOMMIT, GI_PENDN, GI_NHOT, GI_NWB, GI_AGEBASE, GI_NPTOT, GI_ANY, GI_TAKE, GI_POS,
-       GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_N };
-enum { GQ_KSQ, GQ_TMIN, GQ_N };
+       GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_FRONT, GI_LAST, GI_NRELOAD, GI_N };
+enum { GQ_KSQ, GQ_TMIN, GQ_QHEAD, GQ_N };
 enum { GS_SUB, GS_POPS, GS_EXEC, GS_SQ_EPS, GS_SQ_BOUND, GS_SQ_LOST, GS_SLOW, GS_FORCED, GS_RELOAD, GS_RUNINS, GS_WININS, GS_WINEV, GS_COLD,
        GS_DRAIN, GS_BURST, GS_N };
 
@@ -194,7 +197,8 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     __shared__ HeapEnt pend[GRP_PEND];
     __shared__ HeapEnt hotb[GRP_PEND];
     __shared__ uint32_t pvox[GRP_NCH * GRP_CH], pval[GRP_NCH * GRP_CH];
-    __shared__ unsigned short cnext[GRP_NCH], freech[GRP_NCH];
+    __shared__ unsigned short freech[GRP_NCH];
+    __shared__ unsigned short chtab[GRP_W][GRP_T / GRP_CH];             // chunk c of the list of slot s (entry i lives in chunk i / 8)
     __shared__ unsigned short resch[GRP_T / GRP_CH + 2];                 // the front episode's reserve (one full list)
     __shared__ unsigned long long okey[GRP_W], succ[GRP_W];
     __shared__ unsigned short oslot[GRP_W], freeslot[GRP_W];
@@ -270,90 +274,121 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     int cur_addr = -1, cur_li = -1, np = 0, npop = 0;
     uint32_t mx = 0, resmin = 0xFFFFFFFFu;
     int ncand = 0, ndef = 0;
-    uint32_t cv[GRP_CMAX], cx[GRP_CMAX], cla[GRP_CMAX];           // cla: list index << 16 | pool address
-    int chfirst = -1, chlast = -1, spare = -1;
+    // register candidates: value << 32 | discovery index << 16 | pool address -- one 64-bit compare orders them like the
+    // reference orders its heap entries of one episode (value, then push order)
+    unsigned long long ck[GRP_CMAX];
+    int chlast = -1, spare = -1;
 #pragma unroll
-    for (int k = 0; k < GRP_CMAX; ++k) { cv[k] = 0; cx[k] = 0; cla[k] = 0; }
+    for (int k = 0; k < GRP_CMAX; ++k) ck[k] = ~0ull;
 
     auto ep_fresh = [&]() {
         started = false; cur = root; curv = 0; cur_addr = -1; cur_li = -1; np = 0; npop = 0; mx = 0; resmin = 0xFFFFFFFFu;
-        ncand = 0; ndef = 0; chfirst = -1; chlast = -1; spare = -1;
+        ncand = 0; ndef = 0; chlast = -1; spare = -1;
     };
-    auto free_chunks = [&]() {                       // pushes only: never in a phase that allocates
-        for (int ch = chfirst; ch >= 0;) { const int n = cnext[ch] == 0xFFFFu ? -1 : (int)cnext[ch]; freech[atomicAdd(&shI[GI_NFREECH], 1)] = (unsigned short)ch; ch = n; }
+    auto free_chunks = [&]() {                       // pushes only: never in a phase that allocates (uses np: call before ep_fresh)
+        const int nc = (np + GRP_CH - 1) / GRP_CH;
+        for (int c2 = 0; c2 < nc; ++c2) freech[atomicAdd(&shI[GI_NFREECH], 1)] = chtab[tid][c2];
         if (spare >= 0) freech[atomicAdd(&shI[GI_NFREECH], 1)] = (unsigned short)spare;
-        chfirst = chlast = spare = -1;
+        chlast = spare = -1;
     };
     auto squash_me = [&]() {
         if (started) {
             atomicAdd(&lstat[GS_SQ_EPS], 1u);
-            int ch = chfirst;
+            int ch = 0;
             for (int i = 0; i < np; ++i) {
-                if (i && (i % GRP_CH) == 0) ch = (int)cnext[ch];
-                const uint32_t vq = pvox[ch * GRP_CH + i % GRP_CH];
+                if ((i & (GRP_CH - 1)) == 0) ch = (int)chtab[tid][i >> 3];
+                const uint32_t vq = pvox[ch * GRP_CH + (i & (GRP_CH - 1))];
                 if (vq < (uint32_t)PN) atomicCAS(&state[vq], key, ST_FREE);
                 else if (stats) { atomicAdd(&stats[20], 1ull); stats[21] = 1ull; }
             }
         }
         free_chunks();
         ep_fresh();
+        pub_info[tid] = 0u; pub_res[tid] = 0xFFFFFFFFu; pub_mx[tid] = 0u;      // "not started" is what the commit phase must see
     };
-    // candidate order: (value, discovery index); every deferred entry sorts after every register candidate
-    auto cand_add = [&](uint32_t v, uint32_t x, int li, int ad) {
-        const uint32_t la = ((uint32_t)li << 16) | (uint32_t)ad;
-        int mk = -1; uint32_t mv = 0, ml = 0;
+    // every deferred entry (below the bound, unpopped, only in the list) sorts after every register candidate
+    auto cand_add = [&](uint32_t v, int li, int ad) {
+        const unsigned long long nk_ = ((unsigned long long)v << 32) | ((unsigned long long)(uint32_t)li << 16) | (unsigned long long)(uint32_t)ad;
+        if (ndef == 0 && ncand < GRP_CMAX) {
 #pragma unroll
-        for (int k = 0; k < GRP_CMAX; ++k)
-            if (k < ncand && (mk < 0 || mv < cv[k] || (mv == cv[k] && ml < (cla[k] >> 16)))) { mk = k; mv = cv[k]; ml = cla[k] >> 16; }
-        const bool below_max = mk >= 0 && (v < mv || (v == mv && (uint32_t)li < ml));
-        if (ncand < GRP_CMAX && (ndef == 0 || below_max)) {
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) ck[k] = nk_;
+            ++ncand;
+            return;
+        }
+        int mk = -1; unsigned long long mv = 0ull;
 #pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) { cv[k] = v; cx[k] = x; cla[k] = la; }
+        for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand && (mk < 0 || ck[k] > mv)) { mk = k; mv = ck[k]; }
+        const bool below_max = mk >= 0 && nk_ < mv;
+        if (ncand < GRP_CMAX && below_max) {
+#pragma unroll
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) ck[k] = nk_;
             ++ncand;
             return;
         }
         if (ncand == GRP_CMAX && below_max) {
 #pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) { cv[k] = v; cx[k] = x; cla[k] = la; }
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) ck[k] = nk_;
         }
         ++ndef;
     };
-    auto reload = [&](uint32_t bound) {             // candidates / deferred count / resmin from the list
-        ncand = 0; ndef = 0; resmin = 0xFFFFFFFFu;
-        atomicAdd(&lstat[GS_RELOAD], 1u);
-        int ch = chfirst;
-        for (int i = 0; i < np; ++i) {
-            if (i && (i % GRP_CH) == 0) ch = (int)cnext[ch];
-            const int a = ch * GRP_CH + i % GRP_CH;
-            const uint32_t v = pval[a];
-            if (v == WIN_POPPED) continue;
-            if (cur != GRP_NONE && a == cur_addr) continue;
-            if (v < bound) cand_add(v, pvox[a], i, a);
-            else if (v < resmin) resmin = v;
-        }
-    };
-    auto select_next = [&](uint32_t bound) {
-        if (ncand == 0 && ndef > 0) reload(bound);
-        int mk = -1; uint32_t mv = 0, ml = 0;
+    // The candidates of lane L's episode rebuilt from its list by the WHOLE wave (three entries per lane): candidates,
+    // deferred count and the minimum of the residuals.  Runs when the six registers are used up and discoveries below
+    // the bound remain in the list only -- a long descent does that every few pops, and one lane walking 190 entries
+    // (with every other lane of the work-group waiting at the next barrier) was the single most expensive step.
+    auto coop_reload = [&](int L, uint32_t bnd) {
+        const int slot = (wave << 6) + L;
+        const int npL = (int)rdlane((uint32_t)np, L);
+        unsigned long long k3[3];
+        uint32_t rm = 0xFFFFFFFFu, cnt = 0;
 #pragma unroll
-        for (int k = 0; k < GRP_CMAX; ++k)
-            if (k < ncand && (mk < 0 || cv[k] < mv || (cv[k] == mv && (cla[k] >> 16) < ml))) { mk = k; mv = cv[k]; ml = cla[k] >> 16; }
-        if (mk >= 0 && mv < bound) {
-            uint32_t lx = 0, ll = 0, lv = 0;
-#pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) {
-                if (k == mk) { cur = cx[k]; curv = cv[k]; cur_addr = (int)(cla[k] & 0xFFFFu); cur_li = (int)(cla[k] >> 16); }
-                if (k == ncand - 1) { lx = cx[k]; ll = cla[k]; lv = cv[k]; }
+        for (int u = 0; u < 3; ++u) {
+            const int i = lane + 64 * u;
+            k3[u] = ~0ull;
+            if (i < npL) {
+                const int a = (int)chtab[slot][i >> 3] * GRP_CH + (i & (GRP_CH - 1));
+                const uint32_t v = pval[a];
+                if (v != WIN_POPPED) {
+                    if (v < bnd) { k3[u] = ((unsigned long long)v << 32) | ((unsigned long long)(uint32_t)i << 16) | (unsigned long long)(uint32_t)a; ++cnt; }
+                    else if (v < rm) rm = v;
+                }
             }
+        }
+        const uint32_t total = rdlane(wave_incl_sum(cnt), 63);
+        const uint32_t rmin = rdlane(wave_prefix_min(rm), 63);
 #pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) { cx[k] = lx; cla[k] = ll; cv[k] = lv; }
+        for (int r = 0; r < GRP_CMAX; ++r) {
+            unsigned long long m = k3[0] < k3[1] ? k3[0] : k3[1];
+            m = k3[2] < m ? k3[2] : m;
+            const uint32_t vmin = rdlane(wave_prefix_min((uint32_t)(m >> 32)), 63);
+            const uint32_t lmin = rdlane(wave_prefix_min((uint32_t)(m >> 32) == vmin ? (uint32_t)m : 0xFFFFFFFFu), 63);
+            const unsigned long long best = ((unsigned long long)vmin << 32) | lmin;
+            if (lane == L) ck[r] = vmin != 0xFFFFFFFFu ? best : ~0ull;
+            if (vmin != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) if (k3[u] == best) k3[u] = ~0ull;
+            }
+        }
+        if (lane == L) { ncand = (int)(total < (uint32_t)GRP_CMAX ? total : (uint32_t)GRP_CMAX); ndef = (int)total - ncand; resmin = rmin; }
+    };
+    // next pop: the smallest unpopped discovery if it sorts below the bound (never called with ncand == 0 && ndef > 0)
+    auto select_next = [&](uint32_t bound) {
+        int mk = -1; unsigned long long mv = ~0ull;
+#pragma unroll
+        for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand && ck[k] < mv) { mk = k; mv = ck[k]; }
+        if (mk >= 0 && (uint32_t)(mv >> 32) < bound) {
+            curv = (uint32_t)(mv >> 32); cur_li = (int)((mv >> 16) & 0xFFFFull); cur_addr = (int)(mv & 0xFFFFull);
+            cur = pvox[cur_addr];
+            unsigned long long lastk = ~0ull;
+#pragma unroll
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand - 1) lastk = ck[k];
+#pragma unroll
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) ck[k] = lastk;
             --ncand;
             return;
         }
-#pragma unroll
-        for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand && cv[k] < resmin) resmin = cv[k];
-        ncand = 0;
-        if (ndef > 0) reload(bound);                 // the deferred ones sort after every candidate, i.e. at or above the bound
+        // idle: what is left in the registers sorts at or above the bound, and every deferred entry sorts after every
+        // register candidate -- the smallest candidate is the smallest of all of them
+        if (mk >= 0 && (uint32_t)(mv >> 32) < resmin) resmin = (uint32_t)(mv >> 32);
         ncand = 0; ndef = 0;
         cur = GRP_NONE;
     };
@@ -369,6 +404,12 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     };
     uint32_t st_sub = 0;
     auto ord_at = [&](int p) -> int { return (shI[GI_OH] + p) & (GRP_W - 1); };
+    // lane 0, end of a sub-round: what every lane needs at the top of the next one (front / last slot, head of the run)
+    auto publish_heads = [&]() {
+        const int nwp = shI[GI_NW];
+        if (nwp > 0) { shI[GI_FRONT] = (int)oslot[ord_at(0)]; shI[GI_LAST] = (int)oslot[ord_at(nwp - 1)]; }
+        shQ[GQ_QHEAD] = shI[GI_SCOUNT] > 0 ? srun[shI[GI_SHEAD]].key : ~0ull;
+    };
     // development (ISX_FLOOD_BURSTS bit 0x400): window sorted, window <= run head, run sorted -- the first violation is
     // reported with its tag and the component stops (all lanes call it, between barriers)
     auto check_order = [&](int tag) {
@@ -432,6 +473,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             else if (wave == 0) grp_w0_seed_append(&scold, keys, first, in_hot, ns, out, shI, lane);
         }
         __syncthreads();
+        if (tid == 0) publish_heads();
     }
 
 #ifdef ISX_FLOOD_PROF
@@ -490,8 +532,8 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         if (tid == 0 && stats && shI[GI_SCOUNT] == 0 && cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0)) {
             if (atomicAdd(&stats[20], 1ull) == 0ull) { stats[21] = 200ull; stats[10] = (unsigned long long)st_sub | ((unsigned long long)shI[GI_COLD_COUNT] << 32); }
         }
-        const unsigned long long qhead = shI[GI_SCOUNT] > 0 ? srun[shI[GI_SHEAD]].key : ~0ull;
-        const int lastslot = (int)oslot[ord_at(nw - 1)], frontslot = (int)oslot[ord_at(0)];
+        const unsigned long long qhead = shQ[GQ_QHEAD];                         // published by lane 0 at the end of the last sub-round
+        const int lastslot = shI[GI_LAST], frontslot = shI[GI_FRONT];
         const bool dirty = shI[GI_DIRTY] != 0;
         // ---- A: an episode that popped (or holds) something at or above its bound is wrong; a bound only drops after an
         //         insertion right behind the episode, so the check runs after insertions only -------------------------------------------
@@ -506,12 +548,12 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 // candidates that the lower bound turned into residuals
 #pragma unroll
                 for (int k = GRP_CMAX - 1; k >= 0; --k) {
-                    if (k < ncand && cv[k] >= bound) {
-                        if (cv[k] < resmin) resmin = cv[k];
-                        uint32_t lx = 0, ll = 0, lv = 0;
+                    if (k < ncand && (uint32_t)(ck[k] >> 32) >= bound) {
+                        if ((uint32_t)(ck[k] >> 32) < resmin) resmin = (uint32_t)(ck[k] >> 32);
+                        unsigned long long lastk = ~0ull;
 #pragma unroll
-                        for (int q = 0; q < GRP_CMAX; ++q) if (q == ncand - 1) { lx = cx[q]; ll = cla[q]; lv = cv[q]; }
-                        cx[k] = lx; cla[k] = ll; cv[k] = lv;
+                        for (int q = 0; q < GRP_CMAX; ++q) if (q == ncand - 1) lastk = ck[q];
+                        ck[k] = lastk;
                         --ncand;
                     }
                 }
@@ -633,39 +675,50 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             for (int k = 0; k < 6; ++k) {
                 if (wonm & (1u << k)) {
                     const uint32_t v = ford(val[k] * sc[ax[k]] + 0.0f);
-                    if ((np % GRP_CH) == 0) {                                    // next chunk (reserved before the pop)
-                        const int ch = spare; spare = -1;
-                        cnext[ch] = (unsigned short)0xFFFFu;
-                        if (chfirst < 0) chfirst = ch; else cnext[chlast] = (unsigned short)ch;
-                        chlast = ch;
+                    if ((np & (GRP_CH - 1)) == 0) {                              // next chunk (reserved before the pop)
+                        chlast = spare; spare = -1;
+                        chtab[tid][np >> 3] = (unsigned short)chlast;
                     }
-                    const int a = chlast * GRP_CH + np % GRP_CH;
+                    const int a = chlast * GRP_CH + (np & (GRP_CH - 1));
                     pvox[a] = nbv[k]; pval[a] = v;
-                    if (v < bound) cand_add(v, nbv[k], np, a); else if (v < resmin) resmin = v;
+                    if (v < bound) cand_add(v, np, a); else if (v < resmin) resmin = v;
                     ++np;
                 }
             }
+        }
+        {   // register candidates used up while the list still holds discoveries below the bound: rebuilt by the wave
+            unsigned long long need = __ballot(active && ncand == 0 && ndef > 0);
+            if (need && lane == 0) atomicAdd(&lstat[GS_RELOAD], (uint32_t)__popcll(need));
+            while (need) {
+                const int L = __ffsll((long long)need) - 1;
+                coop_reload(L, rdlane(bound, L));
+                need &= need - 1ull;
+            }
+        }
+        if (active) {
             select_next(bound);
-            atomicAdd(&lstat[GS_EXEC], 1u);
+            pub_res[tid] = resmin; pub_mx[tid] = mx;
+            pub_info[tid] = (uint32_t)np | ((uint32_t)npop << 8) | (1u << 16) | ((cur == GRP_NONE ? 1u : 0u) << 17);
+        }
+        {
+            const unsigned long long ab = __ballot(active);
+            if (ab && lane == 0) atomicAdd(&lstat[GS_EXEC], (uint32_t)__popcll(ab));
         }
         GTICK(11);
-        __syncthreads();                                                        // (S5) lists written, take-over verdict in
+        __syncthreads();                                                        // (S5) lists written and published, take-over verdict in
         GTICK(2);
         {
             const unsigned long long ksq = shQ[GQ_KSQ];
-            const bool any_sq = ksq != ~0ull;
-            if (any_sq) {
-                if (has && key >= ksq) squash_me();
+            if (ksq != ~0ull) {                                                 // uniform
+                if (has && key >= ksq) squash_me();                             // (publishes "not started")
                 if (tid == 0) atomicAdd(&lstat[GS_SQ_LOST], 1u);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
-            // an idle episode appends nothing more: its spare chunk goes back (frees only in this phase)
+            // an idle episode appends nothing more: its spare chunk goes back (frees only from here to the end of the sub-round)
             if (has && started && cur == GRP_NONE && spare >= 0) { freech[atomicAdd(&shI[GI_NFREECH], 1)] = (unsigned short)spare; spare = -1; }
-            if (has) { pub_res[tid] = resmin; pub_mx[tid] = mx; pub_info[tid] = (uint32_t)np | ((uint32_t)npop << 8) | ((started ? 1u : 0u) << 16) | ((started && cur == GRP_NONE ? 1u : 0u) << 17); }
         }
-        __syncthreads();                                                        // (S6)
         GTICK(3);
-        if (tid == 0) { shQ[GQ_KSQ] = ~0ull; shQ[GQ_TMIN] = ~0ull; shI[GI_NTOOK] = 0; shI[GI_NLOST] = 0; shI[GI_NT] = 0; shI[GI_NL] = 0; }
         // ---- E: commit the idle episodes at the front, in order; bursts as wide as the window ------------------------------------------------
         bool front_ready = shI[GI_FORCED] != 0 || ((pub_info[frontslot] >> 17) & 1u);
         const bool forced_front = shI[GI_FORCED] != 0;
@@ -678,10 +731,10 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             const int fslot = (int)oslot[ord_at(0)];
             if (burst == 0 && forced_front && tid == fslot && has && started && cur != GRP_NONE) {
                 uint32_t rm = 0xFFFFFFFFu;
-                int ch = chfirst;
+                int ch = 0;
                 for (int i = 0; i < np; ++i) {
-                    if (i && (i % GRP_CH) == 0) ch = (int)cnext[ch];
-                    const uint32_t v = pval[ch * GRP_CH + i % GRP_CH];
+                    if ((i & (GRP_CH - 1)) == 0) ch = (int)chtab[tid][i >> 3];
+                    const uint32_t v = pval[ch * GRP_CH + (i & (GRP_CH - 1))];
                     if (v != WIN_POPPED && v < rm) rm = v;
                 }
                 cur = GRP_NONE; ncand = 0; ndef = 0; resmin = rm;
@@ -744,10 +797,10 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             if (has && ci_off[tid] != GRP_NONE) {
                 uint32_t po = ci_off[tid];
                 const uint32_t mybase = ci_age[tid];
-                int ch = chfirst;
+                int ch = 0;
                 for (int i = 0; i < np; ++i) {
-                    if (i && (i % GRP_CH) == 0) ch = (int)cnext[ch];
-                    const int a = ch * GRP_CH + i % GRP_CH;
+                    if ((i & (GRP_CH - 1)) == 0) ch = (int)chtab[tid][i >> 3];
+                    const int a = ch * GRP_CH + (i & (GRP_CH - 1));
                     const uint32_t vx = pvox[a], f = pval[a];
                     if (vx >= (uint32_t)PN) { if (stats) { atomicAdd(&stats[20], 1ull); stats[21] = 2ull; } continue; }
                     __hip_atomic_store(&state[vx], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -930,8 +983,11 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             __syncthreads();
             if (tid == 0) shI[GI_ANY] = 0;
         }
-        __syncthreads();
-        if (tid == 0) { shI[GI_FORCED] = 0; shI[GI_ANY] = 0; }
+        __syncthreads();                                                        // everybody has read this sub-round's verdicts
+        if (tid == 0) {
+            shI[GI_FORCED] = 0; shI[GI_ANY] = 0;
+            shQ[GQ_KSQ] = ~0ull; shQ[GQ_TMIN] = ~0ull; shI[GI_NTOOK] = 0; shI[GI_NLOST] = 0; shI[GI_NT] = 0; shI[GI_NL] = 0;
+        }
         if (shI[GI_SERIAL]) continue;
         GTICK(6);
         // ---- G: refill the window from the run (from the buckets when the run is empty) ------------------------------------------------------
@@ -967,7 +1023,10 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         GTICK(7);
         check_order(30);
         // the front's reserve is topped up from the pool (nobody allocates or frees between here and the next (S0))
-        if (tid == 0) { while (shI[GI_NRES] < reserve && shI[GI_NFREECH] > 0) resch[shI[GI_NRES]++] = freech[--shI[GI_NFREECH]]; }
+        if (tid == 0) {
+            while (shI[GI_NRES] < reserve && shI[GI_NFREECH] > 0) resch[shI[GI_NRES]++] = freech[--shI[GI_NFREECH]];
+            publish_heads();
+        }
     }
     __syncthreads();
 
