@@ -1158,7 +1158,9 @@ __device__ __forceinline__ void lds_sort(HeapEnt *srun, int n, int lane)
 }
 
 // Move the <= COLD_DRAIN smallest elements of the lowest bucket into srun[0, taken), sorted.  srun must be empty.
-__device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int lane, int drain_n)
+// sorted_out (optional): the caller sorts -- *sorted_out tells whether srun[0, taken) still needs it (the work-group kernel
+// sorts with all of its waves)
+__device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int lane, int drain_n, bool *sorted_out = nullptr)
 {
     const uint32_t b = cold_lowest(c, lane);
     if (b == c.cb) c.cb = COLD_NONE;                    // the drain rewrites this bucket's state
@@ -1333,7 +1335,8 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (!fifo) lds_sort(srun, taken, lane);
+    if (sorted_out) *sorted_out = fifo;
+    else if (!fifo) lds_sort(srun, taken, lane);
     c.count -= (uint32_t)taken;
     c.low = c.count > 0 ? cold_lowest(c, lane) : (uint32_t)COLD_NBK;
     return taken;
@@ -1892,11 +1895,12 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     if (const char *e = getenv("ISX_FLOOD_GROUP_MIN")) group_min = strtoull(e, nullptr, 10);
     if (group_min == 0 || !window_mode) group_min = ~0ull;
     if (group_min != ~0ull && group_min < coop_min) group_min = coop_min;
-    int gwcap = GRP_W, gtcap = GRP_T;
+    int gwcap = GRP_W, gtcap = GRP_T, gsteps = 64;     // ISX_FLOOD_GSTEPS: pops a wave may make between two work-group barriers (1 = one)
+    if (const char *e = getenv("ISX_FLOOD_GSTEPS")) gsteps = atoi(e);
     if (const char *e = getenv("ISX_FLOOD_GWIN")) gwcap = atoi(e);
     if (const char *e = getenv("ISX_FLOOD_GLIST")) gtcap = atoi(e);
     ISX_REQUIRE(wcap >= 1 && wcap <= WIN_W && tcap >= 6 && tcap <= WIN_T, "ISX_FLOOD_WIN / ISX_FLOOD_LIST out of range");
-    ISX_REQUIRE(gwcap >= 1 && gwcap <= GRP_W && gtcap >= 6 && gtcap <= GRP_T, "ISX_FLOOD_GWIN / ISX_FLOOD_GLIST out of range");
+    ISX_REQUIRE(gwcap >= 1 && gwcap <= GRP_W && gtcap >= 6 && gtcap <= GRP_T && gsteps >= 1, "ISX_FLOOD_GWIN / ISX_FLOOD_GLIST / ISX_FLOOD_GSTEPS out of range");
     Scratch<uint32_t> claim(ctx, (window_mode && !getenv("ISX_FLOOD_TRACE")) ? 1 : (size_t)std::max<unsigned long long>((unsigned long long)PN, 3 * (total + 1)));
     Scratch<unsigned long long> vstate(ctx, window_mode ? (size_t)PN : 1);
     Scratch<unsigned long long> stats(ctx, 48);
@@ -1921,7 +1925,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         const float rlo = unord(hmm[0]), rhi = unord(hmm[1]);
         const float smin = std::min(s[0], std::min(s[1], s[2])), smax = std::max(s[0], std::max(s[1], s[2]));
         const float vlo = std::min(std::min(rlo * smin, rlo * smax), 0.0f), vhi = std::max(std::max(rhi * smin, rhi * smax), vlo);
-        int nbuckets = 16384;
+        int nbuckets = 4096;             // (16384 until round 3: fewer, larger drains are cheaper for both kernels; config 2: 2.55 -> 2.43 s)
         if (const char *e = getenv("ISX_FLOOD_BUCKETS")) nbuckets = atoi(e);
         ISX_REQUIRE(nbuckets >= 1 && nbuckets <= COLD_NBK, "ISX_FLOOD_BUCKETS out of range");
         bk_lo = vlo;
@@ -1949,7 +1953,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
             flood_group_kernel<<<n_comp, GRP_W, 0, side ? ctx->aux_stream : ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                                    comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1], pshape[2], PN,
                                                                    s[0], s[1], s[2], group_min, run_limit, drain_n, gwcap, gtcap, group_bursts,
-                                                                   bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world);
+                                                                   bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world, gsteps);
             ISX_CHECK_LAUNCH();
         }
         flood_window_kernel<<<n_comp, 64, 0, ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,

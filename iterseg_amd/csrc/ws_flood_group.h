@@ -26,7 +26,7 @@
 // from the victim's key.
 
 #ifndef ISX_GRP_W
-#define ISX_GRP_W 256
+#define ISX_GRP_W 512
 #endif
 static constexpr int GRP_W = ISX_GRP_W;           // lanes = episode slots
 static constexpr int GRP_NWV = GRP_W / 64;        // waves
@@ -42,8 +42,8 @@ static constexpr unsigned long long GROUP_MIN_SIZE = 0;        // 0: off by defa
 
 enum { GI_OH, GI_NW, GI_SHEAD, GI_SCOUNT, GI_NSTAGE, GI_NFREECH, GI_NFREESLOT, GI_SERIAL, GI_FORCED, GI_NTOOK, GI_NLOST, GI_NT, GI_NL,
        GI_DIRTY, GI_COLD_COUNT, GI_COLD_LOW, GI_M, GI_NCOMMIT, GI_PENDN, GI_NHOT, GI_NWB, GI_AGEBASE, GI_NPTOT, GI_ANY, GI_TAKE, GI_POS,
-       GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_FRONT, GI_LAST, GI_NRELOAD, GI_N };
-enum { GQ_KSQ, GQ_TMIN, GQ_QHEAD, GQ_N };
+       GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_FRONT, GI_LAST, GI_NRELOAD, GI_READY, GI_SORTN, GI_N };
+enum { GQ_KSQ, GQ_TMIN, GQ_QHEAD, GQ_KINV, GQ_N };
 enum { GS_SUB, GS_POPS, GS_EXEC, GS_SQ_EPS, GS_SQ_BOUND, GS_SQ_LOST, GS_SLOW, GS_FORCED, GS_RELOAD, GS_RUNINS, GS_WININS, GS_WINEV, GS_COLD,
        GS_DRAIN, GS_BURST, GS_N };
 
@@ -131,8 +131,9 @@ __device__ __noinline__ void grp_w0_drain(Cold *cs, HeapEnt *srun, HeapEnt *stag
     if (shI[GI_NSTAGE] > 0) grp_w0_flush_stage(cs, stage, shI, lstat, lane);
     Cold cold = *cs;
     if (!cold.failed && cold.count > 0) {
-        const int got = cold_drain(cold, srun, hist, lane, drain_n);
-        if (lane == 0) { shI[GI_SCOUNT] = got; shI[GI_SHEAD] = 0; atomicAdd(&lstat[GS_DRAIN], 1u); }
+        bool sorted = true;
+        const int got = cold_drain(cold, srun, hist, lane, drain_n, &sorted);
+        if (lane == 0) { shI[GI_SCOUNT] = got; shI[GI_SHEAD] = 0; shI[GI_SORTN] = sorted ? 0 : got; atomicAdd(&lstat[GS_DRAIN], 1u); }
     }
     grp_publish_cold(cold, shI, lane);
     *cs = cold;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
     HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
     int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long group_min, int run_limit,
-    int drain_n, int wcap, int tcap, int max_bursts, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world)
+    int drain_n, int wcap, int tcap, int max_bursts, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world, int kmax)
 {
     __shared__ HeapEnt srun[COOP_SCAP];
     __shared__ HeapEnt stage[GRP_STAGE];
@@ -568,144 +569,109 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             __syncthreads();                                                    // (S2) releases performed, chunks back
             if (tid == 0) { shQ[GQ_KSQ] = ~0ull; shI[GI_DIRTY] = 0; }
         }
-        // ---- C: one pop per active episode ------------------------------------------------------------------------------------------
-        const int pool_base = shI[GI_NFREECH];                                  // stable: nothing is freed or granted before (S3)
-        bool active = false;
-        if (has && cur != GRP_NONE) {
-            bool room = true;
-            // Chunks: requests of one sub-round take RANKS (a monotonic counter); rank r is served from the stack top as it
-            // stood when the phase began iff r < that count -- a failed request changes nothing (a decrement that is undone
-            // lets another lane pop past a chunk that is still free: two episodes then share a chunk).  The front episode
-            // falls back on a reserve of one full list that only it may touch, so it can always finish or be forced to commit.
-            bool need = false;
-            if (started) {
-                room = np + 6 <= tcap;
-                const int used = np % GRP_CH, left = (np == 0 || used == 0) ? 0 : GRP_CH - used;
-                need = room && left < 6 && spare < 0;
-            } else need = spare < 0;
-            if (need) {
-                const int r = atomicAdd(&shI[GI_REQ], 1);
-                if (r < pool_base) spare = (int)freech[pool_base - 1 - r];
-                else if (tid == frontslot && shI[GI_NRES] > 0) spare = (int)resch[--shI[GI_NRES]];
-                else room = false;
-            }
-            active = room;
-            if (!room && tid == frontslot) {
-                if (started) shI[GI_FORCED] = 1;      // commits what it has done; that returns its chunks
-                // A front episode that has not even popped its root and finds pool AND reserve empty: every chunk is held by
-                // episodes behind it (a residual that became the new front took the place of the episode the reserve was
-                // serving).  Nothing can commit before the front, so everything behind it is squashed -- always legal --
-                // and its chunks come back for the next sub-round.
-                else atomicMin(&shQ[GQ_KSQ], tid == lastslot ? ~0ull : succ[tid]);
-            }
-        }
-        unsigned long long old[6];
-        float val[6];
-        uint32_t nbv[6];
-        uint32_t wonm = 0, tookmask = 0;
+        // ---- C: free-running steps.  Every wave pops on its own -- no work-group barrier between its steps, the claims of the
+        //         eight waves interleave as they come -- until the front episode is idle or stalled, or the wave has nothing left to
+        //         pop.  (A barrier per pop made every wave wait for the slowest of ~500 scattered memory requests, every step.)
+        //         A claim is WON iff the voxel was free or held by a later episode -- and that holder, with everything behind it,
+        //         is squashed when the waves are back (scratch/group_sim.c models this with waves in random order, kmax). ----------------
+        if (tid == frontslot && has && started && cur == GRP_NONE) shI[GI_READY] = 1;
         GTICK(0);
-        if (active) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                nbv[k] = cur + (uint32_t)noff32[k];
-                old[k] = 0ull; val[k] = 0.0f;
-                if (cur >= (uint32_t)PN && stats) { atomicAdd(&stats[20], 1ull); stats[21] = 3ull; }
-                if (nbv[k] < (uint32_t)PN && cur < (uint32_t)PN) {
-                    old[k] = __hip_atomic_fetch_min(&state[nbv[k]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    val[k] = (aff + (int64_t)ax[k] * PN)[k < 3 ? cur : nbv[k]];
+        for (int step = 0; step < kmax; ++step) {
+            if (step > 0 && shI[GI_READY]) break;                               // wave-uniform (one LDS word)
+            bool active = false;
+            if (has && cur != GRP_NONE) {
+                bool room = true, need = false;
+                if (started) {
+                    room = np + 6 <= tcap;
+                    const int used = np & (GRP_CH - 1), left = (np == 0 || used == 0) ? 0 : GRP_CH - used;
+                    need = room && left < 6 && spare < 0;
+                } else need = spare < 0;
+                if (need) {
+                    // pops only (nothing is freed while the waves run free); a request that finds the pool empty undoes its
+                    // decrement -- harmless, nobody can pop "below empty".  The front episode falls back on its reserve.
+                    const int idx = atomicSub(&shI[GI_NFREECH], 1) - 1;
+                    if (idx >= 0) spare = (int)freech[idx];
+                    else {
+                        atomicAdd(&shI[GI_NFREECH], 1);
+                        if (tid == frontslot && shI[GI_NRES] > 0) spare = (int)resch[--shI[GI_NRES]];
+                        else room = false;
+                    }
+                }
+                active = room;
+                if (!room && tid == frontslot) {
+                    if (started) shI[GI_FORCED] = 1;  // commits what it has done; that returns its chunks
+                    // A front episode that has not even popped its root and finds pool AND reserve empty: every chunk is held by
+                    // episodes behind it.  Nothing can commit before the front, so everything behind it is squashed -- always
+                    // legal -- and its chunks come back.
+                    else atomicMin(&shQ[GQ_KSQ], tid == lastslot ? ~0ull : succ[tid]);
+                    shI[GI_READY] = 1;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!__any(active)) break;
+            unsigned long long old[6];
+            float val[6];
+            uint32_t nbv[6];
+            uint32_t wonm = 0;
+            if (active) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (old[k] > key) { wonm |= 1u << k; if (old[k] != ST_FREE) tookmask |= 1u << k; }
-            if (tookmask) atomicAdd(&shI[GI_NTOOK], __popc(tookmask));
-        }
-        GTICK(9);
-        __syncthreads();                                                        // (S3) every claim of this sub-round is performed
-        GTICK(1);
-        if (tid == 0) { const int rq = shI[GI_REQ]; shI[GI_NFREECH] = pool_base - (rq < pool_base ? rq : pool_base); shI[GI_REQ] = 0; }
-        if (shI[GI_NTOOK] > 0) {                                                // uniform: somebody took a voxel over -> everybody reads back
-            uint32_t lost = 0;
-            if (active && wonm) {
-                unsigned long long now[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { now[k] = key; if (wonm & (1u << k)) now[k] = __hip_atomic_load(&state[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                for (int k = 0; k < 6; ++k) {
+                    nbv[k] = cur + (uint32_t)noff32[k];
+                    old[k] = 0ull; val[k] = 0.0f;
+                    if (cur >= (uint32_t)PN && stats) { atomicAdd(&stats[20], 1ull); stats[21] = 3ull; }
+                    if (nbv[k] < (uint32_t)PN && cur < (uint32_t)PN) {
+                        old[k] = __hip_atomic_fetch_min(&state[nbv[k]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        val[k] = (aff + (int64_t)ax[k] * PN)[k < 3 ? cur : nbv[k]];
+                    }
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                unsigned long long tk = ~0ull;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) if ((wonm & (1u << k)) && now[k] != key) lost |= 1u << k;
-            }
-            if (lost) atomicAdd(&shI[GI_NLOST], __popc(lost));
-            // records for the matching (only looked at when the counts differ)
+                for (int k = 0; k < 6; ++k)
+                    if (old[k] > key) { wonm |= 1u << k; if (old[k] != ST_FREE && old[k] < tk) tk = old[k]; }
+                // a voxel taken from a later episode: that episode is wrong from here on -- it is squashed (with everything
+                // behind it) when the waves are back at the barrier, before anything can commit
+                if (tk != ~0ull) atomicMin(&shQ[GQ_KSQ], tk);
+                // discoveries (direction order = the reference's push order, watershed.py:146-158)
+                if (started && cur_li >= 0) { pval[cur_addr] = WIN_POPPED; ++npop; if (curv > mx) mx = curv; }
+                started = true;
+                cur = GRP_NONE;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (tookmask & (1u << k)) {
-                    atomicMin(&shQ[GQ_TMIN], old[k]);
-                    const int i = atomicAdd(&shI[GI_NT], 1);
-                    if (i < GRP_TL) { tlk[0][i] = old[k]; tlv[0][i] = nbv[k]; }
-                }
-                if (lost & (1u << k)) {
-                    const int i = atomicAdd(&shI[GI_NL], 1);
-                    if (i < GRP_TL) { tlk[1][i] = key; tlv[1][i] = nbv[k]; }
-                }
-            }
-            wonm &= ~lost;
-            __syncthreads();                                                    // (S4)
-            if (shI[GI_NTOOK] != shI[GI_NLOST]) {
-                // a take-over hit a claim of an earlier sub-round: its holder (and everything behind it) is wrong
-                const int nT = shI[GI_NT], nL = shI[GI_NL];
-                if (nT > GRP_TL || nL > GRP_TL) { if (tid == 0) atomicMin(&shQ[GQ_KSQ], shQ[GQ_TMIN]); }     // record overflow: conservative
-                else {
-                    for (int t = tid; t < nT; t += GRP_W) {
-                        bool fresh = false;
-                        for (int l = 0; l < nL; ++l) if (tlk[1][l] == tlk[0][t] && tlv[1][l] == tlv[0][t]) fresh = true;
-                        if (!fresh) atomicMin(&shQ[GQ_KSQ], tlk[0][t]);
+                for (int k = 0; k < 6; ++k) {
+                    if (wonm & (1u << k)) {
+                        const uint32_t v = ford(val[k] * sc[ax[k]] + 0.0f);
+                        if ((np & (GRP_CH - 1)) == 0) {                          // next chunk (reserved before the pop)
+                            chlast = spare; spare = -1;
+                            chtab[tid][np >> 3] = (unsigned short)chlast;
+                        }
+                        const int a = chlast * GRP_CH + (np & (GRP_CH - 1));
+                        pvox[a] = nbv[k]; pval[a] = v;
+                        if (v < bound) cand_add(v, np, a); else if (v < resmin) resmin = v;
+                        ++np;
                     }
                 }
-                if (tid == 0) atomicAdd(&lstat[GS_SLOW], 1u);
             }
-        }
-        // discoveries (direction order = the reference's push order, watershed.py:146-158), next pop
-        GTICK(10);
-        if (active) {
-            if (started && cur_li >= 0) { pval[cur_addr] = WIN_POPPED; ++npop; if (curv > mx) mx = curv; }
-            started = true;
-            cur = GRP_NONE;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (wonm & (1u << k)) {
-                    const uint32_t v = ford(val[k] * sc[ax[k]] + 0.0f);
-                    if ((np & (GRP_CH - 1)) == 0) {                              // next chunk (reserved before the pop)
-                        chlast = spare; spare = -1;
-                        chtab[tid][np >> 3] = (unsigned short)chlast;
-                    }
-                    const int a = chlast * GRP_CH + (np & (GRP_CH - 1));
-                    pvox[a] = nbv[k]; pval[a] = v;
-                    if (v < bound) cand_add(v, np, a); else if (v < resmin) resmin = v;
-                    ++np;
+            {   // register candidates used up while the list still holds discoveries below the bound: rebuilt by the wave
+                unsigned long long need = __ballot(active && ncand == 0 && ndef > 0);
+                if (need && lane == 0) atomicAdd(&lstat[GS_RELOAD], (uint32_t)__popcll(need));
+                while (need) {
+                    const int L = __ffsll((long long)need) - 1;
+                    coop_reload(L, rdlane(bound, L));
+                    need &= need - 1ull;
                 }
             }
-        }
-        {   // register candidates used up while the list still holds discoveries below the bound: rebuilt by the wave
-            unsigned long long need = __ballot(active && ncand == 0 && ndef > 0);
-            if (need && lane == 0) atomicAdd(&lstat[GS_RELOAD], (uint32_t)__popcll(need));
-            while (need) {
-                const int L = __ffsll((long long)need) - 1;
-                coop_reload(L, rdlane(bound, L));
-                need &= need - 1ull;
+            if (active) {
+                select_next(bound);
+                pub_res[tid] = resmin; pub_mx[tid] = mx;
+                pub_info[tid] = (uint32_t)np | ((uint32_t)npop << 8) | (1u << 16) | ((cur == GRP_NONE ? 1u : 0u) << 17);
+                if (tid == frontslot && cur == GRP_NONE) shI[GI_READY] = 1;
             }
-        }
-        if (active) {
-            select_next(bound);
-            pub_res[tid] = resmin; pub_mx[tid] = mx;
-            pub_info[tid] = (uint32_t)np | ((uint32_t)npop << 8) | (1u << 16) | ((cur == GRP_NONE ? 1u : 0u) << 17);
-        }
-        {
-            const unsigned long long ab = __ballot(active);
-            if (ab && lane == 0) atomicAdd(&lstat[GS_EXEC], (uint32_t)__popcll(ab));
+            {
+                const unsigned long long ab = __ballot(active);
+                if (ab && lane == 0) atomicAdd(&lstat[GS_EXEC], (uint32_t)__popcll(ab));
+            }
         }
         GTICK(11);
-        __syncthreads();                                                        // (S5) lists written and published, take-over verdict in
+        __syncthreads();                                                        // (S5) the waves are back: lists written and published
         GTICK(2);
         {
             const unsigned long long ksq = shQ[GQ_KSQ];
@@ -793,30 +759,65 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             if (j == ncommit - 1) { shI[GI_NPTOT] = (int)(nbase + e_np); shI[GI_PENDN] = (int)(poff + pc); }
             __syncthreads();                                                    // (E4) orders are out
             GTICK(4);
-            // the committing lanes: labels (watershed.py:153), residuals in age order, chunks and slot back
-            if (has && ci_off[tid] != GRP_NONE) {
-                uint32_t po = ci_off[tid];
-                const uint32_t mybase = ci_age[tid];
-                int ch = 0;
-                for (int i = 0; i < np; ++i) {
-                    if ((i & (GRP_CH - 1)) == 0) ch = (int)chtab[tid][i >> 3];
-                    const int a = ch * GRP_CH + (i & (GRP_CH - 1));
-                    const uint32_t vx = pvox[a], f = pval[a];
-                    if (vx >= (uint32_t)PN) { if (stats) { atomicAdd(&stats[20], 1ull); stats[21] = 2ull; } continue; }
-                    __hip_atomic_store(&state[vx], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    out[vx] = lab;
-                    if (f != WIN_POPPED) {
-                        HeapEnt r;
-                        r.key = ((unsigned long long)f << 32) | (unsigned long long)(mybase + (uint32_t)i + 1u);
-                        r.idx = vx; r.pad = lab;
-                        pend[po++] = r;
+            // the committing episodes: labels (watershed.py:153), residuals in age order, chunks and slot back.  A LONG list (the
+            // front's descent: up to 190 entries while everybody else waits) is written by its whole wave, 64 entries per pass
+            // with the residuals ranked by ballot; the short ones by their own lanes in parallel.
+            {
+                const bool mine = has && ci_off[tid] != GRP_NONE;
+                const uint32_t my_po = mine ? ci_off[tid] : 0u, my_base = mine ? ci_age[tid] : 0u;
+                unsigned long long longb = __ballot(mine && np > 12);
+                while (longb) {
+                    const int L = __ffsll((long long)longb) - 1;
+                    const int slot = (wave << 6) + L;
+                    const int npL = (int)rdlane((uint32_t)np, L);
+                    const uint32_t labL = rdlane(lab, L), baseL = rdlane(my_base, L);
+                    uint32_t poL = rdlane(my_po, L);
+                    for (int b0 = 0; b0 < npL; b0 += 64) {
+                        const int i = b0 + lane;
+                        const bool v_ = i < npL;
+                        uint32_t vx = 0u, f = WIN_POPPED;
+                        if (v_) { const int a = (int)chtab[slot][i >> 3] * GRP_CH + (i & (GRP_CH - 1)); vx = pvox[a]; f = pval[a]; }
+                        const bool okv = v_ && vx < (uint32_t)PN;
+                        if (okv) { __hip_atomic_store(&state[vx], (unsigned long long)labL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); out[vx] = labL; }
+                        const bool isres = okv && f != WIN_POPPED;
+                        const unsigned long long rb = __ballot(isres);
+                        if (isres) {
+                            HeapEnt r;
+                            r.key = ((unsigned long long)f << 32) | (unsigned long long)(baseL + (uint32_t)i + 1u);
+                            r.idx = vx; r.pad = labL;
+                            pend[poL + (uint32_t)__popcll(rb & lt_mask)] = r;
+                        }
+                        poL += (uint32_t)__popcll(rb);
                     }
+                    longb &= longb - 1ull;
                 }
-                atomicAdd(&lstat[GS_POPS], (uint32_t)npop + 1u);
-                free_chunks();
-                has = false;
-                ci_off[tid] = GRP_NONE;
-                freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
+                if (mine) {
+                    if (np <= 12) {
+                        uint32_t po = my_po;
+                        int ch = 0;
+                        for (int i = 0; i < np; ++i) {
+                            if ((i & (GRP_CH - 1)) == 0) ch = (int)chtab[tid][i >> 3];
+                            const int a = ch * GRP_CH + (i & (GRP_CH - 1));
+                            const uint32_t vx = pvox[a], f = pval[a];
+                            if (vx >= (uint32_t)PN) { if (stats) { atomicAdd(&stats[20], 1ull); stats[21] = 2ull; } continue; }
+                            __hip_atomic_store(&state[vx], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            out[vx] = lab;
+                            if (f != WIN_POPPED) {
+                                HeapEnt r;
+                                r.key = ((unsigned long long)f << 32) | (unsigned long long)(my_base + (uint32_t)i + 1u);
+                                r.idx = vx; r.pad = lab;
+                                pend[po++] = r;
+                            }
+                        }
+                    }
+                    free_chunks();
+                    has = false;
+                    ci_off[tid] = GRP_NONE;
+                    freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
+                }
+                // committed pops of this wave: one counter update
+                const uint32_t pops_w = rdlane(wave_incl_sum(mine ? (uint32_t)npop + 1u : 0u), 63);
+                if (lane == 0 && pops_w) atomicAdd(&lstat[GS_POPS], pops_w);
             }
             __syncthreads();                                                    // (E5)
             if (tid == 0) {
@@ -986,7 +987,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         __syncthreads();                                                        // everybody has read this sub-round's verdicts
         if (tid == 0) {
             shI[GI_FORCED] = 0; shI[GI_ANY] = 0;
-            shQ[GQ_KSQ] = ~0ull; shQ[GQ_TMIN] = ~0ull; shI[GI_NTOOK] = 0; shI[GI_NLOST] = 0; shI[GI_NT] = 0; shI[GI_NL] = 0;
+            shQ[GQ_KSQ] = ~0ull; shQ[GQ_KINV] = ~0ull; shI[GI_READY] = 0;
         }
         if (shI[GI_SERIAL]) continue;
         GTICK(6);
@@ -999,6 +1000,27 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                     if (wave == 0) grp_w0_drain(&scold, srun, stage, hist, shI, lstat, drain_n, lane);
                     __syncthreads();
                     if (shI[GI_SERIAL]) break;
+                    // the drained bucket comes unsorted unless its list was in key order: a bitonic sort over ALL waves (one
+                    // wave sorting 1024 entries was two thirds of a drain)
+                    const int sn = shI[GI_SORTN];
+                    if (sn > 1) {
+                        int np2 = 2;
+                        while (np2 < sn) np2 <<= 1;
+                        for (int q = sn + tid; q < np2; q += GRP_W) { HeapEnt pad_; pad_.key = ~0ull; pad_.idx = 0; pad_.pad = 0; srun[q] = pad_; }
+                        __syncthreads();
+                        for (int k2 = 2; k2 <= np2; k2 <<= 1)
+                            for (int j2 = k2 >> 1, lj = 31 - __clz(j2); j2 > 0; j2 >>= 1, --lj) {
+                                for (int t = tid; t < np2 / 2; t += GRP_W) {
+                                    const int i2 = ((t >> lj) << (lj + 1)) | (t & (j2 - 1));
+                                    const u32x4 a2 = run_ld(srun, i2), b2 = run_ld(srun, i2 + j2);
+                                    const unsigned long long ka = ((unsigned long long)a2.y << 32) | a2.x, kb = ((unsigned long long)b2.y << 32) | b2.x;
+                                    const bool up = (i2 & k2) == 0;
+                                    if ((ka > kb) == up) { run_st(srun, i2, b2); run_st(srun, i2 + j2, a2); }
+                                }
+                                __syncthreads();
+                            }
+                    }
+                    if (tid == 0) shI[GI_SORTN] = 0;
                 }
                 const int nw5 = shI[GI_NW], sc5 = shI[GI_SCOUNT], sh5 = shI[GI_SHEAD], nf5 = shI[GI_NFREESLOT];
                 int take = wcap - nw5;

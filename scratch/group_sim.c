@@ -51,6 +51,8 @@ static slot_t S[WMAX];
 static u32 pvox[NCH * CH], pval[NCH * CH]; static int cnext[NCH], freech[NCH], nfreech;
 static u64 okey[WMAX]; static int oslot[WMAX]; static int oh, nw; static u64 succ[WMAX];
 static int freeslot[WMAX], nfreeslot;
+static int resch[64], nres;
+static u64 ksq_pool = ~0ull;
 static ent run[RCAP]; static int shead, scount;
 static ent pend[PENDCAP];
 static int64_t stats[32];
@@ -108,7 +110,6 @@ static void select_next(slot_t *e, u32 bound)
     if (e->ndef > 0) reload(e, bound);              // deferred ones are >= every candidate, i.e. >= bound: fold them in
     e->ncand = 0; e->ndef = 0;                       // (reload put nothing below the bound: all of them are >= bound)
     e->cur = NONE;
-    if (e->spare >= 0) { freech[nfreech++] = e->spare; e->spare = -1; }      // an idle episode appends nothing more
 }
 
 // ---- queue pieces ------------------------------------------------------------------------------------------
@@ -192,7 +193,7 @@ static void refill(int wcap, int drain_n)
 }
 
 int64_t group_sim(const float *aff, const int64_t *seeds, int64_t ns, const uint8_t *mask, u32 *out, const int64_t *dims,
-                  int wcap, int tcap, int run_limit, int drain_n, int max_bursts, unsigned seed, int64_t *st_out)
+                  int wcap, int tcap, int run_limit, int drain_n, int max_bursts, unsigned seed, int64_t *st_out, int kmax)
 {
     const int64_t N = dims[0] * dims[1] * dims[2], SZ = dims[1] * dims[2], SY = dims[2];
     const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
@@ -204,6 +205,9 @@ int64_t group_sim(const float *aff, const int64_t *seeds, int64_t ns, const uint
     for (int64_t i = 0; i < N; ++i) state[i] = mask[i] ? (out[i] ? (u64)out[i] : ST_FREE) : 0ull;
     chn = 0; cold_low = 0xFFFFFFFFu;
     nfreech = 0; for (int c = NCH - 1; c >= 0; --c) freech[nfreech++] = c;
+    const int reserve = (tcap + CH - 1) / CH + 1;
+    nres = 0; for (int i = 0; i < reserve; ++i) resch[nres++] = freech[--nfreech];
+    ksq_pool = ~0ull;
     nfreeslot = 0; for (int s = WMAX - 1; s >= 0; --s) { S[s].has = 0; freeslot[nfreeslot++] = s; }
     oh = 0; nw = 0; shead = 0; scount = 0;
     if (wcap > WMAX) wcap = WMAX;
@@ -243,83 +247,73 @@ int64_t group_sim(const float *aff, const int64_t *seeds, int64_t ns, const uint
             }
         }
         if (ksq != ~0ull) { ++stats[14]; for (int s = 0; s < WMAX; ++s) if (S[s].has && S[s].key >= ksq) squash_one(&S[s], state); }
-        // ---- C: one pop per active episode -------------------------------------------------------------------
-        int active[WMAX]; int front_forced = 0;
+        // ---- C: free-running steps.  Every wave (64 slots) pops on its own -- no barrier between its steps, claims of the
+        //         waves interleave arbitrarily (here: waves in random order each step) -- until the front episode is idle or
+        //         stalled, or the wave has nothing left to pop.  A claim is won iff the voxel was free or held by a later
+        //         episode; its previous holder (with everything behind it) is squashed when the waves are back at the barrier.
+        int front_forced = 0, front_ready = 0;
         const int fs = oslot[ord_at(0)];
-        for (int s = 0; s < WMAX; ++s) {
-            slot_t *e = &S[s]; active[s] = 0;
-            if (!e->has || e->cur == NONE) continue;
-            int room = 1;
-            // chunk pool: everybody but the front episode leaves a reserve of one full list, so the front can always finish
-            // (or be forced to commit what it has), which is what releases chunks
-            const int avail = s == fs ? nfreech : nfreech - (tcap + CH - 1) / CH;
-            if (e->started) {
-                room = e->np + 6 <= tcap;
-                const int used = e->np % CH, left = (e->np == 0 || used == 0) ? 0 : CH - used;
-                if (room && left < 6 && e->spare < 0) { if (avail > 0) e->spare = freech[--nfreech]; else room = 0; }
-            } else if (e->spare < 0) { if (avail > 0) e->spare = freech[--nfreech]; else room = 0; }
-            if (room) active[s] = 1;
-            else if (s == fs) front_forced = 1;
-        }
-        for (int s = 0; s < WMAX; ++s) order[s] = s;
-        for (int s = WMAX - 1; s > 0; --s) { int j = rand() % (s + 1), t = order[s]; order[s] = order[j]; order[j] = t; }
-        static u64 old[WMAX][6]; static float val[WMAX][6];
-        for (int oi = 0; oi < WMAX; ++oi) {                       // claims, in arrival order
-            const int s = order[oi]; slot_t *e = &S[s];
-            if (!active[s]) continue;
-            for (int k = 0; k < 6; ++k) {
-                const int64_t nb = (int64_t)e->cur + noff[k];
-                old[s][k] = state[nb]; if (e->key < state[nb]) state[nb] = e->key;       // atomicMin
-                val[s][k] = aff[(int64_t)ax[k] * N + (k < 3 ? e->cur : nb)];
-            }
-        }
-        // (barrier) read back; take-overs T, fresh losses L
-        static u64 Tk[WMAX * 6], Lk[WMAX * 6]; static u32 Tv[WMAX * 6], Lv[WMAX * 6]; int nT = 0, nL = 0;
-        int won[WMAX];
-        for (int s = 0; s < WMAX; ++s) {
-            slot_t *e = &S[s]; won[s] = 0;
-            if (!active[s]) continue;
-            for (int k = 0; k < 6; ++k) {
-                const u32 nb = (u32)((int64_t)e->cur + noff[k]);
-                if (!(old[s][k] > e->key)) continue;                // not mine: off-mask (0), labelled, or an earlier episode's
-                if (old[s][k] != ST_FREE) { Tk[nT] = old[s][k]; Tv[nT] = nb; ++nT; }
-                if (state[nb] != e->key) { Lk[nL] = e->key; Lv[nL] = nb; ++nL; continue; }
-                won[s] |= 1 << k;
-            }
-        }
-        u64 ksq2 = ~0ull;
-        if (nT != nL) {
-            ++stats[19];
-            for (int t = 0; t < nT; ++t) { int fresh = 0; for (int l = 0; l < nL; ++l) if (Lk[l] == Tk[t] && Lv[l] == Tv[t]) fresh = 1; if (!fresh && Tk[t] < ksq2) ksq2 = Tk[t]; }
-        }
-        // discoveries, next pop
-        for (int s = 0; s < WMAX; ++s) {
-            slot_t *e = &S[s];
-            if (!active[s]) continue;
-            ++stats[2];
-            const u64 nk = s == ls ? qhead : succ[s];
-            const u32 bound = (u32)(nk >> 32);
-            if (e->started && e->cur_li >= 0) { pval[e->cur_addr] = POPPED; ++e->npop; if (e->curv > e->mx) e->mx = e->curv; }
-            e->started = 1;
-            const u32 cv = e->cur;
-            e->cur = NONE;
-            for (int k = 0; k < 6; ++k) {
-                if (!(won[s] & (1 << k))) continue;
-                const u32 nb = (u32)((int64_t)cv + noff[k]);
-                const u32 v = ford(val[s][k] + 0.0f);
-                if (e->np % CH == 0) {                              // next chunk (reserved before the pop)
-                    const int c = e->spare; e->spare = -1; cnext[c] = -1;
-                    if (e->first < 0) e->first = c; else cnext[e->last] = c;
-                    e->last = c;
+        int wave_done[WMAX / 64]; for (int w = 0; w < WMAX / 64; ++w) wave_done[w] = 0;
+        if (S[fs].has && S[fs].started && S[fs].cur == NONE) front_ready = 1;
+        for (int step = 0; step < kmax; ++step) {
+            int worder[WMAX / 64];
+            for (int w = 0; w < WMAX / 64; ++w) worder[w] = w;
+            for (int w = WMAX / 64 - 1; w > 0; --w) { int jj = rand() % (w + 1), t = worder[w]; worder[w] = worder[jj]; worder[jj] = t; }
+            int any_wave = 0;
+            for (int wi = 0; wi < WMAX / 64; ++wi) {
+                const int w = worder[wi];
+                if (wave_done[w]) continue;
+                if (step > 0 && front_ready) { wave_done[w] = 1; continue; }
+                int any = 0;
+                for (int s = 64 * w; s < 64 * w + 64; ++s) {
+                    slot_t *e = &S[s];
+                    if (!e->has || e->cur == NONE) continue;
+                    int room = 1;
+                    if (e->started) {
+                        room = e->np + 6 <= tcap;
+                        const int used = e->np % CH, left = (e->np == 0 || used == 0) ? 0 : CH - used;
+                        if (room && left < 6 && e->spare < 0) { if (nfreech > 0) e->spare = freech[--nfreech]; else if (s == fs && nres > 0) e->spare = resch[--nres]; else room = 0; }
+                    } else if (e->spare < 0) { if (nfreech > 0) e->spare = freech[--nfreech]; else if (s == fs && nres > 0) e->spare = resch[--nres]; else room = 0; }
+                    if (!room) {
+                        if (s == fs) { if (e->started) front_forced = 1; else if (s != ls && succ[s] < ksq_pool) ksq_pool = succ[s]; front_ready = 1; }
+                        continue;
+                    }
+                    any = 1;
+                    ++stats[2];
+                    const u64 nk = s == ls ? qhead : succ[s];
+                    const u32 bound = (u32)(nk >> 32);
+                    if (e->started && e->cur_li >= 0) { pval[e->cur_addr] = POPPED; ++e->npop; if (e->curv > e->mx) e->mx = e->curv; }
+                    e->started = 1;
+                    const u32 cv = e->cur;
+                    e->cur = NONE;
+                    for (int k = 0; k < 6; ++k) {
+                        const int64_t nbi = (int64_t)cv + noff[k];
+                        const u64 oldv = state[nbi];
+                        if (!(oldv > e->key)) continue;                  // not mine: off-mask (0), labelled, or an earlier episode's
+                        state[nbi] = e->key;                             // atomicMin
+                        if (oldv != ST_FREE && oldv < ksq_pool) ksq_pool = oldv;   // its holder is wrong from here on: squashed when the waves are back
+                        const u32 nb = (u32)nbi;
+                        const u32 v = ford(aff[(int64_t)ax[k] * N + (k < 3 ? cv : nb)] + 0.0f);
+                        if (e->np % CH == 0) {
+                            const int c = e->spare; e->spare = -1; cnext[c] = -1;
+                            if (e->first < 0) e->first = c; else cnext[e->last] = c;
+                            e->last = c;
+                        }
+                        const int a = e->last * CH + e->np % CH;
+                        pvox[a] = nb; pval[a] = v;
+                        if (v < bound) cand_add(e, v, nb, e->np, a); else if (v < e->resmin) e->resmin = v;
+                        ++e->np;
+                    }
+                    select_next(e, bound);
+                    if (s == fs && e->cur == NONE) front_ready = 1;
                 }
-                const int a = e->last * CH + e->np % CH;
-                pvox[a] = nb; pval[a] = v;
-                if (v < bound) cand_add(e, v, nb, e->np, a); else if (v < e->resmin) e->resmin = v;
-                ++e->np;
+                if (!any) wave_done[w] = 1; else any_wave = 1;
             }
-            select_next(e, bound);
+            if (!any_wave) break;
         }
-        if (ksq2 != ~0ull) { ++stats[11]; for (int s = 0; s < WMAX; ++s) if (S[s].has && S[s].key >= ksq2) squash_one(&S[s], state); }
+        if (ksq_pool != ~0ull) { ++stats[11]; for (int s = 0; s < WMAX; ++s) if (S[s].has && S[s].key >= ksq_pool) squash_one(&S[s], state); ksq_pool = ~0ull; }
+        // an idle episode appends nothing more: its spare chunk goes back (frees never run beside the allocations above)
+        for (int s = 0; s < WMAX; ++s) if (S[s].has && S[s].started && S[s].cur == NONE && S[s].spare >= 0) { freech[nfreech++] = S[s].spare; S[s].spare = -1; }
         // ---- E: commit the idle episodes at the front, in order ------------------------------------------------
         for (int burst = 0; burst < max_bursts && nw > 0; ++burst) {
             const u64 qh = scount > 0 ? run[shead].key : ~0ull;
@@ -371,6 +365,7 @@ int64_t group_sim(const float *aff, const int64_t *seeds, int64_t ns, const uint
         }
         // ---- G: refill -----------------------------------------------------------------------------------------
         refill(wcap, drain_n);
+        while (nres < reserve && nfreech > 0) resch[nres++] = freech[--nfreech];
         if (stats[0] > 64 * N + 4096) { fprintf(stderr, "watchdog\n"); break; }
     }
     free(state);
