@@ -207,8 +207,6 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     __shared__ uint32_t ci_age[GRP_W], ci_off[GRP_W];                    // commit orders of a burst (ci_off: GRP_NONE = not committing)
     __shared__ u32x4 newroot[GRP_W];                                     // {key.lo, key.hi, voxel, label}
     __shared__ uint32_t newflag[GRP_W];
-    __shared__ unsigned long long tlk[2][GRP_TL];
-    __shared__ uint32_t tlv[2][GRP_TL];
     __shared__ int wtmp[4][GRP_NWV];
     __shared__ int hist[64];
     __shared__ int shI[GI_N];
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 if ((i & (GRP_CH - 1)) == 0) ch = (int)chtab[tid][i >> 3];
                 const uint32_t vq = pvox[ch * GRP_CH + (i & (GRP_CH - 1))];
                 if (vq < (uint32_t)PN) atomicCAS(&state[vq], key, ST_FREE);
-                else if (stats) { atomicAdd(&stats[20], 1ull); stats[21] = 1ull; }
+                else if (vq != GRP_NONE && stats) { atomicAdd(&stats[20], 1ull); stats[21] = 1ull; }     // (GRP_NONE: dropped at a verification)
             }
         }
         free_chunks();
@@ -572,8 +570,8 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         // ---- C: free-running steps.  Every wave pops on its own -- no work-group barrier between its steps, the claims of the
         //         eight waves interleave as they come -- until the front episode is idle or stalled, or the wave has nothing left to
         //         pop.  (A barrier per pop made every wave wait for the slowest of ~500 scattered memory requests, every step.)
-        //         A claim is WON iff the voxel was free or held by a later episode -- and that holder, with everything behind it,
-        //         is squashed when the waves are back (scratch/group_sim.c models this with waves in random order, kmax). ----------------
+        //         A claim is WON iff the voxel was free or held by a later episode; what that costs the holder is settled when it
+        //         commits (E).  scratch/group_sim.c models this with the waves stepping in random order (kmax). -------------------------
         if (tid == frontslot && has && started && cur == GRP_NONE) shI[GI_READY] = 1;
         GTICK(0);
         for (int step = 0; step < kmax; ++step) {
@@ -624,13 +622,12 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                unsigned long long tk = ~0ull;
+                // a voxel taken from a later episode: that episode finds out when it commits -- a lost discovery it has not popped
+                // is dropped there (sequentially it would never have discovered it), a lost discovery it HAS popped makes it and
+                // everything behind it wrong.  (Squashing the holder at once cost 95 % of the work on tie plateaus, where the
+                // episodes of a sub-round claim the same free voxels all the time.)
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    if (old[k] > key) { wonm |= 1u << k; if (old[k] != ST_FREE && old[k] < tk) tk = old[k]; }
-                // a voxel taken from a later episode: that episode is wrong from here on -- it is squashed (with everything
-                // behind it) when the waves are back at the barrier, before anything can commit
-                if (tk != ~0ull) atomicMin(&shQ[GQ_KSQ], tk);
+                for (int k = 0; k < 6; ++k) if (old[k] > key) wonm |= 1u << k;
                 // discoveries (direction order = the reference's push order, watershed.py:146-158)
                 if (started && cur_li >= 0) { pval[cur_addr] = WIN_POPPED; ++npop; if (curv > mx) mx = curv; }
                 started = true;
@@ -750,12 +747,73 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             for (int w = GRP_NWV - 1; w >= 0; --w) if (wtmp[0][w] < (w + 1) * 64) ncommit = wtmp[0][w];
             if (ncommit > nwb) ncommit = nwb;
             if (ncommit == 0) break;                                            // uniform
-            did_commit = true;
             const uint32_t agebase = (uint32_t)shI[GI_AGEBASE];
             if (j < ncommit) { ci_age[s] = agebase + nbase; ci_off[s] = poff; }
+            const bool cap_cut = j == ncommit && j < nwb && inm && (uint32_t)(ek >> 32) <= F && (e_mx == 0u || (e_mx < F && e_mx < succv));
+            __syncthreads();                                                    // (E3a) tentative orders are out
+            // ---- verification: every POPPED discovery of a committing episode must still be its own; an unpopped one that an
+            //      earlier episode took in the meantime is dropped (voxel slot <- GRP_NONE).  Short lists by their own lanes, four
+            //      loads in flight; long ones by the whole wave, 64 per trip.
+            {
+                const bool mine = has && ci_off[tid] != GRP_NONE;
+                bool wrong = false;
+                unsigned long long longb = __ballot(mine && np > 12);
+                while (longb) {
+                    const int L = __ffsll((long long)longb) - 1;
+                    const int slot = (wave << 6) + L;
+                    const int npL = (int)rdlane((uint32_t)np, L);
+                    const unsigned long long keyL = rdlane64(key, L);
+                    bool bad = false;
+                    for (int b0 = 0; b0 < npL; b0 += 64) {
+                        const int i = b0 + lane;
+                        if (i < npL) {
+                            const int a = (int)chtab[slot][i >> 3] * GRP_CH + (i & (GRP_CH - 1));
+                            const uint32_t vx = pvox[a];
+                            const unsigned long long stv = vx < (uint32_t)PN ? __hip_atomic_load(&state[vx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : keyL;
+                            if (stv != keyL) { if (pval[a] == WIN_POPPED) bad = true; else pvox[a] = GRP_NONE; }
+                        }
+                    }
+                    if (__any(bad) && lane == L) wrong = true;
+                    longb &= longb - 1ull;
+                }
+                if (mine && np <= 12) {
+                    for (int i0 = 0; i0 < np; i0 += 4) {
+                        unsigned long long st4[4]; int a4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = i0 + u;
+                            st4[u] = key; a4[u] = -1;
+                            if (i < np) {
+                                a4[u] = (int)chtab[tid][i >> 3] * GRP_CH + (i & (GRP_CH - 1));
+                                const uint32_t vx = pvox[a4[u]];
+                                if (vx < (uint32_t)PN) st4[u] = __hip_atomic_load(&state[vx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (a4[u] >= 0 && st4[u] != key) { if (pval[a4[u]] == WIN_POPPED) wrong = true; else pvox[a4[u]] = GRP_NONE; }
+                    }
+                }
+                if (wrong) atomicMin(&shQ[GQ_KINV], key);
+            }
+            __syncthreads();                                                    // (E3b)
+            const unsigned long long kinv = shQ[GQ_KINV];
+            if (kinv != ~0ull) {                                                // uniform: a committing episode is wrong -- it and everything behind it restart
+                const unsigned long long below = __ballot(j < ncommit && ek < kinv);
+                if (lane == 0) wtmp[0][wave] = __popcll(below);
+                if (has && key >= kinv) { ci_off[tid] = GRP_NONE; squash_me(); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                                // (E3c)
+                int nc2 = 0;
+#pragma unroll
+                for (int w = 0; w < GRP_NWV; ++w) nc2 += wtmp[0][w];
+                ncommit = nc2;
+                if (tid == 0) { shQ[GQ_KINV] = ~0ull; atomicAdd(&lstat[GS_SQ_LOST], 1u); }
+                if (ncommit == 0) break;                                        // uniform
+            }
+            did_commit = true;
             // cut only because `pend` is full?  then another burst of this sub-round takes the rest
-            if (j == ncommit && j < nwb)
-                shI[GI_ANY] = (inm && (uint32_t)(ek >> 32) <= F && (e_mx == 0u || (e_mx < F && e_mx < succv))) ? 1 : 0;
+            if (kinv == ~0ull && j == ncommit && j < nwb) shI[GI_ANY] = cap_cut ? 1 : 0;
             if (j == ncommit - 1) { shI[GI_NPTOT] = (int)(nbase + e_np); shI[GI_PENDN] = (int)(poff + pc); }
             __syncthreads();                                                    // (E4) orders are out
             GTICK(4);
@@ -777,7 +835,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                         const bool v_ = i < npL;
                         uint32_t vx = 0u, f = WIN_POPPED;
                         if (v_) { const int a = (int)chtab[slot][i >> 3] * GRP_CH + (i & (GRP_CH - 1)); vx = pvox[a]; f = pval[a]; }
-                        const bool okv = v_ && vx < (uint32_t)PN;
+                        const bool okv = v_ && vx < (uint32_t)PN;            // (a dropped entry carries GRP_NONE)
                         if (okv) { __hip_atomic_store(&state[vx], (unsigned long long)labL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); out[vx] = labL; }
                         const bool isres = okv && f != WIN_POPPED;
                         const unsigned long long rb = __ballot(isres);
@@ -789,6 +847,11 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                         }
                         poL += (uint32_t)__popcll(rb);
                     }
+                    // the slots reserved for residuals that were dropped stay empty
+                    {
+                        const uint32_t endL = rdlane(my_po, L) + rdlane((uint32_t)np - (uint32_t)npop, L);
+                        for (uint32_t q = poL + (uint32_t)lane; q < endL; q += 64u) { HeapEnt r; r.key = ~0ull; r.idx = 0; r.pad = 0; pend[q] = r; }
+                    }
                     longb &= longb - 1ull;
                 }
                 if (mine) {
@@ -799,7 +862,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                             if ((i & (GRP_CH - 1)) == 0) ch = (int)chtab[tid][i >> 3];
                             const int a = ch * GRP_CH + (i & (GRP_CH - 1));
                             const uint32_t vx = pvox[a], f = pval[a];
-                            if (vx >= (uint32_t)PN) { if (stats) { atomicAdd(&stats[20], 1ull); stats[21] = 2ull; } continue; }
+                            if (vx >= (uint32_t)PN) continue;                 // dropped at the verification (GRP_NONE)
                             __hip_atomic_store(&state[vx], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             out[vx] = lab;
                             if (f != WIN_POPPED) {
@@ -809,6 +872,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                                 pend[po++] = r;
                             }
                         }
+                        for (const uint32_t endp = my_po + (uint32_t)np - (uint32_t)npop; po < endp; ++po) { HeapEnt r; r.key = ~0ull; r.idx = 0; r.pad = 0; pend[po] = r; }
                     }
                     free_chunks();
                     has = false;
@@ -843,8 +907,9 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 const unsigned long long lastwin = nw2 > 0 ? okey[ord_at(nw2 - 1)] : 0ull;
                 const bool cold_ne = cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0);
                 HeapEnt r; r.key = 0; r.idx = 0; r.pad = 0;
-                const bool hasr = tid < P;
+                bool hasr = tid < P;
                 if (hasr) r = pend[tid];
+                hasr = hasr && r.key != ~0ull;                                  // (a slot of a dropped residual)
                 const bool tocold = hasr && cold_ne && !(hot_ne && r.key < hot_max) && cold_bucket(cold, r.key) >= (uint32_t)shI[GI_COLD_LOW];
                 const bool towin = hasr && !tocold && nw2 > 0 && r.key < lastwin;
                 const bool torun = hasr && !tocold && !towin;
@@ -1104,7 +1169,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 const int sc = shI[GI_SCOUNT], sh_ = shI[GI_SHEAD];
                 for (int j = 0; j < sc; ++j) { HeapEnt e = srun[(sh_ + j) & SMASK]; e.pad = 0; heap_push(heap, hn, e); }
                 for (int j = 0; j < shI[GI_NSTAGE]; ++j) { HeapEnt e = stage[j]; e.pad = 0; heap_push(heap, hn, e); }
-                for (int j = 0; j < shI[GI_PENDN]; ++j) { HeapEnt e = pend[j]; e.pad = 0; heap_push(heap, hn, e); }
+                for (int j = 0; j < shI[GI_PENDN]; ++j) { HeapEnt e = pend[j]; e.pad = 0; if (e.key != ~0ull) heap_push(heap, hn, e); }
                 for (int j = 0; j < shI[GI_NHOT]; ++j) { HeapEnt e = hotb[j]; e.pad = 0; heap_push(heap, hn, e); }
                 for (int j = shI[GI_WB0]; j < shI[GI_NWB]; ++j) { HeapEnt e = pend[j]; e.pad = 0; heap_push(heap, hn, e); }
             }

@@ -291,7 +291,8 @@ int64_t group_sim(const float *aff, const int64_t *seeds, int64_t ns, const uint
                         const u64 oldv = state[nbi];
                         if (!(oldv > e->key)) continue;                  // not mine: off-mask (0), labelled, or an earlier episode's
                         state[nbi] = e->key;                             // atomicMin
-                        if (oldv != ST_FREE && oldv < ksq_pool) ksq_pool = oldv;   // its holder is wrong from here on: squashed when the waves are back
+                        // (its previous holder finds out when it commits: a lost discovery it has not popped is dropped there,
+                        //  a lost discovery it HAS popped makes it -- and everything behind it -- wrong)
                         const u32 nb = (u32)nbi;
                         const u32 v = ford(aff[(int64_t)ax[k] * N + (k < 3 ? cv : nb)] + 0.0f);
                         if (e->np % CH == 0) {
@@ -345,6 +346,24 @@ int64_t group_sim(const float *aff, const int64_t *seeds, int64_t ns, const uint
                 ++ncommit;
             }
             if (ncommit == 0) break;
+            // verification: every POPPED discovery of a committing episode must still be its own; an unpopped one that an
+            // earlier episode took in the meantime is dropped (sequentially this episode would never have discovered it)
+            {
+                u64 kinv = ~0ull; int cut = ncommit;
+                for (int j = 0; j < ncommit && kinv == ~0ull; ++j) {
+                    slot_t *e = &S[oslot[ord_at(j)]];
+                    for (int i = 0; i < e->np; ++i) {
+                        const int a = entry_addr(e, i);
+                        if (state[pvox[a]] != e->key && pval[a] == POPPED) { kinv = e->key; cut = j; break; }
+                    }
+                }
+                if (kinv != ~0ull) {
+                    ++stats[19];
+                    for (int s2 = 0; s2 < WMAX; ++s2) if (S[s2].has && S[s2].key >= kinv) squash_one(&S[s2], state);
+                    ncommit = cut;
+                }
+            }
+            if (ncommit == 0) break;
             if (forced0) ++stats[15];
             u32 po = 0;
             for (int j = 0; j < ncommit; ++j) {
@@ -352,6 +371,7 @@ int64_t group_sim(const float *aff, const int64_t *seeds, int64_t ns, const uint
                 stats[1] += e->npop + 1;
                 for (int i = 0; i < e->np; ++i) {
                     const int a = entry_addr(e, i);
+                    if (state[pvox[a]] != e->key) { ++stats[17]; continue; }           // lost, unpopped: dropped
                     out[pvox[a]] = e->lab; state[pvox[a]] = (u64)e->lab;
                     if (pval[a] != POPPED) { ent r = {((u64)pval[a] << 32) | (u64)(agebase + (u32)i + 1u), pvox[a], e->lab}; pend[po++] = r; }
                 }
