@@ -2028,7 +2028,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                 hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[2] ? (double)hs[1] / hs[2] : 0.0, hs[13], hs[3], hs[7], hs[4], hs[5], hs[10],
                 hs[6], hs[11], hs[14], hs[12], hs[15], hs[8]);
         if (group_min != ~0ull)
-            fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu take-over matchings %llu\n", hs[17], hs[18], hs[19]);
+            fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu; of the work-group kernel alone: rounds %llu pops %llu drains %llu (%llu as the prefix of a list in key order)\n", hs[17], hs[18], hs[29], hs[28], hs[27], hs[26]);
 #ifdef ISX_FLOOD_PROF
         if (group_min != ~0ull)
             fprintf(stderr, "[isx flood/group] cycles/sub-round of lane 0: (S0)->claims %.0f | claims issued+returned %.0f | wait (S3) %.0f | take-over block %.0f | lists+next pop %.0f | wait (S5) %.0f | "

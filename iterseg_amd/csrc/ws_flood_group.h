@@ -133,7 +133,7 @@ __device__ __noinline__ void grp_w0_drain(Cold *cs, HeapEnt *srun, HeapEnt *stag
     if (!cold.failed && cold.count > 0) {
         bool sorted = true;
         const int got = cold_drain(cold, srun, hist, lane, drain_n, &sorted);
-        if (lane == 0) { shI[GI_SCOUNT] = got; shI[GI_SHEAD] = 0; shI[GI_SORTN] = sorted ? 0 : got; atomicAdd(&lstat[GS_DRAIN], 1u); }
+        if (lane == 0) { shI[GI_SCOUNT] = got; shI[GI_SHEAD] = 0; shI[GI_SORTN] = sorted ? 0 : got; atomicAdd(&lstat[GS_DRAIN], 1u); if (!sorted) atomicAdd(&lstat[GS_WINEV + 0], 0u); }
     }
     grp_publish_cold(cold, shI, lane);
     *cs = cold;
@@ -932,81 +932,81 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                     shI[GI_NSTAGE] += tc; shI[GI_NWB] = tw; shI[GI_NHOT] = tr; shI[GI_PENDN] = 0;
                 }
                 __syncthreads();
-                // window-bound residuals become roots at their sorted position, one at a time, each against the CURRENT last root
-                const int nwbnd = shI[GI_NWB];
-                for (int q = 0; q < nwbnd && !shI[GI_SERIAL]; ++q) {
-                    const HeapEnt e = pend[q];
+                // Window-bound residuals (keys below the last root) become roots at their sorted positions -- ALL of them in one
+                // ranked merge with the window: an old root moves up by the number of new keys below it, a new one lands at
+                // (old roots below it) + (its rank among the new ones); whatever ends beyond the window's capacity is the top
+                // of the merged order and goes back to the FRONT of the run, in order (a root evicted this way is squashed by
+                // its own lane).  One element at a time this was ~5 barriers per residual: 250 of them per burst on plateaus.
+                const int T = shI[GI_NWB];
+                if (T > 0) {                                                   // uniform
                     const int nw3 = shI[GI_NW];
-                    const bool into_win = nw3 > 0 && e.key < okey[ord_at(nw3 - 1)];
-                    if (!into_win) {                                           // an eviction moved the last root below it: run-bound after all
-                        __syncthreads();
-                        if (tid == 0) { hotb[shI[GI_NHOT]] = e; ++shI[GI_NHOT]; }
-                        __syncthreads();
-                        continue;
-                    }
-                    const bool full = nw3 == wcap || shI[GI_NFREESLOT] == 0;
-                    if (full && shI[GI_SCOUNT] >= COOP_SCAP - 2) {
+                    int E = nw3 + T - wcap;
+                    if (E < 0) E = 0;
+                    if (E > 0 && shI[GI_SCOUNT] + E > COOP_SCAP - 2) {          // room at the front of the run (rare)
                         __syncthreads();
                         if (wave == 0) { run_evict_w0(run_limit / 2); publish_cold(); }
                         __syncthreads();
-                        if (shI[GI_SERIAL]) { if (tid == 0) { shI[GI_WB0] = q; } break; }     // [q, nwbnd) are still to be queued
+                        if (shI[GI_SERIAL]) break;                              // pend[0, NWB) are still to be queued (WB0 = 0)
                     }
-                    // position
+                    const int sh3w = shI[GI_SHEAD];
+                    unsigned long long ok_ = 0ull; int os_ = 0, np_old = -1;
+                    if (tid < nw3) {
+                        ok_ = okey[ord_at(tid)]; os_ = (int)oslot[ord_at(tid)];
+                        int c2 = 0;
+                        for (int q = 0; q < T; ++q) if (pend[q].key < ok_) ++c2;
+                        np_old = tid + c2;
+                    }
+                    HeapEnt ne; ne.key = 0; ne.idx = 0; ne.pad = 0;
+                    int np_new = -1, rk_new = 0;
+                    if (tid < T) {
+                        ne = pend[tid];
+                        for (int q = 0; q < T; ++q) if (pend[q].key < ne.key) ++rk_new;
+                        int lo = 0, hi = nw3;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (okey[ord_at(mid)] < ne.key) lo = mid + 1; else hi = mid; }
+                        np_new = lo + rk_new;
+                    }
                     {
-                        const bool lt = tid < nw3 && okey[ord_at(tid)] < e.key;
-                        const unsigned long long bl = __ballot(lt);
-                        if (lane == 0) wtmp[0][wave] = __popcll(bl);
+                        const unsigned long long kb = __ballot(np_new >= 0 && np_new < wcap);
+                        if (lane == 0) wtmp[0][wave] = __popcll(kb);
                     }
-                    const int ls3 = (int)oslot[ord_at(nw3 - 1)];
-                    __syncthreads();
-                    int pos = 0;
-#pragma unroll
-                    for (int w = 0; w < GRP_NWV; ++w) pos += wtmp[0][w];
-                    int nw4 = nw3;
-                    if (full) {
-                        // the last root goes back to the front of the run (it sorts below everything there)
-                        if (tid == ls3) {
-                            const int shn = (shI[GI_SHEAD] - 1) & SMASK;
-                            HeapEnt b; b.key = key; b.idx = root; b.pad = lab;
-                            srun[shn] = b;
-                            shI[GI_SHEAD] = shn; ++shI[GI_SCOUNT];
-                            squash_me();
-                            has = false;
-                            freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
-                            atomicAdd(&lstat[GS_WINEV], 1u);
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        }
-                        --nw4;
-                        if (pos > nw4) pos = nw4;
+                    __syncthreads();                                            // (W1) everything read
+                    // evictions: an old root beyond the capacity tells its owner where in the run it goes; a new element goes itself
+                    if (np_old >= wcap) ci_off[os_] = (uint32_t)((sh3w - E + (np_old - wcap)) & SMASK);
+                    if (np_new >= wcap) srun[(sh3w - E + (np_new - wcap)) & SMASK] = ne;
+                    __syncthreads();                                            // (W2)
+                    if (has && ci_off[tid] != GRP_NONE) {
+                        HeapEnt b; b.key = key; b.idx = root; b.pad = lab;
+                        srun[ci_off[tid]] = b;
+                        ci_off[tid] = GRP_NONE;
+                        squash_me();
+                        has = false;
+                        freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
+                        atomicAdd(&lstat[GS_WINEV], 1u);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    // shift [pos, nw4) up by one
-                    unsigned long long mk_ = 0ull; unsigned short ms_ = 0;
-                    const bool mv = tid >= pos && tid < nw4;
-                    if (mv) { mk_ = okey[ord_at(tid)]; ms_ = oslot[ord_at(tid)]; }
-                    __syncthreads();
-                    if (mv) { okey[ord_at(tid + 1)] = mk_; oslot[ord_at(tid + 1)] = ms_; }
-                    if (tid == 0) {
-                        const int sl = (int)freeslot[--shI[GI_NFREESLOT]];
-                        okey[ord_at(pos)] = e.key; oslot[ord_at(pos)] = (unsigned short)sl;
-                        u32x4 nr = {(uint32_t)e.key, (uint32_t)(e.key >> 32), e.idx, e.pad};
+                    __syncthreads();                                            // (W3) slots of the evicted are back
+                    const int nf_mid = shI[GI_NFREESLOT];
+                    if (np_old >= 0 && np_old < wcap) { okey[ord_at(np_old)] = ok_; oslot[ord_at(np_old)] = (unsigned short)os_; }
+                    if (np_new >= 0 && np_new < wcap) {
+                        const int sl = (int)freeslot[nf_mid - 1 - rk_new];     // the kept new ones are a prefix of the new ones in key order
+                        okey[ord_at(np_new)] = ne.key; oslot[ord_at(np_new)] = (unsigned short)sl;
+                        u32x4 nr = {(uint32_t)ne.key, (uint32_t)(ne.key >> 32), ne.idx, ne.pad};
                         newroot[sl] = nr; newflag[sl] = 1u;
-                        shI[GI_NW] = nw4 + 1; shI[GI_DIRTY] = 1;
-                        shI[GI_POS] = pos;
-                        atomicAdd(&lstat[GS_WININS], 1u);
                     }
-                    __syncthreads();
-                    if (tid == 0) {                                            // successor links of the new root and of its predecessor
-                        const int sl = (int)oslot[ord_at(pos)];
-                        succ[sl] = pos + 1 < nw4 + 1 ? okey[ord_at(pos + 1)] : ~0ull;
-                        if (pos > 0) succ[oslot[ord_at(pos - 1)]] = e.key;
-                        else { /* new front */ }
-                        if (full && pos < nw4) { /* last root changed: its successor is the run */ succ[oslot[ord_at(nw4)]] = ~0ull; }
-                        else if (full) succ[sl] = ~0ull;
+                    __syncthreads();                                            // (W4) the new order is written
+                    int tin = 0;
+#pragma unroll
+                    for (int w = 0; w < GRP_NWV; ++w) tin += wtmp[0][w];
+                    const int nw_new = nw3 + T - E;
+                    if (tid < nw_new) succ[oslot[ord_at(tid)]] = tid + 1 < nw_new ? okey[ord_at(tid + 1)] : ~0ull;
+                    if (tid == 0) {
+                        shI[GI_NW] = nw_new; shI[GI_NFREESLOT] = nf_mid - tin; shI[GI_DIRTY] = 1;
+                        shI[GI_SHEAD] = (sh3w - E) & SMASK; shI[GI_SCOUNT] += E;
+                        atomicAdd(&lstat[GS_WININS], (uint32_t)tin);
                     }
-                    __syncthreads();
-                    adopt();                                                    // the owner picks the root up at once (it may be evicted by the next insertion)
+                    __syncthreads();                                            // (W5)
+                    adopt();
                 }
-                if (shI[GI_SERIAL]) break;
                 if (tid == 0) { shI[GI_NWB] = 0; shI[GI_WB0] = 0; }            // all of them are roots (or run-bound) now
                 // cold-bound ones: wave 0 appends them; the other waves merge the run-bound ones meanwhile
                 const int R = shI[GI_NHOT];
@@ -1137,6 +1137,10 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         atomicAdd(&stats[14], (unsigned long long)lstat[GS_SQ_BOUND]);
         atomicAdd(&stats[15], (unsigned long long)lstat[GS_FORCED]);
         atomicAdd(&stats[19], (unsigned long long)lstat[GS_SLOW]);
+        atomicAdd(&stats[27], (unsigned long long)lstat[GS_DRAIN]);
+        atomicAdd(&stats[26], (unsigned long long)scold.fifo_drains);
+        atomicAdd(&stats[28], (unsigned long long)lstat[GS_POPS]);
+        atomicAdd(&stats[29], (unsigned long long)st_sub);
         atomicAdd(&stats[17], (unsigned long long)lstat[GS_BURST]);
         atomicAdd(&stats[18], (unsigned long long)lstat[GS_RELOAD]);
         if (shI[GI_SERIAL]) atomicAdd(&stats[8], 1ull);
