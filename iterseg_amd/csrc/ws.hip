@@ -1097,6 +1097,89 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
     // s_waitcnt vmcnt(0), so these stores complete under the LDS work that follows
 }
 
+// Append src[0, n) (LDS, list order = src order) to ONE bucket: the wave-uniform form of cold_append for a batch whose elements
+// all map to bucket b (plateaus: every residual of a commit burst has the same value).  One state update and at most one new
+// segment for the whole batch instead of one cold_append per 64 elements (the work-group kernel's flush of ~350 residuals per
+// sub-round was 6 calls of ~5 k cycles each on one wave while seven waited).  `ascending`: src is in key order.
+__device__ __forceinline__ void cold_append_bucket(Cold &c, const HeapEnt *src, int n, uint32_t b, bool ascending,
+                                                   unsigned long long first_key, unsigned long long last_key, int lane)
+{
+    uint32_t tail, cnt, tn = 0, tcap = 0;
+    bool unsorted;
+    unsigned long long last;
+    if (b == c.cb) {
+        tail = c.cb_tail; cnt = c.cb_cnt; tn = c.cb_tn; tcap = c.cb_tcap; unsorted = c.cb_unsorted; last = c.cb_last;
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tail = cld32(&c.btail()[b]);
+        cnt = cld32(&c.bcount()[b]);
+        const uint32_t fill = cld32(&c.bfill()[b]), meta = cld32(&c.bmeta()[b]);
+        last = cld64(&c.blast()[b]);
+        if (tail != COLD_NONE) { tn = fill & 0xFFFFFFu; tcap = 1u << (fill >> 24); }
+        unsorted = (meta & COLD_UNSORTED) != 0u;
+    }
+    const bool viol = !ascending || (tail != COLD_NONE && cnt > 0 && last > first_key);
+    if (viol && !unsorted) { unsorted = true; if (lane == 0) atomicOr(&c.bmeta()[b], COLD_UNSORTED); }
+    const uint32_t free_tail = tcap - tn;
+    const uint32_t need_new = (uint32_t)n > free_tail ? (uint32_t)n - free_tail : 0u;
+    uint32_t newcap = 0;
+    if (need_new) {
+        newcap = tcap ? tcap * 2u : 4u;
+        if (newcap > 65536u) newcap = 65536u;
+        while (newcap < need_new) newcap *= 2u;
+    }
+    const uint32_t alloc = need_new ? newcap + 1u : 0u;
+    if ((unsigned long long)c.bump + alloc > c.pool_cap) { c.failed = true; return; }
+    const uint32_t my_off = c.bump;
+    c.bump += alloc;
+    if (lane == 0) {
+        if (need_new) {
+            HeapEnt h;
+            h.key = (unsigned long long)COLD_NONE | ((unsigned long long)need_new << 32);
+            h.idx = newcap;
+            h.pad = 0;
+            c.pool()[my_off] = h;
+            if (tail != COLD_NONE) {
+                HeapEnt ht;
+                ht.key = (unsigned long long)my_off | ((unsigned long long)tcap << 32);    // old tail is now full
+                ht.idx = tcap;
+                ht.pad = 0;
+                c.pool()[tail] = ht;
+            } else {
+                c.bhead()[b] = my_off;
+            }
+            c.btail()[b] = my_off;
+        } else {
+            HeapEnt ht;
+            ht.key = (unsigned long long)COLD_NONE | ((unsigned long long)(tn + (uint32_t)n) << 32);
+            ht.idx = tcap;
+            ht.pad = 0;
+            c.pool()[tail] = ht;
+        }
+        c.bcount()[b] = cnt + (uint32_t)n;
+        const uint32_t f_tn = need_new ? need_new : tn + (uint32_t)n, f_cap = need_new ? newcap : tcap;
+        c.bfill()[b] = f_tn | ((uint32_t)(31 - __clz((int)f_cap)) << 24);
+        c.blast()[b] = last_key;
+        if (cnt == 0) {
+            atomicOr(&c.bm0()[b >> 6], 1ull << (b & 63));
+            atomicOr(&c.bm1()[b >> 12], 1ull << ((b >> 6) & 63));
+        }
+    }
+    for (uint32_t j = (uint32_t)lane; j < (uint32_t)n; j += 64u) {
+        const uint32_t slot = j < free_tail ? tail + 1u + tn + j : my_off + 1u + (j - free_tail);
+        c.pool()[slot] = src[j];
+    }
+    c.cb = b;
+    c.cb_tail = need_new ? my_off : tail;
+    c.cb_tn = need_new ? need_new : tn + (uint32_t)n;
+    c.cb_tcap = need_new ? newcap : tcap;
+    c.cb_cnt = cnt + (uint32_t)n;
+    c.cb_unsorted = unsorted;
+    c.cb_last = last_key;
+    c.count += (uint32_t)n;
+    c.low = b < c.low ? b : c.low;
+}
+
 // lowest non-empty bucket (c.count > 0)
 __device__ __forceinline__ uint32_t cold_lowest(const Cold &c, int lane)
 {
@@ -1277,6 +1360,12 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
         // ---- extract bins < B into the run; compact the rest in place (write cursor trails the read cursor) ----
         // A row's loads are issued before any store of that row and later rows lie at higher addresses than anything
         // stored so far, so no load ever has to wait for a store: two rows are loaded ahead.
+        // While the rest streams by, check whether it is in key order again: a list that went out of order through a few
+        // small keys (a run eviction, an early element) loses exactly those to this drain, and everything that follows can
+        // take the prefix path.  (Without this one stray append made every later drain of a growing plateau bucket a
+        // select over the whole bucket: 2.5 M cycles per drain on a 5 M-voxel component.)
+        bool rest_sorted = true;
+        unsigned long long prev_last = 0ull;
         uint32_t wseg = head, wn = 0, wcap = cld_ent(&c.pool()[head]).idx, kept = 0;
         for (uint32_t seg = head; seg != COLD_NONE;) {
             const HeapEnt h = cld_ent(&c.pool()[seg]);
@@ -1297,6 +1386,12 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
                     const bool valid = valid2[u];
                     const bool take = valid && e.key >= lo && ((e.key - lo) >> sh) < (unsigned long long)B;
                     const unsigned long long tb = __ballot(take), kb = __ballot(valid && !take);
+                    if (rest_sorted && kb) {
+                        const unsigned long long below = kb & ((1ull << lane) - 1ull);
+                        const unsigned long long pk = shfl64(e.key, below ? 63 - __clzll((long long)below) : lane);
+                        if (__any(valid && !take && e.key < (below ? pk : prev_last))) rest_sorted = false;
+                        prev_last = rdlane64(e.key, 63 - __clzll((long long)kb));
+                    }
                     if (take) srun[taken + __popcll(tb & ((1ull << lane) - 1ull))] = e;
                     taken += __popcll(tb);
                     int krank = __popcll(kb & ((1ull << lane) - 1ull));
@@ -1330,7 +1425,8 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
             c.btail()[b] = wseg;
             c.bfill()[b] = wn | ((uint32_t)(31 - __clz((int)wcap)) << 24);
             c.bcount()[b] = kept;
-            c.bmeta()[b] = COLD_UNSORTED;                 // compacted from the start of the head segment
+            c.bmeta()[b] = rest_sorted ? 0u : COLD_UNSORTED;     // compacted from the start of the head segment
+            if (rest_sorted) c.blast()[b] = prev_last;           // the list's last element: what the next append is checked against
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1897,15 +1993,17 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     if (group_min != ~0ull && group_min < coop_min) group_min = coop_min;
     int gwcap = GRP_W, gtcap = GRP_T, gsteps = 64;     // ISX_FLOOD_GSTEPS: pops a wave may make between two work-group barriers (1 = one)
     if (const char *e = getenv("ISX_FLOOD_GSTEPS")) gsteps = atoi(e);
+    int gminsteps = 4;                                  // ISX_FLOOD_GMINSTEPS: steps every wave makes before the front's "ready" stops it
+    if (const char *e = getenv("ISX_FLOOD_GMINSTEPS")) gminsteps = atoi(e);
     if (const char *e = getenv("ISX_FLOOD_GWIN")) gwcap = atoi(e);
     if (const char *e = getenv("ISX_FLOOD_GLIST")) gtcap = atoi(e);
     ISX_REQUIRE(wcap >= 1 && wcap <= WIN_W && tcap >= 6 && tcap <= WIN_T, "ISX_FLOOD_WIN / ISX_FLOOD_LIST out of range");
-    ISX_REQUIRE(gwcap >= 1 && gwcap <= GRP_W && gtcap >= 6 && gtcap <= GRP_T && gsteps >= 1, "ISX_FLOOD_GWIN / ISX_FLOOD_GLIST / ISX_FLOOD_GSTEPS out of range");
+    ISX_REQUIRE(gwcap >= 1 && gwcap <= GRP_W && gtcap >= 6 && gtcap <= GRP_T && gsteps >= 1 && gsteps <= 255 && gminsteps >= 1 && gminsteps <= 255, "ISX_FLOOD_GWIN / ISX_FLOOD_GLIST / ISX_FLOOD_GSTEPS out of range");
     Scratch<uint32_t> claim(ctx, (window_mode && !getenv("ISX_FLOOD_TRACE")) ? 1 : (size_t)std::max<unsigned long long>((unsigned long long)PN, 3 * (total + 1)));
     Scratch<unsigned long long> vstate(ctx, window_mode ? (size_t)PN : 1);
-    Scratch<unsigned long long> stats(ctx, 48);
+    Scratch<unsigned long long> stats(ctx, 64);
     if (!pool.ok() || !claim.ok() || !arena.ok() || !stats.ok() || !vstate.ok()) return ISX_ERR_NOMEM;
-    ISX_HIP(hipMemsetAsync(stats.p, 0, 48 * 8, ctx->stream));
+    ISX_HIP(hipMemsetAsync(stats.p, 0, 64 * 8, ctx->stream));
     float s[3] = {1.f, 1.f, 1.f};
     if (scale) for (int a = 0; a < 3; ++a) s[a] = fabsf(scale[a]);
     // value range of the (scaled) edge values -> linear bucket map of the cold tier (any monotone map is correct; this
@@ -1953,7 +2051,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
             flood_group_kernel<<<n_comp, GRP_W, 0, side ? ctx->aux_stream : ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                                    comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1], pshape[2], PN,
                                                                    s[0], s[1], s[2], group_min, run_limit, drain_n, gwcap, gtcap, group_bursts,
-                                                                   bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world, gsteps);
+                                                                   bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world, gsteps | (gminsteps << 8));
             ISX_CHECK_LAUNCH();
         }
         flood_window_kernel<<<n_comp, 64, 0, ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
@@ -1988,7 +2086,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         ISX_CHECK_LAUNCH();
     }
     if (window_mode) {
-        unsigned long long hs[48];
+        unsigned long long hs[64];
         ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         ISX_HIP(hipStreamSynchronize(ctx->stream));
 #ifdef ISX_FLOOD_CHECK          // these slots carry the phase timers in the ISX_FLOOD_PROF build
@@ -2031,10 +2129,13 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
             fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu; of the work-group kernel alone: rounds %llu pops %llu drains %llu (%llu as the prefix of a list in key order)\n", hs[17], hs[18], hs[29], hs[28], hs[27], hs[26]);
 #ifdef ISX_FLOOD_PROF
         if (group_min != ~0ull)
-            fprintf(stderr, "[isx flood/group] cycles/sub-round of lane 0: (S0)->claims %.0f | claims issued+returned %.0f | wait (S3) %.0f | take-over block %.0f | lists+next pop %.0f | wait (S5) %.0f | "
-                            "squash+publish %.0f | decide %.0f | labels %.0f | enqueue %.0f | refill+drain %.0f | loop end %.0f\n",
-                    (double)hs[32] / hs[0], (double)hs[41] / hs[0], (double)hs[33] / hs[0], (double)hs[42] / hs[0], (double)hs[43] / hs[0], (double)hs[34] / hs[0],
-                    (double)hs[35] / hs[0], (double)hs[36] / hs[0], (double)hs[37] / hs[0], (double)hs[38] / hs[0], (double)hs[39] / hs[0], (double)hs[40] / hs[0]);
+            fprintf(stderr, "[isx flood/group] cycles/sub-round of lane 0: (S0)->C %.0f | C loop %.0f | wait (S5) %.0f | squash %.0f | to (E0) %.0f | order (E1-E3a) %.0f | verify %.0f | labels %.0f | enqueue %.0f | "
+                            "burst-loop exit %.0f | drain call %.0f | drain sort %.0f | refill %.0f | loop end %.0f || C: claims+loads wait %.0f ; flush %.0f\n",
+                    (double)hs[32] / hs[0], (double)hs[43] / hs[0], (double)hs[34] / hs[0], (double)hs[35] / hs[0], (double)hs[44] / hs[0], (double)hs[33] / hs[0], (double)hs[36] / hs[0],
+                    (double)hs[37] / hs[0], (double)hs[38] / hs[0], (double)hs[45] / hs[0], (double)hs[41] / hs[0], (double)hs[42] / hs[0], (double)hs[39] / hs[0], (double)hs[40] / hs[0], (double)hs[46] / hs[0], (double)hs[47] / hs[0]);
+        if (group_min != ~0ull)
+            fprintf(stderr, "[isx flood/group] bursts cut by: front not ready (rounds) %llu | not started %llu | running %llu | bound %llu | pend full %llu | whole window %llu ; window fill at first burst %.1f ; flushes %llu (one-bucket %llu, 64-element appends %llu)\n",
+                    hs[48], hs[49], hs[50], hs[51], hs[52], hs[53], hs[29] ? (double)hs[54] / hs[29] : 0.0, hs[57], hs[55], hs[56]);
         fprintf(stderr, "[isx flood/window] cycles/sub-round: loop+evict %.0f | scan %.0f | trip %.0f | lists %.0f | squash %.0f | commit: decide %.0f labels %.0f enqueue %.0f | refill %.0f\n",
                 (double)hs[32] / hs[0], (double)hs[33] / hs[0], (double)hs[34] / hs[0], (double)hs[35] / hs[0], (double)hs[36] / hs[0],
                 (double)hs[37] / hs[0], (double)hs[38] / hs[0], (double)hs[39] / hs[0], (double)hs[40] / hs[0]);

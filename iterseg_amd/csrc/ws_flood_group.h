@@ -34,18 +34,19 @@ static constexpr int GRP_T = GRP_W > 256 ? 128 : 192;   // discoveries one episo
 static constexpr int GRP_CH = 8;                  // entries per chunk
 static constexpr int GRP_NCH = GRP_W > 256 ? 640 : GRP_W + GRP_W / 2;   // chunks in the pool
 static constexpr int GRP_CMAX = 6;                // register candidates
-static constexpr int GRP_PEND = GRP_W;            // residuals of one commit burst (one per lane in the enqueue)
-static constexpr int GRP_STAGE = GRP_PEND + 64;   // staged cold-bound elements
+static constexpr int GRP_PEND = 2 * GRP_W;        // residuals of one commit burst (enqueued in slices of one per lane)
+static constexpr int GRP_STAGE = GRP_W + 64;      // staged cold-bound elements (flushed down to < 64 after every slice)
 static constexpr int GRP_TL = 256;                // take-over / fresh-loss records of one sub-round
 static constexpr uint32_t GRP_NONE = 0xFFFFFFFFu;
-static constexpr unsigned long long GROUP_MIN_SIZE = 0;        // 0: off by default (ISX_FLOOD_GROUP_MIN enables it) until it beats the single-wave kernel
+static constexpr unsigned long long GROUP_MIN_SIZE = 262144;   // components from this size flood on the work-group kernel (ISX_FLOOD_GROUP_MIN; 0 = never).  Measured r3:
+                                                               // config 2 (one 8.3 M chain-like component) 3.01 -> 1.55 s, blobs 256^3 (one 5.4 M) 0.95 -> 0.70 s, structured 512^3 +3..6 %
 
 enum { GI_OH, GI_NW, GI_SHEAD, GI_SCOUNT, GI_NSTAGE, GI_NFREECH, GI_NFREESLOT, GI_SERIAL, GI_FORCED, GI_NTOOK, GI_NLOST, GI_NT, GI_NL,
        GI_DIRTY, GI_COLD_COUNT, GI_COLD_LOW, GI_M, GI_NCOMMIT, GI_PENDN, GI_NHOT, GI_NWB, GI_AGEBASE, GI_NPTOT, GI_ANY, GI_TAKE, GI_POS,
-       GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_FRONT, GI_LAST, GI_NRELOAD, GI_READY, GI_SORTN, GI_N };
+       GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_FRONT, GI_LAST, GI_NRELOAD, GI_READY, GI_SORTN, GI_PEND0, GI_N };
 enum { GQ_KSQ, GQ_TMIN, GQ_QHEAD, GQ_KINV, GQ_N };
 enum { GS_SUB, GS_POPS, GS_EXEC, GS_SQ_EPS, GS_SQ_BOUND, GS_SQ_LOST, GS_SLOW, GS_FORCED, GS_RELOAD, GS_RUNINS, GS_WININS, GS_WINEV, GS_COLD,
-       GS_DRAIN, GS_BURST, GS_N };
+       GS_DRAIN, GS_BURST, GS_C_NOTREADY, GS_C_NOTSTARTED, GS_C_RUNNING, GS_C_BOUND, GS_C_CAP, GS_C_ALL, GS_NWSUM, GS_F_BULK, GS_F_CALLS, GS_F_FLUSHES, GS_N };
 
 // ---- the cold tier, driven by wave 0, OUT OF LINE: cold_append / cold_drain are large, and inlined into the kernel their
 // registers pushed the episode words of the hot loop into scratch memory (a scratch round trip per phase).  The tier's
@@ -61,7 +62,27 @@ __device__ __noinline__ void grp_w0_flush_stage(Cold *cs, HeapEnt *stage, int *s
     Cold cold = *cs;
     const int nstage = shI[GI_NSTAGE];
     int done = 0;
-    while (done < nstage) {
+    if (nstage > 64) {
+        // one bucket for the whole batch (a plateau)?  then one append
+        const uint32_t b0 = cold_bucket(cold, stage[0].key);
+        bool same = true, asc = true;
+        for (int j = lane; j < nstage; j += 64) {
+            const unsigned long long k = stage[j].key;
+            same = same && cold_bucket(cold, k) == b0;
+            if (j > 0) asc = asc && stage[j - 1].key <= k;
+        }
+        if (__all(same)) {
+            cold_append_bucket(cold, stage, nstage, b0, __all(asc) != 0, stage[0].key, stage[nstage - 1].key, lane);
+            if (!cold.failed) done = nstage;
+#ifdef ISX_FLOOD_PROF
+            if (lane == 0) atomicAdd(&lstat[GS_F_BULK], 1u);
+#endif
+        }
+    }
+#ifdef ISX_FLOOD_PROF
+    if (lane == 0) { atomicAdd(&lstat[GS_F_FLUSHES], 1u); atomicAdd(&lstat[GS_F_CALLS], (uint32_t)((nstage - done + 63) / 64)); }
+#endif
+    while (done < nstage && !cold.failed) {
         const int m = nstage - done < 64 ? nstage - done : 64;
         const bool hs = lane < m;
         HeapEnt e; e.key = 0; e.idx = 0; e.pad = 0;
@@ -196,7 +217,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     __shared__ HeapEnt srun[COOP_SCAP];
     __shared__ HeapEnt stage[GRP_STAGE];
     __shared__ HeapEnt pend[GRP_PEND];
-    __shared__ HeapEnt hotb[GRP_PEND];
+    __shared__ HeapEnt hotb[GRP_W];
     __shared__ uint32_t pvox[GRP_NCH * GRP_CH], pval[GRP_NCH * GRP_CH];
     __shared__ unsigned short freech[GRP_NCH];
     __shared__ unsigned short chtab[GRP_W][GRP_T / GRP_CH];             // chunk c of the list of slot s (entry i lives in chunk i / 8)
@@ -257,6 +278,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     }
     if (tid == 0) scold = cold;
     const bool cold_on = cold.on;
+    const int kmin = ((kmax >> 8) & 0xFF) > 1 ? ((kmax >> 8) & 0xFF) : 1;   // steps a wave makes before it looks at the front's "ready"
     for (int i = tid; i < GI_N; i += GRP_W) shI[i] = i == GI_COLD_LOW ? COLD_NBK : 0;
     if (tid < GQ_N) shQ[tid] = ~0ull;
     for (int i = tid; i < GS_N; i += GRP_W) lstat[i] = 0u;
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     }
 
 #ifdef ISX_FLOOD_PROF
-    unsigned long long tk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_prev = __builtin_readcyclecounter();
+    unsigned long long tk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk_prev = __builtin_readcyclecounter();
 #define GTICK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tk_acc[i] += t_ - tk_prev; tk_prev = t_; } while (0)
 #else
 #define GTICK(i) do { } while (0)
@@ -574,8 +596,8 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         //         commits (E).  scratch/group_sim.c models this with the waves stepping in random order (kmax). -------------------------
         if (tid == frontslot && has && started && cur == GRP_NONE) shI[GI_READY] = 1;
         GTICK(0);
-        for (int step = 0; step < kmax; ++step) {
-            if (step > 0 && shI[GI_READY]) break;                               // wave-uniform (one LDS word)
+        for (int step = 0; step < (kmax & 0xFF); ++step) {
+            if (step >= kmin && shI[GI_READY]) break;                           // wave-uniform (one LDS word)
             bool active = false;
             if (has && cur != GRP_NONE) {
                 bool room = true, need = false;
@@ -610,6 +632,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             float val[6];
             uint32_t nbv[6];
             uint32_t wonm = 0;
+            GTICK(11);
             if (active) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
@@ -622,6 +645,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                GTICK(14);
                 // a voxel taken from a later episode: that episode finds out when it commits -- a lost discovery it has not popped
                 // is dropped there (sequentially it would never have discovered it), a lost discovery it HAS popped makes it and
                 // everything behind it wrong.  (Squashing the holder at once cost 95 % of the work on tie plateaus, where the
@@ -686,6 +710,9 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         bool front_ready = shI[GI_FORCED] != 0 || ((pub_info[frontslot] >> 17) & 1u);
         const bool forced_front = shI[GI_FORCED] != 0;
         bool did_commit = false;
+#ifdef ISX_FLOOD_PROF
+        if (tid == 0) { if (!front_ready) atomicAdd(&lstat[GS_C_NOTREADY], 1u); atomicAdd(&lstat[GS_NWSUM], (uint32_t)shI[GI_NW]); }
+#endif
         for (int burst = 0; front_ready && burst < (max_bursts & 0xFF) && shI[GI_NW] > 0 && !shI[GI_SERIAL]; ++burst) {
             const int nwb = shI[GI_NW];
             const unsigned long long qh = shI[GI_SCOUNT] > 0 ? srun[shI[GI_SHEAD]].key : ~0ull;
@@ -705,6 +732,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 atomicAdd(&lstat[GS_FORCED], 1u);
             }
             __syncthreads();                                                    // (E0)
+            GTICK(12);
             // lane j = window position j
             const int j = tid;
             const bool valid = j < nwb;
@@ -746,11 +774,20 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
 #pragma unroll
             for (int w = GRP_NWV - 1; w >= 0; --w) if (wtmp[0][w] < (w + 1) * 64) ncommit = wtmp[0][w];
             if (ncommit > nwb) ncommit = nwb;
+#ifdef ISX_FLOOD_PROF
+            if (ncommit == nwb) { if (tid == 0) atomicAdd(&lstat[GS_C_ALL], 1u); }
+            else if (j == ncommit) {
+                if (!inm) atomicAdd(&lstat[((info >> 16) & 1u) ? GS_C_RUNNING : GS_C_NOTSTARTED], 1u);
+                else if (!((uint32_t)(ek >> 32) <= F && (e_mx == 0u || (e_mx < F && e_mx < succv)))) atomicAdd(&lstat[GS_C_BOUND], 1u);
+                else atomicAdd(&lstat[GS_C_CAP], 1u);
+            }
+#endif
             if (ncommit == 0) break;                                            // uniform
             const uint32_t agebase = (uint32_t)shI[GI_AGEBASE];
             if (j < ncommit) { ci_age[s] = agebase + nbase; ci_off[s] = poff; }
             const bool cap_cut = j == ncommit && j < nwb && inm && (uint32_t)(ek >> 32) <= F && (e_mx == 0u || (e_mx < F && e_mx < succv));
             __syncthreads();                                                    // (E3a) tentative orders are out
+            GTICK(1);
             // ---- verification: every POPPED discovery of a committing episode must still be its own; an unpopped one that an
             //      earlier episode took in the meantime is dropped (voxel slot <- GRP_NONE).  Short lists by their own lanes, four
             //      loads in flight; long ones by the whole wave, 64 per trip.
@@ -814,7 +851,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             did_commit = true;
             // cut only because `pend` is full?  then another burst of this sub-round takes the rest
             if (kinv == ~0ull && j == ncommit && j < nwb) shI[GI_ANY] = cap_cut ? 1 : 0;
-            if (j == ncommit - 1) { shI[GI_NPTOT] = (int)(nbase + e_np); shI[GI_PENDN] = (int)(poff + pc); }
+            if (j == ncommit - 1) { shI[GI_NPTOT] = (int)(nbase + e_np); shI[GI_PENDN] = (int)(poff + pc); shI[GI_PEND0] = 0; }
             __syncthreads();                                                    // (E4) orders are out
             GTICK(4);
             // the committing episodes: labels (watershed.py:153), residuals in age order, chunks and slot back.  A LONG list (the
@@ -893,11 +930,13 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             __syncthreads();                                                    // (E6)
             GTICK(5);
             // ---- enqueue the burst's residuals --------------------------------------------------------------------------------------------
-            const int P = shI[GI_PENDN];
-            if (P > 0) {
+            // (slices of one residual per lane; pend[GI_PEND0, GI_PENDN) is what the serial continuation would still have to queue)
+            const int Ptot = shI[GI_PENDN];
+            for (int p0 = 0; p0 < Ptot; p0 += GRP_W) {
+                const int P = Ptot - p0 < GRP_W ? Ptot - p0 : GRP_W;
                 // capacity first: an eviction moves the hot maximum, so the batch is judged against the tiers AFTER it
                 if (shI[GI_SCOUNT] + P > run_limit || shI[GI_SCOUNT] + P > COOP_SCAP - 8) {
-                    if (wave == 0) { int keep = run_limit / 2; if (keep > COOP_SCAP - GRP_PEND - 8) keep = COOP_SCAP - GRP_PEND - 8; run_evict_w0(keep); publish_cold(); }
+                    if (wave == 0) { int keep = run_limit / 2; if (keep > COOP_SCAP - GRP_W - 8) keep = COOP_SCAP - GRP_W - 8; run_evict_w0(keep); publish_cold(); }
                     __syncthreads();
                     if (shI[GI_SERIAL]) break;                                  // `pend` keeps the batch for the serial continuation
                 }
@@ -908,7 +947,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 const bool cold_ne = cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0);
                 HeapEnt r; r.key = 0; r.idx = 0; r.pad = 0;
                 bool hasr = tid < P;
-                if (hasr) r = pend[tid];
+                if (hasr) r = pend[p0 + tid];
                 hasr = hasr && r.key != ~0ull;                                  // (a slot of a dropped residual)
                 const bool tocold = hasr && cold_ne && !(hot_ne && r.key < hot_max) && cold_bucket(cold, r.key) >= (uint32_t)shI[GI_COLD_LOW];
                 const bool towin = hasr && !tocold && nw2 > 0 && r.key < lastwin;
@@ -929,7 +968,8 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 if (tid == 0) {
                     int tc = 0, tw = 0, tr = 0;
                     for (int w = 0; w < GRP_NWV; ++w) { tc += wtmp[0][w]; tw += wtmp[1][w]; tr += wtmp[2][w]; }
-                    shI[GI_NSTAGE] += tc; shI[GI_NWB] = tw; shI[GI_NHOT] = tr; shI[GI_PENDN] = 0;
+                    shI[GI_NSTAGE] += tc; shI[GI_NWB] = tw; shI[GI_NHOT] = tr;
+                    if (p0 + P >= Ptot) { shI[GI_PENDN] = 0; shI[GI_PEND0] = 0; } else shI[GI_PEND0] = p0 + P;
                 }
                 __syncthreads();
                 // Window-bound residuals (keys below the last root) become roots at their sorted positions -- ALL of them in one
@@ -1039,11 +1079,15 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                     }
                 } else __syncthreads();
                 if (mypos >= 0) srun[(sh3 + mypos) & SMASK] = me;
+                GTICK(6);
                 if (wave == 0 && shI[GI_NSTAGE] >= 64) { flush_stage_w0(); publish_cold(); }
+                GTICK(15);
                 if (tid == 0 && R > 0) { shI[GI_SCOUNT] = sc3 + R; shI[GI_NHOT] = 0; shI[GI_DIRTY] = 1; atomicAdd(&lstat[GS_RUNINS], (uint32_t)R); }
                 __syncthreads();
                 if (shI[GI_SERIAL]) break;
             }
+            if (shI[GI_SERIAL]) break;                                          // uniform (set before a barrier every thread has passed)
+            GTICK(6);
             check_order(10 + burst);
             if (ncommit < nwb && !shI[GI_ANY]) break;                           // uniform (GI_ANY: written before E4)
             __syncthreads();
@@ -1055,15 +1099,17 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             shQ[GQ_KSQ] = ~0ull; shQ[GQ_KINV] = ~0ull; shI[GI_READY] = 0;
         }
         if (shI[GI_SERIAL]) continue;
-        GTICK(6);
+        GTICK(13);
         // ---- G: refill the window from the run (from the buckets when the run is empty) ------------------------------------------------------
         if (did_commit || shI[GI_NW] < wcap) {
             for (;;) {
                 __syncthreads();
                 const bool need_drain = shI[GI_SCOUNT] == 0 && cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0);
                 if (need_drain) {
+                    GTICK(7);
                     if (wave == 0) grp_w0_drain(&scold, srun, stage, hist, shI, lstat, drain_n, lane);
                     __syncthreads();
+                    GTICK(9);
                     if (shI[GI_SERIAL]) break;
                     // the drained bucket comes unsorted unless its list was in key order: a bitonic sort over ALL waves (one
                     // wave sorting 1024 entries was two thirds of a drain)
@@ -1086,6 +1132,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                             }
                     }
                     if (tid == 0) shI[GI_SORTN] = 0;
+                    GTICK(10);
                 }
                 const int nw5 = shI[GI_NW], sc5 = shI[GI_SCOUNT], sh5 = shI[GI_SHEAD], nf5 = shI[GI_NFREESLOT];
                 int take = wcap - nw5;
@@ -1120,7 +1167,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
 #ifdef ISX_FLOOD_PROF
     // phase timers of the work-group's first lane: 0 bounds (A), 1 claims up to (S3), 2 read-back + lists + next pop, 3 squash + publish,
     // 4 commit decision, 5 labels + residuals, 6 enqueue, 7 refill + drains, 8 loop end
-    if (stats && tid == 0) for (int i = 0; i < 12; ++i) atomicAdd(&stats[32 + i], tk_acc[i]);
+    if (stats && tid == 0) for (int i = 0; i < 16; ++i) atomicAdd(&stats[32 + i], tk_acc[i]);
 #endif
 #undef GTICK
     if (stats && tid == 0) {
@@ -1144,6 +1191,9 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         atomicAdd(&stats[17], (unsigned long long)lstat[GS_BURST]);
         atomicAdd(&stats[18], (unsigned long long)lstat[GS_RELOAD]);
         if (shI[GI_SERIAL]) atomicAdd(&stats[8], 1ull);
+#ifdef ISX_FLOOD_PROF
+        for (int i = 0; i < 10; ++i) atomicAdd(&stats[48 + i], (unsigned long long)lstat[GS_C_NOTREADY + i]);
+#endif
     }
     if (shI[GI_SERIAL]) {
         // Exact continuation on one lane: every queued element (window roots -- their speculative work is dropped, `out`
@@ -1173,7 +1223,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 const int sc = shI[GI_SCOUNT], sh_ = shI[GI_SHEAD];
                 for (int j = 0; j < sc; ++j) { HeapEnt e = srun[(sh_ + j) & SMASK]; e.pad = 0; heap_push(heap, hn, e); }
                 for (int j = 0; j < shI[GI_NSTAGE]; ++j) { HeapEnt e = stage[j]; e.pad = 0; heap_push(heap, hn, e); }
-                for (int j = 0; j < shI[GI_PENDN]; ++j) { HeapEnt e = pend[j]; e.pad = 0; if (e.key != ~0ull) heap_push(heap, hn, e); }
+                for (int j = shI[GI_PEND0]; j < shI[GI_PENDN]; ++j) { HeapEnt e = pend[j]; e.pad = 0; if (e.key != ~0ull) heap_push(heap, hn, e); }
                 for (int j = 0; j < shI[GI_NHOT]; ++j) { HeapEnt e = hotb[j]; e.pad = 0; heap_push(heap, hn, e); }
                 for (int j = shI[GI_WB0]; j < shI[GI_NWB]; ++j) { HeapEnt e = pend[j]; e.pad = 0; heap_push(heap, hn, e); }
             }
