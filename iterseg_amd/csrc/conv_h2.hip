@@ -107,7 +107,9 @@ __device__ __forceinline__ void round8(const float4 &a, const float4 &b, uint4 &
 }
 
 // TX = 3: all 27 taps (14 pairs).  TX = 1: the 9 taps with dx = 0 (5 pairs) -- the folded tail layer, whose three
-// x-taps live in the output columns (see conv_mfma_kernel / tail_combine_kernel).
+// x-taps live in the output columns (see conv_mfma_kernel / tail_combine_kernel).  TX = 2: 3 x 2 x 2 taps (6 pairs) over the
+// rows a.oy[] and columns a.ox[] -- one parity class of a decoder convolution with the transposed convolution folded into
+// its weights (UpFoldPacks, unet_state.h): the tile runs over the COARSE tensor and writes the class's output voxels (a.remap).
 // MT = 32-row tiles per wave (1: 128 voxels per work-group, 2: 256).  With 32 columns, MT = 2 gives the wave a
 // 64 x 32 tile whose six fragment reads feed six MFMAs, like the 32 x 64 tile of the 64-column variant.
 template <int BN, int TX, int MT, int PM>
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     constexpr int ROWS = 128 * MT, TXW = 8 * MT;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     constexpr int NT = BN / 32;
-    constexpr int NTAPS = 9 * TX, NPAIR = (NTAPS + 1) / 2;
+    constexpr int NTAPS = TX == 2 ? 12 : 9 * TX, NPAIR = (NTAPS + 1) / 2;
     constexpr int BU = 2 * NPAIR * BN;                    // uint4 per half of the weight slab (hi | lo)
     constexpr int SLAB = SPLIT ? 2 * BU : BU;             // uint4 of weights staged per K step (single-product modes: hi only)
     constexpr int NB = (SLAB + 255) / 256;                // uint4 of weights per thread per stage (14 / 7 / 3; halved without lo)
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     const int b = lin / a.tiles_per_chunk, tile = lin % a.tiles_per_chunk;
     const int D = a.D, H = a.H, W = a.W;
     const int64_t M = (int64_t)D * H * W;
+    const int64_t Mout = a.remap ? a.Mout : M;
 
     // ---- tile geometry: identical to conv_mfma_kernel with one row tile per wave ---------------------------
     int PS, RS, S;
@@ -174,6 +177,18 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
             int zz = r / TP, p = p0 + r % TP;
             int z = z0 + zz;
             if (z < D && p < H * W) g = z * H * W + p;
+        }
+        if (a.remap && g >= 0) {
+            // class voxel (z, i, j) of the coarse grid -> output voxel (z, 2i + py - off, 2j + px - off); bits 24..29: which
+            // faces of the output box the voxel lies on (selects the row of the bias table)
+            const int z = g / (H * W), i = (g / W) % H, j = g % W;
+            const int Y = 2 * i + a.rpy - a.roff, X = 2 * j + a.rpx - a.roff;
+            if (Y < 0 || Y >= a.rH || X < 0 || X >= a.rW) g = -1;
+            else {
+                const int cfg = (z == 0 ? 1 : 0) | (z == D - 1 ? 2 : 0) | (Y == 0 ? 4 : 0) | (Y == a.rH - 1 ? 8 : 0) |
+                                (X == 0 ? 16 : 0) | (X == a.rW - 1 ? 32 : 0);
+                g = ((z * a.rH + Y) * a.rW + X) | (cfg << 24);
+            }
         }
         rowinfo[r] = g;
     }
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     auto tap_off = [&](int t) __attribute__((always_inline)) -> int {
         if (t > NTAPS - 1) t = NTAPS - 1;
         if (TX == 3) return (t / 9 - 1) * PS + ((t / 3) % 3 - 1) * RS + (t % 3 - 1);
+        if (TX == 2) return (t / 4 - 1) * PS + a.oy[(t >> 1) & 1] * RS + a.ox[t & 1];
         return (t / 3 - 1) * PS + (t % 3 - 1) * RS;
     };
 
@@ -328,12 +344,16 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = (wave * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const int g = rowinfo[row];
+                int g = rowinfo[row];
                 if (g >= 0) {
+                    float bv = bsv;
+                    if (a.remap) { bv = a.bias[(g >> 24) * a.Cout + ch]; g &= 0xFFFFFF; }
                     float v;
-                    if constexpr (SPLIT) v = fmaf(acc_lo[m][j][i], 1.f / H2_SCALE, acc_hi[m][j][i]) + bsv;
-                    else v = acc_hi[m][j][i] + bsv;
-                    if (ch < a.store_cols) a.out[((int64_t)b * M + g) * a.store_cols + ch] = v;
+                    if constexpr (SPLIT) v = fmaf(acc_lo[m][j][i], 1.f / H2_SCALE, acc_hi[m][j][i]) + bv;
+                    else v = acc_hi[m][j][i] + bv;
+                    float *op = &a.out[((int64_t)b * Mout + g) * a.store_cols + ch];
+                    if (a.accum) v += *op;
+                    if (ch < a.store_cols) *op = v;
                     s += v;
                     q += v * v;
                 }
@@ -370,8 +390,30 @@ int conv_h2_bn(const isx_tune &tune, int slots, int cout)
     return (cout % 64 == 0 && (force64 || 2 * lds64 <= 160 * 1024)) ? 64 : 32;
 }
 
-// w: reference layout [Cout][Cin][27] fp32 -> [Cout/BN][Cin/8][hi|lo][28 taps][BN][8 channels] halves
+// w: [Cout][Cin][ntap] fp32 -> [Cout/BN][Cin/8][hi|lo][ntap_pad taps][BN][8 channels] halves
 // pm = 0: split halves (hi | lo); 1: f16 round-to-nearest in hi; 2: bf16 round-to-nearest in hi (lo stays zero, unused)
+void pack_h2_taps(const float *w, int cout, int cin, int ntap, int ntap_pad, int bn, std::vector<uint16_t> &out, int pm)
+{
+    const int ntiles = cout / bn, nsteps = cin / 8;
+    const size_t half_slab = (size_t)ntap_pad * bn * 8;
+    out.assign((size_t)ntiles * nsteps * 2 * half_slab + 4096, 0);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < ntap; ++t) {
+                _Float16 h, l;
+                split_h2(w[((size_t)co * cin + ci) * ntap + t], h, l);
+                const size_t base = ((size_t)(co / bn) * nsteps + ci / 8) * 2 * half_slab;
+                const size_t e = ((size_t)t * bn + co % bn) * 8 + ci % 8;
+                uint16_t hb, lb;
+                memcpy(&hb, &h, 2);
+                memcpy(&lb, &l, 2);
+                if (pm == 2) { hb = bf16_rne_bits(w[((size_t)co * cin + ci) * ntap + t]); lb = 0; }
+                out[base + e] = hb;
+                out[base + half_slab + e] = lb;
+            }
+}
+
+// w: reference layout [Cout][Cin][27] fp32 -> [Cout/BN][Cin/8][hi|lo][28 taps][BN][8 channels] halves
 void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out, int pm)
 {
     const int ntiles = cout / bn, nsteps = cin / 8;
@@ -449,9 +491,15 @@ size_t h2_pack_halves(int cout_p, int cin_p, int bn) { return (size_t)(cout_p / 
 
 // fold != 0: the folded tail layer (TX = 1, 32 columns of which store_cols = 16 are stored, no statistics)
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used, int pm)
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used, int pm, const H2Extra *ex)
 {
     ConvArgs a;
+    const int tx2 = ex ? ex->tx2 : 0;
+    a.oy[0] = ex ? ex->oy[0] : 0; a.oy[1] = ex ? ex->oy[1] : 0; a.ox[0] = ex ? ex->ox[0] : 0; a.ox[1] = ex ? ex->ox[1] : 0;
+    a.remap = ex ? ex->remap : 0; a.rH = ex ? ex->rH : 0; a.rW = ex ? ex->rW : 0; a.rpy = ex ? ex->rpy : 0; a.rpx = ex ? ex->rpx : 0;
+    a.roff = ex ? ex->roff : 0; a.Mout = ex ? ex->Mout : 0; a.accum = ex ? ex->accum : 0;
+    ISX_REQUIRE(!(tx2 && fold), "internal: class convolution and folded tail are different kernels");
+    ISX_REQUIRE(!a.remap || a.Mout < (1 << 24), "internal: remapped output of %ld voxels per chunk", (long)a.Mout);
     a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
     a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
     a.w = (const float *)w_h2; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
@@ -476,7 +524,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     }
     ISX_REQUIRE(a.slots_max <= (mt == 2 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     a.ntiles = fold ? 1 : cout / BN;
-    const int npair = fold ? 5 : 14;
+    const int npair = fold ? 5 : (tx2 ? 6 : 14);
     const size_t lds = (size_t)((pm == 0 ? 2 : 1) * (2 * npair * BN + a.slots_max)) * 16 + (128 * mt + 4 * BN * 2) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
@@ -488,6 +536,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<BN_, TX_, MT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (!attr_done) {
         ISX_H2_ATTR(64, 3, 1) ISX_H2_ATTR(32, 3, 1) ISX_H2_ATTR(32, 3, 2) ISX_H2_ATTR(32, 1, 1) ISX_H2_ATTR(32, 1, 2)
+        ISX_H2_ATTR(64, 2, 1) ISX_H2_ATTR(32, 2, 1) ISX_H2_ATTR(32, 2, 2)
         attr_done = true;
     }
 #undef ISX_H2_ATTR
@@ -497,6 +546,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
          else conv_h2_kernel<BN_, TX_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
     if (fold && mt == 2) ISX_H2_GO(32, 1, 2);
     else if (fold) ISX_H2_GO(32, 1, 1);
+    else if (tx2 && BN == 64) ISX_H2_GO(64, 2, 1);
+    else if (tx2 && mt == 2) ISX_H2_GO(32, 2, 2);
+    else if (tx2) ISX_H2_GO(32, 2, 1);
     else if (BN == 64) ISX_H2_GO(64, 3, 1);
     else if (mt == 2) ISX_H2_GO(32, 3, 2);
     else ISX_H2_GO(32, 3, 1);

@@ -1,0 +1,8 @@
+set -e
+cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/tf; mkdir -p $O
+cd $R
+for f in 1 0; do
+  ISX_UP_FOLD=$f rocprofv3 --kernel-trace --output-format csv -d $O/p$f -o t -- python3 scratch/bench_unet.py 64 > $O/run$f.log 2>&1
+  python3 scratch/trace_fold_sum.py $O/p$f > $O/sum$f.txt
+done

@@ -264,3 +264,32 @@ def test_reduced_precision_modes_full_size_chunk(mode):
     fm = u.predict_volume(torch.from_numpy(vol).cuda(), (4, 32, 32), (1, 8, 8)).cpu().numpy()
     ref_fm = ou.predict_volume(sd, vol, (4, 32, 32), (1, 8, 8))
     assert np.abs(fm - ref_fm).max() <= REDUCED_TOL[mode]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
+def test_folded_up_convolution_equals_materialised_one(precision, monkeypatch):
+    """ISX_UP_FOLD=1: up1 / up2 (ConvTranspose3d + crop, unet.py:215-242,339-349) folded into the weights of c6.conv0 / c7.conv0
+    -- four 12-tap class convolutions over the coarse tensor, the phantom taps of the cropped faces taken back, the skip half
+    accumulated on top -- against the default form that materialises the up-sampled tensor.  Faces and corners included."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(3)
+    nets = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("ISX_UP_FOLD", fold)
+        u = UNet(1, 5, batch=1, precision=precision)
+        u.load_state_dict(sd)
+        nets.append(u)
+    tol = 2e-5 if precision == "split-f16" else 3e-2       # the single-product modes round the folded weights once instead of
+    rng = np.random.default_rng(5)                          # activations and weights separately
+    for shape in [(4, 32, 32), (10, 80, 48)]:
+        x = rng.random((1, 1) + shape, dtype=np.float32)
+        ya, yb = nets[0](x), nets[1](x)
+        assert np.abs(ya - yb).max() <= tol
+        for name in ("c6_0.conv0", "c7_0.conv0"):
+            ta, tb = nets[0].tap(name), nets[1].tap(name)
+            assert np.abs(ta - tb).max() <= tol * max(1.0, np.abs(tb).max()), name
+        # the tap of an up-sampled tensor the folded forward never wrote is computed on demand
+        assert np.abs(nets[0].tap("up1.cropped") - nets[1].tap("up1.cropped")).max() <= tol
