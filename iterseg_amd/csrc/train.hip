@@ -507,6 +507,182 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad on the bf16 matrix cores (precision "bf16": BASELINE config 4's mixed arithmetic).  Same decomposition as
+// wgrad_mfma_kernel -- grid (co_tiles * ci_tiles, 9 (dz, dy) taps, splits), three x-taps per work-group from one staged
+// input tile, K = voxels in blocks of 64 -- with both operands rounded to bfloat16 (round to nearest even) when they are
+// staged and v_mfma_f32_32x32x16_bf16 (K = 16 voxels per instruction; fp32 accumulation, fp32 partials, the same fixed-order
+// reduction).  The operands of that instruction are K-major per lane (8 consecutive voxels of one channel) while the tensors
+// are channel-major per voxel: the tiles stay [voxel][channel] in LDS and the fragments are read with the transposing
+// ds_read_b64_tr_b16 (four rows of 16 channels per 16-lane group, scratch/tr_read_test.hip checks the lane map).  Row
+// strides of 192 B (64-channel tiles; 64 B for 32-channel ones) keep the four rows of a read on different banks.  The dY
+// tile is staged three times -- as is, with the voxels at x = 0 zeroed (tap dx = -1 has no left neighbour there) and with
+// those at x = W - 1 zeroed (dx = +1) -- because a per-element mask on packed fragments would cost more than the MFMAs.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t wg_pack_bf16(float x, float y)
+{
+    uint32_t a = __float_as_uint(x), b = __float_as_uint(y);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+
+template <int TCO, int TCI>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
+{
+    constexpr int NSUB = (TCO / 32) * (TCI / 32), KG = 4 / NSUB, KSTEPS = 4 / KG;     // 16-voxel K steps of a block per wave
+    constexpr int NY = TCO / 16;
+    constexpr int XROWS = 66, XQ = TCI / 4, NX = (XROWS * XQ + 255) / 256;
+    constexpr int YSTR = TCO == 64 ? 192 : 64, XSTR = TCI == 64 ? 192 : 64;           // bytes per LDS row
+    __shared__ __attribute__((aligned(16))) unsigned char Ys[3][64 * YSTR];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[(XROWS + 2) * XSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
+    const int co_t = blockIdx.x / a.ci_tiles, ci_t = blockIdx.x % a.ci_tiles;
+    const int tap9 = blockIdx.y, split = blockIdx.z;
+    const int dz = tap9 / 3 - 1, dy = tap9 % 3 - 1;
+    const int D = a.D, H = a.H, W = a.W, Cin = a.CA + a.CB;
+    const int64_t M = (int64_t)D * H * W;
+    const int64_t v_begin = (int64_t)split * a.vox_per_split;
+    int64_t v_end = v_begin + a.vox_per_split;
+    if (v_end > M) v_end = M;
+    const int sub = wave % NSUB, kg = wave / NSUB;
+    const int wr = sub / (TCI / 32), wc = sub % (TCI / 32);
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const int co0 = co_t * TCO, ci0 = ci_t * TCI;
+    constexpr int YQ = TCO / 4, YV = 256 / YQ;
+    const int yq = tid % YQ, yv = tid / YQ;
+    float4 ry[NY], rx[NX];
+    int rxm[NY];                                              // x coordinate of the dY voxel (-1: outside the split)
+
+    auto load_block = [&](int64_t v0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < NY; ++p) {
+            const int64_t v = v0 + yv + YV * p;
+            float4 yvv = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int co = co0 + 4 * yq;
+            rxm[p] = -1;
+            if (v < v_end) {
+                rxm[p] = (int)((uint32_t)v % (uint32_t)W);
+                if (co + 3 < a.Cout) yvv = *(const float4 *)&a.dy[v * a.dy_stride + co];
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (co + j < a.Cout) (&yvv.x)[j] = a.dy[v * a.dy_stride + co + j];
+            }
+            ry[p] = yvv;
+        }
+#pragma unroll
+        for (int p = 0; p < NX; ++p) {
+            const int idx = tid + 256 * p;
+            const int row = idx / XQ, xq = idx % XQ;
+            const int64_t u = v0 - 1 + row;
+            float4 xvv = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ci = ci0 + 4 * xq;
+            if (row < XROWS && u >= 0 && u < M && ci < Cin) {
+                const int x = (int)(u % W), y = (int)((u / W) % H) + dy, z = (int)(u / ((int64_t)W * H)) + dz;
+                if (z >= 0 && z < D && y >= 0 && y < H) {
+                    const int64_t g = ((int64_t)z * H + y) * W + x;
+                    const bool fromB = ci >= a.CA;
+                    const float *src = fromB ? a.srcB : a.srcA, *sc = fromB ? a.scaleB : a.scaleA, *sh = fromB ? a.shiftB : a.shiftA;
+                    const int C = fromB ? a.CB : a.CA, cc = fromB ? ci - a.CA : ci;
+                    if (cc + 3 < C) {
+                        xvv = *(const float4 *)&src[g * C + cc];
+                        if (sc) {
+                            const float4 s4 = *(const float4 *)&sc[cc], h4 = *(const float4 *)&sh[cc];
+                            xvv.x = fmaxf(fmaf(xvv.x, s4.x, h4.x), 0.f);
+                            xvv.y = fmaxf(fmaf(xvv.y, s4.y, h4.y), 0.f);
+                            xvv.z = fmaxf(fmaf(xvv.z, s4.z, h4.z), 0.f);
+                            xvv.w = fmaxf(fmaf(xvv.w, s4.w, h4.w), 0.f);
+                        }
+                    } else {
+                        for (int j = 0; j < 4; ++j)
+                            if (cc + j < C) {
+                                float t = src[g * C + cc + j];
+                                if (sc) t = fmaxf(fmaf(t, sc[cc + j], sh[cc + j]), 0.f);
+                                (&xvv.x)[j] = t;
+                            }
+                    }
+                }
+            }
+            rx[p] = xvv;
+        }
+    };
+
+    // fragment addresses: lane (group g of 16, i = 4q + p) supplies row q, channels 16g + 4p .. +3 of its wave's 32-channel half
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gg = (lane >> 4) & 1;
+    const int yoff = (8 * hh + gq) * YSTR + (wr * 32 + 16 * gg + 4 * gp) * 2;
+    const int xoff = (8 * hh + gq) * XSTR + (wc * 32 + 16 * gg + 4 * gp) * 2;
+    typedef __attribute__((address_space(3))) v4s16 *lds_v4;
+    union Frag { v4s16 h[2]; bf16x8w v; };
+
+    if (v_begin < v_end) load_block(v_begin);
+    for (int64_t v0 = v_begin; v0 < v_end; v0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NY; ++p) {
+            const uint2 pk = make_uint2(wg_pack_bf16(ry[p].x, ry[p].y), wg_pack_bf16(ry[p].z, ry[p].w));
+            const uint2 zero = make_uint2(0u, 0u);
+            const int o = (yv + YV * p) * YSTR + 8 * yq;
+            *(uint2 *)&Ys[0][o] = rxm[p] > 0 ? pk : zero;                    // dx = -1: no left neighbour at x = 0
+            *(uint2 *)&Ys[1][o] = pk;
+            *(uint2 *)&Ys[2][o] = (rxm[p] >= 0 && rxm[p] < W - 1) ? pk : zero;     // dx = +1: none at x = W - 1
+        }
+#pragma unroll
+        for (int p = 0; p < NX; ++p) {
+            const int idx = tid + 256 * p;
+            if (idx < XROWS * XQ) *(uint2 *)&Xs[(idx / XQ) * XSTR + 8 * (idx % XQ)] = make_uint2(wg_pack_bf16(rx[p].x, rx[p].y), wg_pack_bf16(rx[p].z, rx[p].w));
+        }
+        __syncthreads();
+        if (v0 + 64 < v_end) load_block(v0 + 64);          // in flight while the matrix cores run
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int kb = (kg * KSTEPS + ks) * 16;
+            Frag ya[3], xb[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ya[t].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(&Ys[t][0] + yoff + kb * YSTR));
+                ya[t].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(&Ys[t][0] + yoff + (kb + 4) * YSTR));
+                xb[t].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(&Xs[0] + xoff + (kb + t) * XSTR));
+                xb[t].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(&Xs[0] + xoff + (kb + t + 4) * XSTR));
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[t].v, xb[t].v, acc[t], 0, 0, 0);
+        }
+    }
+    if (KG > 1) {
+        __shared__ float red[(KG > 1 ? (KG - 1) * NSUB : 1) * 1024];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            __syncthreads();
+            if (kg > 0)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[(((kg - 1) * NSUB + sub) * 16 + i) * 64 + lane] = acc[t][i];
+            __syncthreads();
+            if (kg == 0)
+                for (int g = 1; g < KG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] += red[(((g - 1) * NSUB + sub) * 16 + i) * 64 + lane];
+        }
+    }
+    if (kg == 0) {
+        const int CoP = a.co_tiles * TCO, CiP = a.ci_tiles * TCI;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            float *dst = a.partial + (((int64_t)split * 27 + (tap9 * 3 + t)) * CoP) * CiP;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const int ci = ci0 + wc * 32 + nn;
+                dst[(int64_t)co * CiP + ci] = acc[t][i];
+            }
+        }
+    }
+}
+
 // dW[co][ci][tap] = sum over splits (fixed order)
 __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int splits, int Cout, int Cin, int CoP, int CiP,
                                     float *__restrict__ dw)
@@ -836,7 +1012,15 @@ static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
     const size_t need = (size_t)a.splits * 27 * a.co_tiles * tco * a.ci_tiles * tci;
     ISX_REQUIRE(need <= t->wpart_floats, "internal: wgrad partial buffer too small (%zu > %zu)", need, t->wpart_floats);
     const dim3 wgrid(a.co_tiles * a.ci_tiles, 9, a.splits);
-    if (tco == 64 && tci == 64) wgrad_mfma_kernel<64, 64><<<wgrid, 256, 0, ctx->stream>>>(a);
+    // precision "bf16": every layer with Cin % 32 == 0 (the wide layers, whose forward runs on the bf16 matrix cores, and the
+    // 64 -> n tail layer) takes its weight gradient there too; c0.conv0, the n -> n layer and every other precision keep fp32 products
+    const bool bfw = u->precision == ISX_PRECISION_BF16 && L.cin % 32 == 0 && ctx->tune.bf16_wgrad;      // (also the 64 -> n tail layer)
+    if (bfw) {
+        if (tco == 64 && tci == 64) wgrad_bf16_kernel<64, 64><<<wgrid, 256, 0, ctx->stream>>>(a);
+        else if (tco == 32 && tci == 64) wgrad_bf16_kernel<32, 64><<<wgrid, 256, 0, ctx->stream>>>(a);
+        else if (tco == 64 && tci == 32) wgrad_bf16_kernel<64, 32><<<wgrid, 256, 0, ctx->stream>>>(a);
+        else wgrad_bf16_kernel<32, 32><<<wgrid, 256, 0, ctx->stream>>>(a);
+    } else if (tco == 64 && tci == 64) wgrad_mfma_kernel<64, 64><<<wgrid, 256, 0, ctx->stream>>>(a);
     else if (tco == 32 && tci == 64) wgrad_mfma_kernel<32, 64><<<wgrid, 256, 0, ctx->stream>>>(a);
     else if (tco == 64 && tci == 32) wgrad_mfma_kernel<64, 32><<<wgrid, 256, 0, ctx->stream>>>(a);
     else wgrad_mfma_kernel<32, 32><<<wgrid, 256, 0, ctx->stream>>>(a);
@@ -909,7 +1093,7 @@ static int backward(isx_ctx *ctx)
             const Level &ls = lv[MOD_LEVEL[layer_module(li_in)]];
             const ConvBN &Lin = u->cv[li_in];
             const int kt = U.kz * 4;
-            const int vpb = 1024;
+            const int vpb = 128;                                      // (1024 until round 3: 163 work-groups for up3's 166 k source voxels, 1 ms)
             const int blocks = (int)((ls.M + vpb - 1) / vpb);
             ISX_REQUIRE((size_t)blocks * (kt + 1) * U.C <= t->part_floats, "internal: partial buffer too small");
             upsample_bwd_kernel<<<blocks, 256, (size_t)(256 / (U.C / 4)) * (kt + 1) * U.C * sizeof(float), ctx->stream>>>(

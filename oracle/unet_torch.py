@@ -101,11 +101,17 @@ def _bf16_dgrad(name, cin, cout):
     return _bf16_forward(cin, cout) and cin % 32 == 0 and cout % 8 == 0
 
 
+def _bf16_wgrad(cin, cout):
+    # train.hip wgrad(): the bf16 weight-gradient kernel serves every layer with Cin % 32 == 0
+    return cin % 32 == 0
+
+
 class _ConvMixed(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, rf, rd):
         ctx.save_for_backward(x, w)
         ctx.rd = rd
+        ctx.rf = rf
         return F.conv3d(_rb(x) if rf else x, _rb(w) if rf else w, b, padding=1)
 
     @staticmethod
@@ -114,7 +120,10 @@ class _ConvMixed(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.nn.grad.conv3d_input(x.shape, _rb(w) if ctx.rd else w, _rb(g) if ctx.rd else g, padding=1)
-        gw = torch.nn.grad.conv3d_weight(x, w.shape, g, padding=1)          # fp32 operands, unrounded
+        # the weight gradient of a wide layer rounds its two operands too (train.hip wgrad_bf16_kernel: the conv input after
+        # BatchNorm + ReLU and d(raw), both to bfloat16; fp32 accumulation); _BF16["wgrad"] = False restates round 2's step
+        rw = _bf16_wgrad(int(w.shape[1]), int(w.shape[0])) and _BF16.get("wgrad", True)
+        gw = torch.nn.grad.conv3d_weight(_rb(x) if rw else x, w.shape, _rb(g) if rw else g, padding=1)
         return gx, gw, g.sum((0, 2, 3, 4)), None, None
 
 

@@ -4,7 +4,7 @@ from iterseg_amd import weights
 from iterseg_amd.train import Trainer
 from tests.synth import positive_volume
 patch = (10, 256, 256)
-t = Trainer(weights.generate_state_dict(0), 5, patch)
+t = Trainer(weights.generate_state_dict(0), 5, patch, precision=os.environ.get("ISX_TRAIN_PRECISION", "fp32"))
 x = torch.from_numpy(positive_volume(patch, 1)).cuda()
 y = torch.from_numpy((np.random.default_rng(1).random((5,) + patch) < 0.5).astype(np.float32)).cuda()
 for _ in range(2): t.train_step(x, y)

@@ -374,6 +374,26 @@ def test_bf16_convolutions_pinned_layer_by_layer_against_the_rounding_oracle():
                 assert err <= 1e-3, ("dgrad", m, j, err)
                 n_dg += 1
     assert n_fwd == 15 and n_dg == 15, (n_fwd, n_dg)
+    # the weight gradients of the same layers: d(raw) and the layer's input, both rounded, on the bf16 matrix cores
+    # (wgrad_bf16_kernel: transposed LDS fragment reads, three x-taps per staged tile, masked dY copies at the row ends)
+    n_wg = 0
+    for mi, m in enumerate(mods):
+        for j in (0, 1):
+            li = 2 * mi + j
+            w = torch.from_numpy(sd[f"{m}.conv{j}.weight"])
+            cout, cin = int(w.shape[0]), int(w.shape[1])
+            if not ou._bf16_wgrad(cin, cout):
+                continue
+            D, H, W = inputs[(m, j)].shape[1:]
+            g = torch.from_numpy(t.grad_tap(f"draw:{li}")).reshape(D, H, W, -1)[..., :cout].permute(3, 0, 1, 2).contiguous()   # (thin layers: padded stride)
+            ref = torch.nn.grad.conv3d_weight(rb(inputs[(m, j)])[None], w.shape, rb(g)[None], padding=1)
+            got = t.grad(f"{m}.conv{j}.weight").cpu()
+            err = float((got - ref).abs().max() / ref.abs().max())
+            assert err <= 1e-3, ("wgrad", m, j, err)
+            plain = torch.nn.grad.conv3d_weight(inputs[(m, j)][None], w.shape, g[None], padding=1)
+            assert float((got - plain).abs().max()) > 3 * float((got - ref).abs().max()), ("wgrad is rounded", m, j)
+            n_wg += 1
+    assert n_wg == 16, n_wg                # the 15 wide layers + c8_0.conv0 (64 -> 5)
     # diagnostic only (see above): the whole step against the rounding oracle and against the fp32 oracle
     lo, _, go, _ = ou.train_step(sd, x, y, bf16=True)
     lf, _, gf, _ = ou.train_step(sd, x, y)
