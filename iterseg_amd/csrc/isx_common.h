@@ -90,10 +90,12 @@ struct isx_ctx {
     int ws_shard_rank = 0, ws_shard_world = 1;     // W4 component sharding (isx_ws_set_shard)
     void *comm = nullptr;                          // RCCL communicator (isx_comm_init), ncclComm_t
     int comm_rank = 0, comm_world = 1;
-    hipStream_t aux_stream = nullptr;               // side stream of the flood's work-group kernel (forked from / joined to `stream`)
-    hipEvent_t aux_ev[2] = {nullptr, nullptr};
-    int aux_fork();
-    int aux_join();
+    // side streams of the flood (forked from / joined to `stream`): 0 = the work-group kernel of the giants, 1 = the large
+    // tier of the window kernel, so that giants, large and mid-size components flood side by side
+    hipStream_t aux_streams[2] = {nullptr, nullptr};
+    hipEvent_t aux_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int aux_fork(int i = 0);
+    int aux_join(int i = 0);
     void *pinned_buf[2] = {nullptr, nullptr};      // host staging of isx_segment_volume_host (0: frame in, 1: labels out)
     size_t pinned_bytes[2] = {0, 0};
 

@@ -67,22 +67,22 @@ void isx_ctx::trim()
     free_blocks.clear();
 }
 
-int isx_ctx::aux_fork()
+int isx_ctx::aux_fork(int i)
 {
-    if (!aux_stream) {
-        ISX_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
-        ISX_HIP(hipEventCreateWithFlags(&aux_ev[0], hipEventDisableTiming));
-        ISX_HIP(hipEventCreateWithFlags(&aux_ev[1], hipEventDisableTiming));
+    if (!aux_streams[i]) {
+        ISX_HIP(hipStreamCreateWithFlags(&aux_streams[i], hipStreamNonBlocking));
+        ISX_HIP(hipEventCreateWithFlags(&aux_ev[i][0], hipEventDisableTiming));
+        ISX_HIP(hipEventCreateWithFlags(&aux_ev[i][1], hipEventDisableTiming));
     }
-    ISX_HIP(hipEventRecord(aux_ev[0], stream));
-    ISX_HIP(hipStreamWaitEvent(aux_stream, aux_ev[0], 0));
+    ISX_HIP(hipEventRecord(aux_ev[i][0], stream));
+    ISX_HIP(hipStreamWaitEvent(aux_streams[i], aux_ev[i][0], 0));
     return ISX_OK;
 }
 
-int isx_ctx::aux_join()
+int isx_ctx::aux_join(int i)
 {
-    ISX_HIP(hipEventRecord(aux_ev[1], aux_stream));
-    ISX_HIP(hipStreamWaitEvent(stream, aux_ev[1], 0));
+    ISX_HIP(hipEventRecord(aux_ev[i][1], aux_streams[i]));
+    ISX_HIP(hipStreamWaitEvent(stream, aux_ev[i][1], 0));
     return ISX_OK;
 }
 
@@ -187,8 +187,10 @@ void isx_ctx_destroy(isx_ctx *c)
     c->live_blocks.clear();
     c->trim();
     c->pinned_free();
-    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
-    for (auto e : c->aux_ev) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (c->aux_streams[i]) { (void)hipStreamSynchronize(c->aux_streams[i]); (void)hipStreamDestroy(c->aux_streams[i]); }
+        for (auto e : c->aux_ev[i]) if (e) (void)hipEventDestroy(e);
+    }
     for (auto &s : c->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

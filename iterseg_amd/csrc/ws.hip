@@ -2050,19 +2050,37 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
             // (ISX_FLOOD_GROUP_STREAM=0: same stream, one kernel after the other -- structured 512^3 seed 3, one 345 k-voxel
             // giant among 2 900 mid-size components: 150 ms against 104 ms side by side)
             if (side) ISX_TRY(ctx->aux_fork());
-            flood_group_kernel<<<n_comp, GRP_W, 0, side ? ctx->aux_stream : ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
+            flood_group_kernel<<<n_comp, GRP_W, 0, side ? ctx->aux_streams[0] : ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                                    comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1], pshape[2], PN,
                                                                    s[0], s[1], s[2], group_min, run_limit, drain_n, gwcap, gtcap, group_bursts,
                                                                    bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world, gsteps | (gminsteps << 8));
             ISX_CHECK_LAUNCH();
         }
-        flood_window_kernel<<<n_comp, 64, 0, ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
-                                                            comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
-                                                            pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, wcap, tcap, max_bursts,
-                                                            bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world,
-                                                            getenv("ISX_FLOOD_TRACE") ? claim.p : nullptr, group_min);
+        // two tiers of the single-wave kernel: components below small_max voxels on the small instantiation (~30 KB of LDS:
+        // five per CU instead of one), the others on the large one, side by side on their own streams
+        unsigned long long small_max = WIN_SMALL_MAX;
+        if (const char *e = getenv("ISX_FLOOD_SMALL_MAX")) small_max = strtoull(e, nullptr, 10);      // 0: no small tier
+        if (small_max < coop_min) small_max = coop_min;
+        if (group_min != ~0ull && small_max > group_min) small_max = group_min;
+        uint32_t *trace_p = getenv("ISX_FLOOD_TRACE") ? claim.p : nullptr;
+        const bool two = small_max > coop_min && side;
+        if (two) ISX_TRY(ctx->aux_fork(1));
+        flood_window_kernel<WIN_W, WIN_T, WIN_RCAP, WIN_PEND><<<n_comp, 64, 0, two ? ctx->aux_streams[1] : ctx->stream>>>(
+            order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p, comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
+            pshape[2], PN, s[0], s[1], s[2], small_max, run_limit, drain_n, wcap, tcap, max_bursts, bk_lo, bk_inv, stats.p, ctx->ws_shard_rank,
+            ctx->ws_shard_world, trace_p, group_min);
         ISX_CHECK_LAUNCH();
-        if (group_min != ~0ull && side) ISX_TRY(ctx->aux_join());
+        if (small_max > coop_min) {
+            const int s_wcap = wcap < WIN_SW ? wcap : WIN_SW, s_tcap = tcap < WIN_ST ? tcap : WIN_ST;
+            const int s_run = run_limit < WIN_SRCAP - 64 ? run_limit : WIN_SRCAP - 64, s_drain = drain_n < 256 ? (drain_n < s_run ? drain_n : s_run) : 256;
+            flood_window_kernel<WIN_SW, WIN_ST, WIN_SRCAP, WIN_SPEND><<<n_comp, 64, 0, ctx->stream>>>(
+                order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p, comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
+                pshape[2], PN, s[0], s[1], s[2], coop_min, s_run, s_drain, s_wcap, s_tcap, max_bursts, bk_lo, bk_inv, stats.p, ctx->ws_shard_rank,
+                ctx->ws_shard_world, trace_p, small_max);
+            ISX_CHECK_LAUNCH();
+        }
+        if (two) ISX_TRY(ctx->aux_join(1));
+        if (group_min != ~0ull && side) ISX_TRY(ctx->aux_join(0));
 
         if (const char *tp = getenv("ISX_FLOOD_TRACE")) {      // development: commit order of every component's roots
             ISX_HIP(hipStreamSynchronize(ctx->stream));

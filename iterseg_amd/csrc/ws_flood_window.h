@@ -26,11 +26,17 @@
 //
 // Queue = window (roots) + sorted run in LDS + the cold bucket arena in HBM (unchanged: cold_append / cold_drain).
 
+// Two instantiations (flood_impl): the large tier <WIN_W, WIN_T, WIN_RCAP, WIN_PEND> (130 KB of LDS: one component per CU) and the
+// small tier <WIN_SW, WIN_ST, WIN_SRCAP, WIN_SPEND> (~30 KB: five mid-size components per CU) for components below WIN_SMALL_MAX voxels.
 static constexpr int WIN_W = 192;                 // episodes in flight (physical slots)
 static constexpr int WIN_T = 48;                  // discoveries one episode holds before it must become the front
 static constexpr int WIN_RCAP = 2048;             // LDS run capacity
 static constexpr int WIN_STAGE = 128;             // staged cold-bound elements (flushed 64 at a time)
 static constexpr int WIN_PEND = 512;              // residuals of one commit burst, in age order
+static constexpr int WIN_SW = 48, WIN_ST = 24, WIN_SRCAP = 512, WIN_SPEND = 128;      // the small tier
+static constexpr unsigned long long WIN_SMALL_MAX = 8192;       // components below this many voxels use it (ISX_FLOOD_SMALL_MAX; 0 = none).  Measured r3,
+                                                                // structured 512^3: seed 3 (2 939 components >= 512 voxels) 102.8 -> 96.5 ms, seed 0 77.2 -> 77.7;
+                                                                // at 32 768 the mid-size components flood slower on the 48-episode window than they wait: seed 0 81.8 ms
 static constexpr uint32_t WIN_NONE = 0xFFFFFFFFu;
 static constexpr unsigned long long ST_FREE = ~0ull;
 static constexpr uint32_t WIN_POPPED = 0xFFFFFFFFu;     // ford() of no real value
@@ -65,6 +71,7 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
     return v;
 }
 
+template <int WW, int WT, int WRCAP, int WPEND>
 __global__ __launch_bounds__(64) void flood_window_kernel(
     const unsigned long long *__restrict__ order,
     const float *__restrict__ aff, const uint8_t *__restrict__ mask, uint32_t *__restrict__ out,
@@ -75,20 +82,20 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     int drain_n, int wcap, int tcap, int max_bursts, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world,
     uint32_t *dbg_log, unsigned long long coop_max_size)
 {
-    __shared__ HeapEnt srun[WIN_RCAP];            // .pad carries the element's label
+    __shared__ HeapEnt srun[WRCAP];            // .pad carries the element's label
     __shared__ HeapEnt stage[WIN_STAGE];
-    __shared__ HeapEnt pend[WIN_PEND];            // residuals of the episodes committing now, in (episode, discovery) = age order
-    __shared__ u32x4 winq0[WIN_W];                // {key.lo, key.hi, root voxel, label}
-    __shared__ u32x4 winq1[WIN_W];                // {cur voxel | WIN_NONE, meta, max popped value excl. cur, value of cur}; meta = npush | started << 8 | plist << 16 | cur entry << 24
-    __shared__ __attribute__((aligned(16))) uint32_t pidx[WIN_W * WIN_T];   // discoveries of an episode: voxel ...
-    __shared__ __attribute__((aligned(16))) uint32_t pval[WIN_W * WIN_T];   // ... and ordered value (WIN_POPPED once popped)
-    __shared__ unsigned short pfree[WIN_W];
-    __shared__ unsigned short actpos[WIN_W];
+    __shared__ HeapEnt pend[WPEND];            // residuals of the episodes committing now, in (episode, discovery) = age order
+    __shared__ u32x4 winq0[WW];                // {key.lo, key.hi, root voxel, label}
+    __shared__ u32x4 winq1[WW];                // {cur voxel | WIN_NONE, meta, max popped value excl. cur, value of cur}; meta = npush | started << 8 | plist << 16 | cur entry << 24
+    __shared__ __attribute__((aligned(16))) uint32_t pidx[WW * WT];   // discoveries of an episode: voxel ...
+    __shared__ __attribute__((aligned(16))) uint32_t pval[WW * WT];   // ... and ordered value (WIN_POPPED once popped)
+    __shared__ unsigned short pfree[WW];
+    __shared__ unsigned short actpos[WW];
     __shared__ HeapEnt ovl[6 * 64];               // take-overs of this row (at most one per lane and direction): key = old holder, idx = voxel
     __shared__ int hist[64];
     __shared__ uint32_t lstat[16];
 #ifdef ISX_FLOOD_CHECK
-    __shared__ int dbg_seen[WIN_W];
+    __shared__ int dbg_seen[WW];
 #endif
     const int lane = threadIdx.x;
     if (blockIdx.x >= n_comp) return;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     const int ax[6] = {0, 1, 2, 2, 1, 0};
     const float sc[3] = {s0, s1, s2};
     const unsigned long long ZKEY = (unsigned long long)0x80000000u << 32;
-    constexpr int SMASK = WIN_RCAP - 1;
+    constexpr int SMASK = WRCAP - 1;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // ---- cold tier (large components only): arena views + clean metadata (as flood_wave_kernel) ---------------
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     }
 
     // ---- queue state (wave-uniform) ---------------------------------------------------------------------------
-    int wh = 0, nw = 0, npfree = 0;               // window: circular over WIN_W slots, at most wcap used
+    int wh = 0, nw = 0, npfree = 0;               // window: circular over WW slots, at most wcap used
     int shead = 0, scount = 0, nstage = 0;
     uint32_t agebase = ns - 1;                    // seeds carry ages 0..ns-1 in index order; pushes continue
     uint32_t nspill = 0;                          // elements that could not be queued (kept for the serial continuation)
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
 #define WTICK(i) do { } while (0)
 #endif
 
-    auto slot_of = [&](int p) -> int { const int s = wh + p; return s >= WIN_W ? s - WIN_W : s; };
+    auto slot_of = [&](int p) -> int { const int s = wh + p; return s >= WW ? s - WW : s; };
     auto key_at = [&](int s) -> unsigned long long { const u32x4 q = winq0[s]; return ((unsigned long long)q.y << 32) | q.x; };
     auto fresh_q1 = [&](uint32_t root_idx, int pl) -> u32x4 { u32x4 q = {root_idx, ((uint32_t)pl << 16) | (0xFFu << 24), 0u, 0u}; return q; };   // root not popped yet
 
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     // give the claims of one episode back (lane-parallel over its discoveries)
     auto release_one = [&](unsigned long long key, int pl, int np) {
         for (int i = lane; i < np; i += 64) {
-            const uint32_t v = pidx[pl * WIN_T + i];
+            const uint32_t v = pidx[pl * WT + i];
             atomicCAS(&state[v], key, ST_FREE);
         }
     };
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             const unsigned long long key = ((unsigned long long)q0.y << 32) | q0.x;
             WSTAT(ST_SQ_EPS, (uint32_t)__popcll(__ballot(st)));
             for (int i = 0; __any(i < np); ++i)
-                if (i < np) { const uint32_t v = pidx[pl * WIN_T + i]; atomicCAS(&state[v], key, ST_FREE); }
+                if (i < np) { const uint32_t v = pidx[pl * WT + i]; atomicCAS(&state[v], key, ST_FREE); }
             if (valid) winq1[s] = fresh_q1(q0.z, pl);
         }
         WIN_FENCE();
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             }
         }
         // every window episode owns its own discovery list; free list and owned lists partition the ids
-        for (int i = lane; i < WIN_W; i += 64) dbg_seen[i] = 0;
+        for (int i = lane; i < WW; i += 64) dbg_seen[i] = 0;
         WIN_FENCE();
         for (int base = 0; base < nw; base += 64) {
             const int p = base + lane;
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         }
         for (int i = lane; i < npfree; i += 64) atomicAdd(&dbg_seen[pfree[i]], 1);
         WIN_FENCE();
-        for (int i = lane; i < WIN_W; i += 64)
+        for (int i = lane; i < WW; i += 64)
             if (dbg_seen[i] != 1 && !bad) { bad = true; bk = (unsigned long long)i; bnk = (unsigned long long)dbg_seen[i]; bp = npfree; where = 5; }
         const unsigned long long bb = __ballot(bad);
         if (bb) serial = true;             // stop here: the serial continuation finishes the component
@@ -453,12 +460,12 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         }
 #endif
         if (nw > 0 && ek < key_at(slot_of(nw - 1))) {
-            if ((nw == wcap || npfree == 0) && scount >= WIN_RCAP - 2) { run_evict(); if (serial) { spill64(lane == 0, ek, ei); return; } }
+            if ((nw == wcap || npfree == 0) && scount >= WRCAP - 2) { run_evict(); if (serial) { spill64(lane == 0, ek, ei); return; } }
             win_insert(ek, ei, el);
             return;
         }
         if (scount == 0 && nw < wcap && npfree > 0) { win_insert(ek, ei, el); return; }
-        if (scount >= WIN_RCAP - 2) {
+        if (scount >= WRCAP - 2) {
             run_evict();
             if (serial) { spill64(lane == 0, ek, ei); return; }
             // the eviction lowered the hot maximum (and possibly cold.low): the element was judged against the old tiers
@@ -530,10 +537,10 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
     };
 
     // ---- start: seeds (value 0, age = rank in index order) -------------------------------------------------------
-    if (wcap > WIN_W) wcap = WIN_W;
-    if (tcap > WIN_T) tcap = WIN_T;
-    for (int i = lane; i < WIN_W; i += 64) pfree[i] = (unsigned short)(WIN_W - 1 - i);
-    npfree = WIN_W;
+    if (wcap > WW) wcap = WW;
+    if (tcap > WT) tcap = WT;
+    for (int i = lane; i < WW; i += 64) pfree[i] = (unsigned short)(WW - 1 - i);
+    npfree = WW;
     WIN_FENCE();
     {
         started_any = true;
@@ -735,8 +742,8 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 for (int k = 0; k < 6; ++k)
                     if (won & (1u << k)) {
                         const float v = val[k] * sc[ax[k]] + 0.0f;              // -0.0 == +0.0 in the order
-                        pidx[pl * WIN_T + np] = nbv[k];
-                        pval[pl * WIN_T + np] = ford(v);
+                        pidx[pl * WT + np] = nbv[k];
+                        pval[pl * WT + np] = ford(v);
                         ++np;
                     }
             }
@@ -746,12 +753,12 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             int bi = -1;
             {
                 // sixteen entries per trip: the four reads of a group are issued together (the kernel is bound by dependent
-                // LDS trips, not by LDS bandwidth); entries past `np` are stale but in bounds (WIN_T = 48) and masked
-                const u32x4 *pv4 = (const u32x4 *)&pval[pl * WIN_T];
+                // LDS trips, not by LDS bandwidth); entries past `np` are stale but in bounds (WT = 48) and masked
+                const u32x4 *pv4 = (const u32x4 *)&pval[pl * WT];
                 for (int i4 = 0; __any(act && 4 * i4 < np); i4 += 4) {
                     u32x4 g[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) g[k] = pv4[i4 + k < WIN_T / 4 ? i4 + k : WIN_T / 4 - 1];
+                    for (int k = 0; k < 4; ++k) g[k] = pv4[i4 + k < WT / 4 ? i4 + k : WT / 4 - 1];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int i = 4 * (i4 + k);
@@ -769,9 +776,9 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 // commit rule needs it every sub-round until the episode commits, and the list does not change any more
                 uint32_t cur = WIN_NONE, curi = 0xFFu, curv = bf;
                 if (bi >= 0 && bf < bound) {
-                    cur = pidx[pl * WIN_T + bi];
+                    cur = pidx[pl * WT + bi];
                     curi = (uint32_t)bi;
-                    pval[pl * WIN_T + bi] = WIN_POPPED;
+                    pval[pl * WT + bi] = WIN_POPPED;
                     ++npop;
                 }
                 q1.x = cur;
@@ -835,7 +842,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             // the front episode with a full list commits what it has done: the element it was about to pop goes back to
             // the queue like any other residual
             const bool forced = burst == 0 && front_forced && j == 0 && st && q1.x != WIN_NONE && np + 6 > tcap;
-            if (forced) { pval[pl * WIN_T + (int)(q1.y >> 24)] = q1.w; idle = true; }
+            if (forced) { pval[pl * WT + (int)(q1.y >> 24)] = q1.w; idle = true; }
             WIN_FENCE();
             const unsigned long long nb_ = ~__ballot(idle);
             const int m = nb_ ? __ffsll((long long)nb_) - 1 : 64;       // leading idle episodes
@@ -851,7 +858,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
             const bool scan_me = j < m && forced;
 #endif
             {
-                const u32x4 *pv4 = (const u32x4 *)&pval[pl * WIN_T];
+                const u32x4 *pv4 = (const u32x4 *)&pval[pl * WT];
                 for (int i4 = 0; __any(scan_me && 4 * i4 < np); ++i4) {
                     if (scan_me && 4 * i4 < np) {
                         const u32x4 v4 = pv4[i4];
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 if (j >= ncommit) pc = 0u;
                 uint32_t poff = wave_incl_sum(pc) - pc;
                 {
-                    const unsigned long long fits = __ballot(j >= ncommit || poff + pc <= (uint32_t)WIN_PEND);
+                    const unsigned long long fits = __ballot(j >= ncommit || poff + pc <= (uint32_t)WPEND);
                     const int nf = (~fits) ? __ffsll((long long)~fits) - 1 : 64;
                     if (nf < ncommit) ncommit = nf;                    // >= 1: one list always fits
                 }
@@ -911,7 +918,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                         dl[2ull * tot_ + dbg_count + (uint32_t)j] = (uint32_t)np | ((uint32_t)st_sub << 8);
                         for (int i = 0; i < np; ++i) {
                             const uint32_t o_ = dbg_ecount + np_incl - (uint32_t)np + (uint32_t)i;
-                            if (o_ < (uint32_t)csize) dl[tot_ + o_] = pidx[pl * WIN_T + i] | (pval[pl * WIN_T + i] == WIN_POPPED ? 0x80000000u : 0u);
+                            if (o_ < (uint32_t)csize) dl[tot_ + o_] = pidx[pl * WT + i] | (pval[pl * WT + i] == WIN_POPPED ? 0x80000000u : 0u);
                         }
                     }
                     dbg_ecount += tot;
@@ -920,7 +927,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
                 }
 #endif
                 {
-                    const u32x4 *pi4 = (const u32x4 *)&pidx[pl * WIN_T], *pv4 = (const u32x4 *)&pval[pl * WIN_T];
+                    const u32x4 *pi4 = (const u32x4 *)&pidx[pl * WT], *pv4 = (const u32x4 *)&pval[pl * WT];
                     for (int i4 = 0; __any(cm && 4 * i4 < np); ++i4) {
                         if (cm && 4 * i4 < np) {
                             const u32x4 v4 = pi4[i4], f4 = pv4[i4];

@@ -147,20 +147,20 @@ def test_against_oracle_on_seeded_fields(ws, shape, seed):
 
 FLOOD_ENVS = {
     # every component through the speculative-window flood (LDS tiers only) / through the one-lane heap
-    "coop-all": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000"},
+    "coop-all": {"ISX_FLOOD_SMALL_MAX": "0", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000"},
     "serial-all": {"ISX_FLOOD_COOP_MIN": "100000000"},
     # window flood with a cold arena and a deliberately tiny hot tier: bucket append / select-drain / eviction /
     # compaction carry most of the queue even on small inputs
-    "cold-stress": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "96", "ISX_FLOOD_DRAIN": "48"},
-    "cold-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "8", "ISX_FLOOD_DRAIN": "4"},
+    "cold-stress": {"ISX_FLOOD_SMALL_MAX": "0", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "96", "ISX_FLOOD_DRAIN": "48"},
+    "cold-tiny": {"ISX_FLOOD_SMALL_MAX": "0", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "8", "ISX_FLOOD_DRAIN": "4"},
     # window corner cases: a window of one episode (pure sequential episodes), a few episodes with the shortest
     # possible discovery list (every started episode stalls until it is the front and commits partially), a full
     # window with short lists, and short lists over a tiny hot tier (window evictions + mid-window insertions)
-    "win-one": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_WIN": "1"},
-    "win-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_WIN": "3", "ISX_FLOOD_LIST": "6",
+    "win-one": {"ISX_FLOOD_SMALL_MAX": "0", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_WIN": "1"},
+    "win-tiny": {"ISX_FLOOD_SMALL_MAX": "0", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_WIN": "3", "ISX_FLOOD_LIST": "6",
                  "ISX_FLOOD_RUN_LIMIT": "8", "ISX_FLOOD_DRAIN": "4"},
-    "win-shortlist": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000", "ISX_FLOOD_LIST": "8"},
-    "win-mid": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_WIN": "17", "ISX_FLOOD_LIST": "12",
+    "win-shortlist": {"ISX_FLOOD_SMALL_MAX": "0", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000", "ISX_FLOOD_LIST": "8"},
+    "win-mid": {"ISX_FLOOD_SMALL_MAX": "0", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_WIN": "17", "ISX_FLOOD_LIST": "12",
                 "ISX_FLOOD_RUN_LIMIT": "40", "ISX_FLOOD_DRAIN": "16"},
     # the work-group kernel (ws_flood_group.h: one episode per lane, 512-wide window, chunked lists) for EVERY component:
     # defaults, LDS tiers only (overflow -> hand-over to the serial heap), a tiny hot tier, a window of one / three episodes
@@ -175,6 +175,17 @@ FLOOD_ENVS = {
     "group-shortlist": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_GLIST": "8"},
     "group-mid": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_GWIN": "17",
                   "ISX_FLOOD_GLIST": "12", "ISX_FLOOD_RUN_LIMIT": "40", "ISX_FLOOD_DRAIN": "16", "ISX_FLOOD_BURSTS": "1"},
+    # the small instantiation of the single-wave kernel (W = 48, T = 24, run 512: ~30 KB of LDS, five components per CU;
+    # round 3) for EVERY component: LDS tiers only (its 512-entry run overflows early: hand-over to the serial heap), with an
+    # arena, a tiny hot tier, one episode, three episodes with the shortest lists, short lists
+    "small-all": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000", "ISX_FLOOD_SMALL_MAX": "100000000"},
+    "small-cold": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_SMALL_MAX": "100000000"},
+    "small-cold-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_SMALL_MAX": "100000000", "ISX_FLOOD_RUN_LIMIT": "8",
+                        "ISX_FLOOD_DRAIN": "4"},
+    "small-win-one": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_SMALL_MAX": "100000000", "ISX_FLOOD_WIN": "1"},
+    "small-win-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_SMALL_MAX": "100000000", "ISX_FLOOD_WIN": "3",
+                       "ISX_FLOOD_LIST": "6", "ISX_FLOOD_RUN_LIMIT": "8", "ISX_FLOOD_DRAIN": "4"},
+    "small-shortlist": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000", "ISX_FLOOD_SMALL_MAX": "100000000", "ISX_FLOOD_LIST": "8"},
     # the round-based wave kernel of round 1 (kept selectable for A/B runs)
     "wave-legacy": {"ISX_FLOOD_MODE": "wave", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "96",
                     "ISX_FLOOD_DRAIN": "48"},
