@@ -263,12 +263,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
         int64_t r1 = r0 + rows_per_block;
         if (r1 > M) r1 = M;
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-        for (int64_t m = r0 + rslot; m < r1; m += nslot) {
-            float x = raw[m * C + c];
-            float z = fmaf(x, sc, sh);
-            float dz = act_grad(g[m * gstride + c], z, act);
-            s1 += (double)dz;
-            s2 += (double)dz * (double)((x - mu) * is);
+        // four rows' loads in flight per thread; the sums keep their order (bit-identical to the one-row loop, which ran at
+        // 1.1 TB/s: one dependent pair of 4-byte loads per iteration)
+        for (int64_t m = r0 + rslot; m < r1; m += 4 * nslot) {
+            float xv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t mm = m + (int64_t)u * nslot;
+                xv[u] = mm < r1 ? raw[mm * C + c] : 0.f;
+                gv[u] = mm < r1 ? g[mm * gstride + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (m + (int64_t)u * nslot >= r1) break;
+                const float x = xv[u];
+                const float z = fmaf(x, sc, sh);
+                const float dz = act_grad(gv[u], z, act);
+                s1 += (double)dz;
+                s2 += (double)dz * (double)((x - mu) * is);
+            }
         }
     }
     smd[threadIdx.x * 2] = s1;
@@ -321,14 +334,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
         int64_t r1 = r0 + rows_per_block;
         if (r1 > M) r1 = M;
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c], c1 = coef[2 * c], c2 = coef[2 * c + 1];
-        for (int64_t m = r0 + rslot; m < r1; m += nslot) {
-            float x = raw[m * C + c];
-            float z = fmaf(x, sc, sh);
-            float dz = act_grad(g[m * gstride + c], z, act);
-            float xh = (x - mu) * is;
-            float d = sc * (dz - c1 - xh * c2);          // sc = gamma * invstd
-            draw[m * dstride + c] = d;
-            s1 += d;
+        for (int64_t m = r0 + rslot; m < r1; m += 4 * nslot) {      // (four rows in flight, sums in the same order: see the reduce kernel)
+            float xv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t mm = m + (int64_t)u * nslot;
+                xv[u] = mm < r1 ? raw[mm * C + c] : 0.f;
+                gv[u] = mm < r1 ? g[mm * gstride + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t mm = m + (int64_t)u * nslot;
+                if (mm >= r1) break;
+                const float x = xv[u];
+                const float z = fmaf(x, sc, sh);
+                const float dz = act_grad(gv[u], z, act);
+                const float xh = (x - mu) * is;
+                const float d = sc * (dz - c1 - xh * c2);          // sc = gamma * invstd
+                draw[mm * dstride + c] = d;
+                s1 += d;
+            }
         }
     }
     sm[threadIdx.x] = s1;
@@ -986,12 +1011,142 @@ static int bn_backward(isx_ctx *ctx, int li, const float *g, int gstride, int ac
     return ISX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad of the thin layers at the full-resolution level (round 3).  On the matrix-core kernel a 1 -> 32 or 5 -> 5 layer
+// computed zero-padded 32 x 32 tiles for nine (dz, dy) rows of work-groups, each re-reading dY: 0.6 ms per layer for
+// 0.5 GFLOP.  Here every voxel's dY row is read once and the 27 shifted inputs come from L1.
+//   wgrad_cin1_kernel: Cin = 1.  thread = (output channel, voxel lane); 27 accumulators per thread.
+//   wgrad_few_kernel:  Cin, Cout <= 8.  thread = (tap, voxel lane); Cout x Cin accumulators per thread.
+// Partials [block][27][Cout][Cin] (fp32 sums over <= 2048 voxels), reduced in block order by wgrad_thin_reduce_kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_cin1_kernel(const float *__restrict__ dy, int dy_stride, const float *__restrict__ x, int Cout,
+                                                         int D, int H, int W, int rows_per_block, float *__restrict__ part)
+{
+    extern __shared__ float sred[];                           // [nslot][27][Cout]
+    const int co = threadIdx.x % Cout, vl = threadIdx.x / Cout, nslot = 256 / Cout;
+    const int64_t M = (int64_t)D * H * W;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+    if (vl < nslot)
+        for (int64_t m = r0 + vl; m < r1; m += nslot) {
+            const float g = dy[m * dy_stride + co];
+            const int xx = (int)(m % W), yy = (int)((m / W) % H), zz = (int)(m / ((int64_t)W * H));
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const int z = zz + t / 9 - 1, y = yy + (t / 3) % 3 - 1, xc = xx + t % 3 - 1;
+                const bool in = z >= 0 && z < D && y >= 0 && y < H && xc >= 0 && xc < W;
+                const float xv = in ? x[((int64_t)z * H + y) * W + xc] : 0.f;
+                acc[t] = fmaf(g, xv, acc[t]);
+            }
+        }
+    if (vl < nslot)
+#pragma unroll
+        for (int t = 0; t < 27; ++t) sred[(vl * 27 + t) * Cout + co] = acc[t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
+        float a = 0.f;
+        for (int k = 0; k < nslot; ++k) a += sred[k * 27 * Cout + i];
+        part[(int64_t)blockIdx.x * 27 * Cout + i] = a;         // [t][co] (Cin = 1)
+    }
+}
+
+template <int CO, int CI>
+__global__ __launch_bounds__(256) void wgrad_few_kernel(const float *__restrict__ dy, int dy_stride, const float *__restrict__ src,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift, int D, int H,
+                                                        int W, int rows_per_block, float *__restrict__ part)
+{
+    constexpr int NL = 9;                                     // voxel lanes: 27 taps x 9 = 243 threads
+    __shared__ float sred[NL * 27 * CO * CI];
+    const int t = threadIdx.x % 27, vl = threadIdx.x / 27;
+    const int64_t M = (int64_t)D * H * W;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float acc[CO][CI];
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int c = 0; c < CI; ++c) acc[o][c] = 0.f;
+    float sc[CI], sh[CI];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) { sc[c] = scale ? scale[c] : 1.f; sh[c] = scale ? shift[c] : 0.f; }
+    const int dz = t / 9 - 1, dyy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+    if (vl < NL)
+        for (int64_t m = r0 + vl; m < r1; m += NL) {
+            const int xx = (int)(m % W) + dx, yy = (int)((m / W) % H) + dyy, zz = (int)(m / ((int64_t)W * H)) + dz;
+            if (zz < 0 || zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const int64_t nb = ((int64_t)zz * H + yy) * W + xx;
+            float xv[CI], g[CO];
+#pragma unroll
+            for (int c = 0; c < CI; ++c) {
+                const float v = src[nb * CI + c];
+                xv[c] = scale ? fmaxf(fmaf(v, sc[c], sh[c]), 0.f) : v;
+            }
+#pragma unroll
+            for (int o = 0; o < CO; ++o) g[o] = dy[m * dy_stride + o];
+#pragma unroll
+            for (int o = 0; o < CO; ++o)
+#pragma unroll
+                for (int c = 0; c < CI; ++c) acc[o][c] = fmaf(g[o], xv[c], acc[o][c]);
+        }
+    if (vl < NL)
+#pragma unroll
+        for (int o = 0; o < CO; ++o)
+#pragma unroll
+            for (int c = 0; c < CI; ++c) sred[((vl * 27 + t) * CO + o) * CI + c] = acc[o][c];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * CO * CI; i += 256) {
+        float a = 0.f;
+        for (int k = 0; k < NL; ++k) a += sred[k * 27 * CO * CI + i];
+        part[(int64_t)blockIdx.x * 27 * CO * CI + i] = a;      // [t][co][ci]
+    }
+}
+
+// dW[co][ci][t] = sum over blocks (block order) of partial[block][t][co][ci]
+__global__ void wgrad_thin_reduce_kernel(const float *__restrict__ part, int blocks, int Cout, int Cin, float *__restrict__ dw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 27 * Cout * Cin;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int b = 0; b < blocks; ++b) a += part[(int64_t)b * n + i];
+    const int ci = i % Cin, co = (i / Cin) % Cout, t = i / (Cin * Cout);
+    dw[((int64_t)co * Cin + ci) * 27 + t] = a;
+}
+
 static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
 {
     UNetState *u = ctx->unet;
     TrainState *t = u->train;
     const ConvBN &L = u->cv[li];
     const Level &l = u->lv[MOD_LEVEL[layer_module(li)]];
+    if (ctx->tune.thin_wgrad && sb.C == 0 && sa.C == L.cin) {
+        // the thin layers at the big levels: dedicated kernels (see above)
+        const int rows = 2048;
+        const int blocks = (int)((l.M + rows - 1) / rows);
+        const size_t need = (size_t)blocks * 27 * L.cout * L.cin;
+        bool done = false;
+        if (need <= t->wpart_floats) {
+            if (L.cin == 1 && !sa.scale && 256 % L.cout == 0 && L.cout >= 8) {
+                wgrad_cin1_kernel<<<blocks, 256, (size_t)(256 / L.cout) * 27 * L.cout * sizeof(float), ctx->stream>>>(
+                    t->draw[li], t->dstride[li], sa.p, L.cout, l.D, l.H, l.W, rows, t->wpart);
+                done = true;
+            } else if (L.cin == 5 && L.cout == 5) {
+                wgrad_few_kernel<5, 5><<<blocks, 256, 0, ctx->stream>>>(t->draw[li], t->dstride[li], sa.p, sa.scale, sa.shift, l.D, l.H, l.W, rows, t->wpart);
+                done = true;
+            }
+        }
+        if (done) {
+            ISX_CHECK_LAUNCH();
+            wgrad_thin_reduce_kernel<<<cdiv(27 * L.cout * L.cin, 256), 256, 0, ctx->stream>>>(t->wpart, blocks, L.cout, L.cin, t->G + t->off_w[li]);
+            ISX_CHECK_LAUNCH();
+            return ISX_OK;
+        }
+    }
     WgradArgs a;
     a.dy = t->draw[li];
     a.dy_stride = t->dstride[li];
