@@ -876,14 +876,29 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
 }
 
 // up-conv parameter gradients: reference layout dW[c][kidx], db[c]
-__global__ void up_grad_finalize_kernel(const float *__restrict__ part, int blocks, int C, int kt,
-                                        float *__restrict__ dw, float *__restrict__ db, int accumulate)
+// one wave per output: lane l sums the blocks l, l + 64, ... (double), then a fixed xor tree -- deterministic, and 1 300 blocks
+// (up3 at 128 source voxels per block) no longer cost a serial walk per output
+__device__ __forceinline__ double wave_sum_f64(double v)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (kt + 1) * C) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __shfl_xor((int)(b & 0xFFFFFFFFll), o), hi = __shfl_xor((int)(b >> 32), o);
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void up_grad_finalize_kernel(const float *__restrict__ part, int blocks, int C, int kt,
+                                                               float *__restrict__ dw, float *__restrict__ db, int accumulate)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= (kt + 1) * C) return;                          // (whole waves leave together)
     const int r = i / C, c = i % C;
     double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += (double)part[(int64_t)b * (kt + 1) * C + i];
+    for (int b = lane; b < blocks; b += 64) s += (double)part[(int64_t)b * (kt + 1) * C + i];
+    s = wave_sum_f64(s);
+    if (lane != 0) return;
     // accumulate: the transposed convolutions are shared by the decoders of a forked network (unet.py:213-242)
     if (r < kt) dw[(int64_t)c * kt + r] = (float)s + (accumulate ? dw[(int64_t)c * kt + r] : 0.f);
     else db[c] = (float)s + (accumulate ? db[c] : 0.f);
@@ -1020,26 +1035,38 @@ static int bn_backward(isx_ctx *ctx, int li, const float *g, int gstride, int ac
 // Partials [block][27][Cout][Cin] (fp32 sums over <= 2048 voxels), reduced in block order by wgrad_thin_reduce_kernel.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wgrad_cin1_kernel(const float *__restrict__ dy, int dy_stride, const float *__restrict__ x, int Cout,
-                                                         int D, int H, int W, int rows_per_block, float *__restrict__ part)
+                                                         int D, int H, int W, int rows_per_block, int blocks_per_plane, float *__restrict__ part)
 {
-    extern __shared__ float sred[];                           // [nslot][27][Cout]
+    // a block = `rows_per_block` consecutive voxels of ONE z-plane; the input around them (three planes, one image row and
+    // one voxel either side) is staged in LDS once, so a tap is an LDS broadcast read instead of a global load per lane
+    extern __shared__ float sm1[];                            // xs[3][rows + 2 W + 2] | sred[nslot][27][Cout]
+    const int span = rows_per_block + 2 * W + 2;
+    float *xs = sm1, *sred = sm1 + 3 * span;
     const int co = threadIdx.x % Cout, vl = threadIdx.x / Cout, nslot = 256 / Cout;
-    const int64_t M = (int64_t)D * H * W;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+    const int z = blockIdx.x / blocks_per_plane, p0 = (blockIdx.x % blocks_per_plane) * rows_per_block;
+    const int HW = H * W;
+    int p1 = p0 + rows_per_block;
+    if (p1 > HW) p1 = HW;
+    for (int i = threadIdx.x; i < 3 * span; i += 256) {
+        const int pl = i / span, q = p0 - W - 1 + i % span, zz = z + pl - 1;
+        xs[i] = (zz >= 0 && zz < D && q >= 0 && q < HW) ? x[(int64_t)zz * HW + q] : 0.f;
+    }
+    __syncthreads();
     float acc[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t] = 0.f;
     if (vl < nslot)
-        for (int64_t m = r0 + vl; m < r1; m += nslot) {
-            const float g = dy[m * dy_stride + co];
-            const int xx = (int)(m % W), yy = (int)((m / W) % H), zz = (int)(m / ((int64_t)W * H));
+        for (int p = p0 + vl; p < p1; p += nslot) {
+            const float g = dy[((int64_t)z * HW + p) * dy_stride + co];
+            const int xx = p % W, yy = p / W;
+            const float *c0 = xs + (p - p0) + W + 1;          // this voxel in plane z - 1
 #pragma unroll
             for (int t = 0; t < 27; ++t) {
-                const int z = zz + t / 9 - 1, y = yy + (t / 3) % 3 - 1, xc = xx + t % 3 - 1;
-                const bool in = z >= 0 && z < D && y >= 0 && y < H && xc >= 0 && xc < W;
-                const float xv = in ? x[((int64_t)z * H + y) * W + xc] : 0.f;
+                const int dz = t / 9 - 1, dyy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+                // planes outside the volume and positions outside the plane were staged as zeros; what is left are the
+                // wrap-arounds of the linear index: x +- 1 across a row end, y +- 1 across the plane's first / last row
+                const bool in = (unsigned)(xx + dx) < (unsigned)W && (unsigned)(yy + dyy) < (unsigned)H;
+                const float xv = in ? c0[(dz + 1) * span + dyy * W + dx] : 0.f;
                 acc[t] = fmaf(g, xv, acc[t]);
             }
         }
@@ -1106,16 +1133,18 @@ __global__ __launch_bounds__(256) void wgrad_few_kernel(const float *__restrict_
     }
 }
 
-// dW[co][ci][t] = sum over blocks (block order) of partial[block][t][co][ci]
-__global__ void wgrad_thin_reduce_kernel(const float *__restrict__ part, int blocks, int Cout, int Cin, float *__restrict__ dw)
+// dW[co][ci][t] = sum over blocks of partial[block][t][co][ci]: one wave per output (lane l: blocks l, l + 64, ...; fixed xor tree)
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float *__restrict__ part, int blocks, int Cout, int Cin, float *__restrict__ dw)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int n = 27 * Cout * Cin;
     if (i >= n) return;
-    float a = 0.f;
-    for (int b = 0; b < blocks; ++b) a += part[(int64_t)b * n + i];
+    double a = 0.0;
+    for (int b = lane; b < blocks; b += 64) a += (double)part[(int64_t)b * n + i];
+    a = wave_sum_f64(a);
+    if (lane != 0) return;
     const int ci = i % Cin, co = (i / Cin) % Cout, t = i / (Cin * Cout);
-    dw[((int64_t)co * Cin + ci) * 27 + t] = a;
+    dw[((int64_t)co * Cin + ci) * 27 + t] = (float)a;
 }
 
 static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
@@ -1127,13 +1156,16 @@ static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
     if (ctx->tune.thin_wgrad && sb.C == 0 && sa.C == L.cin) {
         // the thin layers at the big levels: dedicated kernels (see above)
         const int rows = 2048;
-        const int blocks = (int)((l.M + rows - 1) / rows);
+        int blocks = (int)((l.M + rows - 1) / rows);
+        const int rows1 = 1024, bpp = (int)(((int64_t)l.H * l.W + rows1 - 1) / rows1);       // Cin = 1: blocks stay inside a z-plane
+        const size_t lds1 = ((size_t)3 * (rows1 + 2 * l.W + 2) + (size_t)(L.cout ? 256 / L.cout : 1) * 27 * L.cout) * sizeof(float);
+        const bool cin1 = L.cin == 1 && !sa.scale && L.cout >= 8 && 256 % L.cout == 0 && lds1 <= 64 * 1024;
+        if (cin1) blocks = l.D * bpp;
         const size_t need = (size_t)blocks * 27 * L.cout * L.cin;
         bool done = false;
         if (need <= t->wpart_floats) {
-            if (L.cin == 1 && !sa.scale && 256 % L.cout == 0 && L.cout >= 8) {
-                wgrad_cin1_kernel<<<blocks, 256, (size_t)(256 / L.cout) * 27 * L.cout * sizeof(float), ctx->stream>>>(
-                    t->draw[li], t->dstride[li], sa.p, L.cout, l.D, l.H, l.W, rows, t->wpart);
+            if (cin1) {
+                wgrad_cin1_kernel<<<blocks, 256, lds1, ctx->stream>>>(t->draw[li], t->dstride[li], sa.p, L.cout, l.D, l.H, l.W, rows1, bpp, t->wpart);
                 done = true;
             } else if (L.cin == 5 && L.cout == 5) {
                 wgrad_few_kernel<5, 5><<<blocks, 256, 0, ctx->stream>>>(t->draw[li], t->dstride[li], sa.p, sa.scale, sa.shift, l.D, l.H, l.W, rows, t->wpart);
@@ -1142,7 +1174,7 @@ static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
         }
         if (done) {
             ISX_CHECK_LAUNCH();
-            wgrad_thin_reduce_kernel<<<cdiv(27 * L.cout * L.cin, 256), 256, 0, ctx->stream>>>(t->wpart, blocks, L.cout, L.cin, t->G + t->off_w[li]);
+            wgrad_thin_reduce_kernel<<<cdiv(27 * L.cout * L.cin, 4), 256, 0, ctx->stream>>>(t->wpart, blocks, L.cout, L.cin, t->G + t->off_w[li]);
             ISX_CHECK_LAUNCH();
             return ISX_OK;
         }
@@ -1255,7 +1287,7 @@ static int backward(isx_ctx *ctx)
                 u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, t->dcat[f][k], 2 * U.C, lo.D, lo.H,
                 lo.W, t->gact[li_in], t->part, vpb);
             ISX_CHECK_LAUNCH();
-            up_grad_finalize_kernel<<<cdiv((kt + 1) * U.C, 256), 256, 0, ctx->stream>>>(t->part, blocks, U.C, kt, t->G + t->off_upw[k],
+            up_grad_finalize_kernel<<<cdiv((kt + 1) * U.C, 4), 256, 0, ctx->stream>>>(t->part, blocks, U.C, kt, t->G + t->off_upw[k],
                                                                                      t->G + t->off_upb[k],
                                                                                      (u->nforks > 1 && f == 0 && k > 0) ? 1 : 0);
             ISX_CHECK_LAUNCH();
