@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     constexpr int ROWS = 128 * MT, TXW = 8 * MT;
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     constexpr int NT = BN / 32;
-    constexpr int NTAPS = TX == 2 ? 12 : 9 * TX, NPAIR = (NTAPS + 1) / 2;
+    constexpr bool UPA = TX == 4;                         // TX = 4: the taps of TX = 1 + source A up-sampled on read (see ConvArgs::upw)
+    constexpr int NTAPS = TX == 2 ? 12 : (UPA ? 9 : 9 * TX), NPAIR = (NTAPS + 1) / 2;
     constexpr int BU = 2 * NPAIR * BN;                    // uint4 per half of the weight slab (hi | lo)
     constexpr int SLAB = SPLIT ? 2 * BU : BU;             // uint4 of weights staged per K step (single-product modes: hi only)
     constexpr int NB = (SLAB + 255) / 256;                // uint4 of weights per thread per stage (14 / 7 / 3; halved without lo)
@@ -220,6 +221,15 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     };
     const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + 256), gv2 = slot_voxel(tid + 512), gv3 = slot_voxel(tid + 768),
               gv4 = MT > 1 ? slot_voxel(tid + 1024) : -2;
+    // source A up-sampled on read (UPA): the slot's voxel (z, y, x) of the output grid reads the COARSE voxel
+    // (z, (y + off) >> 1, (x + off) >> 1) of srcA and multiplies by the transposed convolution's weight of its parity
+    auto slot_up = [&](int g) __attribute__((always_inline)) -> int {      // coarse index | parity << 28 (g: voxel index or < 0)
+        if (!UPA || g < 0) return 0;
+        const int z = g / (H * W), y = (g / W) % H + a.uoff, x = g % W + a.uoff;
+        return ((z * a.uH + (y >> 1)) * a.uW + (x >> 1)) | ((((y & 1) << 1) | (x & 1)) << 28);
+    };
+    const int gu0 = slot_up(gv0), gu1 = slot_up(gv1), gu2 = slot_up(gv2), gu3 = slot_up(gv3), gu4 = slot_up(gv4);
+    const int64_t Mup = UPA ? (int64_t)D * a.uH * a.uW : 0;
 
     const int nsteps = (a.CA + a.CB) >> 3;
     f32x16 acc_hi[MT][NT], acc_lo[SPLIT ? MT : 1][SPLIT ? NT : 1];
@@ -233,10 +243,13 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     // named prefetch registers (arrays that live across the K loop end up in scratch)
     float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
     uint4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rb8, rb9, rb10, rb11, rb12, rb13;
-    bool has_affine = false;
+    bool has_affine = false, stage_up = false;
+    float4 vb0 = make_float4(0.f, 0.f, 0.f, 0.f), vb1 = vb0;   // (UPA) bias of the transposed convolution for this stage's channels
+    int up_cc = 0;
 #define H2_LOAD_A(k)                                                                              \
     if constexpr (k < 4 || MT > 1) {                                                              \
-        const float *pp = &src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];            \
+        const float *pp = (UPA && stage_up) ? &src[((int64_t)b * Mup + (gu##k & 0x0FFFFFFF)) * C + cc]      \
+                                            : &src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];   \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }
@@ -249,6 +262,8 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         if (c0 < a.CA) { src = a.srcA; sc = a.scaleA; sh = a.shiftA; C = a.CA; cc = c0; }         \
         else { src = a.srcB; sc = a.scaleB; sh = a.shiftB; C = a.CB; cc = c0 - a.CA; }            \
         has_affine = sc != nullptr;                                                               \
+        stage_up = UPA && c0 < a.CA;                                                              \
+        if (UPA && stage_up) { up_cc = cc; vb0 = *(const float4 *)&a.upb[cc]; vb1 = *(const float4 *)&a.upb[cc + 4]; } \
         const float *scp = has_affine ? sc : a.bias, *shp = has_affine ? sh : a.bias;             \
         const int64_t so = has_affine ? (int64_t)b * C + cc : 0;                                  \
         vs0 = *(const float4 *)&scp[so]; vs1 = *(const float4 *)&scp[so + 4];                     \
@@ -265,6 +280,12 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     if ((k < 4 || MT > 1) && gv##k != -2) {                                                       \
         float4 v = ra##k, w = rc##k;                                                              \
         if (has_affine) { H2_AFF(v, vs0, vh0) H2_AFF(w, vs1, vh1) }                               \
+        if (UPA && st_up) {                                                                       \
+            const float *uw = &a.upw[(int64_t)((unsigned)gu##k >> 28) * a.CA + st_cc];           \
+            const float4 u0 = *(const float4 *)uw, u1 = *(const float4 *)(uw + 4);                \
+            v.x = fmaf(v.x, u0.x, sb0.x); v.y = fmaf(v.y, u0.y, sb0.y); v.z = fmaf(v.z, u0.z, sb0.z); v.w = fmaf(v.w, u0.w, sb0.w); \
+            w.x = fmaf(w.x, u1.x, sb1.x); w.y = fmaf(w.y, u1.y, sb1.y); w.z = fmaf(w.z, u1.z, sb1.z); w.w = fmaf(w.w, u1.w, sb1.w); \
+        }                                                                                         \
         if (gv##k < 0) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }                            \
         uint4 hi, lo;                                                                             \
         if constexpr (SPLIT) { split8(v, w, hi, lo); AsL[tid + 256 * k] = lo; }                   \
@@ -284,6 +305,10 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     H2_LOAD_STAGE(0)
     for (int step = 0; step < nsteps; ++step) {
         __syncthreads();
+        const bool st_up = stage_up;                           // of the stage being stored (the next load overwrites them)
+        const int st_cc = up_cc;
+        const float4 sb0 = vb0, sb1 = vb1;
+        (void)st_up; (void)st_cc; (void)sb0; (void)sb1;
         H2_STORE_A(0) H2_STORE_A(1) H2_STORE_A(2) H2_STORE_A(3) H2_STORE_A(4)
         H2_STORE_B(0) H2_STORE_B(1) H2_STORE_B(2) H2_STORE_B(3) H2_STORE_B(4) H2_STORE_B(5) H2_STORE_B(6)
         H2_STORE_B(7) H2_STORE_B(8) H2_STORE_B(9) H2_STORE_B(10) H2_STORE_B(11) H2_STORE_B(12) H2_STORE_B(13)
@@ -498,6 +523,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.oy[0] = ex ? ex->oy[0] : 0; a.oy[1] = ex ? ex->oy[1] : 0; a.ox[0] = ex ? ex->ox[0] : 0; a.ox[1] = ex ? ex->ox[1] : 0;
     a.remap = ex ? ex->remap : 0; a.rH = ex ? ex->rH : 0; a.rW = ex ? ex->rW : 0; a.rpy = ex ? ex->rpy : 0; a.rpx = ex ? ex->rpx : 0;
     a.roff = ex ? ex->roff : 0; a.Mout = ex ? ex->Mout : 0; a.accum = ex ? ex->accum : 0;
+    const int upa = ex ? ex->upA : 0;
+    a.uH = ex ? ex->uH : 0; a.uW = ex ? ex->uW : 0; a.uoff = ex ? ex->uoff : 0; a.upw = ex ? ex->upw : nullptr; a.upb = ex ? ex->upb : nullptr;
+    ISX_REQUIRE(!upa || (fold && a.upw && a.upb), "internal: up-sampling on read is built for the folded tail layer");
     ISX_REQUIRE(!(tx2 && fold), "internal: class convolution and folded tail are different kernels");
     ISX_REQUIRE(!a.remap || a.Mout < (1 << 24), "internal: remapped output of %ld voxels per chunk", (long)a.Mout);
     a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
@@ -536,7 +564,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<BN_, TX_, MT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (!attr_done) {
         ISX_H2_ATTR(64, 3, 1) ISX_H2_ATTR(32, 3, 1) ISX_H2_ATTR(32, 3, 2) ISX_H2_ATTR(32, 1, 1) ISX_H2_ATTR(32, 1, 2)
-        ISX_H2_ATTR(64, 2, 1) ISX_H2_ATTR(32, 2, 1) ISX_H2_ATTR(32, 2, 2)
+        ISX_H2_ATTR(64, 2, 1) ISX_H2_ATTR(32, 2, 1) ISX_H2_ATTR(32, 2, 2) ISX_H2_ATTR(32, 4, 1) ISX_H2_ATTR(32, 4, 2)
         attr_done = true;
     }
 #undef ISX_H2_ATTR
@@ -544,7 +572,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     do { if (pm == 0) conv_h2_kernel<BN_, TX_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
          else if (pm == 1) conv_h2_kernel<BN_, TX_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
          else conv_h2_kernel<BN_, TX_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
-    if (fold && mt == 2) ISX_H2_GO(32, 1, 2);
+    if (fold && upa && mt == 2) ISX_H2_GO(32, 4, 2);
+    else if (fold && upa) ISX_H2_GO(32, 4, 1);
+    else if (fold && mt == 2) ISX_H2_GO(32, 1, 2);
     else if (fold) ISX_H2_GO(32, 1, 1);
     else if (tx2 && BN == 64) ISX_H2_GO(64, 2, 1);
     else if (tx2 && mt == 2) ISX_H2_GO(32, 2, 2);

@@ -65,6 +65,8 @@ struct isx_tune {
     int h2_force_bn64 = 0;          // ISX_H2_FORCE_BN64
     int xcd_remap = 1;              // ISX_CONV_XCD_REMAP
     long mt2_min_vox = 1L << 60;    // ISX_CONV_MT2_MIN_VOX
+    int up_on_read = 0;             // ISX_UP_ON_READ: 1 = the tail layer up-samples up3 while staging it instead of reading a materialised tensor.
+                                    // Bit-identical, deletes 16 ms of upsample_kernel per 512^3 frame and costs the tail kernel 36 ms (r3): off
     int thin_wgrad = 1;             // ISX_THIN_WGRAD: 0 = the 1 -> 32 and 5 -> 5 layers' weight gradients on the padded matrix-core tiles (round 2)
     int bf16_wgrad = 1;             // ISX_BF16_WGRAD: 0 = precision "bf16" keeps fp32 products in the weight gradients (round 2's form)
     int up_fold = 0;                // ISX_UP_FOLD: 1 = up1/up2 folded into their consumers' weights (UpFoldPacks).  Off: measured r3, it removes

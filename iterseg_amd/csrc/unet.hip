@@ -1256,7 +1256,7 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     return ISX_OK;
 }
 
-static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
+static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb, const H2Extra *ex = nullptr)
 {
     UNetState *u = ctx->unet;
     ConvBN &L = u->cv[li];
@@ -1289,10 +1289,11 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb)
         const bool fold_h2 = u->precision != ISX_PRECISION_FP32 && !u->train && wf && fold_range && conv_mt(ctx->tune, l, u->wbatch, 32) == 1;
         u->arith[li] = fold_h2 ? ISX_ARITH_REDUCED
                                : (u->precision != ISX_PRECISION_FP32 && !u->train && wf && !fold_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
+        ISX_REQUIRE(fold_h2 || !ex, "internal: up-sampling on read needs the reduced-precision tail kernel");
         if (fold_h2) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wf, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
-                                   ctx->tune.xcd_remap, 1, nullptr, pm));
+                                   ctx->tune.xcd_remap, 1, nullptr, pm, ex));
         } else {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ConvArgs a;
@@ -1486,6 +1487,24 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                 continue;
             }
             u->up_folded[ups_index(f, k)] = false;
+            {
+                // the tail layer (64 -> n, its own 9-tap kernel) up-samples its first source while staging it: up3 is the
+                // largest transposed convolution (5.4 GB written and read back per 64-chunk launch set at 256^2)
+                const ConvBN &L0 = u->cv[l0f];
+                const bool bf = u->precision == ISX_PRECISION_BF16;
+                const float bnd = bn_bound(li_in) * U.wmax + U.bmax;
+                const bool on_read = ctx->tune.up_on_read && U.kz == 1 && U.C % 8 == 0 && use_fold(L0.cin, L0.cout) && !u->train &&
+                                     u->precision != ISX_PRECISION_FP32 && (bf ? L0.w_bf_32 : L0.w_h2_32) &&
+                                     (bf || std::max(bnd, bn_bound(skipf)) < 6.0e4f) && conv_mt(ctx->tune, lo, u->wbatch, 32) == 1;
+                if (on_read) {
+                    H2Extra ex;
+                    ex.upA = 1; ex.uH = ls.H; ex.uW = ls.W; ex.uoff = k == 3 ? 1 : 0; ex.upw = U.w; ex.upb = U.bias;
+                    u->up_folded[ups_index(f, k)] = true;
+                    ISX_TRY(run_conv(ctx, l0f, lo, B, Src{u->raw[li_in], Lin.scale, Lin.shift, U.C, bnd}, act(skipf), &ex));
+                    ISX_TRY(run_conv(ctx, dec_layer(f, k, 1), lo, B, act(l0f), none));
+                    continue;
+                }
+            }
             if (!(f > 0 && k == 0)) {
                 ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
                 int64_t total = (int64_t)B * lo.M * (U.C / 4);

@@ -130,6 +130,11 @@ struct ConvArgs {
     int rH, rW, rpy, rpx, roff;   //    bias then is a table [64 border configurations of the OUTPUT voxel][Cout]
     int64_t Mout;          // voxels per chunk of the output tensor (D*H*W unless remap)
     int accum;             // 1: add to what `out` already holds (statistics over the sums)
+    // TX = 4 (folded tail layer only): source A is the COARSE input of a transposed convolution, up-sampled while it is staged:
+    // slot voxel (z, y, x) reads (z, (y + uoff) >> 1, (x + uoff) >> 1) of a (D, uH, uW) tensor, BatchNorm + ReLU as usual, then
+    // * upw[parity][c] + upb[c] (UpConv::w / bias) -- what upsample_kernel would have written to a 4x larger tensor
+    int uH, uW, uoff;
+    const float *upw, *upb;
 };
 
 struct H2Extra {           // optional arguments of launch_conv_h2 (see ConvArgs)
@@ -137,6 +142,8 @@ struct H2Extra {           // optional arguments of launch_conv_h2 (see ConvArgs
     int remap = 0, rH = 0, rW = 0, rpy = 0, rpx = 0, roff = 0;
     int64_t Mout = 0;
     int accum = 0;
+    int upA = 0, uH = 0, uW = 0, uoff = 0;
+    const float *upw = nullptr, *upb = nullptr;
 };
 
 extern const char *MODS[9];

@@ -1,5 +1,6 @@
 set -e
-timeout -k 10 500 python scratch/time_structured.py "ISX_FLOOD_GROUP_MIN=262144,ISX_FLOOD_GMINSTEPS=1;ISX_FLOOD_GROUP_MIN=262144,ISX_FLOOD_GMINSTEPS=2;ISX_FLOOD_GROUP_MIN=262144,ISX_FLOOD_GMINSTEPS=4;ISX_FLOOD_GROUP_MIN=0" 1,2
-for ms in 1 2 4; do
-ISX_FLOOD_GMINSTEPS=$ms ISX_FLOOD_GROUP_MIN=262144 timeout -k 10 200 python scratch/bench_c2.py 2>&1 | grep "rep 1"
-done
+timeout -k 10 900 python -m pytest tests/test_gpu_watershed.py -x -q -m gpu 2>&1 | tail -3
+ISX_FLOOD_COOP_MIN=32768 ISX_FLOOD_GROUP_MIN=32768 timeout -k 10 120 python scratch/bench_ws.py blobs 256 2>&1 | grep "rep 1"
+ISX_FLOOD_COOP_MIN=32768 ISX_FLOOD_GROUP_MIN=0 timeout -k 10 120 python scratch/bench_ws.py blobs 256 2>&1 | grep "rep 1"
+timeout -k 10 400 python scratch/time_structured.py "" 0,3,1,2 2>&1 | grep seed
+timeout -k 10 200 python scratch/bench_c2.py 2>&1 | grep "rep 1"

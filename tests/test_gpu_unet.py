@@ -293,3 +293,25 @@ def test_folded_up_convolution_equals_materialised_one(precision, monkeypatch):
             assert np.abs(ta - tb).max() <= tol * max(1.0, np.abs(tb).max()), name
         # the tap of an up-sampled tensor the folded forward never wrote is computed on demand
         assert np.abs(nets[0].tap("up1.cropped") - nets[1].tap("up1.cropped")).max() <= tol
+
+
+@pytest.mark.gpu
+def test_tail_layer_up_sampling_on_read_is_bit_identical(monkeypatch):
+    """ISX_UP_ON_READ=1: the 64 -> 5 tail layer reads the coarse c7 output and applies up3 (ConvTranspose3d + [1:-1] crop,
+    unet.py:237-242,352-354) while it stages its halo tile -- the same arithmetic in the same order as upsample_kernel, so the
+    outputs are identical bit for bit (measured slower, off by default: DESIGN.md section 4)."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(2)
+    nets = []
+    for v in ("1", "0"):
+        monkeypatch.setenv("ISX_UP_ON_READ", v)
+        u = UNet(1, 5, batch=1)
+        u.load_state_dict(sd)
+        nets.append(u)
+    x = np.random.default_rng(4).random((1, 1, 10, 80, 48), dtype=np.float32)
+    ya, yb = nets[0](x), nets[1](x)
+    assert np.array_equal(ya, yb)
+    assert np.array_equal(nets[0].tap("c8_0.conv0"), nets[1].tap("c8_0.conv0"))
+    assert np.array_equal(nets[0].tap("up3.cropped"), nets[1].tap("up3.cropped"))      # computed on demand on the first one
