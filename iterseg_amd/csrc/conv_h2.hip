@@ -112,19 +112,24 @@ __device__ __forceinline__ void round8(const float4 &a, const float4 &b, uint4 &
 // its weights (UpFoldPacks, unet_state.h): the tile runs over the COARSE tensor and writes the class's output voxels (a.remap).
 // MT = 32-row tiles per wave (1: 128 voxels per work-group, 2: 256).  With 32 columns, MT = 2 gives the wave a
 // 64 x 32 tile whose six fragment reads feed six MFMAs, like the 32 x 64 tile of the 64-column variant.
-template <int BN, int TX, int MT, int PM>
-__global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
+// NW = waves per work-group (4, or 8: a 512-thread work-group over 256 voxels whose eight waves share ONE weight slab -- per
+// voxel half the slab loads, half the slab's LDS stores and half its trips through the vector-memory path of two 4-wave
+// work-groups, at the same registers per wave and the same two waves per SIMD; the tile is the one MT = 2 uses).
+template <int BN, int TX, int MT, int PM, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_h2_kernel(const ConvArgs a)
 {
     constexpr bool SPLIT = PM == 0;
-    constexpr int ROWS = 128 * MT, TXW = 8 * MT;
+    constexpr int THREADS = 64 * NW;
+    constexpr int ROWS = 32 * NW * MT, TXW = 2 * NW * MT;
+    constexpr int NA = NW == 8 ? 3 : (MT > 1 ? 5 : 4);       // halo slots per thread (1280 / 1024 slots at most: launch_conv_h2)
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     constexpr int NT = BN / 32;
     constexpr bool UPA = TX == 4;                         // TX = 4: the taps of TX = 1 + source A up-sampled on read (see ConvArgs::upw)
     constexpr int NTAPS = TX == 2 ? 12 : (UPA ? 9 : 9 * TX), NPAIR = (NTAPS + 1) / 2;
     constexpr int BU = 2 * NPAIR * BN;                    // uint4 per half of the weight slab (hi | lo)
     constexpr int SLAB = SPLIT ? 2 * BU : BU;             // uint4 of weights staged per K step (single-product modes: hi only)
-    constexpr int NB = (SLAB + 255) / 256;                // uint4 of weights per thread per stage (14 / 7 / 3; halved without lo)
-    constexpr bool BEXACT = SLAB % 256 == 0;
+    constexpr int NB = (SLAB + THREADS - 1) / THREADS;    // uint4 of weights per thread per stage (14 / 7 / 3; halved without lo)
+    constexpr bool BEXACT = SLAB % THREADS == 0;
     uint4 *Bs = smem4;                                    // [hi: 28][BN] | [lo: 28][BN]
     uint4 *AsH = smem4 + SLAB;
     uint4 *AsL = AsH + a.slots_max;                       // (SPLIT only)
@@ -219,8 +224,8 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         }
         return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
     };
-    const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + 256), gv2 = slot_voxel(tid + 512), gv3 = slot_voxel(tid + 768),
-              gv4 = MT > 1 ? slot_voxel(tid + 1024) : -2;
+    const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + THREADS), gv2 = slot_voxel(tid + 2 * THREADS),
+              gv3 = NA > 3 ? slot_voxel(tid + 3 * THREADS) : -2, gv4 = NA > 4 ? slot_voxel(tid + 4 * THREADS) : -2;
     // source A up-sampled on read (UPA): the slot's voxel (z, y, x) of the output grid reads the COARSE voxel
     // (z, (y + off) >> 1, (x + off) >> 1) of srcA and multiplies by the transposed convolution's weight of its parity
     auto slot_up = [&](int g) __attribute__((always_inline)) -> int {      // coarse index | parity << 28 (g: voxel index or < 0)
@@ -247,13 +252,13 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     float4 vb0 = make_float4(0.f, 0.f, 0.f, 0.f), vb1 = vb0;   // (UPA) bias of the transposed convolution for this stage's channels
     int up_cc = 0;
 #define H2_LOAD_A(k)                                                                              \
-    if constexpr (k < 4 || MT > 1) {                                                              \
+    if constexpr (k < NA) {                                                                       \
         const float *pp = (UPA && stage_up) ? &src[((int64_t)b * Mup + (gu##k & 0x0FFFFFFF)) * C + cc]      \
                                             : &src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];   \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }
-#define H2_LOAD_B(k) if constexpr (NB > k) { if (BEXACT || tid + 256 * k < SLAB) rb##k = wsrc[tid + 256 * k]; }
+#define H2_LOAD_B(k) if constexpr (NB > k) { if (BEXACT || tid + THREADS * k < SLAB) rb##k = wsrc[tid + THREADS * k]; }
 #define H2_LOAD_STAGE(step_)                                                                      \
     {                                                                                             \
         const int c0 = (step_) << 3;                                                              \
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     v.x = fmaxf(fmaf(v.x, s_.x, h_.x), 0.f); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), 0.f);             \
     v.z = fmaxf(fmaf(v.z, s_.z, h_.z), 0.f); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), 0.f);
 #define H2_STORE_A(k)                                                                             \
-    if ((k < 4 || MT > 1) && gv##k != -2) {                                                       \
+    if (k < NA && gv##k != -2) {                                                       \
         float4 v = ra##k, w = rc##k;                                                              \
         if (has_affine) { H2_AFF(v, vs0, vh0) H2_AFF(w, vs1, vh1) }                               \
         if (UPA && st_up) {                                                                       \
@@ -288,11 +293,11 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
         }                                                                                         \
         if (gv##k < 0) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }                            \
         uint4 hi, lo;                                                                             \
-        if constexpr (SPLIT) { split8(v, w, hi, lo); AsL[tid + 256 * k] = lo; }                   \
+        if constexpr (SPLIT) { split8(v, w, hi, lo); AsL[tid + THREADS * k] = lo; }               \
         else round8<PM>(v, w, hi);                                                                \
-        AsH[tid + 256 * k] = hi;                                                                  \
+        AsH[tid + THREADS * k] = hi;                                                              \
     }
-#define H2_STORE_B(k) if constexpr (NB > k) { if (BEXACT || tid + 256 * k < SLAB) Bs[tid + 256 * k] = rb##k; }
+#define H2_STORE_B(k) if constexpr (NB > k) { if (BEXACT || tid + THREADS * k < SLAB) Bs[tid + THREADS * k] = rb##k; }
 
     // LDS offset of tap t relative to the output voxel's slot (tap 27 = padding pair of tap 26: zero weights)
     auto tap_off = [&](int t) __attribute__((always_inline)) -> int {
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(256) void conv_h2_kernel(const ConvArgs a)
     __syncthreads();
     if (tid < BN && !a.no_stats) {
         float s = 0.f, q = 0.f;
-        for (int wv = 0; wv < 4; ++wv) { s += red[(wv * BN + tid) * 2]; q += red[(wv * BN + tid) * 2 + 1]; }
+        for (int wv = 0; wv < NW; ++wv) { s += red[(wv * BN + tid) * 2]; q += red[(wv * BN + tid) * 2 + 1]; }
         int64_t o = ((int64_t)b * a.tiles_per_chunk + tile) * a.Cout + ntile * BN + tid;
         a.psum[o] = s;
         a.psq[o] = q;
@@ -406,6 +411,16 @@ int h2_mt(const isx_tune &tune, const Level &l, int batch)
 {
     const int on = tune.h2_mt2;                            // 0: never, 1 (default): big launches, 2: always (tests)
     return on == 2 || (on && (int64_t)batch * l.M >= (1 << 21));
+}
+
+// 512-thread work-groups (NW = 8: eight waves on one 64-column weight slab, 256 voxels): every layer with Cout % 64 == 0 whose
+// 256-voxel halo fits the staging plan and whose launch still fills the chip
+bool conv_h2_nw8(const isx_tune &tune, const Level &l, int cout, int batch)
+{
+    if (!tune.h2_nw8 || cout % 64) return false;
+    int ty, tx, tp, sl;
+    const int tiles2 = conv_tiles(l, conv_mode(l), 2, &ty, &tx, &tp, &sl);
+    return sl <= 1536 && (int64_t)batch * tiles2 * (cout / 64) >= 512;
 }
 
 int conv_h2_bn(const isx_tune &tune, int slots, int cout)
@@ -538,22 +553,28 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.no_stats = no_stats;
     a.xcd_remap = xcd_remap;
     ISX_REQUIRE((fold || cout % 32 == 0) && sa.C % 8 == 0 && sb.C % 8 == 0, "internal: split-f16 conv needs Cout %% 32 == 0, Cin %% 8 == 0");
-    int BN = fold ? 32 : conv_h2_bn(ctx->tune, a.slots_max, cout);
+    const bool nw8 = !fold && !tx2 && !a.accum && !a.remap && conv_h2_nw8(ctx->tune, l, cout, B);
+    int BN = fold ? 32 : (nw8 ? 64 : conv_h2_bn(ctx->tune, a.slots_max, cout));
     // 32-column tiles get two row tiles per wave (256-voxel work-groups) when the launch is big enough to fill
     // the chip that way; the partial-sum layout then follows that tiling (mt is fixed per workspace: h2_mt)
     // (the folded layer stays at one row tile: measured 9.7 ms against 10.9 with two; 16-channel stages for it were
     // tried as well and lost a wave per SIMD: 11.6-15.2 ms)
     int mt = (!fold && BN == 32 && h2_mt(ctx->tune, l, ctx->unet->wbatch)) ? 2 : 1;
+    if (nw8) {                          // the tile of MT = 2, one row tile per wave
+        int ty, tx, tp, sl;
+        a.tiles_per_chunk = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
+        a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl;
+    }
     if (mt == 2) {
         int ty, tx, tp, sl;
         const int tiles2 = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
         if (sl <= 1280) { a.tiles_per_chunk = tiles2; a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl; }
         else mt = 1;                   // very narrow levels: the 256-position halo does not fit the staging plan
     }
-    ISX_REQUIRE(a.slots_max <= (mt == 2 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
+    ISX_REQUIRE(a.slots_max <= (nw8 ? 1536 : (mt == 2 ? 1280 : 1024)), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     a.ntiles = fold ? 1 : cout / BN;
     const int npair = fold ? 5 : (tx2 ? 6 : 14);
-    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * (2 * npair * BN + a.slots_max)) * 16 + (128 * mt + 4 * BN * 2) * sizeof(float);
+    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * (2 * npair * BN + a.slots_max)) * 16 + ((nw8 ? 256 : 128 * mt) + (nw8 ? 8 : 4) * BN * 2) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
@@ -565,6 +586,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     if (!attr_done) {
         ISX_H2_ATTR(64, 3, 1) ISX_H2_ATTR(32, 3, 1) ISX_H2_ATTR(32, 3, 2) ISX_H2_ATTR(32, 1, 1) ISX_H2_ATTR(32, 1, 2)
         ISX_H2_ATTR(64, 2, 1) ISX_H2_ATTR(32, 2, 1) ISX_H2_ATTR(32, 2, 2) ISX_H2_ATTR(32, 4, 1) ISX_H2_ATTR(32, 4, 2)
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
 #undef ISX_H2_ATTR
@@ -572,7 +596,11 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     do { if (pm == 0) conv_h2_kernel<BN_, TX_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
          else if (pm == 1) conv_h2_kernel<BN_, TX_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
          else conv_h2_kernel<BN_, TX_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
-    if (fold && upa && mt == 2) ISX_H2_GO(32, 4, 2);
+    if (nw8) {
+        if (pm == 0) conv_h2_kernel<64, 3, 1, 0, 8><<<grid, 512, lds, ctx->stream>>>(a);
+        else if (pm == 1) conv_h2_kernel<64, 3, 1, 1, 8><<<grid, 512, lds, ctx->stream>>>(a);
+        else conv_h2_kernel<64, 3, 1, 2, 8><<<grid, 512, lds, ctx->stream>>>(a);
+    } else if (fold && upa && mt == 2) ISX_H2_GO(32, 4, 2);
     else if (fold && upa) ISX_H2_GO(32, 4, 1);
     else if (fold && mt == 2) ISX_H2_GO(32, 1, 2);
     else if (fold) ISX_H2_GO(32, 1, 1);

@@ -1268,7 +1268,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         int t0, t1, t2, slots;
         conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
         const bool bf = u->precision == ISX_PRECISION_BF16;
-        const bool b64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64;
+        const bool b64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64 || conv_h2_nw8(ctx->tune, l, L.cout, B);
         const void *wh = bf ? (b64 ? L.w_bf_64 : L.w_bf_32) : (b64 ? L.w_h2_64 : L.w_h2_32);
         const bool in_range = bf || std::max(sa.bound, sb.bound) < 6.0e4f;    // else operands could leave the f16 range
         // training keeps fp32 products except in the bf16 mixed-precision mode (its packs are refreshed every step)

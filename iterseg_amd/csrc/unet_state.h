@@ -160,6 +160,7 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
                      int cout, float *out, float *psum, float *psq, int no_stats);
 // split-f16 convolution (conv_h2.hip)
 int conv_h2_bn(const isx_tune &tune, int slots, int cout);
+bool conv_h2_nw8(const isx_tune &tune, const Level &l, int cout, int batch);
 int h2_mt(const isx_tune &tune, const Level &l, int batch);
 void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint16_t> &out, int pm);
 void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out, int pm);
