@@ -420,7 +420,7 @@ bool conv_h2_nw8(const isx_tune &tune, const Level &l, int cout, int batch)
     if (!tune.h2_nw8 || cout % 64) return false;
     int ty, tx, tp, sl;
     const int tiles2 = conv_tiles(l, conv_mode(l), 2, &ty, &tx, &tp, &sl);
-    return sl <= 1536 && (int64_t)batch * tiles2 * (cout / 64) >= 512;
+    return sl <= 1536 && (tune.h2_nw8 == 2 || (int64_t)batch * tiles2 * (cout / 64) >= 512);        // 2: always (tests)
 }
 
 int conv_h2_bn(const isx_tune &tune, int slots, int cout)

@@ -315,3 +315,28 @@ def test_tail_layer_up_sampling_on_read_is_bit_identical(monkeypatch):
     assert np.array_equal(ya, yb)
     assert np.array_equal(nets[0].tap("c8_0.conv0"), nets[1].tap("c8_0.conv0"))
     assert np.array_equal(nets[0].tap("up3.cropped"), nets[1].tap("up3.cropped"))      # computed on demand on the first one
+
+
+@pytest.mark.gpu
+def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
+    """ISX_H2_NW8=2: every layer with Cout % 64 == 0 on 512-thread work-groups (eight waves, one weight slab, 256-voxel tiles
+    -- conv_h2_kernel<64, 3, 1, PM, 8>); the K order of every output is unchanged."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(4)
+    nets = []
+    for v in ("2", "0"):
+        monkeypatch.setenv("ISX_H2_NW8", v)
+        u = UNet(1, 5, batch=2)
+        u.load_state_dict(sd)
+        nets.append(u)
+    for shape in [(4, 32, 32), (10, 96, 80)]:
+        x = np.random.default_rng(6).random((1, 1) + shape, dtype=np.float32)
+        ya, yb = nets[0](x), nets[1](x)
+        # the convolutions are the same sums in the same order; the BatchNorm partial sums are taken over 256-voxel tiles
+        # instead of 128-voxel ones, so the statistics differ in the last bits
+        assert np.abs(ya - yb).max() <= 2e-6, np.abs(ya - yb).max()
+        for name in ("c1.conv1", "c3.conv0", "c5_0.conv0", "c6_0.conv1"):
+            ta, tb = nets[0].tap(name), nets[1].tap(name)
+            assert np.abs(ta - tb).max() <= 2e-5 * max(1.0, np.abs(tb).max()), name
