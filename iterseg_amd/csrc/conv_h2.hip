@@ -123,7 +123,7 @@ template <int BN, int TX, int MT, int PM, int NW, int CORE>
 __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 {
     constexpr bool SPLIT = PM == 0;
-    static_assert(CORE == 0 || TX == 3 || TX == 2, "the 16x16x32 core needs a multiple of four tap slots");
+    // (the tail layer's packs hold 12 tap slots for its 9 taps, so that either core can read them)
     constexpr int THREADS = 64 * NW;
     constexpr int ROWS = 32 * NW * MT, TXW = 2 * NW * MT;
     constexpr int NA = NW == 8 ? 3 : (MT > 1 ? 5 : 4);       // halo slots per thread (1280 / 1024 slots at most: launch_conv_h2)
@@ -131,7 +131,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     constexpr int NT = BN / 32;
     constexpr bool UPA = TX == 4;                         // TX = 4: the taps of TX = 1 + source A up-sampled on read (see ConvArgs::upw)
     constexpr int NTAPS = TX == 2 ? 12 : (UPA ? 9 : 9 * TX), NPAIR = (NTAPS + 1) / 2;
-    constexpr int BU = 2 * NPAIR * BN;                    // uint4 per half of the weight slab (hi | lo)
+    constexpr int NSLOT = (TX == 1 || UPA) ? 12 : 2 * NPAIR;      // tap slots of a weight stage (28 / 12 / 12)
+    constexpr int NQUAD = (NTAPS + 3) / 4;
+    constexpr int BU = NSLOT * BN;                        // uint4 per half of the weight slab (hi | lo)
     constexpr int SLAB = SPLIT ? 2 * BU : BU;             // uint4 of weights staged per K step (single-product modes: hi only)
     constexpr int NB = (SLAB + THREADS - 1) / THREADS;    // uint4 of weights per thread per stage (14 / 7 / 3; halved without lo)
     constexpr bool BEXACT = SLAB % THREADS == 0;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if constexpr (CORE == 1) {
             const uint4 *bqh = Bs + h4 * BN + l16, *bql = bqh + BU;
 #pragma unroll
-            for (int q = 0; q < NPAIR / 2; ++q) {
+            for (int q = 0; q < NQUAD; ++q) {
                 const int t0 = tap_off(4 * q), t1 = tap_off(4 * q + 1), t2 = tap_off(4 * q + 2), t3 = tap_off(4 * q + 3);
                 const int to = h4 == 0 ? t0 : (h4 == 1 ? t1 : (h4 == 2 ? t2 : t3));
                 union FR { uint4 u; f16x8 v; bf16x8 w; };
@@ -506,10 +508,10 @@ __global__ __launch_bounds__(64 * NW) void conv_h2_kernel(const ConvArgs a)
 
 // the 27-tap convolution on the 16x16x32 core.  (The accumulators of the 64-column variant come to 258 registers unless the
 // compiler is told that two waves per SIMD are wanted; the 32x32x16 kernels keep their own allocation.)
-template <int BN, int MT, int PM>
+template <int BN, int TX, int MT, int PM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16_kernel(const ConvArgs a)
 {
-    conv_h2_body<BN, 3, MT, PM, 4, 1>(a);
+    conv_h2_body<BN, TX, MT, PM, 4, 1>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -585,11 +587,11 @@ void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint
             }
 }
 
-// folded tail layer (cout <= 5): [Cin/8][hi|lo][10 (dz,dy) taps][32 columns = dx*cout + o][8 channels] halves
+// folded tail layer (cout <= 5): [Cin/8][hi|lo][12 slots for the 9 (dz,dy) taps][32 columns = dx*cout + o][8 channels] halves
 void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out, int pm)
 {
     const int nsteps = cin / 8;
-    const size_t half_slab = (size_t)10 * 32 * 8;
+    const size_t half_slab = (size_t)12 * 32 * 8;       // 9 taps in 12 slots: five tap pairs of the 32x32x16 core or three tap quads of the 16x16x32 one
     out.assign((size_t)nsteps * 2 * half_slab + 4096, 0);
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
@@ -683,7 +685,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     }
     ISX_REQUIRE(a.slots_max <= (nw8 ? 1536 : (mt == 2 ? 1280 : 1024)), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     a.ntiles = fold ? 1 : cout / BN;
-    const int npair = fold ? 5 : (tx2 ? 6 : 14);
+    const int npair = fold ? 6 : (tx2 ? 6 : 14);          // tap slots / 2 of a weight stage (the tail layer's 9 taps sit in 12 slots)
     const size_t lds = (size_t)((pm == 0 ? 2 : 1) * (2 * npair * BN + a.slots_max)) * 16 + ((nw8 ? 256 : 128 * mt) + (nw8 ? 8 : 4) * BN * 2) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
@@ -696,11 +698,11 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     if (!attr_done) {
         ISX_H2_ATTR(64, 3, 1) ISX_H2_ATTR(32, 3, 1) ISX_H2_ATTR(32, 3, 2) ISX_H2_ATTR(32, 1, 1) ISX_H2_ATTR(32, 1, 2)
         ISX_H2_ATTR(64, 2, 1) ISX_H2_ATTR(32, 2, 1) ISX_H2_ATTR(32, 2, 2) ISX_H2_ATTR(32, 4, 1) ISX_H2_ATTR(32, 4, 2)
-#define ISX_H2_ATTR16(BN_, MT_) \
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, MT_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, MT_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, MT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_H2_ATTR16(64, 1) ISX_H2_ATTR16(32, 1) ISX_H2_ATTR16(32, 2)
+#define ISX_H2_ATTR16(BN_, TX_, MT_) \
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, TX_, MT_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, TX_, MT_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, TX_, MT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_H2_ATTR16(64, 3, 1) ISX_H2_ATTR16(32, 3, 1) ISX_H2_ATTR16(32, 3, 2) ISX_H2_ATTR16(32, 1, 1) ISX_H2_ATTR16(32, 1, 2)
 #undef ISX_H2_ATTR16
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -712,14 +714,16 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     do { if (pm == 0) conv_h2_kernel<BN_, TX_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
          else if (pm == 1) conv_h2_kernel<BN_, TX_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
          else conv_h2_kernel<BN_, TX_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
-#define ISX_H2_GO16(BN_, MT_) \
-    do { if (pm == 0) conv_h2c16_kernel<BN_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
-         else if (pm == 1) conv_h2c16_kernel<BN_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
-         else conv_h2c16_kernel<BN_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
-    const bool core16 = ctx->tune.h2_core16 && !fold && !tx2 && !nw8;
-    if (core16 && BN == 64) ISX_H2_GO16(64, 1);
-    else if (core16 && mt == 2) ISX_H2_GO16(32, 2);
-    else if (core16) ISX_H2_GO16(32, 1);
+#define ISX_H2_GO16(BN_, TX_, MT_) \
+    do { if (pm == 0) conv_h2c16_kernel<BN_, TX_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
+         else if (pm == 1) conv_h2c16_kernel<BN_, TX_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
+         else conv_h2c16_kernel<BN_, TX_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
+    const bool core16 = ctx->tune.h2_core16 && !tx2 && !nw8 && !upa && (!fold || (ctx->tune.h2_core16 & 2));
+    if (core16 && fold && mt == 2) ISX_H2_GO16(32, 1, 2);
+    else if (core16 && fold) ISX_H2_GO16(32, 1, 1);
+    else if (core16 && BN == 64) ISX_H2_GO16(64, 3, 1);
+    else if (core16 && mt == 2) ISX_H2_GO16(32, 3, 2);
+    else if (core16) ISX_H2_GO16(32, 3, 1);
     else if (nw8) {
         if (pm == 0) conv_h2_kernel<64, 3, 1, 0, 8><<<grid, 512, lds, ctx->stream>>>(a);
         else if (pm == 1) conv_h2_kernel<64, 3, 1, 1, 8><<<grid, 512, lds, ctx->stream>>>(a);

@@ -340,3 +340,31 @@ def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
         for name in ("c1.conv1", "c3.conv0", "c5_0.conv0", "c6_0.conv1"):
             ta, tb = nets[0].tap(name), nets[1].tap(name)
             assert np.abs(ta - tb).max() <= 2e-5 * max(1.0, np.abs(tb).max()), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
+def test_both_matrix_core_shapes_give_the_same_feature_maps(precision, monkeypatch):
+    """ISX_H2_CORE16: 0 = v_mfma_f32_32x32x16 (rounds 1-2), 1 = the 27-tap layers on v_mfma_f32_16x16x32 (default: the chip
+    holds a higher clock under that shape), 3 = the tail layer too.  Same operands and products; the taps of a K stage are
+    summed in groups of four instead of two, so the results agree to rounding."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(5)
+    nets = []
+    for v in ("0", "1", "3"):
+        monkeypatch.setenv("ISX_H2_CORE16", v)
+        u = UNet(1, 5, batch=1, precision=precision)
+        u.load_state_dict(sd)
+        nets.append(u)
+    # (a last-bit difference of a sum can flip the f16 / bf16 rounding of an activation in the next layer)
+    tol = {"split-f16": 3e-6, "f16": 5e-3, "bf16": 3e-2}[precision]
+    for shape in [(4, 32, 32), (10, 80, 96)]:
+        x = np.random.default_rng(8).random((1, 1) + shape, dtype=np.float32)
+        ys = [n(x) for n in nets]
+        assert np.abs(ys[1] - ys[0]).max() <= tol and np.abs(ys[2] - ys[0]).max() <= tol
+        for name in ("c0.conv1", "c2.conv0", "c4.conv1", "c6_0.conv0", "c8_0.conv0"):
+            t0 = nets[0].tap(name)
+            for n in nets[1:]:
+                assert np.abs(n.tap(name) - t0).max() <= 10 * tol * max(1.0, np.abs(t0).max()), name
