@@ -85,12 +85,12 @@ def cpu_baseline(sd, chunk, margin):
 
 
 DTYPE = {"fp32": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)",
-         "split-f16": "f32 operands split into two f16 halves each (x = x_h + x_l / 2^11), three v_mfma_f32_32x32x16_f16 per K "
+         "split-f16": "f32 operands split into two f16 halves each (x = x_h + x_l / 2^11), three v_mfma_f32_16x16x32_f16 per K "
                       "block with separate fp32 accumulators: fp32-class results on the f16 matrix cores",
          # reduced-precision characterisation runs only (--precision f16 / bf16): never the default, never the headline
-         "f16": "f16 operands (round to nearest), one v_mfma_f32_32x32x16_f16 per K block, fp32 accumulate -- REDUCED precision "
+         "f16": "f16 operands (round to nearest), one v_mfma_f32_16x16x32_f16 per K block, fp32 accumulate -- REDUCED precision "
                 "(BASELINE config 5's 'fp16 U-Net'; stated tolerance 4e-3 on the sigmoid maps)",
-         "bf16": "bf16 operands, one v_mfma_f32_32x32x16_bf16 per K block, fp32 accumulate -- REDUCED precision (stated tolerance 3e-2)"}
+         "bf16": "bf16 operands, one v_mfma_f32_16x16x32_bf16 per K block, fp32 accumulate -- REDUCED precision (stated tolerance 3e-2)"}
 # roofline.traffic: HBM bytes per launch of the wide-conv kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 # (separate passes, FETCH x2 on gfx950, MI355X_MICROARCH.md) over one launch set of THIS build's kernels.  bench.py
 # cannot collect PMC counters on itself, so it reads the summary that scratch/pmc_traffic_json.py wrote from those
@@ -116,10 +116,10 @@ def conv_roofline(precision, mfma_flops, n_chunks, steps, ms_mfma, n_mfma, batch
     r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
          "traffic": traffic, "traffic_source": traffic_src, "traffic_algorithmic": TRAFFIC_ALGORITHMIC * batch,
          "kernel": ("conv_mfma_kernel (fp32 32x32x2 implicit-GEMM conv, 16 of 18 layers)" if precision == "fp32" else
-                    "conv_h2_kernel (split-f16 32x32x16 implicit-GEMM conv, 16 of 18 layers)"),
+                    "conv_h2c16_kernel / conv_h2_kernel (split-f16 implicit-GEMM conv on v_mfma_f32_16x16x32_f16; the 9-tap tail layer on 32x32x16; 16 of 18 layers)"),
          "avg_launch_ms": ms_mfma / max(n_mfma, 1), "launches": n_mfma, "algorithmic_gflop_per_chunk": mfma_flops / 1e9}
     if precision in ("f16", "bf16"):
-        r["kernel"] = f"conv_h2_kernel ({precision} operands, one MFMA per product, 16 of 18 layers)"
+        r["kernel"] = f"conv_h2c16_kernel / conv_h2_kernel ({precision} operands, one MFMA per product, 16 of 18 layers)"
         r["note"] = "reduced-precision mode: algorithmic FLOPs = executed MFMA FLOPs x 27/28"
     elif precision != "fp32":
         r["note"] = ("achieved = algorithmic (fp32-equivalent) FLOPs; the split executes 3 f16 MFMAs per product (x 28/27 tap "

@@ -5,7 +5,7 @@ FETCH_SIZE and WRITE_SIZE are in KB; FETCH_SIZE counts 64 B per 128-B request on
 (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Only the wide-conv kernel of the precision is summed."""
 import csv, json, os, sys
 prec, fcsv, wcsv, chunks, out, note = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], sys.argv[6]
-kern = "conv_mfma_kernel" if prec == "fp32" else "conv_h2_kernel"
+kern = "conv_mfma_kernel" if prec == "fp32" else "conv_h2"          # conv_h2_kernel and conv_h2c16_kernel
 def total(path, counter):
     t, n = 0.0, 0
     for r in csv.DictReader(open(path)):
