@@ -33,6 +33,9 @@
 
 namespace isx {
 
+#ifndef ISX_H2_ABLATE
+#define ISX_H2_ABLATE 0          // development: 1 = no staging arithmetic, 2 = no matrix phase (timing experiments, wrong results)
+#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -319,6 +322,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         }                                                                                         \
         if (gv##k < 0) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }                            \
         uint4 hi, lo;                                                                             \
+        if (ISX_H2_ABLATE == 1) { hi = make_uint4(__float_as_uint(ra##k.x), __float_as_uint(ra##k.y), __float_as_uint(ra##k.z), __float_as_uint(ra##k.w)); \
+                                  lo = make_uint4(__float_as_uint(rc##k.x), __float_as_uint(rc##k.y), __float_as_uint(rc##k.z), __float_as_uint(rc##k.w)); \
+                                  if constexpr (SPLIT) AsL[tid + THREADS * k] = lo; } else              \
         if constexpr (SPLIT) { split8(v, w, hi, lo); AsL[tid + THREADS * k] = lo; }               \
         else round8<PM>(v, w, hi);                                                                \
         AsH[tid + THREADS * k] = hi;                                                              \
@@ -346,6 +352,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         __syncthreads();
         if (step + 1 < nsteps) H2_LOAD_STAGE(step + 1)
         __builtin_amdgcn_sched_barrier(0);
+        if (ISX_H2_ABLATE == 2) { acc_hi[0][0][0] += (float)step; } else
         if constexpr (CORE == 1) {
             const uint4 *bqh = Bs + h4 * BN + l16, *bql = bqh + BU;
 #pragma unroll
