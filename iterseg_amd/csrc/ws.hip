@@ -2053,7 +2053,8 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
             flood_group_kernel<<<n_comp, GRP_W, 0, side ? ctx->aux_streams[0] : ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                                    comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1], pshape[2], PN,
                                                                    s[0], s[1], s[2], group_min, run_limit, drain_n, gwcap, gtcap, group_bursts,
-                                                                   bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world, gsteps | (gminsteps << 8));
+                                                                   bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world, gsteps | (gminsteps << 8) | ((getenv("ISX_FLOOD_PLATEAU") && atoi(getenv("ISX_FLOOD_PLATEAU")) != 0) ? 0 : 0x10000) |      /* the plateau pass: off unless asked for */
+                                                                   ((getenv("ISX_FLOOD_PLATEAU_MIN") ? (atoi(getenv("ISX_FLOOD_PLATEAU_MIN")) & 0x3FF) : 0) << 17));
             ISX_CHECK_LAUNCH();
         }
         // two tiers of the single-wave kernel: components below small_max voxels on the small instantiation (~30 KB of LDS:
@@ -2146,7 +2147,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                 hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[2] ? (double)hs[1] / hs[2] : 0.0, hs[13], hs[3], hs[7], hs[4], hs[5], hs[10],
                 hs[6], hs[11], hs[14], hs[12], hs[15], hs[8]);
         if (group_min != ~0ull)
-            fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu; of the work-group kernel alone: rounds %llu pops %llu drains %llu (%llu as the prefix of a list in key order)\n", hs[17], hs[18], hs[29], hs[28], hs[27], hs[26]);
+            fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu; of the work-group kernel alone: rounds %llu (plateau passes %llu with %llu pops; not tried: started episode %llu, prefix < 32 %llu; not a plateau %llu) pops %llu drains %llu (%llu as the prefix of a list in key order)\n", hs[17], hs[18], hs[29], hs[30], hs[31], hs[24], hs[25], hs[23], hs[28], hs[27], hs[26]);
 #ifdef ISX_FLOOD_PROF
         if (group_min != ~0ull)
             fprintf(stderr, "[isx flood/group] cycles/sub-round of lane 0: (S0)->C %.0f | C loop %.0f | wait (S5) %.0f | squash %.0f | to (E0) %.0f | order (E1-E3a) %.0f | verify %.0f | labels %.0f | enqueue %.0f | "

@@ -46,7 +46,7 @@ enum { GI_OH, GI_NW, GI_SHEAD, GI_SCOUNT, GI_NSTAGE, GI_NFREECH, GI_NFREESLOT, G
        GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_FRONT, GI_LAST, GI_NRELOAD, GI_READY, GI_SORTN, GI_PEND0, GI_N };
 enum { GQ_KSQ, GQ_TMIN, GQ_QHEAD, GQ_KINV, GQ_N };
 enum { GS_SUB, GS_POPS, GS_EXEC, GS_SQ_EPS, GS_SQ_BOUND, GS_SQ_LOST, GS_SLOW, GS_FORCED, GS_RELOAD, GS_RUNINS, GS_WININS, GS_WINEV, GS_COLD,
-       GS_DRAIN, GS_BURST, GS_C_NOTREADY, GS_C_NOTSTARTED, GS_C_RUNNING, GS_C_BOUND, GS_C_CAP, GS_C_ALL, GS_NWSUM, GS_F_BULK, GS_F_CALLS, GS_F_FLUSHES, GS_N };
+       GS_DRAIN, GS_BURST, GS_PLATEAU, GS_PLPOPS, GS_PLSTARTED, GS_PLSHORT, GS_PLABORT, GS_C_NOTREADY, GS_C_NOTSTARTED, GS_C_RUNNING, GS_C_BOUND, GS_C_CAP, GS_C_ALL, GS_NWSUM, GS_F_BULK, GS_F_CALLS, GS_F_FLUSHES, GS_N };
 
 // ---- the cold tier, driven by wave 0, OUT OF LINE: cold_append / cold_drain are large, and inlined into the kernel their
 // registers pushed the episode words of the hot loop into scratch memory (a scratch round trip per phase).  The tier's
@@ -57,27 +57,57 @@ __device__ __forceinline__ void grp_publish_cold(const Cold &cold, int *shI, int
 }
 
 // append stage[0, nstage) to the buckets, 64 at a time
-__device__ __noinline__ void grp_w0_flush_stage(Cold *cs, HeapEnt *stage, int *shI, uint32_t *lstat, int lane)
+__device__ __noinline__ void grp_w0_flush_stage(Cold *cs, HeapEnt *stage, int *shI, uint32_t *lstat, int lane, HeapEnt *tmp)
 {
     Cold cold = *cs;
-    const int nstage = shI[GI_NSTAGE];
+    int nstage = shI[GI_NSTAGE];
     int done = 0;
-    if (nstage > 64) {
-        // one bucket for the whole batch (a plateau)?  then one append
+    if (nstage > 64 && tmp) {
+        // The elements of the first one's bucket (on a plateau: nearly all of them) leave in ONE append (cold_append_bucket: one
+        // state update, at most one new segment); the others are closed up in place, in order, for the 64-at-a-time path.
+        // `tmp`: GRP_W free entries of LDS (the run-bound batch buffer, empty by now).
         const uint32_t b0 = cold_bucket(cold, stage[0].key);
-        bool same = true, asc = true;
-        for (int j = lane; j < nstage; j += 64) {
-            const unsigned long long k = stage[j].key;
-            same = same && cold_bucket(cold, k) == b0;
-            if (j > 0) asc = asc && stage[j - 1].key <= k;
+        int nm = 0, nn = 0;
+        for (int j0 = 0; j0 < nstage; j0 += 64) {
+            const int j = j0 + lane;
+            HeapEnt e; e.key = 0; e.idx = 0; e.pad = 0;
+            const bool hs = j < nstage;
+            if (hs) e = stage[j];
+            const bool mt = hs && cold_bucket(cold, e.key) == b0;
+            const unsigned long long mb = __ballot(mt), ob = __ballot(hs && !mt);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int room = GRP_W - nm;                        // the batch buffer holds GRP_W entries; what does not fit stays behind
+            const int mr = __popcll(mb & below);
+            const bool take = mt && mr < room;
+            const bool keep = hs && !take;
+            const unsigned long long kb = __ballot(keep);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the whole chunk is in registers before the in-place writes)
+            if (take) tmp[nm + mr] = e;
+            if (keep) stage[nn + __popcll(kb & below)] = e;
+            nm += __popcll(mb) < room ? __popcll(mb) : room;
+            nn += __popcll(kb);
+            (void)ob;
         }
-        if (__all(same)) {
-            cold_append_bucket(cold, stage, nstage, b0, __all(asc) != 0, stage[0].key, stage[nstage - 1].key, lane);
-            if (!cold.failed) done = nstage;
+        if (nm > 0) {
+            bool asc = true;
+            for (int j = lane; j < nm; j += 64) if (j > 0) asc = asc && tmp[j - 1].key <= tmp[j].key;
+            cold_append_bucket(cold, tmp, nm, b0, __all(asc) != 0, tmp[0].key, tmp[nm - 1].key, lane);
 #ifdef ISX_FLOOD_PROF
-            if (lane == 0) atomicAdd(&lstat[GS_F_BULK], 1u);
+            if (lane == 0 && !cold.failed) atomicAdd(&lstat[GS_F_BULK], 1u);
 #endif
         }
+        if (cold.failed) {
+            // nothing was written: put the batch back in front of the rest (GRP_STAGE holds both) for the serial continuation
+            for (int j0 = ((nn - 1) / 64) * 64; j0 >= 0 && nn > 0; j0 -= 64) {
+                HeapEnt e; e.key = 0; e.idx = 0; e.pad = 0;
+                if (j0 + lane < nn) e = stage[j0 + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (j0 + lane < nn) stage[j0 + lane + nm] = e;
+            }
+            for (int j = lane; j < nm; j += 64) stage[j] = tmp[j];
+            nn += nm;
+        } else if (lane == 0 && nm > 0) atomicAdd(&lstat[GS_COLD], (uint32_t)nm);
+        nstage = nn;
     }
 #ifdef ISX_FLOOD_PROF
     if (lane == 0) { atomicAdd(&lstat[GS_F_FLUSHES], 1u); atomicAdd(&lstat[GS_F_CALLS], (uint32_t)((nstage - done + 63) / 64)); }
@@ -149,7 +179,7 @@ __device__ __noinline__ void grp_w0_run_evict(Cold *cs, HeapEnt *srun, int *shI,
 // the run is empty: staged elements to their buckets, then the lowest bucket into the run
 __device__ __noinline__ void grp_w0_drain(Cold *cs, HeapEnt *srun, HeapEnt *stage, int *hist, int *shI, uint32_t *lstat, int drain_n, int lane)
 {
-    if (shI[GI_NSTAGE] > 0) grp_w0_flush_stage(cs, stage, shI, lstat, lane);
+    if (shI[GI_NSTAGE] > 0) grp_w0_flush_stage(cs, stage, shI, lstat, lane, nullptr);
     Cold cold = *cs;
     if (!cold.failed && cold.count > 0) {
         bool sorted = true;
@@ -457,7 +487,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
 
     // ---- wave-0 helpers on the queue tiers (the other waves wait at the next barrier) -----------------------------------------------
     auto publish_cold = [&]() { };                   // (the out-of-line routines publish count / low themselves)
-    auto flush_stage_w0 = [&]() { grp_w0_flush_stage(&scold, stage, shI, lstat, lane); };
+    auto flush_stage_w0 = [&]() { grp_w0_flush_stage(&scold, stage, shI, lstat, lane, hotb); };
     auto run_evict_w0 = [&](int keep) { grp_w0_run_evict(&scold, srun, shI, lstat, stats, keep, lane); };
 
     // ---- start: seeds (value 0, age = rank in index order) ---------------------------------------------------------------------------------
@@ -503,6 +533,167 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
 #else
 #define GTICK(i) do { } while (0)
 #endif
+    // ---- enqueue of a committed batch: pend[0, GI_PENDN) in age order -> cold stage / window / run (a lambda: the commit bursts
+    //      and the plateau round share it).  Returns false when the component has gone to the serial continuation. ---------------
+    auto enqueue_batch = [&]() -> bool {
+        const int Ptot = shI[GI_PENDN];
+        for (int p0 = 0; p0 < Ptot; p0 += GRP_W) {
+            const int P = Ptot - p0 < GRP_W ? Ptot - p0 : GRP_W;
+            // capacity first: an eviction moves the hot maximum, so the batch is judged against the tiers AFTER it
+            if (shI[GI_SCOUNT] + P > run_limit || shI[GI_SCOUNT] + P > COOP_SCAP - 8) {
+                if (wave == 0) { int keep = run_limit / 2; if (keep > COOP_SCAP - GRP_W - 8) keep = COOP_SCAP - GRP_W - 8; run_evict_w0(keep); publish_cold(); }
+                __syncthreads();
+                if (shI[GI_SERIAL]) break;                                  // `pend` keeps the batch for the serial continuation
+            }
+            const int nw2 = shI[GI_NW], sc2 = shI[GI_SCOUNT], sh2 = shI[GI_SHEAD];
+            const bool hot_ne = nw2 > 0 || sc2 > 0;
+            const unsigned long long hot_max = sc2 > 0 ? srun[(sh2 + sc2 - 1) & SMASK].key : (nw2 > 0 ? okey[ord_at(nw2 - 1)] : 0ull);
+            const unsigned long long lastwin = nw2 > 0 ? okey[ord_at(nw2 - 1)] : 0ull;
+            const bool cold_ne = cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0);
+            HeapEnt r; r.key = 0; r.idx = 0; r.pad = 0;
+            bool hasr = tid < P;
+            if (hasr) r = pend[p0 + tid];
+            hasr = hasr && r.key != ~0ull;                                  // (a slot of a dropped residual)
+            const bool tocold = hasr && cold_ne && !(hot_ne && r.key < hot_max) && cold_bucket(cold, r.key) >= (uint32_t)shI[GI_COLD_LOW];
+            const bool towin = hasr && !tocold && nw2 > 0 && r.key < lastwin;
+            const bool torun = hasr && !tocold && !towin;
+            // three compactions (order inside a class is the age order of `pend`)
+            const unsigned long long bc = __ballot(tocold), bw = __ballot(towin), br = __ballot(torun);
+            if (lane == 0) { wtmp[0][wave] = __popcll(bc); wtmp[1][wave] = __popcll(bw); wtmp[2][wave] = __popcll(br); }
+            __syncthreads();
+            int oc = shI[GI_NSTAGE], ow = 0, orr = 0;
+#pragma unroll
+            for (int w = 0; w < GRP_NWV; ++w) if (w < wave) { oc += wtmp[0][w]; ow += wtmp[1][w]; orr += wtmp[2][w]; }
+            if (tocold) stage[oc + __popcll(bc & lt_mask)] = r;
+            // window-bound ones go back into `pend` (every lane has its element in a register by now), run-bound ones into
+            // `hotb`, which also takes the window-bound ones that turn out run-bound below: together at most P
+            if (towin) pend[ow + __popcll(bw & lt_mask)] = r;
+            if (torun) hotb[orr + __popcll(br & lt_mask)] = r;
+            __syncthreads();
+            if (tid == 0) {
+                int tc = 0, tw = 0, tr = 0;
+                for (int w = 0; w < GRP_NWV; ++w) { tc += wtmp[0][w]; tw += wtmp[1][w]; tr += wtmp[2][w]; }
+                shI[GI_NSTAGE] += tc; shI[GI_NWB] = tw; shI[GI_NHOT] = tr;
+                if (p0 + P >= Ptot) { shI[GI_PENDN] = 0; shI[GI_PEND0] = 0; } else shI[GI_PEND0] = p0 + P;
+            }
+            __syncthreads();
+            // Window-bound residuals (keys below the last root) become roots at their sorted positions -- ALL of them in one
+            // ranked merge with the window: an old root moves up by the number of new keys below it, a new one lands at
+            // (old roots below it) + (its rank among the new ones); whatever ends beyond the window's capacity is the top
+            // of the merged order and goes back to the FRONT of the run, in order (a root evicted this way is squashed by
+            // its own lane).  One element at a time this was ~5 barriers per residual: 250 of them per burst on plateaus.
+            const int T = shI[GI_NWB];
+            if (T > 0) {                                                   // uniform
+                const int nw3 = shI[GI_NW];
+                int E = nw3 + T - wcap;
+                if (E < 0) E = 0;
+                if (E > 0 && shI[GI_SCOUNT] + E > COOP_SCAP - 2) {          // room at the front of the run (rare)
+                    __syncthreads();
+                    if (wave == 0) { run_evict_w0(run_limit / 2); publish_cold(); }
+                    __syncthreads();
+                    if (shI[GI_SERIAL]) break;                              // pend[0, NWB) are still to be queued (WB0 = 0)
+                }
+                const int sh3w = shI[GI_SHEAD];
+                unsigned long long ok_ = 0ull; int os_ = 0, np_old = -1;
+                if (tid < nw3) {
+                    ok_ = okey[ord_at(tid)]; os_ = (int)oslot[ord_at(tid)];
+                    int c2 = 0;
+                    for (int q = 0; q < T; ++q) if (pend[q].key < ok_) ++c2;
+                    np_old = tid + c2;
+                }
+                HeapEnt ne; ne.key = 0; ne.idx = 0; ne.pad = 0;
+                int np_new = -1, rk_new = 0;
+                if (tid < T) {
+                    ne = pend[tid];
+                    for (int q = 0; q < T; ++q) if (pend[q].key < ne.key) ++rk_new;
+                    int lo = 0, hi = nw3;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (okey[ord_at(mid)] < ne.key) lo = mid + 1; else hi = mid; }
+                    np_new = lo + rk_new;
+                }
+                {
+                    const unsigned long long kb = __ballot(np_new >= 0 && np_new < wcap);
+                    if (lane == 0) wtmp[0][wave] = __popcll(kb);
+                }
+                __syncthreads();                                            // (W1) everything read
+                // evictions: an old root beyond the capacity tells its owner where in the run it goes; a new element goes itself
+                if (np_old >= wcap) ci_off[os_] = (uint32_t)((sh3w - E + (np_old - wcap)) & SMASK);
+                if (np_new >= wcap) srun[(sh3w - E + (np_new - wcap)) & SMASK] = ne;
+                __syncthreads();                                            // (W2)
+                if (has && ci_off[tid] != GRP_NONE) {
+                    HeapEnt b; b.key = key; b.idx = root; b.pad = lab;
+                    srun[ci_off[tid]] = b;
+                    ci_off[tid] = GRP_NONE;
+                    squash_me();
+                    has = false;
+                    freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
+                    atomicAdd(&lstat[GS_WINEV], 1u);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();                                            // (W3) slots of the evicted are back
+                const int nf_mid = shI[GI_NFREESLOT];
+                if (np_old >= 0 && np_old < wcap) { okey[ord_at(np_old)] = ok_; oslot[ord_at(np_old)] = (unsigned short)os_; }
+                if (np_new >= 0 && np_new < wcap) {
+                    const int sl = (int)freeslot[nf_mid - 1 - rk_new];     // the kept new ones are a prefix of the new ones in key order
+                    okey[ord_at(np_new)] = ne.key; oslot[ord_at(np_new)] = (unsigned short)sl;
+                    u32x4 nr = {(uint32_t)ne.key, (uint32_t)(ne.key >> 32), ne.idx, ne.pad};
+                    newroot[sl] = nr; newflag[sl] = 1u;
+                }
+                __syncthreads();                                            // (W4) the new order is written
+                int tin = 0;
+#pragma unroll
+                for (int w = 0; w < GRP_NWV; ++w) tin += wtmp[0][w];
+                const int nw_new = nw3 + T - E;
+                if (tid < nw_new) succ[oslot[ord_at(tid)]] = tid + 1 < nw_new ? okey[ord_at(tid + 1)] : ~0ull;
+                if (tid == 0) {
+                    shI[GI_NW] = nw_new; shI[GI_NFREESLOT] = nf_mid - tin; shI[GI_DIRTY] = 1;
+                    shI[GI_SHEAD] = (sh3w - E) & SMASK; shI[GI_SCOUNT] += E;
+                    atomicAdd(&lstat[GS_WININS], (uint32_t)tin);
+                }
+                __syncthreads();                                            // (W5)
+                adopt();
+            }
+            if (tid == 0) { shI[GI_NWB] = 0; shI[GI_WB0] = 0; }            // all of them are roots (or run-bound) now
+            // cold-bound ones: wave 0 appends them; the other waves merge the run-bound ones meanwhile
+            const int R = shI[GI_NHOT];
+            const int sc3 = shI[GI_SCOUNT], sh3 = shI[GI_SHEAD];
+            // a new element: rank among the new ones + number of run elements below it (against the run as it stands)
+            int mypos = -1; HeapEnt me; me.key = 0; me.idx = 0; me.pad = 0;
+            if (tid < R) {
+                me = hotb[tid];
+                int rk = 0;
+                for (int q = 0; q < R; ++q) if (hotb[q].key < me.key) ++rk;
+                int lo = 0, hi = sc3;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (srun[(sh3 + mid) & SMASK].key < me.key) lo = mid + 1; else hi = mid; }
+                mypos = lo + rk;
+            }
+            // the run's own entries move up by the number of new keys below them, from the top of the run down, one entry
+            // per lane and round: an entry lands at or above its place, so a round never overwrites what a later round reads
+            if (R > 0 && sc3 > 0) {
+                for (int base = ((sc3 - 1) / GRP_W) * GRP_W; base >= 0; base -= GRP_W) {
+                    const int pp = base + tid;
+                    const bool mv = pp < sc3;
+                    u32x4 e = {0u, 0u, 0u, 0u};
+                    int np2 = pp;
+                    if (mv) {
+                        e = run_ld(srun, (sh3 + pp) & SMASK);
+                        const unsigned long long k0 = ((unsigned long long)e.y << 32) | e.x;
+                        for (int q = 0; q < R; ++q) if (hotb[q].key < k0) ++np2;
+                    }
+                    __syncthreads();                                        // this round's entries (and, first round, the searches) are read
+                    if (mv && np2 != pp) run_st(srun, (sh3 + np2) & SMASK, e);
+                }
+            } else __syncthreads();
+            if (mypos >= 0) srun[(sh3 + mypos) & SMASK] = me;
+            GTICK(6);
+            if (wave == 0 && shI[GI_NSTAGE] >= 64) { flush_stage_w0(); publish_cold(); }
+            GTICK(15);
+            if (tid == 0 && R > 0) { shI[GI_SCOUNT] = sc3 + R; shI[GI_NHOT] = 0; shI[GI_DIRTY] = 1; atomicAdd(&lstat[GS_RUNINS], (uint32_t)R); }
+            __syncthreads();
+            if (shI[GI_SERIAL]) break;
+        }
+        return !shI[GI_SERIAL];
+    };
+
     // ================================================= sub-rounds ==================================================================
     // watchdog: sub-rounds (never expected to be reached; ISX_FLOOD_GWATCHDOG sets a tiny limit to test the hand-over it leads to)
     const uint32_t sub_limit = (max_bursts >> 16) ? (uint32_t)(max_bursts >> 16) : (csize > 60000000ull ? 0xFFFFFFFFu : 4096u + 64u * (uint32_t)csize);
@@ -553,6 +744,155 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         if (tid == 0 && stats && shI[GI_SCOUNT] == 0 && cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0)) {
             if (atomicAdd(&stats[20], 1ull) == 0ull) { stats[21] = 200ull; stats[10] = (unsigned long long)st_sub | ((unsigned long long)shI[GI_COLD_COUNT] << 32); }
         }
+        // ---- P: plateau round.  When every root of the window has the same value v and no episode has started, every episode is
+        //         its root's pop and nothing else (the bound of a root is the next root's VALUE, and a discovery cannot sort below a
+        //         root of its own value: it is younger): the sequential flood is a breadth-first sweep in age order.  The whole
+        //         window then commits in ONE pass -- claims (one trip), verification after a barrier (one trip: a voxel two roots
+        //         of this pass claimed belongs to the older one), ages by a prefix sum over the window positions in (position,
+        //         direction) order = the reference's push order (watershed.py:146-158), labels, residuals -- with no discovery
+        //         lists, chunk pool, candidates or commit decision.  A discovery BELOW v (only possible when v is not the smallest
+        //         value of the map) ends the pass before anything is written: the claims are released and the general sub-round
+        //         runs instead.  (Maps whose affinities are zero inside the objects -- the reference's own demo construction --
+        //         spend most of their pops on that plateau: 345 pops per 43 us sub-round on the general path.) ----------------------
+        bool pl_done = false, did_commit = false;
+        const int pl_min = ((kmax >> 17) & 0x3FF) ? ((kmax >> 17) & 0x3FF) : 32;     // shortest prefix worth a pass (ISX_FLOOD_PLATEAU_MIN)
+        if (nw >= pl_min && !(kmax & 0x10000)) {                              // (bit set unless ISX_FLOOD_PLATEAU=1: measured r3 -- blobs 256^3
+                                                                                // 700 -> 660 ms, structured 512^3 seed 1 1340 -> 1440 ms: off by default)
+            // the pass covers the leading roots of value v0 (the window is sorted: they are a prefix); the roots behind them sit
+            // this sub-round out -- a claim of theirs that a plateau root takes over is settled at their commit, as always
+            const uint32_t v0 = (uint32_t)(okey[ord_at(0)] >> 32);
+            const bool mine_p = has && (uint32_t)(key >> 32) == v0;
+            bool okp = !shI[GI_FORCED];
+            if (okp) { okp = !__syncthreads_or(mine_p && started); if (!okp && tid == 0) atomicAdd(&lstat[GS_PLSTARTED], 1u); }
+            int mpre = 0;
+            if (okp) {
+                const unsigned long long inp = __ballot(tid < nw && (uint32_t)(okey[ord_at(tid)] >> 32) == v0);
+                if (lane == 0) wtmp[2][wave] = __popcll(inp);
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < GRP_NWV; ++w) mpre += wtmp[2][w];
+                okp = mpre >= pl_min;
+                if (!okp && tid == 0) atomicAdd(&lstat[GS_PLSHORT], 1u);
+            }
+            if (okp) {
+                unsigned long long pold[6];
+                float pval_[6];
+                uint32_t pnb[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { pold[k] = 0ull; pval_[k] = 0.f; pnb[k] = 0u; }
+                if (mine_p) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        pnb[k] = root + (uint32_t)noff32[k];
+                        if (pnb[k] < (uint32_t)PN && root < (uint32_t)PN) {
+                            pold[k] = __hip_atomic_fetch_min(&state[pnb[k]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            pval_[k] = (aff + (int64_t)ax[k] * PN)[k < 3 ? root : pnb[k]];
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                                // (P1) every claim of this pass is in
+                uint32_t pwon = 0, pv[6];
+                int pcnt = 0;
+                bool plow = false;
+                if (has) ci_age[tid] = 0u;
+                if (mine_p) {
+                    unsigned long long st6[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        st6[k] = pold[k] > key ? __hip_atomic_load(&state[pnb[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        pv[k] = 0u;
+                        if (pold[k] > key && st6[k] == key) {
+                            pwon |= 1u << k;
+                            pv[k] = ford(pval_[k] * sc[ax[k]] + 0.0f);
+                            plow = plow || pv[k] < v0;
+                            ++pcnt;
+                        }
+                    }
+                    ci_age[tid] = (uint32_t)pcnt | (plow ? 0x80000000u : 0u);      // bit 31: found a voxel BELOW the plateau
+                }
+                __syncthreads();                                                // (P2)
+                {
+                    const int j = tid;
+                    const bool valid = j < mpre;
+                    const int s_ = valid ? (int)oslot[ord_at(j)] : 0;
+                    const uint32_t cw = valid ? ci_age[s_] : 0u;
+                    const uint32_t cj = cw & 0xFFu;
+                    // a root that discovered a voxel below the plateau is the LAST one of this pass: that voxel pops before the
+                    // roots behind it (it comes back as the front of the window), so they wait -- their claims are released
+                    const bool lowj = (cw >> 31) != 0u;
+                    const uint32_t incl = wave_incl_sum(cj);
+                    if (lane == 63) wtmp[0][wave] = (int)incl;
+                    __syncthreads();                                            // (P3)
+                    uint32_t pre = incl - cj;
+#pragma unroll
+                    for (int w = 0; w < GRP_NWV; ++w) if (w < wave) pre += (uint32_t)wtmp[0][w];
+                    const bool fits = valid && pre + cj <= (uint32_t)GRP_PEND;
+                    {
+                        const unsigned long long nfit = ~__ballot(fits), lowb = __ballot(valid && lowj);
+                        if (lane == 0) {
+                            wtmp[1][wave] = nfit ? wave * 64 + __ffsll((long long)nfit) - 1 : (wave + 1) * 64;
+                            wtmp[3][wave] = lowb ? wave * 64 + __ffsll((long long)lowb) - 1 : GRP_W;
+                        }
+                    }
+                    __syncthreads();                                            // (P4)
+                    int ncommit = GRP_W;
+#pragma unroll
+                    for (int w = GRP_NWV - 1; w >= 0; --w) if (wtmp[1][w] < (w + 1) * 64) ncommit = wtmp[1][w];
+                    if (ncommit > mpre) ncommit = mpre;
+#pragma unroll
+                    for (int w = 0; w < GRP_NWV; ++w) if (wtmp[3][w] + 1 < ncommit) ncommit = wtmp[3][w] + 1;
+                    if (j < ncommit) ci_off[s_] = pre;
+                    if (j == ncommit - 1) { shI[GI_PENDN] = (int)(pre + cj); shI[GI_PEND0] = 0; }
+                    const uint32_t agebase = (uint32_t)shI[GI_AGEBASE];
+                    __syncthreads();                                            // (P5) orders are out
+                    bool committed = false;
+                    if (mine_p) {
+                        const uint32_t po = ci_off[tid];
+                        if (po != GRP_NONE) {
+                            uint32_t i = 0;
+#pragma unroll
+                            for (int k = 0; k < 6; ++k)
+                                if (pwon & (1u << k)) {
+                                    __hip_atomic_store(&state[pnb[k]], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    out[pnb[k]] = lab;
+                                    HeapEnt r;
+                                    r.key = ((unsigned long long)pv[k] << 32) | (unsigned long long)(agebase + po + i + 1u);
+                                    r.idx = pnb[k]; r.pad = lab;
+                                    pend[po + i] = r;
+                                    ++i;
+                                }
+                            has = false;
+                            committed = true;
+                            ci_off[tid] = GRP_NONE;
+                            freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
+                        } else {                                                // behind the cut (capacity of `pend`, or a voxel below the plateau): next sub-round
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) if (pwon & (1u << k)) atomicCAS(&state[pnb[k]], key, ST_FREE);
+                        }
+                    }
+                    {
+                        const uint32_t pops_w = (uint32_t)__popcll(__ballot(committed));
+                        if (lane == 0 && pops_w) { atomicAdd(&lstat[GS_POPS], pops_w); atomicAdd(&lstat[GS_PLPOPS], pops_w); }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();                                            // (P6)
+                    if (tid == 0) {
+                        shI[GI_AGEBASE] = (int)(agebase + (uint32_t)shI[GI_PENDN]);
+                        shI[GI_OH] = (shI[GI_OH] + ncommit) & (GRP_W - 1);
+                        shI[GI_NW] = nw - ncommit;
+                        atomicAdd(&lstat[GS_BURST], 1u);
+                        atomicAdd(&lstat[GS_PLATEAU], 1u);
+                    }
+                    __syncthreads();                                            // (P7)
+                    pl_done = did_commit = true;
+                    if (!enqueue_batch()) continue;
+                }
+            }
+        }
+        if (!pl_done) {
         const unsigned long long qhead = shQ[GQ_QHEAD];                         // published by lane 0 at the end of the last sub-round
         const int lastslot = shI[GI_LAST], frontslot = shI[GI_FRONT];
         const bool dirty = shI[GI_DIRTY] != 0;
@@ -709,7 +1049,6 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         // ---- E: commit the idle episodes at the front, in order; bursts as wide as the window ------------------------------------------------
         bool front_ready = shI[GI_FORCED] != 0 || ((pub_info[frontslot] >> 17) & 1u);
         const bool forced_front = shI[GI_FORCED] != 0;
-        bool did_commit = false;
 #ifdef ISX_FLOOD_PROF
         if (tid == 0) { if (!front_ready) atomicAdd(&lstat[GS_C_NOTREADY], 1u); atomicAdd(&lstat[GS_NWSUM], (uint32_t)shI[GI_NW]); }
 #endif
@@ -931,167 +1270,13 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             GTICK(5);
             // ---- enqueue the burst's residuals --------------------------------------------------------------------------------------------
             // (slices of one residual per lane; pend[GI_PEND0, GI_PENDN) is what the serial continuation would still have to queue)
-            const int Ptot = shI[GI_PENDN];
-            for (int p0 = 0; p0 < Ptot; p0 += GRP_W) {
-                const int P = Ptot - p0 < GRP_W ? Ptot - p0 : GRP_W;
-                // capacity first: an eviction moves the hot maximum, so the batch is judged against the tiers AFTER it
-                if (shI[GI_SCOUNT] + P > run_limit || shI[GI_SCOUNT] + P > COOP_SCAP - 8) {
-                    if (wave == 0) { int keep = run_limit / 2; if (keep > COOP_SCAP - GRP_W - 8) keep = COOP_SCAP - GRP_W - 8; run_evict_w0(keep); publish_cold(); }
-                    __syncthreads();
-                    if (shI[GI_SERIAL]) break;                                  // `pend` keeps the batch for the serial continuation
-                }
-                const int nw2 = shI[GI_NW], sc2 = shI[GI_SCOUNT], sh2 = shI[GI_SHEAD];
-                const bool hot_ne = nw2 > 0 || sc2 > 0;
-                const unsigned long long hot_max = sc2 > 0 ? srun[(sh2 + sc2 - 1) & SMASK].key : (nw2 > 0 ? okey[ord_at(nw2 - 1)] : 0ull);
-                const unsigned long long lastwin = nw2 > 0 ? okey[ord_at(nw2 - 1)] : 0ull;
-                const bool cold_ne = cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0);
-                HeapEnt r; r.key = 0; r.idx = 0; r.pad = 0;
-                bool hasr = tid < P;
-                if (hasr) r = pend[p0 + tid];
-                hasr = hasr && r.key != ~0ull;                                  // (a slot of a dropped residual)
-                const bool tocold = hasr && cold_ne && !(hot_ne && r.key < hot_max) && cold_bucket(cold, r.key) >= (uint32_t)shI[GI_COLD_LOW];
-                const bool towin = hasr && !tocold && nw2 > 0 && r.key < lastwin;
-                const bool torun = hasr && !tocold && !towin;
-                // three compactions (order inside a class is the age order of `pend`)
-                const unsigned long long bc = __ballot(tocold), bw = __ballot(towin), br = __ballot(torun);
-                if (lane == 0) { wtmp[0][wave] = __popcll(bc); wtmp[1][wave] = __popcll(bw); wtmp[2][wave] = __popcll(br); }
-                __syncthreads();
-                int oc = shI[GI_NSTAGE], ow = 0, orr = 0;
-#pragma unroll
-                for (int w = 0; w < GRP_NWV; ++w) if (w < wave) { oc += wtmp[0][w]; ow += wtmp[1][w]; orr += wtmp[2][w]; }
-                if (tocold) stage[oc + __popcll(bc & lt_mask)] = r;
-                // window-bound ones go back into `pend` (every lane has its element in a register by now), run-bound ones into
-                // `hotb`, which also takes the window-bound ones that turn out run-bound below: together at most P
-                if (towin) pend[ow + __popcll(bw & lt_mask)] = r;
-                if (torun) hotb[orr + __popcll(br & lt_mask)] = r;
-                __syncthreads();
-                if (tid == 0) {
-                    int tc = 0, tw = 0, tr = 0;
-                    for (int w = 0; w < GRP_NWV; ++w) { tc += wtmp[0][w]; tw += wtmp[1][w]; tr += wtmp[2][w]; }
-                    shI[GI_NSTAGE] += tc; shI[GI_NWB] = tw; shI[GI_NHOT] = tr;
-                    if (p0 + P >= Ptot) { shI[GI_PENDN] = 0; shI[GI_PEND0] = 0; } else shI[GI_PEND0] = p0 + P;
-                }
-                __syncthreads();
-                // Window-bound residuals (keys below the last root) become roots at their sorted positions -- ALL of them in one
-                // ranked merge with the window: an old root moves up by the number of new keys below it, a new one lands at
-                // (old roots below it) + (its rank among the new ones); whatever ends beyond the window's capacity is the top
-                // of the merged order and goes back to the FRONT of the run, in order (a root evicted this way is squashed by
-                // its own lane).  One element at a time this was ~5 barriers per residual: 250 of them per burst on plateaus.
-                const int T = shI[GI_NWB];
-                if (T > 0) {                                                   // uniform
-                    const int nw3 = shI[GI_NW];
-                    int E = nw3 + T - wcap;
-                    if (E < 0) E = 0;
-                    if (E > 0 && shI[GI_SCOUNT] + E > COOP_SCAP - 2) {          // room at the front of the run (rare)
-                        __syncthreads();
-                        if (wave == 0) { run_evict_w0(run_limit / 2); publish_cold(); }
-                        __syncthreads();
-                        if (shI[GI_SERIAL]) break;                              // pend[0, NWB) are still to be queued (WB0 = 0)
-                    }
-                    const int sh3w = shI[GI_SHEAD];
-                    unsigned long long ok_ = 0ull; int os_ = 0, np_old = -1;
-                    if (tid < nw3) {
-                        ok_ = okey[ord_at(tid)]; os_ = (int)oslot[ord_at(tid)];
-                        int c2 = 0;
-                        for (int q = 0; q < T; ++q) if (pend[q].key < ok_) ++c2;
-                        np_old = tid + c2;
-                    }
-                    HeapEnt ne; ne.key = 0; ne.idx = 0; ne.pad = 0;
-                    int np_new = -1, rk_new = 0;
-                    if (tid < T) {
-                        ne = pend[tid];
-                        for (int q = 0; q < T; ++q) if (pend[q].key < ne.key) ++rk_new;
-                        int lo = 0, hi = nw3;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (okey[ord_at(mid)] < ne.key) lo = mid + 1; else hi = mid; }
-                        np_new = lo + rk_new;
-                    }
-                    {
-                        const unsigned long long kb = __ballot(np_new >= 0 && np_new < wcap);
-                        if (lane == 0) wtmp[0][wave] = __popcll(kb);
-                    }
-                    __syncthreads();                                            // (W1) everything read
-                    // evictions: an old root beyond the capacity tells its owner where in the run it goes; a new element goes itself
-                    if (np_old >= wcap) ci_off[os_] = (uint32_t)((sh3w - E + (np_old - wcap)) & SMASK);
-                    if (np_new >= wcap) srun[(sh3w - E + (np_new - wcap)) & SMASK] = ne;
-                    __syncthreads();                                            // (W2)
-                    if (has && ci_off[tid] != GRP_NONE) {
-                        HeapEnt b; b.key = key; b.idx = root; b.pad = lab;
-                        srun[ci_off[tid]] = b;
-                        ci_off[tid] = GRP_NONE;
-                        squash_me();
-                        has = false;
-                        freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
-                        atomicAdd(&lstat[GS_WINEV], 1u);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    __syncthreads();                                            // (W3) slots of the evicted are back
-                    const int nf_mid = shI[GI_NFREESLOT];
-                    if (np_old >= 0 && np_old < wcap) { okey[ord_at(np_old)] = ok_; oslot[ord_at(np_old)] = (unsigned short)os_; }
-                    if (np_new >= 0 && np_new < wcap) {
-                        const int sl = (int)freeslot[nf_mid - 1 - rk_new];     // the kept new ones are a prefix of the new ones in key order
-                        okey[ord_at(np_new)] = ne.key; oslot[ord_at(np_new)] = (unsigned short)sl;
-                        u32x4 nr = {(uint32_t)ne.key, (uint32_t)(ne.key >> 32), ne.idx, ne.pad};
-                        newroot[sl] = nr; newflag[sl] = 1u;
-                    }
-                    __syncthreads();                                            // (W4) the new order is written
-                    int tin = 0;
-#pragma unroll
-                    for (int w = 0; w < GRP_NWV; ++w) tin += wtmp[0][w];
-                    const int nw_new = nw3 + T - E;
-                    if (tid < nw_new) succ[oslot[ord_at(tid)]] = tid + 1 < nw_new ? okey[ord_at(tid + 1)] : ~0ull;
-                    if (tid == 0) {
-                        shI[GI_NW] = nw_new; shI[GI_NFREESLOT] = nf_mid - tin; shI[GI_DIRTY] = 1;
-                        shI[GI_SHEAD] = (sh3w - E) & SMASK; shI[GI_SCOUNT] += E;
-                        atomicAdd(&lstat[GS_WININS], (uint32_t)tin);
-                    }
-                    __syncthreads();                                            // (W5)
-                    adopt();
-                }
-                if (tid == 0) { shI[GI_NWB] = 0; shI[GI_WB0] = 0; }            // all of them are roots (or run-bound) now
-                // cold-bound ones: wave 0 appends them; the other waves merge the run-bound ones meanwhile
-                const int R = shI[GI_NHOT];
-                const int sc3 = shI[GI_SCOUNT], sh3 = shI[GI_SHEAD];
-                // a new element: rank among the new ones + number of run elements below it (against the run as it stands)
-                int mypos = -1; HeapEnt me; me.key = 0; me.idx = 0; me.pad = 0;
-                if (tid < R) {
-                    me = hotb[tid];
-                    int rk = 0;
-                    for (int q = 0; q < R; ++q) if (hotb[q].key < me.key) ++rk;
-                    int lo = 0, hi = sc3;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (srun[(sh3 + mid) & SMASK].key < me.key) lo = mid + 1; else hi = mid; }
-                    mypos = lo + rk;
-                }
-                // the run's own entries move up by the number of new keys below them, from the top of the run down, one entry
-                // per lane and round: an entry lands at or above its place, so a round never overwrites what a later round reads
-                if (R > 0 && sc3 > 0) {
-                    for (int base = ((sc3 - 1) / GRP_W) * GRP_W; base >= 0; base -= GRP_W) {
-                        const int pp = base + tid;
-                        const bool mv = pp < sc3;
-                        u32x4 e = {0u, 0u, 0u, 0u};
-                        int np2 = pp;
-                        if (mv) {
-                            e = run_ld(srun, (sh3 + pp) & SMASK);
-                            const unsigned long long k0 = ((unsigned long long)e.y << 32) | e.x;
-                            for (int q = 0; q < R; ++q) if (hotb[q].key < k0) ++np2;
-                        }
-                        __syncthreads();                                        // this round's entries (and, first round, the searches) are read
-                        if (mv && np2 != pp) run_st(srun, (sh3 + np2) & SMASK, e);
-                    }
-                } else __syncthreads();
-                if (mypos >= 0) srun[(sh3 + mypos) & SMASK] = me;
-                GTICK(6);
-                if (wave == 0 && shI[GI_NSTAGE] >= 64) { flush_stage_w0(); publish_cold(); }
-                GTICK(15);
-                if (tid == 0 && R > 0) { shI[GI_SCOUNT] = sc3 + R; shI[GI_NHOT] = 0; shI[GI_DIRTY] = 1; atomicAdd(&lstat[GS_RUNINS], (uint32_t)R); }
-                __syncthreads();
-                if (shI[GI_SERIAL]) break;
-            }
-            if (shI[GI_SERIAL]) break;                                          // uniform (set before a barrier every thread has passed)
+            if (!enqueue_batch()) break;                                        // uniform (set before a barrier every thread has passed)
             GTICK(6);
             check_order(10 + burst);
             if (ncommit < nwb && !shI[GI_ANY]) break;                           // uniform (GI_ANY: written before E4)
             __syncthreads();
             if (tid == 0) shI[GI_ANY] = 0;
+        }
         }
         __syncthreads();                                                        // everybody has read this sub-round's verdicts
         if (tid == 0) {
@@ -1190,6 +1375,11 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         atomicAdd(&stats[29], (unsigned long long)st_sub);
         atomicAdd(&stats[17], (unsigned long long)lstat[GS_BURST]);
         atomicAdd(&stats[18], (unsigned long long)lstat[GS_RELOAD]);
+        atomicAdd(&stats[30], (unsigned long long)lstat[GS_PLATEAU]);
+        atomicAdd(&stats[31], (unsigned long long)lstat[GS_PLPOPS]);
+        atomicAdd(&stats[24], (unsigned long long)lstat[GS_PLSTARTED]);
+        atomicAdd(&stats[25], (unsigned long long)lstat[GS_PLSHORT]);
+        atomicAdd(&stats[23], (unsigned long long)lstat[GS_PLABORT]);
         if (shI[GI_SERIAL]) atomicAdd(&stats[8], 1ull);
 #ifdef ISX_FLOOD_PROF
         for (int i = 0; i < 10; ++i) atomicAdd(&stats[48 + i], (unsigned long long)lstat[GS_C_NOTREADY + i]);
