@@ -1101,8 +1101,11 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
 // all map to bucket b (plateaus: every residual of a commit burst has the same value).  One state update and at most one new
 // segment for the whole batch instead of one cold_append per 64 elements (the work-group kernel's flush of ~350 residuals per
 // sub-round was 6 calls of ~5 k cycles each on one wave while seven waited).  `ascending`: src is in key order.
+// src == nullptr: only the bookkeeping -- the caller's lanes write the n elements themselves: element j goes to pool slot
+// where[0] + j for j < where[1], to where[2] + (j - where[1]) beyond (where: three words, written by lane 0).
 __device__ __forceinline__ void cold_append_bucket(Cold &c, const HeapEnt *src, int n, uint32_t b, bool ascending,
-                                                   unsigned long long first_key, unsigned long long last_key, int lane)
+                                                   unsigned long long first_key, unsigned long long last_key, int lane,
+                                                   uint32_t *where = nullptr)
 {
     uint32_t tail, cnt, tn = 0, tcap = 0;
     bool unsorted;
@@ -1165,10 +1168,12 @@ __device__ __forceinline__ void cold_append_bucket(Cold &c, const HeapEnt *src, 
             atomicOr(&c.bm1()[b >> 12], 1ull << ((b >> 6) & 63));
         }
     }
-    for (uint32_t j = (uint32_t)lane; j < (uint32_t)n; j += 64u) {
-        const uint32_t slot = j < free_tail ? tail + 1u + tn + j : my_off + 1u + (j - free_tail);
-        c.pool()[slot] = src[j];
-    }
+    if (src)
+        for (uint32_t j = (uint32_t)lane; j < (uint32_t)n; j += 64u) {
+            const uint32_t slot = j < free_tail ? tail + 1u + tn + j : my_off + 1u + (j - free_tail);
+            c.pool()[slot] = src[j];
+        }
+    if (where && lane == 0) { where[0] = tail + 1u + tn; where[1] = free_tail; where[2] = my_off + 1u; }
     c.cb = b;
     c.cb_tail = need_new ? my_off : tail;
     c.cb_tn = need_new ? need_new : tn + (uint32_t)n;
@@ -2054,6 +2059,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                                                                    comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1], pshape[2], PN,
                                                                    s[0], s[1], s[2], group_min, run_limit, drain_n, gwcap, gtcap, group_bursts,
                                                                    bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world, gsteps | (gminsteps << 8) | ((getenv("ISX_FLOOD_PLATEAU") && atoi(getenv("ISX_FLOOD_PLATEAU")) != 0) ? 0 : 0x10000) |      /* the plateau pass: off unless asked for */
+                                                                   ((getenv("ISX_FLOOD_PLATEAU") && atoi(getenv("ISX_FLOOD_PLATEAU")) == 2) ? 0x8000000 : 0) |    /* 2: + the wide pass */
                                                                    ((getenv("ISX_FLOOD_PLATEAU_MIN") ? (atoi(getenv("ISX_FLOOD_PLATEAU_MIN")) & 0x3FF) : 0) << 17));
             ISX_CHECK_LAUNCH();
         }
@@ -2147,7 +2153,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                 hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[2] ? (double)hs[1] / hs[2] : 0.0, hs[13], hs[3], hs[7], hs[4], hs[5], hs[10],
                 hs[6], hs[11], hs[14], hs[12], hs[15], hs[8]);
         if (group_min != ~0ull)
-            fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu; of the work-group kernel alone: rounds %llu (plateau passes %llu with %llu pops; not tried: started episode %llu, prefix < 32 %llu; not a plateau %llu) pops %llu drains %llu (%llu as the prefix of a list in key order)\n", hs[17], hs[18], hs[29], hs[30], hs[31], hs[24], hs[25], hs[23], hs[28], hs[27], hs[26]);
+            fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu; of the work-group kernel alone: rounds %llu (plateau passes %llu, %llu of them wide, with %llu pops; not tried: started episode %llu, prefix < 32 %llu; not a plateau %llu) pops %llu drains %llu (%llu as the prefix of a list in key order)\n", hs[17], hs[18], hs[29], hs[30], hs[59], hs[31], hs[24], hs[25], hs[23], hs[28], hs[27], hs[26]);
 #ifdef ISX_FLOOD_PROF
         if (group_min != ~0ull)
             fprintf(stderr, "[isx flood/group] cycles/sub-round of lane 0: (S0)->C %.0f | C loop %.0f | wait (S5) %.0f | squash %.0f | to (E0) %.0f | order (E1-E3a) %.0f | verify %.0f | labels %.0f | enqueue %.0f | "

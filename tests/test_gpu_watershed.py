@@ -192,6 +192,11 @@ FLOOD_ENVS = {
                       "ISX_FLOOD_PLATEAU_MIN": "1"},
     "group-plateau-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_PLATEAU": "1",
                            "ISX_FLOOD_PLATEAU_MIN": "2", "ISX_FLOOD_RUN_LIMIT": "8", "ISX_FLOOD_DRAIN": "4", "ISX_FLOOD_GWIN": "40"},
+    # ... and its wide form (ISX_FLOOD_PLATEAU=2: window roots + run elements in one pass, discoveries straight to the bucket)
+    "group-plateau-wide": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_PLATEAU": "2",
+                           "ISX_FLOOD_PLATEAU_MIN": "1"},
+    "group-plateau-wide-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_PLATEAU": "2",
+                                "ISX_FLOOD_PLATEAU_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "40", "ISX_FLOOD_DRAIN": "16", "ISX_FLOOD_GWIN": "17"},
     # the round-based wave kernel of round 1 (kept selectable for A/B runs)
     "wave-legacy": {"ISX_FLOOD_MODE": "wave", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "96",
                     "ISX_FLOOD_DRAIN": "48"},
