@@ -85,7 +85,7 @@ __global__ void gather_chunks_kernel(const float *__restrict__ vol, int64_t Y, i
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x0, const float *__restrict__ w,
                                                          const float *__restrict__ bias, int D, int H, int W,
                                                          float *__restrict__ out, float *__restrict__ psum,
-                                                         float *__restrict__ psq, int blocks_per_chunk)
+                                                         float *__restrict__ psq, int blocks_per_chunk, int nt_store)
 {
     __shared__ float red[4][32][2];
     const int b = blockIdx.x / blocks_per_chunk, blk = blockIdx.x % blocks_per_chunk;
@@ -129,7 +129,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int f = lane + 64 * k, row = f >> 3, c4 = f & 7;
-        if (m0 + row < M) *(float4 *)&out[((int64_t)b * M + m0 + row) * 32 + 4 * c4] = *(const float4 *)&T[wave][row * 36 + 4 * c4];
+        if (m0 + row < M) {
+            const float4 tv = *(const float4 *)&T[wave][row * 36 + 4 * c4];
+            f32x4 tn = {tv.x, tv.y, tv.z, tv.w};
+            if (nt_store) __builtin_nontemporal_store(tn, (f32x4 *)&out[((int64_t)b * M + m0 + row) * 32 + 4 * c4]);
+            else *(float4 *)&out[((int64_t)b * M + m0 + row) * 32 + 4 * c4] = tv;
+        }
     }
     s += __shfl_xor(s, 32);
     q += __shfl_xor(q, 32);
@@ -1369,7 +1374,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         ProfScope ps(ctx, ISX_PROF_CONV_DIRECT);
         ISX_REQUIRE(L.cout == 32 && !sa.scale, "internal: conv_first shape");
         conv_first_kernel<<<(unsigned)(B * L.tiles), 256, 0, ctx->stream>>>(sa.p, L.w, L.bias, l.D, l.H, l.W, u->raw[li],
-                                                                           L.psum, L.psq, L.tiles);
+                                                                           L.psum, L.psq, L.tiles, ctx->tune.conv_first_nt);
         ISX_CHECK_LAUNCH();
     } else {
         ProfScope ps(ctx, ISX_PROF_CONV_DIRECT);
