@@ -458,7 +458,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                         else v = c_hi[m][j][i] + bv;
                         float *op = &a.out[((int64_t)b * Mout + g) * a.store_cols + ch];
                         if (a.accum) v += *op;
-                        if (ch < a.store_cols) *op = v;
+                        if (ch < a.store_cols) { if (a.nt_out) __builtin_nontemporal_store(v, op); else *op = v; }
                         s += v;
                         q += v * v;
                     }
@@ -487,7 +487,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                     else v = acc_hi[m][j][i] + bv;
                     float *op = &a.out[((int64_t)b * Mout + g) * a.store_cols + ch];
                     if (a.accum) v += *op;
-                    if (ch < a.store_cols) *op = v;
+                    if (ch < a.store_cols) { if (a.nt_out) __builtin_nontemporal_store(v, op); else *op = v; }
                     s += v;
                     q += v * v;
                 }
@@ -657,6 +657,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.oy[0] = ex ? ex->oy[0] : 0; a.oy[1] = ex ? ex->oy[1] : 0; a.ox[0] = ex ? ex->ox[0] : 0; a.ox[1] = ex ? ex->ox[1] : 0;
     a.remap = ex ? ex->remap : 0; a.rH = ex ? ex->rH : 0; a.rW = ex ? ex->rW : 0; a.rpy = ex ? ex->rpy : 0; a.rpx = ex ? ex->rpx : 0;
     a.roff = ex ? ex->roff : 0; a.Mout = ex ? ex->Mout : 0; a.accum = ex ? ex->accum : 0;
+    a.nt_out = ctx->tune.h2_nt_out;
     const int upa = ex ? ex->upA : 0;
     a.uH = ex ? ex->uH : 0; a.uW = ex ? ex->uW : 0; a.uoff = ex ? ex->uoff : 0; a.upw = ex ? ex->upw : nullptr; a.upb = ex ? ex->upb : nullptr;
     ISX_REQUIRE(!upa || (fold && a.upw && a.upb), "internal: up-sampling on read is built for the folded tail layer");

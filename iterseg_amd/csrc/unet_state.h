@@ -130,6 +130,7 @@ struct ConvArgs {
     int rH, rW, rpy, rpx, roff;   //    bias then is a table [64 border configurations of the OUTPUT voxel][Cout]
     int64_t Mout;          // voxels per chunk of the output tensor (D*H*W unless remap)
     int accum;             // 1: add to what `out` already holds (statistics over the sums)
+    int nt_out;            // 1: streaming stores for the output tensor
     // TX = 4 (folded tail layer only): source A is the COARSE input of a transposed convolution, up-sampled while it is staged:
     // slot voxel (z, y, x) reads (z, (y + uoff) >> 1, (x + uoff) >> 1) of a (D, uH, uW) tensor, BatchNorm + ReLU as usual, then
     // * upw[parity][c] + upb[c] (UpConv::w / bias) -- what upsample_kernel would have written to a 4x larger tensor
