@@ -2,7 +2,7 @@
 # kernels (both arithmetic modes), kernel stats of the training step (fp32 / bf16) and of the config-2 and structured floods.
 set -e
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3q; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3r; mkdir -p $O
 cd $R
 echo "== kernel stats of the headline (warm-up + 1 step)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o r03 -- python3 bench.py --steps 1 --warmup 1 --no-extra-legs > $O/r03_bench512_under_rocprof.json 2> $O/prof_bench.err
