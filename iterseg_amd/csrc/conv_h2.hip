@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "unet_state.h"
+#include "h2_split.h"
 
 namespace isx {
 
@@ -40,41 +41,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-static constexpr float H2_SCALE = 2048.f, H2_MIN = 6.103515625e-05f, H2_MAX = 65504.f;
-
-__host__ __device__ inline void split_h2(float x, _Float16 &h, _Float16 &l)
-{
-    x = x < -H2_MAX ? -H2_MAX : (x > H2_MAX ? H2_MAX : x);
-    h = (x < H2_MIN && x > -H2_MIN) ? (_Float16)0.f : (_Float16)x;
-    const float r = (x - (float)h) * H2_SCALE;
-    l = (r < H2_MIN && r > -H2_MIN) ? (_Float16)0.f : (_Float16)r;
-}
-
-// 8 fp32 -> 8 halves (hi) + 8 halves (lo), each packed in a uint4.  Device staging version of split_h2: the high
-// part is rounded toward zero (v_cvt_pkrtz_f16_f32, two values per instruction) -- any rounding works, the low part
-// absorbs the remainder -- and subnormal halves are kept (the f16 matrix cores honour them; checked on MI355X with
-// scratch/h2/mfma_layout.hip), so only the clamp remains of the host routine's special cases.
-__device__ __forceinline__ void split2(float x, float y, uint32_t &hi, uint32_t &lo)
-{
-    typedef __fp16 h2v __attribute__((ext_vector_type(2)));
-    union { h2v v; uint32_t u; } H, L;
-    x = __builtin_amdgcn_fmed3f(x, -H2_MAX, H2_MAX);
-    y = __builtin_amdgcn_fmed3f(y, -H2_MAX, H2_MAX);
-    H.v = __builtin_amdgcn_cvt_pkrtz(x, y);
-    const float rx = (x - (float)H.v[0]) * H2_SCALE, ry = (y - (float)H.v[1]) * H2_SCALE;
-    L.v = __builtin_amdgcn_cvt_pkrtz(rx, ry);
-    hi = H.u;
-    lo = L.u;
-}
-
-__device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo)
-{
-    split2(a.x, a.y, hi.x, lo.x);
-    split2(a.z, a.w, hi.y, lo.y);
-    split2(b.x, b.y, hi.z, lo.z);
-    split2(b.z, b.w, hi.w, lo.w);
-}
 
 // 8 fp32 -> 8 f16 (round to nearest even, clamped) / 8 bf16 (round to nearest even), packed in a uint4
 __device__ __forceinline__ uint32_t pack_f16_rn(float x, float y)
@@ -277,7 +243,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     // named prefetch registers (arrays that live across the K loop end up in scratch)
     float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
     uint4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rb8, rb9, rb10, rb11, rb12, rb13;
-    bool has_affine = false, stage_up = false;
+    bool has_affine = false, stage_up = false, stage_ps = false;      // stage_ps: the stage's source is stored already split (ConvArgs::presplitA/B)
     float4 vb0 = make_float4(0.f, 0.f, 0.f, 0.f), vb1 = vb0;   // (UPA) bias of the transposed convolution for this stage's channels
     int up_cc = 0;
 #define H2_LOAD_A(k)                                                                              \
@@ -296,6 +262,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if (c0 < a.CA) { src = a.srcA; sc = a.scaleA; sh = a.shiftA; C = a.CA; cc = c0; }         \
         else { src = a.srcB; sc = a.scaleB; sh = a.shiftB; C = a.CB; cc = c0 - a.CA; }            \
         has_affine = sc != nullptr;                                                               \
+        stage_ps = SPLIT && (c0 < a.CA ? a.presplitA : a.presplitB) != 0;                         \
         stage_up = UPA && c0 < a.CA;                                                              \
         if (UPA && stage_up) { up_cc = cc; vb0 = *(const float4 *)&a.upb[cc]; vb1 = *(const float4 *)&a.upb[cc + 4]; } \
         const float *scp = has_affine ? sc : a.bias, *shp = has_affine ? sh : a.bias;             \
@@ -322,6 +289,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         }                                                                                         \
         if (gv##k < 0) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }                            \
         uint4 hi, lo;                                                                             \
+        if (stage_ps) {      /* [hi: 8 halves | lo: 8 halves] per voxel and stage, written by the producer: a copy */ \
+            hi = make_uint4(__float_as_uint(ra##k.x), __float_as_uint(ra##k.y), __float_as_uint(ra##k.z), __float_as_uint(ra##k.w)); \
+            lo = make_uint4(__float_as_uint(rc##k.x), __float_as_uint(rc##k.y), __float_as_uint(rc##k.z), __float_as_uint(rc##k.w)); \
+            if (gv##k < 0) { hi = make_uint4(0u, 0u, 0u, 0u); lo = hi; }                          \
+            if constexpr (SPLIT) AsL[tid + THREADS * k] = lo;                                     \
+        } else                                                                                    \
         if (ISX_H2_ABLATE == 1) { hi = make_uint4(__float_as_uint(ra##k.x), __float_as_uint(ra##k.y), __float_as_uint(ra##k.z), __float_as_uint(ra##k.w)); \
                                   lo = make_uint4(__float_as_uint(rc##k.x), __float_as_uint(rc##k.y), __float_as_uint(rc##k.z), __float_as_uint(rc##k.w)); \
                                   if constexpr (SPLIT) AsL[tid + THREADS * k] = lo; } else              \
@@ -658,6 +631,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.remap = ex ? ex->remap : 0; a.rH = ex ? ex->rH : 0; a.rW = ex ? ex->rW : 0; a.rpy = ex ? ex->rpy : 0; a.rpx = ex ? ex->rpx : 0;
     a.roff = ex ? ex->roff : 0; a.Mout = ex ? ex->Mout : 0; a.accum = ex ? ex->accum : 0;
     a.nt_out = ctx->tune.h2_nt_out;
+    a.presplitA = sa.presplit ? 1 : 0; a.presplitB = sb.presplit ? 1 : 0;
+    ISX_REQUIRE(!(a.presplitA || a.presplitB) || pm == 0, "internal: a pre-split source needs the split-f16 arithmetic");
+    ISX_REQUIRE(!(a.presplitA && sa.scale) && !(a.presplitB && sb.scale), "internal: a pre-split source carries no BatchNorm");
     const int upa = ex ? ex->upA : 0;
     a.uH = ex ? ex->uH : 0; a.uW = ex ? ex->uW : 0; a.uoff = ex ? ex->uoff : 0; a.upw = ex ? ex->upw : nullptr; a.upb = ex ? ex->upb : nullptr;
     ISX_REQUIRE(!upa || (fold && a.upw && a.upb), "internal: up-sampling on read is built for the folded tail layer");

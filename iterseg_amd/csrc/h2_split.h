@@ -1,0 +1,46 @@
+// h2_split.h -- the operand split of the split-f16 convolutions (conv_h2.hip): x = x_h + x_l / 2^11.  Shared with the kernels that
+// can write an activation tensor already split (unet.hip: pool / transposed convolution), so that its consumer stages it by copy.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace isx {
+
+static constexpr float H2_SCALE = 2048.f, H2_MIN = 6.103515625e-05f, H2_MAX = 65504.f;
+
+__host__ __device__ inline void split_h2(float x, _Float16 &h, _Float16 &l)
+{
+    x = x < -H2_MAX ? -H2_MAX : (x > H2_MAX ? H2_MAX : x);
+    h = (x < H2_MIN && x > -H2_MIN) ? (_Float16)0.f : (_Float16)x;
+    const float r = (x - (float)h) * H2_SCALE;
+    l = (r < H2_MIN && r > -H2_MIN) ? (_Float16)0.f : (_Float16)r;
+}
+
+// 8 fp32 -> 8 halves (hi) + 8 halves (lo), each packed in a uint4.  Device staging version of split_h2: the high
+// part is rounded toward zero (v_cvt_pkrtz_f16_f32, two values per instruction) -- any rounding works, the low part
+// absorbs the remainder -- and subnormal halves are kept (the f16 matrix cores honour them; checked on MI355X with
+// scratch/h2/mfma_layout.hip), so only the clamp remains of the host routine's special cases.
+__device__ __forceinline__ void split2(float x, float y, uint32_t &hi, uint32_t &lo)
+{
+    typedef __fp16 h2v __attribute__((ext_vector_type(2)));
+    union { h2v v; uint32_t u; } H, L;
+    x = __builtin_amdgcn_fmed3f(x, -H2_MAX, H2_MAX);
+    y = __builtin_amdgcn_fmed3f(y, -H2_MAX, H2_MAX);
+    H.v = __builtin_amdgcn_cvt_pkrtz(x, y);
+    const float rx = (x - (float)H.v[0]) * H2_SCALE, ry = (y - (float)H.v[1]) * H2_SCALE;
+    L.v = __builtin_amdgcn_cvt_pkrtz(rx, ry);
+    hi = H.u;
+    lo = L.u;
+}
+
+__device__ __forceinline__ void split8(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo)
+{
+    split2(a.x, a.y, hi.x, lo.x);
+    split2(a.z, a.w, hi.y, lo.y);
+    split2(b.x, b.y, hi.z, lo.z);
+    split2(b.z, b.w, hi.w, lo.w);
+}
+
+}  // namespace isx

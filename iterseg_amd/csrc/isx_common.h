@@ -65,6 +65,7 @@ struct isx_tune {
     int h2_force_bn64 = 0;          // ISX_H2_FORCE_BN64
     int xcd_remap = 1;              // ISX_CONV_XCD_REMAP
     long mt2_min_vox = 1L << 60;    // ISX_CONV_MT2_MIN_VOX
+    int presplit = 0;               // ISX_PRESPLIT: pool / transposed convolution write their output already split for the split-f16 convolution that reads it
     int h2_nt_out = 1;              // ISX_H2_NT_OUT: streaming stores in the epilogue of the split-f16 convolutions (conv stage -2 ms per frame)
     int conv_first_nt = 1;          // ISX_CONV_FIRST_NT: streaming stores for c0.conv0's 5.4 GB output per launch set (34.7 -> 31.5 ms per frame)
     int up_per_source = 1;          // ISX_UP_PER_SOURCE: 0 = the transposed convolutions one thread per OUTPUT voxel (rounds 1-2)
@@ -74,6 +75,7 @@ struct isx_tune {
                                     // Cout % 64 == 0: half the slab traffic per voxel, same results -- and the same time (r3: 93.0 vs 92.8 ms per launch set)
     int up_on_read = 0;             // ISX_UP_ON_READ: 1 = the tail layer up-samples up3 while staging it instead of reading a materialised tensor.
                                     // Bit-identical, deletes 16 ms of upsample_kernel per 512^3 frame and costs the tail kernel 36 ms (r3): off
+    int wgrad_wgs = 4096;           // ISX_WGRAD_WGS: work-groups a matrix-core weight gradient aims for (its split count: fewer = fewer partials to write and reduce)
     int thin_wgrad = 1;             // ISX_THIN_WGRAD: 0 = the 1 -> 32 and 5 -> 5 layers' weight gradients on the padded matrix-core tiles (round 2)
     int bf16_wgrad = 1;             // ISX_BF16_WGRAD: 0 = precision "bf16" keeps fp32 products in the weight gradients (round 2's form)
     int up_fold = 0;                // ISX_UP_FOLD: 1 = up1/up2 folded into their consumers' weights (UpFoldPacks).  Off: measured r3, it removes

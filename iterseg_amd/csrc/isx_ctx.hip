@@ -165,12 +165,14 @@ isx_ctx *isx_ctx_create(int device)
     if (const char *e = getenv("ISX_CONV_XCD_REMAP")) c->tune.xcd_remap = atoi(e);
     if (const char *e = getenv("ISX_UP_FOLD")) c->tune.up_fold = atoi(e);
     if (const char *e = getenv("ISX_BF16_WGRAD")) c->tune.bf16_wgrad = atoi(e);
+    if (const char *e = getenv("ISX_WGRAD_WGS")) c->tune.wgrad_wgs = std::max(18, atoi(e));
     if (const char *e = getenv("ISX_THIN_WGRAD")) c->tune.thin_wgrad = atoi(e);
     if (const char *e = getenv("ISX_UP_ON_READ")) c->tune.up_on_read = atoi(e);
     if (const char *e = getenv("ISX_H2_NW8")) c->tune.h2_nw8 = atoi(e);
     if (const char *e = getenv("ISX_H2_CORE16")) c->tune.h2_core16 = atoi(e);
     if (const char *e = getenv("ISX_UP_PER_SOURCE")) c->tune.up_per_source = atoi(e);
     if (const char *e = getenv("ISX_CONV_FIRST_NT")) c->tune.conv_first_nt = atoi(e);
+    if (const char *e = getenv("ISX_PRESPLIT")) c->tune.presplit = atoi(e);
     if (const char *e = getenv("ISX_H2_NT_OUT")) c->tune.h2_nt_out = atoi(e);
     if (const char *e = getenv("ISX_CONV_MT2_MIN_VOX")) c->tune.mt2_min_vox = atol(e);
     c->device = device;
