@@ -34,6 +34,21 @@
 
 namespace isx {
 
+// development: -DISX_H2_STAMP accumulates, per launch, the cycles wave 0 of every work-group spends in each part of a K stage
+// (h2_stamp[]: barrier 1, wait for the prefetched loads, staging stores, barrier 2, load issue, matrix phase, prologue, epilogue,
+// stages, work-groups) and the launcher prints them (it synchronises: timing experiments only).
+// -DISX_H2_STAMP=2: only the work-group's span in shader-clock cycles and at 100 MHz (the clock the chip holds), no stamps in the loop
+#ifdef ISX_H2_STAMP
+__device__ unsigned long long h2_stamp[12];
+#endif
+#if defined(ISX_H2_STAMP) && ISX_H2_STAMP != 2
+#define H2_STAGE_STAMPS 1
+#define H2_T(var) const unsigned long long var = __builtin_readcyclecounter();
+#define H2_ACC(i, d) tk[i] += (d);
+#else
+#define H2_T(var)
+#define H2_ACC(i, d)
+#endif
 #ifndef ISX_H2_ABLATE
 #define ISX_H2_ABLATE 0          // development: 1 = no staging arithmetic, 2 = no matrix phase (timing experiments, wrong results)
 #endif
@@ -246,15 +261,19 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     bool has_affine = false, stage_up = false, stage_ps = false;      // stage_ps: the stage's source is stored already split (ConvArgs::presplitA/B)
     float4 vb0 = make_float4(0.f, 0.f, 0.f, 0.f), vb1 = vb0;   // (UPA) bias of the transposed convolution for this stage's channels
     int up_cc = 0;
+    // the stage being loaded: source pointer (chunk b, channel offset included), its row length, the weight slab
+    const float *ld_src = nullptr;
+    int ld_C = 0;
+    const uint4 *ld_wsrc = nullptr;
 #define H2_LOAD_A(k)                                                                              \
     if constexpr (k < NA) {                                                                       \
-        const float *pp = (UPA && stage_up) ? &src[((int64_t)b * Mup + (gu##k & 0x0FFFFFFF)) * C + cc]      \
-                                            : &src[((int64_t)b * M + (gv##k > 0 ? gv##k : 0)) * C + cc];   \
+        const float *pp = (UPA && stage_up) ? &ld_src[(int64_t)(gu##k & 0x0FFFFFFF) * ld_C]      \
+                                            : &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];   \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }
-#define H2_LOAD_B(k) if constexpr (NB > k) { if (BEXACT || tid + THREADS * k < SLAB) rb##k = wsrc[tid + THREADS * k]; }
-#define H2_LOAD_STAGE(step_)                                                                      \
+#define H2_LOAD_B(k) if constexpr (NB > k) { if (BEXACT || tid + THREADS * k < SLAB) rb##k = ld_wsrc[tid + THREADS * k]; }
+#define H2_LOAD_HEAD(step_)                                                                       \
     {                                                                                             \
         const int c0 = (step_) << 3;                                                              \
         const float *src, *sc, *sh;                                                               \
@@ -269,8 +288,26 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         const int64_t so = has_affine ? (int64_t)b * C + cc : 0;                                  \
         vs0 = *(const float4 *)&scp[so]; vs1 = *(const float4 *)&scp[so + 4];                     \
         vh0 = *(const float4 *)&shp[so]; vh1 = *(const float4 *)&shp[so + 4];                     \
+        ld_src = src + ((UPA && stage_up) ? (int64_t)b * Mup : (int64_t)b * M) * C + cc;          \
+        ld_C = C;                                                                                 \
+        ld_wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  /* packs keep the hi|lo stride in every mode */ \
+    }
+#define H2_LOAD_STAGE(step_)                                                                      \
+    {                                                                                             \
+        H2_LOAD_HEAD(step_)                                                                       \
         H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4)                          \
-        const uint4 *wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  /* packs keep the hi|lo stride in every mode */ \
+        H2_LOAD_B(0) H2_LOAD_B(1) H2_LOAD_B(2) H2_LOAD_B(3) H2_LOAD_B(4) H2_LOAD_B(5) H2_LOAD_B(6) \
+        H2_LOAD_B(7) H2_LOAD_B(8) H2_LOAD_B(9) H2_LOAD_B(10) H2_LOAD_B(11) H2_LOAD_B(12) H2_LOAD_B(13) \
+    }
+// (16x16x32 core) the stage's loads one at a time, between the matrix instructions of step s_ of the matrix phase
+#define H2_LOAD_SLOT(s_)                                                                          \
+    switch (s_) {                                                                                 \
+        case 0: H2_LOAD_A(0) break; case 1: H2_LOAD_A(1) break; case 2: H2_LOAD_A(2) break;        \
+        case 3: H2_LOAD_A(3) break; case 4: H2_LOAD_A(4) break; default: break;                   \
+    }
+#define H2_LOAD_B_ALL(step_)                                                                      \
+    {                                                                                             \
+        ld_wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);            \
         H2_LOAD_B(0) H2_LOAD_B(1) H2_LOAD_B(2) H2_LOAD_B(3) H2_LOAD_B(4) H2_LOAD_B(5) H2_LOAD_B(6) \
         H2_LOAD_B(7) H2_LOAD_B(8) H2_LOAD_B(9) H2_LOAD_B(10) H2_LOAD_B(11) H2_LOAD_B(12) H2_LOAD_B(13) \
     }
@@ -312,9 +349,36 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         return (t / 3 - 1) * PS + (t % 3 - 1) * RS;
     };
 
-    H2_LOAD_STAGE(0)
+    // (16x16x32 core) the lane's tap offset of every tap quad: the same in every K stage, selected once -- selected inside the
+    // matrix phase, the four-way choice by lane group compiled to divergent branches, one basic block per quad, and nothing
+    // (fragment reads least of all) was scheduled across them
+    int toq[CORE == 1 ? NQUAD : 1];
+    if constexpr (CORE == 1) {
+#pragma unroll
+        for (int q = 0; q < NQUAD; ++q) {
+            const int t0 = tap_off(4 * q), t1 = tap_off(4 * q + 1), t2 = tap_off(4 * q + 2), t3 = tap_off(4 * q + 3);
+            toq[q] = (h4 & 2) ? ((h4 & 1) ? t3 : t2) : ((h4 & 1) ? t1 : t0);
+        }
+    }
+#ifdef ISX_H2_STAMP
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tk_begin = __builtin_readcyclecounter();
+    const unsigned long long tr_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    // 16x16x32 core: a stage's weight slab is loaded at the top of its own iteration (its registers are then free during the
+    // matrix phase, which keeps its fragments two steps ahead in them) and lands behind the barrier and the halo arithmetic
+    if constexpr (CORE == 1) { H2_LOAD_HEAD(0) H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4) }
+    else H2_LOAD_STAGE(0)
+    H2_T(tk_loop)
     for (int step = 0; step < nsteps; ++step) {
+        H2_T(t0)
+        if constexpr (CORE == 1) H2_LOAD_B_ALL(step)
         __syncthreads();
+        H2_T(t1)
+#ifdef H2_STAGE_STAMPS
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        H2_T(t1b)
         const bool st_up = stage_up;                           // of the stage being stored (the next load overwrites them)
         const int st_cc = up_cc;
         const float4 sb0 = vb0, sb1 = vb1;
@@ -322,48 +386,78 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         H2_STORE_A(0) H2_STORE_A(1) H2_STORE_A(2) H2_STORE_A(3) H2_STORE_A(4)
         H2_STORE_B(0) H2_STORE_B(1) H2_STORE_B(2) H2_STORE_B(3) H2_STORE_B(4) H2_STORE_B(5) H2_STORE_B(6)
         H2_STORE_B(7) H2_STORE_B(8) H2_STORE_B(9) H2_STORE_B(10) H2_STORE_B(11) H2_STORE_B(12) H2_STORE_B(13)
+        H2_T(t2)
         __syncthreads();
-        if (step + 1 < nsteps) H2_LOAD_STAGE(step + 1)
+        H2_T(t3)
+        const bool more = step + 1 < nsteps;
+        if constexpr (CORE == 1) { if (more) H2_LOAD_HEAD(step + 1) }       // its loads go out between the matrix instructions below
+        else { if (more) H2_LOAD_STAGE(step + 1) }
         __builtin_amdgcn_sched_barrier(0);
+        H2_T(t4)
         if (ISX_H2_ABLATE == 2) { acc_hi[0][0][0] += (float)step; } else
         if constexpr (CORE == 1) {
+            // Software-pipelined by hand, one step = one 16-column tile j of one tap quad q (3 MT16 matrix instructions): the
+            // B fragments of step s + 2 and the A fragments of the next quad are read from LDS before the matrix instructions
+            // of step s are issued, and one of the next stage's global loads goes out per step.  The compiler's own schedule
+            // read every fragment right before its use (its register budget is spent on the prefetched stage) and issued the
+            // 24 global loads back to back before the first matrix instruction: 2 100-2 800 cycles per stage waiting for room
+            // in the load queue with the matrix pipe idle (scratch ISX_H2_STAMP build).
             const uint4 *bqh = Bs + h4 * BN + l16, *bql = bqh + BU;
-#pragma unroll
-            for (int q = 0; q < NQUAD; ++q) {
-                const int t0 = tap_off(4 * q), t1 = tap_off(4 * q + 1), t2 = tap_off(4 * q + 2), t3 = tap_off(4 * q + 3);
-                const int to = h4 == 0 ? t0 : (h4 == 1 ? t1 : (h4 == 2 ? t2 : t3));
-                union FR { uint4 u; f16x8 v; bf16x8 w; };
-                FR ah[MT16], al[MT16];
-#pragma unroll
-                for (int m = 0; m < MT16; ++m) {
-                    ah[m].u = AsH[aslot16[m] + to];
-                    if constexpr (SPLIT) al[m].u = AsL[aslot16[m] + to];
-                }
-#pragma unroll
-                for (int j = 0; j < NT16; ++j) {
-                    FR bh, bl;
-                    bh.u = bqh[(4 * q) * BN + 16 * j];
-                    if constexpr (SPLIT) {
-                        bl.u = bql[(4 * q) * BN + 16 * j];
-#pragma unroll
-                        for (int m = 0; m < MT16; ++m) {
-                            c_hi[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m].v, bh.v, c_hi[m][j], 0, 0, 0);
-                            c_lo[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m].v, bl.v, c_lo[m][j], 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int m = 0; m < MT16; ++m)
-                            c_lo[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m].v, bh.v, c_lo[m][j], 0, 0, 0);
-                    } else if constexpr (PM == 1) {
-#pragma unroll
-                        for (int m = 0; m < MT16; ++m)
-                            c_hi[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m].v, bh.v, c_hi[m][j], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < MT16; ++m)
-                            c_hi[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m].w, bh.w, c_hi[m][j], 0, 0, 0);
-                    }
-                }
+            union FR { uint4 u; f16x8 v; bf16x8 w; };
+            constexpr int NS = NQUAD * NT16;
+            // two row tiles per wave (MT16 = 4: 12 matrix instructions = 192 cycles per step): B one step ahead and the lo halves
+            // of A read at the start of their own quad (first used 8 matrix instructions later) -- the registers do not go further
+            constexpr int BR = MT16 < 4 ? 3 : 2, BD = BR - 1;
+            constexpr bool AL2 = MT16 < 4;
+            FR ah[2][MT16], al[(SPLIT && AL2) ? 2 : 1][SPLIT ? MT16 : 1], bh[BR], bl[SPLIT ? BR : 1];
+#define H2_FRAG_AH(q_)                                                                            \
+            { _Pragma("unroll") for (int m = 0; m < MT16; ++m) ah[(q_) & 1][m].u = AsH[aslot16[m] + toq[q_]]; }
+#define H2_FRAG_AL(q_)                                                                            \
+            if constexpr (SPLIT) { _Pragma("unroll") for (int m = 0; m < MT16; ++m) al[AL2 ? ((q_) & 1) : 0][m].u = AsL[aslot16[m] + toq[q_]]; }
+#define H2_FRAG_B(s_)                                                                             \
+            {                                                                                     \
+                bh[(s_) % BR].u = bqh[(4 * ((s_) / NT16)) * BN + 16 * ((s_) % NT16)];             \
+                if constexpr (SPLIT) bl[(s_) % BR].u = bql[(4 * ((s_) / NT16)) * BN + 16 * ((s_) % NT16)]; \
             }
+            // (the fragment addresses aslot16[m] + toq[q] are loop invariants: hoisted out of the K loop they cost 14-28 registers
+            // and spill; an empty asm that "changes" toq keeps each one add next to its read)
+#pragma unroll
+            for (int q = 0; q < NQUAD; ++q) __asm__ volatile("" : "+v"(toq[q]));
+            H2_FRAG_AH(0)
+            H2_FRAG_B(0)
+            if constexpr (BD > 1) H2_FRAG_B(1)
+            if constexpr (AL2) H2_FRAG_AL(0)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int q = s / NT16, j = s % NT16, qs = q & 1, r = s % BR, ql = AL2 ? qs : 0;
+                if (s + BD < NS) H2_FRAG_B(s + BD)
+                if (!AL2 && j == 0) H2_FRAG_AL(q)
+                if (j == (NT16 >= 2 ? NT16 - 2 : 0) && q + 1 < NQUAD) { H2_FRAG_AH(q + 1) if constexpr (AL2) H2_FRAG_AL(q + 1) }
+                if (more) { H2_LOAD_SLOT(s) }
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int m = 0; m < MT16; ++m) {
+                        c_hi[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[qs][m].v, bh[r].v, c_hi[m][j], 0, 0, 0);
+                        c_lo[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[qs][m].v, bl[r].v, c_lo[m][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT16; ++m)
+                        c_lo[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ql][m].v, bh[r].v, c_lo[m][j], 0, 0, 0);
+                } else if constexpr (PM == 1) {
+#pragma unroll
+                    for (int m = 0; m < MT16; ++m)
+                        c_hi[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[qs][m].v, bh[r].v, c_hi[m][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT16; ++m)
+                        c_hi[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[qs][m].w, bh[r].w, c_hi[m][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            static_assert(NS >= 5, "one halo load per step");
+#undef H2_FRAG_AH
+#undef H2_FRAG_AL
+#undef H2_FRAG_B
         } else {
         const uint4 *bph = Bs + hh * BN + nn, *bpl = bph + BU;
 #pragma unroll
@@ -401,10 +495,18 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef H2_STAGE_STAMPS
+        { H2_T(t5) H2_ACC(0, t1 - t0) H2_ACC(1, t1b - t1) H2_ACC(2, t2 - t1b) H2_ACC(3, t3 - t2) H2_ACC(4, t4 - t3) H2_ACC(5, t5 - t4) }
+#endif
     }
+    H2_T(tk_loop_end)
+    H2_ACC(6, tk_loop - tk_begin)
 #undef H2_LOAD_A
 #undef H2_LOAD_B
 #undef H2_LOAD_STAGE
+#undef H2_LOAD_HEAD
+#undef H2_LOAD_SLOT
+#undef H2_LOAD_B_ALL
 #undef H2_AFF
 #undef H2_STORE_A
 #undef H2_STORE_B
@@ -478,6 +580,23 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         a.psum[o] = s;
         a.psq[o] = q;
     }
+#if defined(ISX_H2_STAMP) && ISX_H2_STAMP == 2
+    if (tid == 0 && (blockIdx.x & 63) == 0) {          // one work-group in 64: two atomics that contend with nothing
+        atomicAdd(&h2_stamp[10], (unsigned long long)(__builtin_readcyclecounter() - tk_begin));
+        atomicAdd(&h2_stamp[11], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - tr_begin));
+    }
+#elif defined(ISX_H2_STAMP)
+    if (tid == 0) {
+#ifdef H2_STAGE_STAMPS
+        tk[7] = __builtin_readcyclecounter() - tk_loop_end;
+#endif
+        for (int i = 0; i < 8; ++i) atomicAdd(&h2_stamp[i], tk[i]);
+        atomicAdd(&h2_stamp[8], (unsigned long long)nsteps);
+        atomicAdd(&h2_stamp[9], 1ull);
+        atomicAdd(&h2_stamp[10], (unsigned long long)(__builtin_readcyclecounter() - tk_begin));        // shader-clock cycles of the work-group
+        atomicAdd(&h2_stamp[11], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - tr_begin));     // the same span at 100 MHz
+    }
+#endif
 }
 
 template <int BN, int TX, int MT, int PM, int NW = 4>
@@ -725,6 +844,33 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
 #undef ISX_H2_GO
 #undef ISX_H2_GO16
     ISX_CHECK_LAUNCH();
+#if defined(ISX_H2_STAMP) && ISX_H2_STAMP == 2
+    {
+        static int nlaunch = 0;                     // no synchronisation per launch: the clock of the back-to-back sequence
+        if (++nlaunch % 288 == 0) {
+            unsigned long long hs[12] = {0};
+            ISX_HIP(hipStreamSynchronize(ctx->stream));
+            ISX_HIP(hipMemcpyFromSymbol(hs, HIP_SYMBOL(h2_stamp), sizeof(hs)));
+            if (getenv("ISX_H2_STAMP_PRINT") && hs[11])
+                fprintf(stderr, "h2clock after %d launches: %.3f GHz (sampled work-groups: %.3e cycles)\n", nlaunch, (double)hs[10] / (double)hs[11] * 0.1, (double)hs[10]);
+            memset(hs, 0, sizeof(hs));
+            ISX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(h2_stamp), hs, sizeof(hs)));
+        }
+    }
+#elif defined(ISX_H2_STAMP)
+    {
+        unsigned long long hs[12] = {0};
+        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        ISX_HIP(hipMemcpyFromSymbol(hs, HIP_SYMBOL(h2_stamp), sizeof(hs)));
+        const double wg = (double)hs[9], st = (double)hs[8];
+        if (getenv("ISX_H2_STAMP_PRINT") && wg > 0 && st > 0)
+            fprintf(stderr, "h2stamp B=%d D=%d H=%d W=%d cin=%d cout=%d BN=%d mt=%d fold=%d core16=%d grid=%u stages/wg=%.1f | per stage: bar1 %.0f loadwait %.0f store %.0f bar2 %.0f issue %.0f matrix %.0f | per wg: prologue %.0f epilogue %.0f | clock %.2f GHz\n",
+                    B, l.D, l.H, l.W, sa.C + sb.C, cout, BN, mt, fold, (int)core16, grid, st / wg, hs[0] / st, hs[1] / st, hs[2] / st, hs[3] / st, hs[4] / st,
+                    hs[5] / st, hs[6] / wg, hs[7] / wg, hs[11] ? (double)hs[10] / (double)hs[11] * 0.1 : 0.0);
+        memset(hs, 0, sizeof(hs));
+        ISX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(h2_stamp), hs, sizeof(hs)));
+    }
+#endif
     return ISX_OK;
 }
 
