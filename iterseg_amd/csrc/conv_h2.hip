@@ -258,7 +258,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     // named prefetch registers (arrays that live across the K loop end up in scratch)
     float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
     uint4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rb8, rb9, rb10, rb11, rb12, rb13;
-    bool has_affine = false, stage_up = false, stage_ps = false;      // stage_ps: the stage's source is stored already split (ConvArgs::presplitA/B)
+    bool has_affine = false, stage_up = false;
+    float relu_lo = 0.f;                                      // ReLU floor of the stage: 0 behind a BatchNorm, -inf for a source without one
     float4 vb0 = make_float4(0.f, 0.f, 0.f, 0.f), vb1 = vb0;   // (UPA) bias of the transposed convolution for this stage's channels
     int up_cc = 0;
     // the stage being loaded: source pointer (chunk b, channel offset included), its row length, the weight slab
@@ -281,13 +282,17 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if (c0 < a.CA) { src = a.srcA; sc = a.scaleA; sh = a.shiftA; C = a.CA; cc = c0; }         \
         else { src = a.srcB; sc = a.scaleB; sh = a.shiftB; C = a.CB; cc = c0 - a.CA; }            \
         has_affine = sc != nullptr;                                                               \
-        stage_ps = SPLIT && (c0 < a.CA ? a.presplitA : a.presplitB) != 0;                         \
         stage_up = UPA && c0 < a.CA;                                                              \
         if (UPA && stage_up) { up_cc = cc; vb0 = *(const float4 *)&a.upb[cc]; vb1 = *(const float4 *)&a.upb[cc + 4]; } \
         const float *scp = has_affine ? sc : a.bias, *shp = has_affine ? sh : a.bias;             \
         const int64_t so = has_affine ? (int64_t)b * C + cc : 0;                                  \
         vs0 = *(const float4 *)&scp[so]; vs1 = *(const float4 *)&scp[so + 4];                     \
         vh0 = *(const float4 *)&shp[so]; vh1 = *(const float4 *)&shp[so + 4];                     \
+        if (!UPA && !has_affine) {                                                                \
+            vs0 = make_float4(1.f, 1.f, 1.f, 1.f); vs1 = vs0;                                     \
+            vh0 = make_float4(0.f, 0.f, 0.f, 0.f); vh1 = vh0;                                     \
+        }                                                                                         \
+        relu_lo = has_affine ? 0.f : -__builtin_inff();                                           \
         ld_src = src + ((UPA && stage_up) ? (int64_t)b * Mup : (int64_t)b * M) * C + cc;          \
         ld_C = C;                                                                                 \
         ld_wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  /* packs keep the hi|lo stride in every mode */ \
@@ -314,7 +319,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #define H2_AFF(v, s_, h_)                                                                         \
     v.x = fmaxf(fmaf(v.x, s_.x, h_.x), 0.f); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), 0.f);             \
     v.z = fmaxf(fmaf(v.z, s_.z, h_.z), 0.f); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), 0.f);
-#define H2_STORE_A(k)                                                                             \
+#define H2_STORE_A_GEN(k)                                                                           \
     if (k < NA && gv##k != -2) {                                                       \
         float4 v = ra##k, w = rc##k;                                                              \
         if (has_affine) { H2_AFF(v, vs0, vh0) H2_AFF(w, vs1, vh1) }                               \
@@ -326,18 +331,33 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         }                                                                                         \
         if (gv##k < 0) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }                            \
         uint4 hi, lo;                                                                             \
-        if (stage_ps) {      /* [hi: 8 halves | lo: 8 halves] per voxel and stage, written by the producer: a copy */ \
-            hi = make_uint4(__float_as_uint(ra##k.x), __float_as_uint(ra##k.y), __float_as_uint(ra##k.z), __float_as_uint(ra##k.w)); \
-            lo = make_uint4(__float_as_uint(rc##k.x), __float_as_uint(rc##k.y), __float_as_uint(rc##k.z), __float_as_uint(rc##k.w)); \
-            if (gv##k < 0) { hi = make_uint4(0u, 0u, 0u, 0u); lo = hi; }                          \
-            if constexpr (SPLIT) AsL[tid + THREADS * k] = lo;                                     \
-        } else                                                                                    \
         if (ISX_H2_ABLATE == 1) { hi = make_uint4(__float_as_uint(ra##k.x), __float_as_uint(ra##k.y), __float_as_uint(ra##k.z), __float_as_uint(ra##k.w)); \
                                   lo = make_uint4(__float_as_uint(rc##k.x), __float_as_uint(rc##k.y), __float_as_uint(rc##k.z), __float_as_uint(rc##k.w)); \
                                   if constexpr (SPLIT) AsL[tid + THREADS * k] = lo; } else              \
         if constexpr (SPLIT) { split8(v, w, hi, lo); AsL[tid + THREADS * k] = lo; }               \
         else round8<PM>(v, w, hi);                                                                \
         AsH[tid + THREADS * k] = hi;                                                              \
+    }
+// The same store without a branch (every kernel but the up-sampling tail): a source without BatchNorm gets scale 1, shift 0 and
+// a ReLU floor of -inf at H2_LOAD_HEAD (x * 1 + 0 and max(x, -inf) are exact), slots outside the volume select zeros after the
+// split, and only the store itself is predicated.  The branchy form above compiled to 19 exec-mask regions and 128 register
+// moves per stage of the 64-column kernel.
+#define H2_AFFL(v, s_, h_)                                                                        \
+    v.x = fmaxf(fmaf(v.x, s_.x, h_.x), relu_lo); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), relu_lo);     \
+    v.z = fmaxf(fmaf(v.z, s_.z, h_.z), relu_lo); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), relu_lo);
+#define H2_STORE_A_FAST(k)                                                                        \
+    if constexpr (k < NA) {                                                                       \
+        float4 v = ra##k, w = rc##k;                                                              \
+        H2_AFFL(v, vs0, vh0) H2_AFFL(w, vs1, vh1)                                                 \
+        uint4 hi, lo = make_uint4(0u, 0u, 0u, 0u);                                                \
+        if constexpr (SPLIT) split8(v, w, hi, lo); else round8<PM>(v, w, hi);                     \
+        const bool dead = gv##k < 0;                                                              \
+        hi.x = dead ? 0u : hi.x; hi.y = dead ? 0u : hi.y; hi.z = dead ? 0u : hi.z; hi.w = dead ? 0u : hi.w; \
+        if constexpr (SPLIT) { lo.x = dead ? 0u : lo.x; lo.y = dead ? 0u : lo.y; lo.z = dead ? 0u : lo.z; lo.w = dead ? 0u : lo.w; } \
+        if (gv##k != -2) {                                                                        \
+            AsH[tid + THREADS * k] = hi;                                                          \
+            if constexpr (SPLIT) AsL[tid + THREADS * k] = lo;                                     \
+        }                                                                                         \
     }
 #define H2_STORE_B(k) if constexpr (NB > k) { if (BEXACT || tid + THREADS * k < SLAB) Bs[tid + THREADS * k] = rb##k; }
 
@@ -383,7 +403,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         const int st_cc = up_cc;
         const float4 sb0 = vb0, sb1 = vb1;
         (void)st_up; (void)st_cc; (void)sb0; (void)sb1;
-        H2_STORE_A(0) H2_STORE_A(1) H2_STORE_A(2) H2_STORE_A(3) H2_STORE_A(4)
+        if constexpr (UPA || ISX_H2_ABLATE == 1) { H2_STORE_A_GEN(0) H2_STORE_A_GEN(1) H2_STORE_A_GEN(2) H2_STORE_A_GEN(3) H2_STORE_A_GEN(4) }
+        else { H2_STORE_A_FAST(0) H2_STORE_A_FAST(1) H2_STORE_A_FAST(2) H2_STORE_A_FAST(3) H2_STORE_A_FAST(4) }
         H2_STORE_B(0) H2_STORE_B(1) H2_STORE_B(2) H2_STORE_B(3) H2_STORE_B(4) H2_STORE_B(5) H2_STORE_B(6)
         H2_STORE_B(7) H2_STORE_B(8) H2_STORE_B(9) H2_STORE_B(10) H2_STORE_B(11) H2_STORE_B(12) H2_STORE_B(13)
         H2_T(t2)
@@ -508,10 +529,57 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #undef H2_LOAD_SLOT
 #undef H2_LOAD_B_ALL
 #undef H2_AFF
-#undef H2_STORE_A
+#undef H2_STORE_A_GEN
+#undef H2_STORE_A_FAST
+#undef H2_AFFL
 #undef H2_STORE_B
 
     // ---- epilogue: HI + LO / 2^11 + bias, store, per-tile BN partial sums (valid rows only) ------------------
+    // 16x16x32 core, plain output (no remap, no accumulation): the tile goes through LDS (free after the last stage) and leaves as
+    // whole rows -- BN consecutive channels of a voxel, one global_store_dwordx4 per lane, four rows per wave instruction --
+    // instead of one dword per lane in 64-byte pieces with the address arithmetic of 32 stores per lane (15-24 k cycles per
+    // work-group in the stamped build: as much as two K stages).  The BatchNorm partial sums are taken from the registers in
+    // the same order as below, the stored values are the same.
+    constexpr int TRS = BN + 4;                                    // floats per row of the LDS tile (16-byte rows, conflict-free both ways)
+    const bool t_out = CORE == 1 && !a.remap && !a.accum && a.store_cols % 4 == 0 &&
+                       (size_t)(SLAB + (SPLIT ? 2 : 1) * a.slots_max) * 16 >= (size_t)ROWS * TRS * sizeof(float);
+    if (CORE == 1 && t_out) {
+        float *T = (float *)smem4;
+        __syncthreads();                                           // every wave has read its last fragments
+#pragma unroll
+        for (int j = 0; j < NT16; ++j) {
+            const int ch = ntile * BN + 16 * j + l16;
+            const float bsv = a.bias[ch];
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT16; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wave * MT * 32 + 16 * m + 4 * h4 + i;
+                    float v;
+                    if constexpr (SPLIT) v = fmaf(c_lo[m][j][i], 1.f / H2_SCALE, c_hi[m][j][i]) + bsv;
+                    else v = c_hi[m][j][i] + bsv;
+                    T[row * TRS + 16 * j + l16] = v;
+                    if (rowinfo[row] >= 0) { s += v; q += v * v; }
+                }
+            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (h4 == 0) { red[(wave * BN + 16 * j + l16) * 2] = s; red[(wave * BN + 16 * j + l16) * 2 + 1] = q; }
+        }
+        __syncthreads();
+        constexpr int C4 = BN / 4;
+#pragma unroll
+        for (int e0 = 0; e0 < ROWS * C4; e0 += THREADS) {
+            const int e = e0 + tid, row = e / C4, c4 = e % C4;
+            const int g = rowinfo[row];
+            const int ch = ntile * BN + 4 * c4;
+            if (g >= 0 && ch < a.store_cols) {
+                const f32x4c o = *(const f32x4c *)&T[row * TRS + 4 * c4];
+                f32x4c *op = (f32x4c *)&a.out[((int64_t)b * Mout + g) * a.store_cols + ch];
+                if (a.nt_out) __builtin_nontemporal_store(o, op); else *op = o;
+            }
+        }
+    } else
     if constexpr (CORE == 1) {
         // C/D of 16x16: column = lane & 15, row = 4 * (lane >> 4) + register
 #pragma unroll
@@ -750,9 +818,6 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.remap = ex ? ex->remap : 0; a.rH = ex ? ex->rH : 0; a.rW = ex ? ex->rW : 0; a.rpy = ex ? ex->rpy : 0; a.rpx = ex ? ex->rpx : 0;
     a.roff = ex ? ex->roff : 0; a.Mout = ex ? ex->Mout : 0; a.accum = ex ? ex->accum : 0;
     a.nt_out = ctx->tune.h2_nt_out;
-    a.presplitA = sa.presplit ? 1 : 0; a.presplitB = sb.presplit ? 1 : 0;
-    ISX_REQUIRE(!(a.presplitA || a.presplitB) || pm == 0, "internal: a pre-split source needs the split-f16 arithmetic");
-    ISX_REQUIRE(!(a.presplitA && sa.scale) && !(a.presplitB && sb.scale), "internal: a pre-split source carries no BatchNorm");
     const int upa = ex ? ex->upA : 0;
     a.uH = ex ? ex->uH : 0; a.uW = ex ? ex->uW : 0; a.uoff = ex ? ex->uoff : 0; a.upw = ex ? ex->upw : nullptr; a.upb = ex ? ex->upb : nullptr;
     ISX_REQUIRE(!upa || (fold && a.upw && a.upb), "internal: up-sampling on read is built for the folded tail layer");

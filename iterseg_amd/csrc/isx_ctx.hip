@@ -172,7 +172,6 @@ isx_ctx *isx_ctx_create(int device)
     if (const char *e = getenv("ISX_H2_CORE16")) c->tune.h2_core16 = atoi(e);
     if (const char *e = getenv("ISX_UP_PER_SOURCE")) c->tune.up_per_source = atoi(e);
     if (const char *e = getenv("ISX_CONV_FIRST_NT")) c->tune.conv_first_nt = atoi(e);
-    if (const char *e = getenv("ISX_PRESPLIT")) c->tune.presplit = atoi(e);
     if (const char *e = getenv("ISX_H2_NT_OUT")) c->tune.h2_nt_out = atoi(e);
     if (const char *e = getenv("ISX_CONV_MT2_MIN_VOX")) c->tune.mt2_min_vox = atol(e);
     c->device = device;

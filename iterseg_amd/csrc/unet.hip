@@ -25,13 +25,11 @@
 #include <vector>
 
 #include "unet_state.h"
-#include "h2_split.h"
 
 namespace isx {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // streaming (non-temporal) 16-byte load.  Tried for the activation tiles of the MFMA conv (r01b): it
 // RAISED L2-miss traffic 93 -> 131 GB per launch set and cost 20 % -- halo overlap needs the L2.
@@ -464,29 +462,13 @@ __global__ void bn_running_kernel(const float *bmean, const float *bvar, int B, 
 // Kernels: max-pool (stride = kernel, padding (0,1,1)) and depthwise transposed convolution
 // (stride = kernel) + crop, both with the producer's BN+ReLU applied on load.  4 channels/thread.
 // ------------------------------------------------------------------------------------------
-// G = 1: thread = 4 channels, fp32 output.  G = 2: thread = 8 channels = one K stage of the split-f16 convolution that consumes
-// the tensor, written ALREADY SPLIT (h2_split.h: 8 hi halves, then 8 lo halves, in the 32 bytes the 8 floats would take), so
-// that the consumer stages it by copy (ConvArgs::presplitA/B) instead of splitting every voxel once per tile that reads it.
-template <int G>
+constexpr int G = 1;        // float4 groups per thread
 __device__ __forceinline__ void put_channels(float *dst, const float4 (&v)[G], bool nt)
 {
-    if constexpr (G == 2) {
-        uint4 hi, lo;
-        split8(v[0], v[1], hi, lo);
-        if (nt) {
-            __builtin_nontemporal_store(u32x4{hi.x, hi.y, hi.z, hi.w}, (u32x4 *)dst);
-            __builtin_nontemporal_store(u32x4{lo.x, lo.y, lo.z, lo.w}, (u32x4 *)dst + 1);
-        } else {
-            ((uint4 *)dst)[0] = hi;
-            ((uint4 *)dst)[1] = lo;
-        }
-    } else {
-        if (nt) __builtin_nontemporal_store(f32x4{v[0].x, v[0].y, v[0].z, v[0].w}, (f32x4 *)dst);
-        else *(float4 *)dst = v[0];
-    }
+    if (nt) __builtin_nontemporal_store(f32x4{v[0].x, v[0].y, v[0].z, v[0].w}, (f32x4 *)dst);
+    else *(float4 *)dst = v[0];
 }
 
-template <int G>
 __global__ void pool_kernel(const float *__restrict__ src, const float *__restrict__ scale,
                             const float *__restrict__ shift, int C, int D, int H, int W, int kz, int Do, int Ho,
                             int Wo, float *__restrict__ dst, int64_t total)
@@ -528,12 +510,11 @@ __global__ void pool_kernel(const float *__restrict__ src, const float *__restri
                     best[g].w = fmaxf(best[g].w, t.w);
                 }
             }
-    put_channels<G>(&dst[((int64_t)b * Mo + m) * C + c0], best, false);
+    put_channels(&dst[((int64_t)b * Mo + m) * C + c0], best, false);
 }
 
 // out[z, y, x, c] = act(in[z/kz, (y+off)/2, (x+off)/2, c]) * w[(z%kz, (y+off)%2, (x+off)%2)][c] + bias[c]
 // for the cropped output box (Do, Ho, Wo); off = 0 for the [:-1] crops, 1 for the [1:-1] crop.
-template <int G>
 __global__ void upsample_kernel(const float *__restrict__ src, const float *__restrict__ scale,
                                 const float *__restrict__ shift, int C, int D, int H, int W, int kz, int off,
                                 const float *__restrict__ w, const float *__restrict__ bias, int Do, int Ho, int Wo,
@@ -565,13 +546,12 @@ __global__ void upsample_kernel(const float *__restrict__ src, const float *__re
         t.w = fmaf(fmaxf(fmaf(t.w, vs.w, vh.w), 0.f), wv.w, bv.w);
         o[g] = t;
     }
-    put_channels<G>(&dst[((int64_t)b * Mo + m) * C + c0], o, nt_store != 0);
+    put_channels(&dst[((int64_t)b * Mo + m) * C + c0], o, nt_store != 0);
 }
 
 // The same operator per SOURCE voxel (kz = 1): one load and one BatchNorm + ReLU feed the four outputs a coarse voxel
 // up-samples to -- a quarter of the loads, address arithmetic and activation math of the per-output kernel above (which ran at
 // 3.7 TB/s against 5.6 TB/s for pool_kernel).  thread = (coarse voxel, 4 G channels).
-template <int G>
 __global__ void upsample_src_kernel(const float *__restrict__ src, const float *__restrict__ scale, const float *__restrict__ shift,
                                     int C, int D, int H, int W, int off, const float *__restrict__ w, const float *__restrict__ bias,
                                     int Ho, int Wo, float *__restrict__ dst, int64_t total)
@@ -609,7 +589,7 @@ __global__ void upsample_src_kernel(const float *__restrict__ src, const float *
                 o[g] = make_float4(fmaf(t[g].x, wv.x, bv[g].x), fmaf(t[g].y, wv.y, bv[g].y), fmaf(t[g].z, wv.z, bv[g].z),
                                    fmaf(t[g].w, wv.w, bv[g].w));
             }
-            put_channels<G>(&dst[((int64_t)b * Mo + ((int64_t)z * Ho + y) * Wo + x) * C + c0], o, true);
+            put_channels(&dst[((int64_t)b * Mo + ((int64_t)z * Ho + y) * Wo + x) * C + c0], o, true);
         }
 }
 
@@ -1345,23 +1325,6 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     return ISX_OK;
 }
 
-// Will run_conv give layer li (sources bounded by `bound`) to the split-f16 kernel?  Then the producers of its post-activation
-// sources may write them already split (Src::presplit); the conditions mirror run_conv's own.
-static bool conv_takes_split(isx_ctx *ctx, int li, const Level &l, int B, float bound)
-{
-    UNetState *u = ctx->unet;
-    const ConvBN &L = u->cv[li];
-    if (!ctx->tune.presplit || u->precision != ISX_PRECISION_SPLIT_F16 || u->train || !(bound < 6.0e4f)) return false;
-    if (use_mfma(L.cin, L.cout)) {
-        int t0, t1, t2, slots;
-        conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
-        const bool b64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64 || conv_h2_nw8(ctx->tune, l, L.cout, B);
-        return (b64 ? L.w_h2_64 : L.w_h2_32) && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1;
-    }
-    if (use_fold(L.cin, L.cout)) return L.w_h2_32 && conv_mt(ctx->tune, l, u->wbatch, 32) == 1;
-    return false;
-}
-
 static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb, const H2Extra *ex = nullptr)
 {
     UNetState *u = ctx->unet;
@@ -1382,7 +1345,6 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
         const bool h2 = reduced && wh && in_range && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1;
         u->arith[li] = h2 ? ISX_ARITH_REDUCED : (reduced && wh && !in_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
-        ISX_REQUIRE((h2 && pm == 0) || !(sa.presplit || sb.presplit), "internal: a pre-split source reached a convolution that does not take it");
         if (h2)
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, 0, &stat_tiles, pm));
         else
@@ -1397,7 +1359,6 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         u->arith[li] = fold_h2 ? ISX_ARITH_REDUCED
                                : (u->precision != ISX_PRECISION_FP32 && !u->train && wf && !fold_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
         ISX_REQUIRE(fold_h2 || !ex, "internal: up-sampling on read needs the reduced-precision tail kernel");
-        ISX_REQUIRE((fold_h2 && pm == 0) || !(sa.presplit || sb.presplit), "internal: a pre-split source reached a convolution that does not take it");
         if (fold_h2) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wf, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
@@ -1566,7 +1527,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
     for (int mi = 0; mi <= 4; ++mi) {
         const Level &l = lv[mi];
         Src in = (mi == 0) ? Src{u->x0, nullptr, nullptr, 1}
-                           : Src{u->pool[mi - 1], nullptr, nullptr, MOD_COUT[mi - 1], bn_bound(2 * (mi - 1) + 1), u->pool_split[mi - 1]};
+                           : Src{u->pool[mi - 1], nullptr, nullptr, MOD_COUT[mi - 1], bn_bound(2 * (mi - 1) + 1)};
         ISX_TRY(run_conv(ctx, 2 * mi, l, B, in, none));
         ISX_TRY(run_conv(ctx, 2 * mi + 1, l, B, act(2 * mi), none));
         if (mi < 4) {
@@ -1575,12 +1536,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             const ConvBN &L = u->cv[2 * mi + 1];
             int64_t total = (int64_t)B * lo.M * (L.cout / 4);
             ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
-            u->pool_split[mi] = L.cout % 8 == 0 && conv_takes_split(ctx, 2 * (mi + 1), lo, B, bn_bound(2 * mi + 1));
-            if (u->pool_split[mi])
-                pool_kernel<2><<<cdiv(total / 2, 256), 256, 0, ctx->stream>>>(u->raw[2 * mi + 1], L.scale, L.shift, L.cout, l.D, l.H, l.W,
-                                                                           mi == 3 ? 2 : 1, lo.D, lo.H, lo.W, u->pool[mi], total / 2);
-            else
-            pool_kernel<1><<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[2 * mi + 1], L.scale, L.shift, L.cout, l.D, l.H,
+            pool_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[2 * mi + 1], L.scale, L.shift, L.cout, l.D, l.H,
                                                                 l.W, mi == 3 ? 2 : 1, lo.D, lo.H, lo.W, u->pool[mi],
                                                                 total);
             ISX_CHECK_LAUNCH();
@@ -1599,7 +1555,6 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             float *upo = u->ups[ups_index(f, k)];
             const int l0f = dec_layer(f, k, 0), skipf = 2 * (3 - k) + 1;
             ISX_REQUIRE(ls.D == lo.D || k == 0, "internal: up%d changes the depth", k);
-            if (!(f > 0 && k == 0)) u->ups_split[ups_index(f, k)] = false;
             if (k > 0 && upfold_usable(ctx, l0f, ls, lo, act(li_in), act(skipf))) {
                 u->up_folded[ups_index(f, k)] = true;
                 ISX_TRY(run_upfold(ctx, l0f, ls, lo, B, act(li_in), act(skipf), U, k == 3 ? 1 : 0));
@@ -1628,31 +1583,22 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             const int l0 = dec_layer(f, k, 0), l1 = dec_layer(f, k, 1);   // c5..c8 of this fork
             const int skip_li = 2 * (3 - k) + 1;                   // c3, c2, c1, c0 second conv
             const float up_bound = bn_bound(li_in) * U.wmax + U.bmax;
-            // up0 is shared by the forks: every fork's consumer decides the same way (same shapes, same bound)
-            const bool ups = U.C % 8 == 0 && conv_takes_split(ctx, l0, lo, B, std::max(up_bound, bn_bound(skip_li)));
-            u->ups_split[ups_index(f, k)] = ups;
             if (!(f > 0 && k == 0)) {
                 ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
                 int64_t total = (int64_t)B * lo.M * (U.C / 4);
                 ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
                 const int64_t total_src = (int64_t)B * ls.M * (U.C / 4);
                 const bool per_src = U.kz == 1 && ctx->tune.up_per_source && total_src < (int64_t)0xFFFFFFFFll;
-                if (per_src && ups)
-                    upsample_src_kernel<2><<<cdiv(total_src / 2, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W,
-                                                                                           k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, upo, total_src / 2);
-                else if (per_src)
-                    upsample_src_kernel<1><<<cdiv(total_src, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W,
+                if (per_src)
+                    upsample_src_kernel<<<cdiv(total_src, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W,
                                                                                     k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, upo, total_src);
-                else if (ups)
-                    upsample_kernel<2><<<cdiv(total / 2, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz,
-                                                                                   k == 3 ? 1 : 0, U.w, U.bias, lo.D, lo.H, lo.W, upo, total / 2, 1);
                 else
-                upsample_kernel<1><<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D,
+                upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D,
                                                                         ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, U.bias, lo.D,
                                                                         lo.H, lo.W, upo, total, 1 /* streaming stores: the 5.4 GB output is far larger than L2 */);
                 ISX_CHECK_LAUNCH();
             }
-            ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound, ups}, act(skip_li)));
+            ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound}, act(skip_li)));
             ISX_TRY(run_conv(ctx, l1, lo, B, act(l0), none));
         }
         {
@@ -1870,30 +1816,18 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
         }
     }
     for (int k = 0; k < 4 && !src; ++k) {
-        if (nm == std::string("d") + std::to_string(k)) {
-            src = u->pool[k]; C = MOD_COUT[k]; level = k + 1;
-            if (u->pool_split[k]) {           // the forward wrote it split for its consumer: the fp32 form is computed here
-                const Level &l = u->lv[k], &lo = u->lv[k + 1];
-                const ConvBN &L = u->cv[2 * k + 1];
-                const int64_t total = (int64_t)u->last_n * lo.M * (L.cout / 4);
-                pool_kernel<1><<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[2 * k + 1], L.scale, L.shift, L.cout, l.D, l.H, l.W, k == 3 ? 2 : 1,
-                                                                       lo.D, lo.H, lo.W, u->pool[k], total);
-                ISX_CHECK_LAUNCH();
-                u->pool_split[k] = false;
-            }
-        }
+        if (nm == std::string("d") + std::to_string(k)) { src = u->pool[k]; C = MOD_COUT[k]; level = k + 1; }
         else if (nm == std::string("up") + std::to_string(k) + ".cropped") {
             src = u->ups[k]; C = UP_C[k]; level = 3 - k;
-            if (u->up_folded[k] || u->ups_split[k]) {   // not materialised (folded forward) or written split: the fp32 form is computed here
+            if (u->up_folded[k]) {            // not materialised by the folded forward: computed here from the resident coarse tensor
                 const int li_in = (k == 0) ? 9 : dec_layer(0, k - 1, 1);
                 const Level &ls = u->lv[MOD_LEVEL[layer_module(li_in)]], &lo = u->lv[3 - k];
                 const UpConv &U = u->up[k];
                 const ConvBN &Lin = u->cv[li_in];
                 const int64_t total = (int64_t)u->last_n * lo.M * (U.C / 4);
-                upsample_kernel<1><<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz,
+                upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz,
                                                                            k == 3 ? 1 : 0, U.w, U.bias, lo.D, lo.H, lo.W, u->ups[k], total, 0);
                 ISX_CHECK_LAUNCH();
-                u->ups_split[k] = false;
             }
         }
     }

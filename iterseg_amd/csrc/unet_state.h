@@ -93,8 +93,6 @@ struct UNetState {
     const int32_t *d_table = nullptr;   // device rows of the launch set in flight
     int last_n = 0;
     UpFoldPacks fold_store[ISX_MAX_LAYERS];   // cv[li].fold points here
-    bool pool_split[4] = {false};              // last forward: pool[k] / ups[i] hold the split layout (h2_split.h), not fp32
-    bool ups_split[ISX_MAX_UPS] = {false};
     bool up_folded[ISX_MAX_UPS] = {false};     // last forward: ups[i] was NOT materialised (its consumer ran the folded form)
     int arith[ISX_MAX_LAYERS] = {0};  // how each convolution ran in the last forward (ISX_ARITH_*, isx_unet_precision_report)
     struct TrainState *train = nullptr;
@@ -107,7 +105,7 @@ struct TrainState;
 // precision switch after fp32 steps never convolves with stale or zero packs.
 int train_ensure_bf16_packs(isx_ctx *ctx);
 
-struct Src { const float *p; const float *scale; const float *shift; int C; float bound = 0.f; bool presplit = false; };   // bound: max |activation| (split-f16 range check)
+struct Src { const float *p; const float *scale; const float *shift; int C; float bound = 0.f; };   // bound: max |activation| (split-f16 range check)
 
 // implicit-GEMM conv on the fp32 matrix cores (unet.hip); see ConvArgs there
 struct ConvArgs {
@@ -133,8 +131,6 @@ struct ConvArgs {
     int64_t Mout;          // voxels per chunk of the output tensor (D*H*W unless remap)
     int accum;             // 1: add to what `out` already holds (statistics over the sums)
     int nt_out;            // 1: streaming stores for the output tensor
-    int presplitA, presplitB;   // the source tensor holds, per voxel and 8-channel K stage, the 8 hi halves then the 8 lo halves of the
-                                // split (h2_split.h) -- same 32 bytes as 8 floats -- written by its producer: staged by copy
     // TX = 4 (folded tail layer only): source A is the COARSE input of a transposed convolution, up-sampled while it is staged:
     // slot voxel (z, y, x) reads (z, (y + uoff) >> 1, (x + uoff) >> 1) of a (D, uH, uW) tensor, BatchNorm + ReLU as usual, then
     // * upw[parity][c] + upb[c] (UpConv::w / bias) -- what upsample_kernel would have written to a 4x larger tensor

@@ -318,34 +318,6 @@ def test_tail_layer_up_sampling_on_read_is_bit_identical(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("forks", [None, (3, 2)])
-def test_producers_that_write_their_output_split_change_nothing(monkeypatch, forks):
-    """ISX_PRESPLIT (default on): max-pool and the transposed convolutions write their output in the split form of the
-    split-f16 convolution that reads it (h2_split.h) and that convolution stages it by copy: the same split of the same
-    values, so every feature map is identical bit for bit; the `d{k}` / `up{k}.cropped` taps (unet.py:317-354) are computed
-    in fp32 on demand."""
-    import numpy as np
-    from iterseg_amd import weights
-    from iterseg_amd.unet import UNet
-    out = 5 if forks is None else forks
-    sd = weights.generate_state_dict(5, out_channels=out)
-    nets = []
-    for v in ("1", "0"):
-        monkeypatch.setenv("ISX_PRESPLIT", v)
-        u = UNet(1, out, batch=2)
-        u.load_state_dict(sd)
-        nets.append(u)
-    for shape in [(4, 32, 32), (10, 80, 48), (6, 48, 112)]:
-        x = np.random.default_rng(9).random((1, 1) + shape, dtype=np.float32)
-        ya, yb = nets[0](x), nets[1](x)
-        assert np.array_equal(ya, yb)
-        for name in ("c1.conv0", "c4.conv0", "c5_0.conv0", "c7_0.conv0", "c8_0.conv0", "d0", "d3", "up0.cropped", "up2.cropped",
-                     "up3.cropped"):
-            assert np.array_equal(nets[0].tap(name), nets[1].tap(name)), name
-        assert np.array_equal(nets[0](x), ya)          # the taps put fp32 back into the buffers: the next forward is unaffected
-
-
-@pytest.mark.gpu
 def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
     """ISX_H2_NW8=2: every layer with Cout % 64 == 0 on 512-thread work-groups (eight waves, one weight slab, 256-voxel tiles
     -- conv_h2_kernel<64, 3, 1, PM, 8>); the K order of every output is unchanged."""
