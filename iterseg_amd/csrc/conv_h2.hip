@@ -50,7 +50,7 @@ __device__ unsigned long long h2_stamp[12];
 #define H2_ACC(i, d)
 #endif
 #ifndef ISX_H2_ABLATE
-#define ISX_H2_ABLATE 0          // development: 1 = no staging arithmetic, 2 = no matrix phase (timing experiments, wrong results)
+#define ISX_H2_ABLATE 0          // development: 1 = no staging arithmetic, 2 = no matrix phase, 3 = no halo loads (timing experiments, wrong results)
 #endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -257,6 +257,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 
     // named prefetch registers (arrays that live across the K loop end up in scratch)
     float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
+    if (ISX_H2_ABLATE == 3) { ra0 = rc0 = ra1 = rc1 = ra2 = rc2 = ra3 = rc3 = ra4 = rc4 = make_float4(0.5f, 0.25f, 0.125f, 1.f); }   // (no halo loads)
     uint4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rb8, rb9, rb10, rb11, rb12, rb13;
     bool has_affine = false, stage_up = false;
     float relu_lo = 0.f;                                      // ReLU floor of the stage: 0 behind a BatchNorm, -inf for a source without one
@@ -267,7 +268,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     int ld_C = 0;
     const uint4 *ld_wsrc = nullptr;
 #define H2_LOAD_A(k)                                                                              \
-    if constexpr (k < NA) {                                                                       \
+    if constexpr (k < NA && ISX_H2_ABLATE != 3) {                                                 \
         const float *pp = (UPA && stage_up) ? &ld_src[(int64_t)(gu##k & 0x0FFFFFFF) * ld_C]      \
                                             : &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];   \
         ra##k = *(const float4 *)pp;                                                              \
@@ -535,17 +536,39 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #undef H2_STORE_B
 
     // ---- epilogue: HI + LO / 2^11 + bias, store, per-tile BN partial sums (valid rows only) ------------------
-    // 16x16x32 core, plain output (no remap, no accumulation): the tile goes through LDS (free after the last stage) and leaves as
+    // Plain output (no remap, no accumulation): the tile goes through LDS (free after the last stage) and leaves as
     // whole rows -- BN consecutive channels of a voxel, one global_store_dwordx4 per lane, four rows per wave instruction --
     // instead of one dword per lane in 64-byte pieces with the address arithmetic of 32 stores per lane (15-24 k cycles per
     // work-group in the stamped build: as much as two K stages).  The BatchNorm partial sums are taken from the registers in
     // the same order as below, the stored values are the same.
     constexpr int TRS = BN + 4;                                    // floats per row of the LDS tile (16-byte rows, conflict-free both ways)
-    const bool t_out = CORE == 1 && !a.remap && !a.accum && a.store_cols % 4 == 0 &&
+    const bool t_out = !a.remap && !a.accum && a.store_cols % 4 == 0 &&
                        (size_t)(SLAB + (SPLIT ? 2 : 1) * a.slots_max) * 16 >= (size_t)ROWS * TRS * sizeof(float);
-    if (CORE == 1 && t_out) {
+    if (t_out) {
         float *T = (float *)smem4;
         __syncthreads();                                           // every wave has read its last fragments
+        if constexpr (CORE == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int ch = ntile * BN + 32 * j + nn;
+                const float bsv = a.bias[ch];
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = (wave * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        float v;
+                        if constexpr (SPLIT) v = fmaf(acc_lo[m][j][i], 1.f / H2_SCALE, acc_hi[m][j][i]) + bsv;
+                        else v = acc_hi[m][j][i] + bsv;
+                        T[row * TRS + 32 * j + nn] = v;
+                        if (rowinfo[row] >= 0) { s += v; q += v * v; }
+                    }
+                s += __shfl_xor(s, 32);
+                q += __shfl_xor(q, 32);
+                if (hh == 0) { red[(wave * BN + 32 * j + nn) * 2] = s; red[(wave * BN + 32 * j + nn) * 2 + 1] = q; }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NT16; ++j) {
             const int ch = ntile * BN + 16 * j + l16;
@@ -565,6 +588,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
             s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
             if (h4 == 0) { red[(wave * BN + 16 * j + l16) * 2] = s; red[(wave * BN + 16 * j + l16) * 2 + 1] = q; }
+        }
         }
         __syncthreads();
         constexpr int C4 = BN / 4;
