@@ -705,6 +705,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     conv_h2_body<BN, TX, MT, PM, 4, 1>(a);
 }
 
+// ... and on 512-thread work-groups (eight waves share one weight slab over 256 voxels)
+template <int PM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8_kernel(const ConvArgs a)
+{
+    conv_h2_body<64, 3, 1, PM, 8, 1>(a);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -896,6 +903,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, TX_, MT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_H2_ATTR16(64, 3, 1) ISX_H2_ATTR16(32, 3, 1) ISX_H2_ATTR16(32, 3, 2) ISX_H2_ATTR16(32, 1, 1) ISX_H2_ATTR16(32, 1, 2)
 #undef ISX_H2_ATTR16
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -916,7 +926,11 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     else if (core16 && BN == 64) ISX_H2_GO16(64, 3, 1);
     else if (core16 && mt == 2) ISX_H2_GO16(32, 3, 2);
     else if (core16) ISX_H2_GO16(32, 3, 1);
-    else if (nw8) {
+    else if (nw8 && ctx->tune.h2_core16) {
+        if (pm == 0) conv_h2c16nw8_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
+        else if (pm == 1) conv_h2c16nw8_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
+        else conv_h2c16nw8_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);
+    } else if (nw8) {
         if (pm == 0) conv_h2_kernel<64, 3, 1, 0, 8><<<grid, 512, lds, ctx->stream>>>(a);
         else if (pm == 1) conv_h2_kernel<64, 3, 1, 1, 8><<<grid, 512, lds, ctx->stream>>>(a);
         else conv_h2_kernel<64, 3, 1, 2, 8><<<grid, 512, lds, ctx->stream>>>(a);
