@@ -96,7 +96,7 @@ DTYPE = {"fp32": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumul
 # cannot collect PMC counters on itself, so it reads the summary that scratch/pmc_traffic_json.py wrote from those
 # passes (committed under profiles/ with the CSVs); without one, or if it was made for another kernel build, traffic
 # is null.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03d_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03e_pmc_traffic.json")
 TRAFFIC_ALGORITHMIC = 0.05725e9          # every activation read once + written once + weights, per chunk-launch
 
 
@@ -116,10 +116,10 @@ def conv_roofline(precision, mfma_flops, n_chunks, steps, ms_mfma, n_mfma, batch
     r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
          "traffic": traffic, "traffic_source": traffic_src, "traffic_algorithmic": TRAFFIC_ALGORITHMIC * batch,
          "kernel": ("conv_mfma_kernel (fp32 32x32x2 implicit-GEMM conv, 16 of 18 layers)" if precision == "fp32" else
-                    "conv_h2c16_kernel / conv_h2_kernel (split-f16 implicit-GEMM conv on v_mfma_f32_16x16x32_f16; the 9-tap tail layer on 32x32x16; 16 of 18 layers)"),
+                    "conv_h2c16nw8_kernel / conv_h2c16_kernel / conv_h2_kernel (split-f16 implicit-GEMM conv on v_mfma_f32_16x16x32_f16, matrix phase software-pipelined; the 9-tap tail layer on 32x32x16; 16 of 18 layers)"),
          "avg_launch_ms": ms_mfma / max(n_mfma, 1), "launches": n_mfma, "algorithmic_gflop_per_chunk": mfma_flops / 1e9}
     if precision in ("f16", "bf16"):
-        r["kernel"] = f"conv_h2c16_kernel / conv_h2_kernel ({precision} operands, one MFMA per product, 16 of 18 layers)"
+        r["kernel"] = f"conv_h2c16nw8_kernel / conv_h2c16_kernel / conv_h2_kernel ({precision} operands, one MFMA per product, 16 of 18 layers)"
         r["note"] = "reduced-precision mode: algorithmic FLOPs = executed MFMA FLOPs x 27/28"
     elif precision != "fp32":
         r["note"] = ("achieved = algorithmic (fp32-equivalent) FLOPs; the split executes 3 f16 MFMAs per product (x 28/27 tap "
