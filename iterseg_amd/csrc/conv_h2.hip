@@ -49,6 +49,9 @@ __device__ unsigned long long h2_stamp[12];
 #define H2_T(var)
 #define H2_ACC(i, d)
 #endif
+#ifndef ISX_H2_DEADLOADS
+#define ISX_H2_DEADLOADS 0      // development: 1 = issue the halo loads of slots beyond the tile too (as before)
+#endif
 #ifndef ISX_H2_ABLATE
 #define ISX_H2_ABLATE 0          // development: 1 = no staging arithmetic, 2 = no matrix phase, 3 = no halo loads (timing experiments, wrong results)
 #endif
@@ -267,8 +270,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     const float *ld_src = nullptr;
     int ld_C = 0;
     const uint4 *ld_wsrc = nullptr;
+    // a wave whose 64 slots of pass k all lie beyond the tile's S slots skips the load: the tile has 400-720 slots, the plan
+    // covers 1024-1536, and a dead load (every lane clamped to voxel 0) costs the load path as much as a live one -- they
+    // were 40-56 % of the halo load instructions
+    const int wbase = __builtin_amdgcn_readfirstlane(tid) & ~63;
 #define H2_LOAD_A(k)                                                                              \
-    if constexpr (k < NA && ISX_H2_ABLATE != 3) {                                                 \
+    if constexpr (k < NA && ISX_H2_ABLATE != 3) if (ISX_H2_DEADLOADS || THREADS * k + wbase < S) {  \
         const float *pp = (UPA && stage_up) ? &ld_src[(int64_t)(gu##k & 0x0FFFFFFF) * ld_C]      \
                                             : &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];   \
         ra##k = *(const float4 *)pp;                                                              \
