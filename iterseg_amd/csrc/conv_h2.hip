@@ -303,6 +303,10 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         relu_lo = has_affine ? 0.f : -__builtin_inff();                                           \
         ld_src = src + ((UPA && stage_up) ? (int64_t)b * Mup : (int64_t)b * M) * C + cc;          \
         ld_C = C;                                                                                 \
+        if (!UPA && (c0 < a.CA ? a.planarA : a.planarB)) {     /* [chunk][C/8][voxel][8]: this stage's plane */ \
+            ld_src = src + ((int64_t)b * (C >> 3) + (cc >> 3)) * M * 8;                           \
+            ld_C = 8;                                                                             \
+        }                                                                                         \
         ld_wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  /* packs keep the hi|lo stride in every mode */ \
     }
 #define H2_LOAD_STAGE(step_)                                                                      \
@@ -542,6 +546,11 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #undef H2_AFFL
 #undef H2_STORE_B
 
+    // element (voxel g, channel ch) of the output tensor, row-major or planar (ConvArgs::out_planar; store_cols = Cout then)
+    auto out_at = [&](int g, int ch) __attribute__((always_inline)) -> float * {
+        if (a.out_planar) return &a.out[(((int64_t)b * (a.store_cols >> 3) + (ch >> 3)) * Mout + g) * 8 + (ch & 7)];
+        return &a.out[((int64_t)b * Mout + g) * a.store_cols + ch];
+    };
     // ---- epilogue: HI + LO / 2^11 + bias, store, per-tile BN partial sums (valid rows only) ------------------
     // Plain output (no remap, no accumulation): the tile goes through LDS (free after the last stage) and leaves as
     // whole rows -- BN consecutive channels of a voxel, one global_store_dwordx4 per lane, four rows per wave instruction --
@@ -601,12 +610,15 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         constexpr int C4 = BN / 4;
 #pragma unroll
         for (int e0 = 0; e0 < ROWS * C4; e0 += THREADS) {
-            const int e = e0 + tid, row = e / C4, c4 = e % C4;
+            const int e = e0 + tid;
+            // row-major: 16 lanes per row (its BN channels); planar: two lanes per (row, plane), rows consecutive
+            const int row = a.out_planar ? (e >> 1) % ROWS : e / C4;
+            const int c4 = a.out_planar ? 2 * (e / (2 * ROWS)) + (e & 1) : e % C4;
             const int g = rowinfo[row];
             const int ch = ntile * BN + 4 * c4;
             if (g >= 0 && ch < a.store_cols) {
                 const f32x4c o = *(const f32x4c *)&T[row * TRS + 4 * c4];
-                f32x4c *op = (f32x4c *)&a.out[((int64_t)b * Mout + g) * a.store_cols + ch];
+                f32x4c *op = (f32x4c *)out_at(g, ch);
                 if (a.nt_out) __builtin_nontemporal_store(o, op); else *op = o;
             }
         }
@@ -630,7 +642,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                         float v;
                         if constexpr (SPLIT) v = fmaf(c_lo[m][j][i], 1.f / H2_SCALE, c_hi[m][j][i]) + bv;
                         else v = c_hi[m][j][i] + bv;
-                        float *op = &a.out[((int64_t)b * Mout + g) * a.store_cols + ch];
+                        float *op = out_at(g, ch);
                         if (a.accum) v += *op;
                         if (ch < a.store_cols) { if (a.nt_out) __builtin_nontemporal_store(v, op); else *op = v; }
                         s += v;
@@ -659,7 +671,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                     float v;
                     if constexpr (SPLIT) v = fmaf(acc_lo[m][j][i], 1.f / H2_SCALE, acc_hi[m][j][i]) + bv;
                     else v = acc_hi[m][j][i] + bv;
-                    float *op = &a.out[((int64_t)b * Mout + g) * a.store_cols + ch];
+                    float *op = out_at(g, ch);
                     if (a.accum) v += *op;
                     if (ch < a.store_cols) { if (a.nt_out) __builtin_nontemporal_store(v, op); else *op = v; }
                     s += v;
@@ -856,9 +868,12 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.remap = ex ? ex->remap : 0; a.rH = ex ? ex->rH : 0; a.rW = ex ? ex->rW : 0; a.rpy = ex ? ex->rpy : 0; a.rpx = ex ? ex->rpx : 0;
     a.roff = ex ? ex->roff : 0; a.Mout = ex ? ex->Mout : 0; a.accum = ex ? ex->accum : 0;
     a.nt_out = ctx->tune.h2_nt_out;
+    a.planarA = sa.planar ? 1 : 0; a.planarB = sb.planar ? 1 : 0; a.out_planar = ex ? ex->out_planar : 0;
     const int upa = ex ? ex->upA : 0;
     a.uH = ex ? ex->uH : 0; a.uW = ex ? ex->uW : 0; a.uoff = ex ? ex->uoff : 0; a.upw = ex ? ex->upw : nullptr; a.upb = ex ? ex->upb : nullptr;
     ISX_REQUIRE(!upa || (fold && a.upw && a.upb), "internal: up-sampling on read is built for the folded tail layer");
+    ISX_REQUIRE(!a.out_planar || (!fold && !a.remap && !a.accum && cout % 8 == 0), "internal: planar output of a plain convolution only");
+    ISX_REQUIRE(!(a.planarA && (upa || sa.C % 8)) && !(a.planarB && sb.C % 8), "internal: planar source with %d / %d channels", sa.C, sb.C);
     ISX_REQUIRE(!(tx2 && fold), "internal: class convolution and folded tail are different kernels");
     ISX_REQUIRE(!a.remap || a.Mout < (1 << 24), "internal: remapped output of %ld voxels per chunk", (long)a.Mout);
     a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;

@@ -168,6 +168,7 @@ isx_ctx *isx_ctx_create(int device)
     if (const char *e = getenv("ISX_WGRAD_WGS")) c->tune.wgrad_wgs = std::max(18, atoi(e));
     if (const char *e = getenv("ISX_THIN_WGRAD")) c->tune.thin_wgrad = atoi(e);
     if (const char *e = getenv("ISX_UP_ON_READ")) c->tune.up_on_read = atoi(e);
+    if (const char *e = getenv("ISX_PLANAR")) c->tune.planar = atoi(e);
     if (const char *e = getenv("ISX_H2_NW8")) c->tune.h2_nw8 = atoi(e);
     if (const char *e = getenv("ISX_H2_CORE16")) c->tune.h2_core16 = atoi(e);
     if (const char *e = getenv("ISX_UP_PER_SOURCE")) c->tune.up_per_source = atoi(e);

@@ -898,13 +898,13 @@ __global__ void final_kernel(const float *__restrict__ raw, const float *__restr
 // materialise an intermediate as NCDHW for isx_unet_tap_host (tests): mode 0 raw, 1 affine,
 // 2 affine+relu, 3 affine+sigmoid
 __global__ void tap_kernel(const float *__restrict__ src, const float *__restrict__ scale,
-                           const float *__restrict__ shift, int C, int64_t M, int mode, float *__restrict__ dst)
+                           const float *__restrict__ shift, int C, int64_t M, int mode, float *__restrict__ dst, int planar)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * C) return;
     int c = (int)(i % C);
     int64_t m = i / C;
-    float v = src[i];
+    float v = planar ? src[((int64_t)(c >> 3) * M + m) * 8 + (c & 7)] : src[i];      // (UNetState::planar)
     if (mode >= 1) v = fmaf(v, scale[c], shift[c]);
     if (mode == 2) v = fmaxf(v, 0.f);
     if (mode == 3) v = 1.f / (1.f + expf(-v));
@@ -1325,13 +1325,35 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     return ISX_OK;
 }
 
-static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb, const H2Extra *ex = nullptr)
+// Will run_conv give layer li (sources bounded by `bound`) to the reduced-precision kernel (conv_h2.hip)?  The conditions are
+// run_conv's own.  Only that kernel reads a planar source, so a producer may write one only if this says yes for its reader.
+static bool conv_takes_h2(isx_ctx *ctx, int li, const Level &l, int B, float bound)
+{
+    UNetState *u = ctx->unet;
+    const ConvBN &L = u->cv[li];
+    const bool bf = u->precision == ISX_PRECISION_BF16;
+    if (u->precision == ISX_PRECISION_FP32 || !(bf || bound < 6.0e4f)) return false;
+    if (use_mfma(L.cin, L.cout)) {
+        int t0, t1, t2, slots;
+        conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
+        const bool b64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64 || conv_h2_nw8(ctx->tune, l, L.cout, B);
+        const void *wh = bf ? (b64 ? L.w_bf_64 : L.w_bf_32) : (b64 ? L.w_h2_64 : L.w_h2_32);
+        return (!u->train || bf) && wh && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1;
+    }
+    if (use_fold(L.cin, L.cout)) return !u->train && (bf ? L.w_bf_32 : L.w_h2_32) && conv_mt(ctx->tune, l, u->wbatch, 32) == 1;
+    return false;
+}
+
+// want_planar: write raw[li] as [chunk][C/8][voxel][8] if this layer runs on the reduced-precision kernel (the caller has
+// checked that its only reader does: conv_takes_h2); UNetState::planar[li] records what was written.
+static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb, const H2Extra *ex = nullptr, bool want_planar = false)
 {
     UNetState *u = ctx->unet;
     ConvBN &L = u->cv[li];
     const int cin = sa.C + sb.C;
     int stat_tiles = L.tiles;                 // tiles per chunk in the partial-sum layout the conv kernel wrote
     ISX_REQUIRE(cin == L.cin, "internal: layer %s fed %d channels, expects %d", L.conv.c_str(), cin, L.cin);
+    u->planar[li] = false;
     if (use_mfma(L.cin, L.cout)) {
         ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
         int t0, t1, t2, slots;
@@ -1345,9 +1367,14 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
         const bool h2 = reduced && wh && in_range && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1;
         u->arith[li] = h2 ? ISX_ARITH_REDUCED : (reduced && wh && !in_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
-        if (h2)
-            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, 0, &stat_tiles, pm));
-        else
+        ISX_REQUIRE(h2 || !(sa.planar || sb.planar), "internal: a planar source reached a convolution that does not read it");
+        if (h2) {
+            H2Extra pl;
+            pl.out_planar = (want_planar && !ex && L.cout % 8 == 0) ? 1 : 0;
+            u->planar[li] = pl.out_planar != 0;
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, 0, &stat_tiles, pm,
+                                   pl.out_planar ? &pl : ex));
+        } else
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
     } else if (use_fold(L.cin, L.cout)) {
         // pass 1 on the matrix cores: 9 (dz,dy) taps, x-taps folded into 3*cout <= 16 output columns
@@ -1359,6 +1386,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         u->arith[li] = fold_h2 ? ISX_ARITH_REDUCED
                                : (u->precision != ISX_PRECISION_FP32 && !u->train && wf && !fold_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
         ISX_REQUIRE(fold_h2 || !ex, "internal: up-sampling on read needs the reduced-precision tail kernel");
+        ISX_REQUIRE(fold_h2 || !(sa.planar || sb.planar), "internal: a planar source reached a convolution that does not read it");
         if (fold_h2) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wf, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
@@ -1522,13 +1550,18 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
     // |relu(BN(x))| <= |gamma| * sqrt(M - 1) + |beta| for batch statistics over M values: the range check of the
     // split-f16 convolution (run_conv) uses these bounds, pooling keeps them, the up-convolution scales them
     auto bn_bound = [&](int li) { const ConvBN &L = u->cv[li]; return L.gmax * sqrtf((float)lv[MOD_LEVEL[layer_module(li)]].M) + L.bmax; };
-    auto act = [&](int li) { const ConvBN &L = u->cv[li]; return Src{u->raw[li], L.scale, L.shift, L.cout, bn_bound(li)}; };
+    auto act = [&](int li) { const ConvBN &L = u->cv[li]; return Src{u->raw[li], L.scale, L.shift, L.cout, bn_bound(li), u->planar[li]}; };
+    // the first convolution of a module has one reader, the second one: if that reader runs on the reduced-precision kernel the
+    // tensor between them is written planar (whole-line halo loads for every K stage of the reader)
+    auto planar_ok = [&](int li_reader, const Level &l, int li_writer) {
+        return ctx->tune.planar && !u->train && u->cv[li_writer].cout % 8 == 0 && conv_takes_h2(ctx, li_reader, l, B, bn_bound(li_writer));
+    };
     // ---- encoder ----------------------------------------------------------------------------
     for (int mi = 0; mi <= 4; ++mi) {
         const Level &l = lv[mi];
         Src in = (mi == 0) ? Src{u->x0, nullptr, nullptr, 1}
                            : Src{u->pool[mi - 1], nullptr, nullptr, MOD_COUT[mi - 1], bn_bound(2 * (mi - 1) + 1)};
-        ISX_TRY(run_conv(ctx, 2 * mi, l, B, in, none));
+        ISX_TRY(run_conv(ctx, 2 * mi, l, B, in, none, nullptr, planar_ok(2 * mi + 1, l, 2 * mi)));
         ISX_TRY(run_conv(ctx, 2 * mi + 1, l, B, act(2 * mi), none));
         if (mi < 4) {
             ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
@@ -1598,7 +1631,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                                                                         lo.H, lo.W, upo, total, 1 /* streaming stores: the 5.4 GB output is far larger than L2 */);
                 ISX_CHECK_LAUNCH();
             }
-            ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound}, act(skip_li)));
+            ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound}, act(skip_li), nullptr, planar_ok(l1, lo, l0)));
             ISX_TRY(run_conv(ctx, l1, lo, B, act(l0), none));
         }
         {
@@ -1802,13 +1835,14 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
     std::string nm(name);
     const float *src = nullptr, *sc = nullptr, *sh = nullptr;
     int C = 0, mode = 0, level = 0;
+    bool tap_planar = false;
     for (int li = 0; li < u->nlayers && !src; li += 2) {        // module names follow the state dict: c0..c4, c5_0..c8_0, c5_1..c8_1
         const int mi = layer_module(li);
         const std::string m = u->cv[li].conv.substr(0, u->cv[li].conv.find('.'));
         for (int j = 0; j < 2; ++j) {
             const ConvBN &L = u->cv[li + j];
-            if (nm == L.conv) { src = u->raw[li + j]; C = L.cout; mode = 0; level = MOD_LEVEL[mi]; }
-            else if (nm == L.bn) { src = u->raw[li + j]; sc = L.scale; sh = L.shift; C = L.cout; mode = 1; level = MOD_LEVEL[mi]; }
+            if (nm == L.conv) { src = u->raw[li + j]; C = L.cout; mode = 0; level = MOD_LEVEL[mi]; tap_planar = u->planar[li + j]; }
+            else if (nm == L.bn) { src = u->raw[li + j]; sc = L.scale; sh = L.shift; C = L.cout; mode = 1; level = MOD_LEVEL[mi]; tap_planar = u->planar[li + j]; }
         }
         if (nm == m) {
             const ConvBN &L = u->cv[li + 1];
@@ -1836,7 +1870,7 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
     ISX_REQUIRE(cap_elems >= l.M * C, "tap buffer too small: need %ld floats", (long)(l.M * C));
     Scratch<float> tmp(ctx, (size_t)l.M * C);
     if (!tmp.ok()) return ISX_ERR_NOMEM;
-    tap_kernel<<<cdiv(l.M * C, 256), 256, 0, ctx->stream>>>(src, sc, sh, C, l.M, mode, tmp.p);     // chunk 0 of the set
+    tap_kernel<<<cdiv(l.M * C, 256), 256, 0, ctx->stream>>>(src, sc, sh, C, l.M, mode, tmp.p, tap_planar ? 1 : 0);     // chunk 0 of the set
     ISX_CHECK_LAUNCH();
     ISX_HIP(hipMemcpyAsync(out, tmp.p, (size_t)l.M * C * 4, hipMemcpyDeviceToHost, ctx->stream));
     ISX_HIP(hipStreamSynchronize(ctx->stream));

@@ -94,6 +94,7 @@ struct UNetState {
     int last_n = 0;
     UpFoldPacks fold_store[ISX_MAX_LAYERS];   // cv[li].fold points here
     bool up_folded[ISX_MAX_UPS] = {false};     // last forward: ups[i] was NOT materialised (its consumer ran the folded form)
+    bool planar[ISX_MAX_LAYERS] = {false};   // last forward: raw[li] is stored planar (first convolution of a module whose only reader is the second)
     int arith[ISX_MAX_LAYERS] = {0};  // how each convolution ran in the last forward (ISX_ARITH_*, isx_unet_precision_report)
     struct TrainState *train = nullptr;
 };
@@ -105,7 +106,7 @@ struct TrainState;
 // precision switch after fp32 steps never convolves with stale or zero packs.
 int train_ensure_bf16_packs(isx_ctx *ctx);
 
-struct Src { const float *p; const float *scale; const float *shift; int C; float bound = 0.f; };   // bound: max |activation| (split-f16 range check)
+struct Src { const float *p; const float *scale; const float *shift; int C; float bound = 0.f; bool planar = false; };   // bound: max |activation| (split-f16 range check)
 
 // implicit-GEMM conv on the fp32 matrix cores (unet.hip); see ConvArgs there
 struct ConvArgs {
@@ -131,6 +132,9 @@ struct ConvArgs {
     int64_t Mout;          // voxels per chunk of the output tensor (D*H*W unless remap)
     int accum;             // 1: add to what `out` already holds (statistics over the sums)
     int nt_out;            // 1: streaming stores for the output tensor
+    // planar tensors: [chunk][C / 8][voxel][8 channels] instead of [chunk][voxel][C] -- a K stage's 32 bytes of consecutive voxels
+    // are contiguous, so a halo load instruction reads whole lines instead of 64 pieces of 16 bytes (UNetState::planar)
+    int planarA, planarB, out_planar;
     // TX = 4 (folded tail layer only): source A is the COARSE input of a transposed convolution, up-sampled while it is staged:
     // slot voxel (z, y, x) reads (z, (y + uoff) >> 1, (x + uoff) >> 1) of a (D, uH, uW) tensor, BatchNorm + ReLU as usual, then
     // * upw[parity][c] + upb[c] (UpConv::w / bias) -- what upsample_kernel would have written to a 4x larger tensor
@@ -139,6 +143,7 @@ struct ConvArgs {
 };
 
 struct H2Extra {           // optional arguments of launch_conv_h2 (see ConvArgs)
+    int out_planar = 0;
     int tx2 = 0, oy[2] = {0, 0}, ox[2] = {0, 0};
     int remap = 0, rH = 0, rW = 0, rpy = 0, rpx = 0, roff = 0;
     int64_t Mout = 0;

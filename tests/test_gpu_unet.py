@@ -318,6 +318,34 @@ def test_tail_layer_up_sampling_on_read_is_bit_identical(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("out", [5, (3, 2)])
+@pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
+def test_planar_intermediate_tensors_change_nothing(monkeypatch, out, precision):
+    """ISX_PLANAR (default on): the first convolution of every module writes its output as [C/8][voxel][8] for the second one,
+    whose halo loads then read whole lines.  Only the memory layout changes: feature maps and every tap
+    (the `cX.conv0` / `cX.batch0` taps are read back through the planar index) are identical bit for bit."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(7, out_channels=out)
+    nets = []
+    for v in ("1", "0"):
+        monkeypatch.setenv("ISX_PLANAR", v)
+        u = UNet(1, out, batch=2, precision=precision)
+        u.load_state_dict(sd)
+        nets.append(u)
+    for shape in [(4, 32, 32), (10, 80, 48), (6, 48, 112), (10, 256, 256)]:
+        x = np.random.default_rng(11).random((1, 1) + shape, dtype=np.float32)
+        ya, yb = nets[0](x), nets[1](x)
+        assert np.array_equal(ya, yb), shape
+        if np.prod(shape) > 100000:        # (the tap buffer of the wrapper holds 2^24 floats: the full-size chunk compares outputs only)
+            continue
+        for name in ("c0.conv0", "c1.conv0", "c1.batch0", "c2.conv0", "c4.conv0", "c4.conv1", "c5_0.conv0", "c6_0.batch0", "c7_0.conv0",
+                     "c8_0.conv0", "c8_0.batch0", "c8_0.conv1", "d1", "up2.cropped"):
+            assert np.array_equal(nets[0].tap(name), nets[1].tap(name)), (shape, name)
+
+
+@pytest.mark.gpu
 def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
     """ISX_H2_NW8=2: every layer with Cout % 64 == 0 on 512-thread work-groups (eight waves, one weight slab, 256-voxel tiles
     -- conv_h2_kernel<64, 3, 1, PM, 8>); the K order of every output is unchanged."""
