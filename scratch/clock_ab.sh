@@ -1,8 +1,10 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python -m pytest tests/test_gpu_unet.py -x -q -k "planar" > gpurun_out/ab_test.log 2>&1
-for v in 0 1 0 1; do
-  ISX_PLANAR=$v timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-extra-legs --no-cpu-baseline > gpurun_out/ab_t.json 2> gpurun_out/ab_t.err
+for v in late early late early; do
+  cp scratch/libs/lib_${v}.so iterseg_amd/libitersegx.so
+  timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-extra-legs --no-cpu-baseline > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
   python -c "
-import json; d=json.loads(open('gpurun_out/ab_t.json').read().strip().splitlines()[-1]); print('planar=$v', d['ms_per_step'], d['roofline']['avg_launch_ms'])" >> gpurun_out/ab_summary.txt
+import json; d=json.loads(open('gpurun_out/ab_$v.json').read().strip().splitlines()[-1]); print('$v', d['ms_per_step'], d['roofline']['avg_launch_ms'])" >> gpurun_out/ab_summary.txt
 done
+cp scratch/libs/lib_early.so iterseg_amd/libitersegx.so
+timeout -k 10 400 python -m pytest tests/test_gpu_unet.py -x -q > gpurun_out/ab_test.log 2>&1
