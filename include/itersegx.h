@@ -218,23 +218,27 @@ int isx_training_labels(isx_ctx *ctx, const int32_t *labels, const int64_t shape
 
 /* Patch sampler of the training data (src/iterseg/train_io.py:224-275, get_image_chunks).  `vol` is a device (Z, Y, X)
  * float32 image, `starts` a HOST list of n (z, y, x) crop offsets, `shape` the crop shape.
- * isx_patch_stats: for every candidate crop the sum (float64) and the maximum of its voxels into the HOST arrays sum_out /
- * max_out -- the reference's brightness test is  x.mean() / x.max() > min_brightness_prop  (train_io.py:249-250); the random
+ * isx_patch_stats: for every candidate crop the sum (float64), the maximum and (optionally) the minimum of its voxels into the
+ * HOST arrays sum_out / max_out / min_out (the minimum decides skimage's clip range in augment_intensity, augment.py:66) -- the reference's brightness test is  x.mean() / x.max() > min_brightness_prop  (train_io.py:249-250); the random
  * draws stay with the caller so that the same draws pick the same crops.
  * isx_patch_gather: the crops themselves, `out` = device [n][shape] of 4-byte elements (float32 image or int32 labels --
  * the reference slices the image, the ground truth and every training-label channel with the same slices, :255,:297-308). */
 int isx_patch_stats(isx_ctx *ctx, const float *vol, const int64_t dims[3], const int32_t *starts, int n,
-                    const int64_t shape[3], double *sum_out, float *max_out);
+                    const int64_t shape[3], double *sum_out, float *max_out, float *min_out /* may be NULL */);
 int isx_patch_gather(isx_ctx *ctx, const void *vol, const int64_t dims[3], const int32_t *starts, int n,
                      const int64_t shape[3], void *out);
 
-/* One array of the reference's augment_images (src/iterseg/augment.py:8-118) in one pass, device (C, Z, Y, X) float32 in -> out:
- * intensity != 0 (the image, augment_intensity :36-73): v * gain + shift with gain = scale / image.max(), then the noise the
- * caller drew (noise_mode 0 none, 1 "gaussian" v + g, 2 "speckle" v + v * g; `noise` = device array of the input's shape),
- * clipped to [0, 1]; then augment_order (:76-118): mirror_axis 0 none / 1 y / 2 x, transpose != 0 swaps y and x (out is
- * (C, Z, X, Y) then).  The image, every label set and the ground truth of a chunk take the same mirror / transpose. */
-int isx_augment_array(isx_ctx *ctx, const float *in, const int64_t shape[4], int intensity, float gain, float shift,
-                      int noise_mode, const float *noise, int mirror_axis, int transpose, float *out);
+/* One array of the reference's augment_images (src/iterseg/augment.py:8-118) in one pass, device 4-D array (C, Z, Y, X) of
+ * 4-byte elements in -> out (3-D arrays: C = 1):
+ * intensity != 0 (the image, float32; augment_intensity :36-73): v * gain + shift with gain = scale / image.max(), then the noise
+ * the caller drew (noise_mode 0 none, 1 additive v + g, 2 "speckle" v + v * g; `noise` = device float32 array of the INPUT's
+ * shape), clipped to [clip_low, 1]: clip_low = 0, or -1 where skimage's random_noise (called at augment.py:66) would see a
+ * negative value and keep the signed range; without noise upstream clips to [0, 1] (:70-71).
+ * Then augment_order (:76-118): mirror along input axis mirror_axis (-1: none), then np.transpose with out axis k = in axis
+ * perm[k] (NULL: identity).  intensity == 0 moves raw 32-bit words (labels and ground truth keep every bit).  The image, every
+ * label set and the ground truth of a chunk take the same mirror / permutation. */
+int isx_augment_array(isx_ctx *ctx, const void *in, const int64_t shape[4], int intensity, float gain, float shift,
+                      int noise_mode, const float *noise, float clip_low, int mirror_axis, const int32_t *perm, void *out);
 
 /* ---------------------------------------------------------------------------------- *
  * Segmentation assessment -- src/iterseg/metrics.py (the pinnable part). *

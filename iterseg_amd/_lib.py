@@ -57,9 +57,10 @@ SIGNATURES = {
     "isx_train_refresh_weights": (C.c_int, [_vp]),
     "isx_train_tap_host": (C.c_int, [_vp, C.c_char_p, _vp, _i64, _i64p]),
     "isx_training_labels": (C.c_int, [_vp, _vp, _i64p, C.c_int, _i32p, _i32p, _i32p, C.POINTER(C.c_double), _vp]),
-    "isx_patch_stats": (C.c_int, [_vp, _vp, _i64p, _i32p, C.c_int, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_float)]),
+    "isx_patch_stats": (C.c_int, [_vp, _vp, _i64p, _i32p, C.c_int, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_float),
+                                  C.POINTER(C.c_float)]),
     "isx_patch_gather": (C.c_int, [_vp, _vp, _i64p, _i32p, C.c_int, _i64p, _vp]),
-    "isx_augment_array": (C.c_int, [_vp, _vp, _i64p, C.c_int, C.c_float, C.c_float, C.c_int, _vp, C.c_int, C.c_int, _vp]),
+    "isx_augment_array": (C.c_int, [_vp, _vp, _i64p, C.c_int, C.c_float, C.c_float, C.c_int, _vp, C.c_float, C.c_int, _i32p, _vp]),
     "isx_label_contingency": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64p]),
     "isx_ws_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
     "isx_comm_unique_id": (C.c_int, [_vp]),

@@ -65,9 +65,14 @@ def get_image_chunks(image, shape=(10, 256, 256), n=25, min_brightness_prop=0.3,
         # train_io.py:240-245 -- the upper bound excludes the last two positions, as upstream
         ri = [int(rng.randint(0, im.shape[j] - dim - 1)) for j, dim in enumerate(shape)]
         st = (C.c_int32 * 3)(*ri)
-        _lib.check(ctx.lib.isx_patch_stats(ctx.handle, C.c_void_p(im.data_ptr()), dims, st, 1, cshape, s_out, m_out))
+        _lib.check(ctx.lib.isx_patch_stats(ctx.handle, C.c_void_p(im.data_ptr()), dims, st, 1, cshape, s_out, m_out, None))
         mx = float(m_out[0])
         mbrightprop = (s_out[0] / nvox) / mx if mx != 0.0 else float('nan')      # x.mean() / x.max(): nan never passes
+        if abs(mbrightprop - min_brightness_prop) <= 1e-5 * abs(min_brightness_prop):
+            # within rounding of the threshold: upstream's quotient is numpy's pairwise float32 mean over the crop -- decide
+            # on exactly that arithmetic (one crop back to the host, once in ~10^5 candidates)
+            x = _gather(im, [tuple(slice(r, r + d) for r, d in zip(ri, shape))], shape)[0].cpu().numpy()
+            mbrightprop = x.mean() / x.max()
         if mbrightprop > min_brightness_prop:
             slices.append(tuple(slice(r, r + d) for r, d in zip(ri, shape)))
             starts.append(ri)
