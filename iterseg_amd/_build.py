@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libitersegx.so")
 
-SOURCES = ["isx_ctx.hip", "prims.hip", "ws.hip", "unet.hip", "conv_h2.hip", "host_pipe.hip", "train.hip", "labels.hip", "train_io.hip", "metrics.hip", "comm.hip"]
+SOURCES = ["isx_ctx.hip", "prims.hip", "ws.hip", "unet.hip", "conv_h2.hip", "conv_tail.hip", "host_pipe.hip", "train.hip", "labels.hip", "train_io.hip", "metrics.hip", "comm.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"]

@@ -1,0 +1,338 @@
+// conv_tail.hip -- the thin tail convolution (c8.conv0: Cin >= 32 -> <= 5 channels, 3x3x3) in ONE pass on the f16 matrix cores.
+//
+// Replaces the same reference operator as conv_h2_kernel<32, 1, ...> + tail_combine_kernel (nn.Conv3d inside
+// ConvModule.forward, src/iterseg/unet.py:63-79,91-106, for the module c8_0 built at unet.py:196-210) when the context's
+// precision is a reduced one; arithmetic and operand split exactly as conv_h2.hip (x = x_h + x_l / 2^11, three
+// v_mfma_f32_16x16x32_f16 per product block, fp32 accumulators; PM = 1 / 2: plain f16 / bf16 operands).
+//
+// Why its own kernel.  The layer has 3 % of the network's FLOPs and took 10.7 % of the convolution time (r03: 9.1 ms per
+// 64-chunk launch set + 0.57 ms for the combine): on the generic 128-voxel tile it is bound by its halo gather (halo = 3.1 x
+// the tile, 3 900-5 200 cycles of load issue per K stage against 1 100 of matrix work), and it wrote and
+// re-read a [voxel][16] partial-sum tensor (84 MB per chunk) for the x-shift.  Here:
+//   * the x-taps stay folded into the N tile (column = dx * nout + o, 15 of 16 columns), so the matrix pass has 9 (dz, dy)
+//     taps = 3 tap quads of the 16x16x32 instruction, and the halo has NO y/z-diagonal x-neighbours to fetch;
+//   * a work-group owns ALL z planes of a 4 (y) x 30 (x) column: 1 200 output voxels on a halo of 12 x 6 x 32 slots
+//     (1.92 x the tile), the 32 x-positions of a halo row being the 30 outputs + the two positions whose partial sums the
+//     x-shift needs -- the shift happens in LDS in the epilogue and the partial sums never reach memory;
+//   * the WHOLE weight tensor (Cin/8 stages x 12 tap slots x 16 columns x hi|lo = 48 KB at Cin = 64) is resident in LDS for
+//     the life of the work-group: a K stage stages only its halo tile (72 KB);
+//   * eight waves x ten 16-row accumulator tiles (80 registers), B fragments of a stage read once (6 reads) for 90 MFMAs.
+// BatchNorm partial sums: per work-group, fixed summation order (deterministic), reduced by bn_finalize_kernel like every
+// other layer's.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "unet_state.h"
+#include "h2_split.h"
+
+namespace isx {
+
+typedef _Float16 t_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 t_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float t_f32x4 __attribute__((ext_vector_type(4)));
+
+struct TailArgs {
+    const float *srcA, *scaleA, *shiftA;   // channels [0, CA): [B][M][CA] (or planar [B][CA/8][M][8]) + optional BN+ReLU
+    const float *srcB, *scaleB, *shiftB;   // channels [CA, CA+CB)
+    int CA, CB, planarA, planarB;
+    const uint4 *w;        // pack_h2_fold_weights: [Cin/8][hi|lo][12 tap slots][32 columns][8 channels] halves (columns 0..15 read)
+    const float *bias;     // [nout]
+    float *out;            // [B][M][nout] raw convolution output (+ bias)
+    float *psum, *psq;     // [B][tiles][nout]
+    int D, H, W, nout;
+    int nzt, nyt, nxt;     // tiles per chunk = nzt * nyt * nxt
+    int xcd_remap;
+};
+
+static constexpr int TL_TZ = 10, TL_TY = 4, TL_TX = 30, TL_PX = 32;          // output tile; PX = TX + 2 positions per halo row
+static constexpr int TL_HY = TL_TY + 2, TL_HZ = TL_TZ + 2;
+static constexpr int TL_SLOTS = TL_HZ * TL_HY * TL_PX;                       // 2304 halo slots
+static constexpr int TL_THREADS = 512, TL_NA = (TL_SLOTS + TL_THREADS - 1) / TL_THREADS;      // 5 slot passes (the last one half full)
+static constexpr int TL_ROWS = TL_TZ * TL_TY * TL_PX;                        // 1280 partial-sum positions = 80 row tiles of 16
+static constexpr int TL_MT = TL_ROWS / 16 / 8;                               // 10 row tiles per wave
+static constexpr int TL_PSTRIDE = 20;                                        // floats per position of the LDS partial-sum tile (conflict-free C stores)
+
+__device__ __forceinline__ uint32_t tl_pack_f16_rn(float x, float y)
+{
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    union { h2v v; uint32_t u; } H;
+    H.v[0] = (_Float16)__builtin_amdgcn_fmed3f(x, -H2_MAX, H2_MAX);
+    H.v[1] = (_Float16)__builtin_amdgcn_fmed3f(y, -H2_MAX, H2_MAX);
+    return H.u;
+}
+__device__ __forceinline__ uint32_t tl_pack_bf16_rn(float x, float y)
+{
+    uint32_t a = __float_as_uint(x), b = __float_as_uint(y);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+
+template <int PM>
+__global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void conv_tail_kernel(const TailArgs a)
+{
+    constexpr bool SPLIT = PM == 0;
+    extern __shared__ __attribute__((aligned(16))) uint4 tl_smem[];
+    const int nsteps = (a.CA + a.CB) >> 3;
+    // LDS: [halo hi: SLOTS][halo lo: SLOTS (split only)][weights: nsteps x (hi|lo) x 12 x 16]; the epilogue's partial-sum tile
+    // (ROWS x PSTRIDE floats) and the reduction scratch alias all of it after the last stage
+    uint4 *AsH = tl_smem;
+    uint4 *AsL = AsH + TL_SLOTS;
+    uint4 *Bs = AsH + (SPLIT ? 2 : 1) * TL_SLOTS;
+    constexpr int BH = 12 * 16;                                 // uint4 per half of a stage's weights
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, h4 = lane >> 4;
+    int lin = blockIdx.x;
+    if (a.xcd_remap) {
+        const int per = gridDim.x >> 3, main = per << 3;
+        if (lin < main) lin = (lin & 7) * per + (lin >> 3);
+    }
+    const int tiles_per_chunk = a.nzt * a.nyt * a.nxt;
+    const int b = lin / tiles_per_chunk, tile = lin % tiles_per_chunk;
+    const int xt = tile % a.nxt, yt = (tile / a.nxt) % a.nyt, zt = tile / (a.nxt * a.nyt);
+    const int z0 = zt * TL_TZ, y0 = yt * TL_TY, x0 = xt * TL_TX;
+    const int D = a.D, H = a.H, W = a.W;
+    const int64_t M = (int64_t)D * H * W;
+
+    // ---- the whole weight tensor -> LDS (columns 0..15 of the 32-column pack) ------------------------------------------
+    for (int e = tid; e < nsteps * 2 * BH; e += TL_THREADS) {
+        const int st = e / (2 * BH), r = e % (2 * BH), half = r / BH, tc = r % BH;       // tc = tap slot * 16 + column
+        if (SPLIT || half == 0) Bs[e] = a.w[((int64_t)(st * 2 + half) * 12 + (tc >> 4)) * 32 + (tc & 15)];
+    }
+
+    // ---- halo slots of this thread: voxel index, -1 outside the volume (zero padding), -2 beyond the slot list -----------
+    auto slot_voxel = [&](int s) __attribute__((always_inline)) -> int {
+        if (s >= TL_SLOTS) return -2;
+        const int hz = s / (TL_HY * TL_PX), hy = (s / TL_PX) % TL_HY, hx = s % TL_PX;
+        const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+        return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
+    };
+    const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + TL_THREADS), gv2 = slot_voxel(tid + 2 * TL_THREADS),
+              gv3 = slot_voxel(tid + 3 * TL_THREADS), gv4 = slot_voxel(tid + 4 * TL_THREADS);
+
+    // ---- accumulators: row tile m of this wave = halo row zy = 5 * wave + m / 2 (z-local * TY + y-local), x half m & 1 ----
+    t_f32x4 c_hi[TL_MT], c_lo[SPLIT ? TL_MT : 1];
+    int aslot[TL_MT];
+#pragma unroll
+    for (int m = 0; m < TL_MT; ++m) {
+        c_hi[m] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT) c_lo[m] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+        const int zy = 5 * wave + (m >> 1), zl = zy / TL_TY, yl = zy % TL_TY;
+        aslot[m] = ((zl + 1) * TL_HY + (yl + 1)) * TL_PX + 16 * (m & 1) + l16;
+    }
+    // tap quad q, lane group h4 -> tap t = 4 q + h4 (dz = t / 3, dy = t % 3; slots 9..11 carry zero weights: any valid slot)
+    int toq[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        int t = 4 * q + h4;
+        if (t > 8) t = 8;
+        toq[q] = (t / 3 - 1) * (TL_HY * TL_PX) + (t % 3 - 1) * TL_PX;
+    }
+
+    float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
+    float relu_lo = 0.f;
+    const float *ld_src = nullptr;
+    int ld_C = 0;
+#define TL_LOAD_HEAD(step_)                                                                       \
+    {                                                                                             \
+        const int c0 = (step_) << 3;                                                              \
+        const float *src, *sc, *sh;                                                               \
+        int C, cc, planar;                                                                        \
+        if (c0 < a.CA) { src = a.srcA; sc = a.scaleA; sh = a.shiftA; C = a.CA; cc = c0; planar = a.planarA; } \
+        else { src = a.srcB; sc = a.scaleB; sh = a.shiftB; C = a.CB; cc = c0 - a.CA; planar = a.planarB; }    \
+        if (sc) {                                                                                 \
+            const int64_t so = (int64_t)b * C + cc;                                               \
+            vs0 = *(const float4 *)&sc[so]; vs1 = *(const float4 *)&sc[so + 4];                   \
+            vh0 = *(const float4 *)&sh[so]; vh1 = *(const float4 *)&sh[so + 4];                   \
+            relu_lo = 0.f;                                                                        \
+        } else {                      /* a source without BatchNorm: x * 1 + 0, max(x, -inf) are exact */ \
+            vs0 = make_float4(1.f, 1.f, 1.f, 1.f); vs1 = vs0;                                     \
+            vh0 = make_float4(0.f, 0.f, 0.f, 0.f); vh1 = vh0;                                     \
+            relu_lo = -__builtin_inff();                                                          \
+        }                                                                                         \
+        if (planar) { ld_src = src + ((int64_t)b * (C >> 3) + (cc >> 3)) * M * 8; ld_C = 8; }     \
+        else { ld_src = src + (int64_t)b * M * C + cc; ld_C = C; }                                \
+    }
+#define TL_LOAD_A(k)                                                                              \
+    if (gv##k != -2) {                                                                            \
+        const float *pp = &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];                       \
+        ra##k = *(const float4 *)pp;                                                              \
+        rc##k = *(const float4 *)(pp + 4);                                                        \
+    }
+#define TL_AFFL(v, s_, h_)                                                                        \
+    v.x = fmaxf(fmaf(v.x, s_.x, h_.x), relu_lo); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), relu_lo);     \
+    v.z = fmaxf(fmaf(v.z, s_.z, h_.z), relu_lo); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), relu_lo);
+#define TL_STORE_A(k)                                                                             \
+    {                                                                                             \
+        float4 v = ra##k, w = rc##k;                                                              \
+        TL_AFFL(v, vs0, vh0) TL_AFFL(w, vs1, vh1)                                                 \
+        uint4 hi, lo = make_uint4(0u, 0u, 0u, 0u);                                                \
+        if constexpr (SPLIT) split8(v, w, hi, lo);                                                \
+        else if constexpr (PM == 1) { hi.x = tl_pack_f16_rn(v.x, v.y); hi.y = tl_pack_f16_rn(v.z, v.w); hi.z = tl_pack_f16_rn(w.x, w.y); hi.w = tl_pack_f16_rn(w.z, w.w); } \
+        else { hi.x = tl_pack_bf16_rn(v.x, v.y); hi.y = tl_pack_bf16_rn(v.z, v.w); hi.z = tl_pack_bf16_rn(w.x, w.y); hi.w = tl_pack_bf16_rn(w.z, w.w); } \
+        const bool dead = gv##k < 0;                                                              \
+        hi.x = dead ? 0u : hi.x; hi.y = dead ? 0u : hi.y; hi.z = dead ? 0u : hi.z; hi.w = dead ? 0u : hi.w; \
+        if constexpr (SPLIT) { lo.x = dead ? 0u : lo.x; lo.y = dead ? 0u : lo.y; lo.z = dead ? 0u : lo.z; lo.w = dead ? 0u : lo.w; } \
+        if (gv##k != -2) {                                                                        \
+            AsH[tid + TL_THREADS * k] = hi;                                                       \
+            if constexpr (SPLIT) AsL[tid + TL_THREADS * k] = lo;                                  \
+        }                                                                                         \
+    }
+
+    TL_LOAD_HEAD(0)
+    TL_LOAD_A(0) TL_LOAD_A(1) TL_LOAD_A(2) TL_LOAD_A(3) TL_LOAD_A(4)
+    union FR { uint4 u; t_f16x8 v; t_bf16x8 w; };
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();                                        // every wave has read the previous stage's fragments
+        TL_STORE_A(0) TL_STORE_A(1) TL_STORE_A(2) TL_STORE_A(3) TL_STORE_A(4)
+        __syncthreads();
+        const bool more = step + 1 < nsteps;
+        if (more) TL_LOAD_HEAD(step + 1)
+        const uint4 *bsh = Bs + (step * 2) * BH + h4 * 16 + l16, *bsl = bsh + BH;
+        FR bh[3], bl[SPLIT ? 3 : 1];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bh[q].u = bsh[(4 * q) * 16];
+            if constexpr (SPLIT) bl[q].u = bsl[(4 * q) * 16];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int m = 0; m < TL_MT; ++m) {
+                FR ah, al;
+                ah.u = AsH[aslot[m] + toq[q]];
+                if constexpr (SPLIT) al.u = AsL[aslot[m] + toq[q]];
+                // the next stage's global loads go out between the matrix instructions, two tiles apart
+                if (more && q == 0) {
+                    if (m == 0) { TL_LOAD_A(0) } else if (m == 2) { TL_LOAD_A(1) } else if (m == 4) { TL_LOAD_A(2) }
+                    else if (m == 6) { TL_LOAD_A(3) } else if (m == 8) { TL_LOAD_A(4) }
+                }
+                if constexpr (SPLIT) {
+                    c_hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[q].v, c_hi[m], 0, 0, 0);
+                    c_lo[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[q].v, c_lo[m], 0, 0, 0);
+                    c_lo[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[q].v, c_lo[m], 0, 0, 0);
+                } else if constexpr (PM == 1) {
+                    c_hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[q].v, c_hi[m], 0, 0, 0);
+                } else {
+                    c_hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.w, bh[q].w, c_hi[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef TL_LOAD_HEAD
+#undef TL_LOAD_A
+#undef TL_AFFL
+#undef TL_STORE_A
+
+    // ---- epilogue: partial sums -> LDS, x-shift + bias, stores, BatchNorm partial sums -----------------------------------
+    // C/D of 16x16: column = lane & 15, row = 4 * (lane >> 4) + register.  Position p = (zy * 32 + px) holds its 16 columns
+    // at P[p * PSTRIDE ..]; the four lane groups of a store land 80 floats apart = 16 banks: conflict-free.
+    float *P = (float *)tl_smem;
+    __syncthreads();                                            // the last fragments are read: the halo / weight LDS is free
+#pragma unroll
+    for (int m = 0; m < TL_MT; ++m) {
+        const int zy = 5 * wave + (m >> 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = zy * TL_PX + 16 * (m & 1) + 4 * h4 + i;
+            float v;
+            if constexpr (SPLIT) v = fmaf(c_lo[m][i], 1.f / H2_SCALE, c_hi[m][i]);
+            else v = c_hi[m][i];
+            P[p * TL_PSTRIDE + l16] = v;
+        }
+    }
+    __syncthreads();
+    // out[z][y][x][o] = bias[o] + sum over dx of P[(z, y, px = x - x0 + dx)][dx * nout + o]  (px = 0 is x0 - 1: a position
+    // outside the volume staged zeros, so its partial sums are the convolution's zero padding).  510 threads walk the
+    // (zy, x, o) elements with a stride of 510 = 0 mod nout*..: a thread's output channel is fixed (stride % nout == 0 below).
+    const int nout = a.nout;
+    const int rowf = TL_TX * nout;                              // floats per output row of the tile
+    const int stride = (TL_THREADS / nout) * nout;
+    const int total = TL_TZ * TL_TY * rowf;
+    float s = 0.f, q = 0.f;
+    const int o = tid % nout;
+    const float bsv = a.bias[o];
+    if (tid < stride) {
+        for (int e = tid; e < total; e += stride) {
+            const int zy = e / rowf, f = e % rowf, j = f / nout;          // (f % nout == o)
+            const int z = z0 + zy / TL_TY, y = y0 + zy % TL_TY, x = x0 + j;
+            if (z < D && y < H && x < W) {
+                const float *pr = &P[(zy * TL_PX + j) * TL_PSTRIDE + o];
+                const float v = bsv + pr[0] + pr[TL_PSTRIDE + nout] + pr[2 * TL_PSTRIDE + 2 * nout];
+                a.out[((int64_t)b * M + ((int64_t)z * H + y) * W + x) * nout + o] = v;
+                s += v;
+                q += v * v;
+            }
+        }
+    }
+    // deterministic reduction: per-thread partials -> 16 groups per channel -> one sum per channel, fixed order
+    float *red = P + TL_ROWS * TL_PSTRIDE;                       // behind the partial-sum tile (102 400 B + 4 096 + 1 280)
+    float *red2 = red + 2 * TL_THREADS;
+    red[2 * tid] = s;
+    red[2 * tid + 1] = q;
+    __syncthreads();
+    if (tid < 16 * nout) {
+        const int oo = tid % nout, grp = tid / nout;
+        float ss = 0.f, qq = 0.f;
+        for (int t = oo + nout * grp; t < stride; t += 16 * nout) { ss += red[2 * t]; qq += red[2 * t + 1]; }
+        red2[2 * tid] = ss;
+        red2[2 * tid + 1] = qq;
+    }
+    __syncthreads();
+    if (tid < nout && a.psum) {
+        float ss = 0.f, qq = 0.f;
+        for (int g = 0; g < 16; ++g) { ss += red2[2 * (tid + nout * g)]; qq += red2[2 * (tid + nout * g) + 1]; }
+        const int64_t oi = ((int64_t)b * tiles_per_chunk + tile) * nout + tid;
+        a.psum[oi] = ss;
+        a.psq[oi] = qq;
+    }
+}
+
+// tiles per chunk of the one-pass tail kernel (the layout of its BatchNorm partial sums)
+int conv_tail_tiles(const Level &l)
+{
+    return ((l.D + TL_TZ - 1) / TL_TZ) * ((l.H + TL_TY - 1) / TL_TY) * ((l.W + TL_TX - 1) / TL_TX);
+}
+
+// LDS bytes of the kernel for `cin` input channels in precision mode pm; 0 if the layer does not fit
+size_t conv_tail_lds(int cin, int pm)
+{
+    const size_t stage = (size_t)((pm == 0 ? 2 : 1) * TL_SLOTS + (cin / 8) * 2 * 12 * 16) * 16;
+    const size_t epi = (size_t)(TL_ROWS * TL_PSTRIDE + 2 * TL_THREADS + 2 * 16 * 8) * sizeof(float);
+    const size_t lds = stage > epi ? stage : epi;
+    return lds <= 160 * 1024 ? lds : 0;
+}
+
+int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_fold, const float *bias, int nout,
+                     float *out, float *psum, float *psq, int pm, int *tiles_used)
+{
+    const int cin = sa.C + sb.C;
+    ISX_REQUIRE(nout >= 1 && nout <= 5 && sa.C % 8 == 0 && sb.C % 8 == 0 && cin >= 8, "internal: tail convolution %d -> %d", cin, nout);
+    ISX_REQUIRE(!(sa.planar && sa.C % 8) && !(sb.planar && sb.C % 8), "internal: planar source with %d / %d channels", sa.C, sb.C);
+    const size_t lds = conv_tail_lds(cin, pm);
+    ISX_REQUIRE(lds, "internal: tail convolution with %d input channels does not fit LDS", cin);
+    TailArgs a;
+    a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C; a.planarA = sa.planar ? 1 : 0;
+    a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C; a.planarB = sb.planar ? 1 : 0;
+    a.w = (const uint4 *)w_fold; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
+    a.D = l.D; a.H = l.H; a.W = l.W; a.nout = nout;
+    a.nzt = (l.D + TL_TZ - 1) / TL_TZ; a.nyt = (l.H + TL_TY - 1) / TL_TY; a.nxt = (l.W + TL_TX - 1) / TL_TX;
+    a.xcd_remap = ctx->tune.xcd_remap;
+    const int tiles = a.nzt * a.nyt * a.nxt;
+    if (tiles_used) *tiles_used = tiles;
+    const unsigned grid = (unsigned)(B * tiles);
+    if (!ctx->tail_attr_done) {
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->tail_attr_done = true;
+    }
+    if (pm == 0) conv_tail_kernel<0><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+    else if (pm == 1) conv_tail_kernel<1><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+    else conv_tail_kernel<2><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+    ISX_CHECK_LAUNCH();
+    return ISX_OK;
+}
+
+}  // namespace isx

@@ -1247,7 +1247,8 @@ static int layer_tiles(const UNetState *u, int li, const Level &l, int batch)
     }
     if (L.cin == 1) return (int)((l.M + 127) / 128);
     if (L.cin == 5 && L.cout == 5) return ((l.D + 1) / 2) * ((l.H + 7) / 8) * ((l.W + 15) / 16);     // conv55 tiles
-    return (int)((l.M + 255) / 256);      // thin kernel blocks, or combine blocks of the folded layer
+    const int blocks = (int)((l.M + 255) / 256);      // thin kernel blocks, or combine blocks of the folded layer
+    return use_fold(L.cin, L.cout) ? std::max(blocks, conv_tail_tiles(l)) : blocks;        // (or the tiles of the one-pass tail kernel)
 }
 
 int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch)
@@ -1387,7 +1388,12 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
                                : (u->precision != ISX_PRECISION_FP32 && !u->train && wf && !fold_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
         ISX_REQUIRE(fold_h2 || !ex, "internal: up-sampling on read needs the reduced-precision tail kernel");
         ISX_REQUIRE(fold_h2 || !(sa.planar || sb.planar), "internal: a planar source reached a convolution that does not read it");
-        if (fold_h2) {
+        // one pass: x-shift in LDS, no partial-sum tensor, all weights resident (conv_tail.hip)
+        const bool one_pass = fold_h2 && !ex && ctx->tune.tail_onepass && conv_tail_lds(cin, pm) != 0;
+        if (one_pass) {
+            ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
+            ISX_TRY(launch_conv_tail(ctx, l, B, sa, sb, wf, L.bias, L.cout, u->raw[li], L.psum, L.psq, pm, &stat_tiles));
+        } else if (fold_h2) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wf, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
                                    ctx->tune.xcd_remap, 1, nullptr, pm, ex));
@@ -1413,7 +1419,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
             ISX_CHECK_LAUNCH();
         }
         // pass 2: shifted combine + bias + BN partial sums
-        {
+        if (!one_pass) {
             ProfScope ps(ctx, ISX_PROF_CONV_DIRECT);
 #define ISX_TAIL(N_) tail_combine_kernel<N_><<<(unsigned)(B * L.tiles), 256, 0, ctx->stream>>>(u->ptail, L.bias, l.W, l.M, \
                                                                                          u->raw[li], L.psum, L.psq, L.tiles)

@@ -175,6 +175,11 @@ size_t h2_pack_halves(int cout_p, int cin_p, int bn);
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
                    float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used, int pm = 0,
                    const H2Extra *ex = nullptr);
+// one-pass thin tail convolution (conv_tail.hip)
+int conv_tail_tiles(const Level &l);
+size_t conv_tail_lds(int cin, int pm);
+int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_fold, const float *bias, int nout,
+                     float *out, float *psum, float *psq, int pm, int *tiles_used);
 void pack_h2_taps(const float *w, int cout, int cin, int ntap, int ntap_pad, int bn, std::vector<uint16_t> &out, int pm);
 int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch);
 int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3]);

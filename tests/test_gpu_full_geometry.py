@@ -137,6 +137,27 @@ def test_structured_512_labels_against_oracle(cold_min, monkeypatch):
     assert int((got != ref).sum()) == 0
 
 
+@pytest.mark.parametrize("seed", [1, 3])
+def test_structured_512_giant_components_against_oracle(seed):
+    """The structured 512^3 construction with the seeds that contain a giant component (seed 1: ~5 M voxels of tie plateaus,
+    seed 3: 345 k), i.e. the inputs on which the work-group flood kernel runs by default -- scratch/time_structured.py's
+    volumes, on which a development build of that kernel faulted in round 3 ("The round-3 memory fault").
+    Whole-volume labels against the C oracle, bit for bit."""
+    from iterseg_amd import watershed as ws
+    from oracle import watershed as ows
+    from tests.synth import blob_feature_map_tiled
+    n = 512
+    fm = blob_feature_map_tiled(n, seed, 0.12, 3.0)
+    pshape = (n + 2,) * 3
+    ref = np.zeros(pshape, np.uint32)
+    ows.segment_output_image(fm, out=ref.ravel(), threads=16)
+    lab = torch.zeros(pshape, dtype=torch.int32, device="cuda")
+    _, _, mask = ws.segment_output_image(torch.from_numpy(fm).cuda(), (0, 1, 2), 4, 3, out=lab)
+    _, sizes = ws.connected_components(mask)
+    assert int(torch.as_tensor(sizes).max()) >= 262144            # the work-group kernel's threshold
+    assert int((lab.cpu().numpy().astype(np.uint32) != ref).sum()) == 0
+
+
 def test_mirrored_512_one_giant_component_against_oracle():
     """One 256^3 demo volume mirrored to 512^3 (tests/synth.blob_feature_map_mirrored): the components that touch a mirror
     plane merge with their images into ONE ~7 M-voxel blob component next to ~10 k small ones.  This is the input that
@@ -162,8 +183,10 @@ def test_mirrored_512_one_giant_component_against_oracle():
 def test_config3_two_frames_at_stated_size(unet):
     """BASELINE configs[2] at its stated frame size: two frames of 32x512x512 (36 chunks each) through the device-resident
     call that bench.py's stack_step makes, through the pipelined host loop (segmentation_loop -> isx_pipe_*) and through
-    the plugin's processing function frame by frame: identical labels, structural properties."""
+    the plugin's processing function frame by frame: identical labels, structural properties -- and, staged parity as for
+    config 2, the labels of each frame against the C oracle's watershed of the HIP feature map, bit for bit."""
     from iterseg_amd import segmentation as seg
+    from oracle import watershed as ows
     from tests.synth import positive_volume
     shape = (32, 512, 512)
     data = np.stack([positive_volume(shape, t) for t in (0, 1)])
@@ -178,6 +201,10 @@ def test_config3_two_frames_at_stated_size(unet):
         seg.affinity_watershed_for_chunks(data[t].copy(), cur, CHUNK, MARGIN, **config)
         assert np.array_equal(cur[1:-1, 1:-1, 1:-1].view(np.int32), store[t]), t
         assert store[t].max() > 0 and not cur[0].any() and not cur[:, 0].any() and not cur[:, :, 0].any()
+        fm = unet.predict_volume(torch.from_numpy(data[t] / data[t].max()).cuda(), CHUNK, MARGIN).cpu().numpy()
+        ref = np.zeros(tuple(s + 2 for s in shape), np.uint32)
+        ows.segment_output_image(fm, out=ref.ravel(), threads=16)
+        assert np.array_equal(cur, ref), t
     assert not np.array_equal(store[0], store[1])                  # the frames differ
 
 
