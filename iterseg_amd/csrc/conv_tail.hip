@@ -11,17 +11,20 @@
 // re-read a [voxel][16] partial-sum tensor (84 MB per chunk) for the x-shift.  Here:
 //   * the x-taps stay folded into the N tile (column = dx * nout + o, 15 of 16 columns), so the matrix pass has 9 (dz, dy)
 //     taps = 3 tap quads of the 16x16x32 instruction, and the halo has NO y/z-diagonal x-neighbours to fetch;
-//   * a work-group owns ALL z planes of a 4 (y) x 30 (x) column: 1 200 output voxels on a halo of 12 x 6 x 32 slots
-//     (1.92 x the tile), the 32 x-positions of a halo row being the 30 outputs + the two positions whose partial sums the
-//     x-shift needs -- the shift happens in LDS in the epilogue and the partial sums never reach memory;
-//   * the WHOLE weight tensor (Cin/8 stages x 12 tap slots x 16 columns x hi|lo = 48 KB at Cin = 64) is resident in LDS for
-//     the life of the work-group: a K stage stages only its halo tile (72 KB);
-//   * eight waves x ten 16-row accumulator tiles (80 registers), B fragments of a stage read once (6 reads) for 90 MFMAs.
+//   * a work-group (4 waves) owns 5 (z) x 4 (y) x 30 (x) output voxels on a halo of 7 x 6 x 32 slots (2.24 x the tile), the
+//     32 x-positions of a halo row being the 30 outputs + the two positions whose partial sums the x-shift needs -- the
+//     shift happens in LDS in the epilogue and the partial sums never reach memory;
+//   * 52 KB of LDS and four waves per work-group: two work-groups per CU, so one's staging / prologue / epilogue runs beside
+//     the other's matrix phase (the first version -- eight waves over all ten z planes with the whole weight tensor resident
+//     in LDS, one work-group per CU -- took 7.6 ms per launch set: every wave of the CU in the same phase);
+//   * ten 16-row accumulator tiles per wave (80 registers), B fragments of a stage read once (6 reads) for 90 MFMAs, matrix
+//     phase software-pipelined by hand (fragments one tile pair ahead, one halo load of the next stage per step).
 // BatchNorm partial sums: per work-group, fixed summation order (deterministic), reduced by bn_finalize_kernel like every
 // other layer's.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "unet_state.h"
 #include "h2_split.h"
@@ -45,13 +48,17 @@ struct TailArgs {
     int xcd_remap;
 };
 
-static constexpr int TL_TZ = 10, TL_TY = 4, TL_TX = 30, TL_PX = 32;          // output tile; PX = TX + 2 positions per halo row
+static constexpr int TL_TZ = 5, TL_TY = 4, TL_TX = 30, TL_PX = 32;           // output tile; PX = TX + 2 positions per halo row
 static constexpr int TL_HY = TL_TY + 2, TL_HZ = TL_TZ + 2;
-static constexpr int TL_SLOTS = TL_HZ * TL_HY * TL_PX;                       // 2304 halo slots
-static constexpr int TL_THREADS = 512, TL_NA = (TL_SLOTS + TL_THREADS - 1) / TL_THREADS;      // 5 slot passes (the last one half full)
-static constexpr int TL_ROWS = TL_TZ * TL_TY * TL_PX;                        // 1280 partial-sum positions = 80 row tiles of 16
-static constexpr int TL_MT = TL_ROWS / 16 / 8;                               // 10 row tiles per wave
+static constexpr int TL_SLOTS = TL_HZ * TL_HY * TL_PX;                       // 1344 halo slots
+static constexpr int TL_THREADS = 256, TL_NW = TL_THREADS / 64;
+
+static constexpr int TL_ROWS = TL_TZ * TL_TY * TL_PX;                        // 640 partial-sum positions = 40 row tiles of 16
+static constexpr int TL_MT = TL_ROWS / 16 / TL_NW;                           // 10 row tiles per wave
+static constexpr int TL_ZYW = TL_TZ * TL_TY / TL_NW;                         // 5 halo rows (z-local * TY + y-local) per wave
 static constexpr int TL_PSTRIDE = 20;                                        // floats per position of the LDS partial-sum tile (conflict-free C stores)
+static constexpr int TL_BH = 12 * 16;                                        // uint4 per half of a stage's weights (12 tap slots x 16 columns)
+static_assert(TL_MT == 2 * TL_ZYW && TL_MT % 2 == 0, "two 16-row tiles per halo row, tiles processed in pairs");
 
 __device__ __forceinline__ uint32_t tl_pack_f16_rn(float x, float y)
 {
@@ -69,18 +76,19 @@ __device__ __forceinline__ uint32_t tl_pack_bf16_rn(float x, float y)
     return (a >> 16) | (b & 0xFFFF0000u);
 }
 
-template <int PM>
+// ABL (development builds, -DISX_TAIL_DEV, timing only -- wrong results): 1 no staging arithmetic, 2 no matrix phase, 3 no halo
+// loads, 4 no epilogue
+template <int PM, int ABL = 0>
 __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void conv_tail_kernel(const TailArgs a)
 {
     constexpr bool SPLIT = PM == 0;
     extern __shared__ __attribute__((aligned(16))) uint4 tl_smem[];
     const int nsteps = (a.CA + a.CB) >> 3;
-    // LDS: [halo hi: SLOTS][halo lo: SLOTS (split only)][weights: nsteps x (hi|lo) x 12 x 16]; the epilogue's partial-sum tile
-    // (ROWS x PSTRIDE floats) and the reduction scratch alias all of it after the last stage
+    // LDS: [halo hi: SLOTS][halo lo: SLOTS (split only)][this stage's weights: (hi|lo) x 12 x 16]; the epilogue's partial-sum
+    // tile (ROWS x PSTRIDE floats) and the reduction scratch alias it after the last stage
     uint4 *AsH = tl_smem;
     uint4 *AsL = AsH + TL_SLOTS;
     uint4 *Bs = AsH + (SPLIT ? 2 : 1) * TL_SLOTS;
-    constexpr int BH = 12 * 16;                                 // uint4 per half of a stage's weights
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, h4 = lane >> 4;
     int lin = blockIdx.x;
@@ -90,16 +98,11 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     }
     const int tiles_per_chunk = a.nzt * a.nyt * a.nxt;
     const int b = lin / tiles_per_chunk, tile = lin % tiles_per_chunk;
-    const int xt = tile % a.nxt, yt = (tile / a.nxt) % a.nyt, zt = tile / (a.nxt * a.nyt);
+    // z fastest: the two z tiles of a (y, x) column run side by side and share two halo planes in L2
+    const int zt = tile % a.nzt, xt = (tile / a.nzt) % a.nxt, yt = tile / (a.nzt * a.nxt);
     const int z0 = zt * TL_TZ, y0 = yt * TL_TY, x0 = xt * TL_TX;
     const int D = a.D, H = a.H, W = a.W;
     const int64_t M = (int64_t)D * H * W;
-
-    // ---- the whole weight tensor -> LDS (columns 0..15 of the 32-column pack) ------------------------------------------
-    for (int e = tid; e < nsteps * 2 * BH; e += TL_THREADS) {
-        const int st = e / (2 * BH), r = e % (2 * BH), half = r / BH, tc = r % BH;       // tc = tap slot * 16 + column
-        if (SPLIT || half == 0) Bs[e] = a.w[((int64_t)(st * 2 + half) * 12 + (tc >> 4)) * 32 + (tc & 15)];
-    }
 
     // ---- halo slots of this thread: voxel index, -1 outside the volume (zero padding), -2 beyond the slot list -----------
     auto slot_voxel = [&](int s) __attribute__((always_inline)) -> int {
@@ -109,16 +112,21 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
     };
     const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + TL_THREADS), gv2 = slot_voxel(tid + 2 * TL_THREADS),
-              gv3 = slot_voxel(tid + 3 * TL_THREADS), gv4 = slot_voxel(tid + 4 * TL_THREADS);
+              gv3 = slot_voxel(tid + 3 * TL_THREADS), gv4 = slot_voxel(tid + 4 * TL_THREADS), gv5 = slot_voxel(tid + 5 * TL_THREADS);
+    // this thread's share of a stage's weights: uint4 e = tid (and 256 + tid for tid < 128) of the [hi|lo][12][16] block,
+    // read from the 32-column pack  [Cin/8][hi|lo][12 tap slots][32 columns]
+    auto wsrc = [&](int e) __attribute__((always_inline)) -> int { return ((e / TL_BH) * 12 + ((e % TL_BH) >> 4)) * 32 + (e & 15); };
+    const int wo0 = wsrc(tid), wo1 = wsrc(tid + TL_THREADS);
+    const bool wb1 = SPLIT && tid < 2 * TL_BH - TL_THREADS;
 
-    // ---- accumulators: row tile m of this wave = halo row zy = 5 * wave + m / 2 (z-local * TY + y-local), x half m & 1 ----
+    // ---- accumulators: row tile m of this wave = halo row zy = ZYW * wave + m / 2 (z-local * TY + y-local), x half m & 1 ----
     t_f32x4 c_hi[TL_MT], c_lo[SPLIT ? TL_MT : 1];
     int aslot[TL_MT];
 #pragma unroll
     for (int m = 0; m < TL_MT; ++m) {
         c_hi[m] = t_f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (SPLIT) c_lo[m] = t_f32x4{0.f, 0.f, 0.f, 0.f};
-        const int zy = 5 * wave + (m >> 1), zl = zy / TL_TY, yl = zy % TL_TY;
+        const int zy = TL_ZYW * wave + (m >> 1), zl = zy / TL_TY, yl = zy % TL_TY;
         aslot[m] = ((zl + 1) * TL_HY + (yl + 1)) * TL_PX + 16 * (m & 1) + l16;
     }
     // tap quad q, lane group h4 -> tap t = 4 q + h4 (dz = t / 3, dy = t % 3; slots 9..11 carry zero weights: any valid slot)
@@ -130,7 +138,8 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         toq[q] = (t / 3 - 1) * (TL_HY * TL_PX) + (t % 3 - 1) * TL_PX;
     }
 
-    float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
+    float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, ra5, rc5, vs0, vs1, vh0, vh1;
+    uint4 rb0, rb1;
     float relu_lo = 0.f;
     const float *ld_src = nullptr;
     int ld_C = 0;
@@ -153,9 +162,12 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         }                                                                                         \
         if (planar) { ld_src = src + ((int64_t)b * (C >> 3) + (cc >> 3)) * M * 8; ld_C = 8; }     \
         else { ld_src = src + (int64_t)b * M * C + cc; ld_C = C; }                                \
+        const uint4 *wst = a.w + (int64_t)(step_) * (2 * 12 * 32);                                \
+        rb0 = wst[wo0];                                                                           \
+        if (wb1) rb1 = wst[wo1];                                                                  \
     }
 #define TL_LOAD_A(k)                                                                              \
-    if (gv##k != -2) {                                                                            \
+    if (ABL != 3 && gv##k != -2) {                                                                            \
         const float *pp = &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];                       \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
@@ -164,10 +176,12 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     v.x = fmaxf(fmaf(v.x, s_.x, h_.x), relu_lo); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), relu_lo);     \
     v.z = fmaxf(fmaf(v.z, s_.z, h_.z), relu_lo); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), relu_lo);
 #define TL_STORE_A(k)                                                                             \
-    {                                                                                             \
+    if (k < 5 || wave == 0) {                                                                     \
         float4 v = ra##k, w = rc##k;                                                              \
-        TL_AFFL(v, vs0, vh0) TL_AFFL(w, vs1, vh1)                                                 \
+        if constexpr (ABL != 1) { TL_AFFL(v, vs0, vh0) TL_AFFL(w, vs1, vh1) }                     \
         uint4 hi, lo = make_uint4(0u, 0u, 0u, 0u);                                                \
+        if constexpr (ABL == 1) { hi = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)); \
+                                  lo = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)); } else \
         if constexpr (SPLIT) split8(v, w, hi, lo);                                                \
         else if constexpr (PM == 1) { hi.x = tl_pack_f16_rn(v.x, v.y); hi.y = tl_pack_f16_rn(v.z, v.w); hi.z = tl_pack_f16_rn(w.x, w.y); hi.w = tl_pack_f16_rn(w.z, w.w); } \
         else { hi.x = tl_pack_bf16_rn(v.x, v.y); hi.y = tl_pack_bf16_rn(v.z, v.w); hi.z = tl_pack_bf16_rn(w.x, w.y); hi.w = tl_pack_bf16_rn(w.z, w.w); } \
@@ -180,45 +194,64 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         }                                                                                         \
     }
 
+    if constexpr (ABL == 3) { ra0 = rc0 = ra1 = rc1 = ra2 = rc2 = ra3 = rc3 = ra4 = rc4 = ra5 = rc5 = make_float4(0.5f, 0.25f, 0.125f, 1.f); }
     TL_LOAD_HEAD(0)
-    TL_LOAD_A(0) TL_LOAD_A(1) TL_LOAD_A(2) TL_LOAD_A(3) TL_LOAD_A(4)
+    TL_LOAD_A(0) TL_LOAD_A(1) TL_LOAD_A(2) TL_LOAD_A(3) TL_LOAD_A(4) TL_LOAD_A(5)
     union FR { uint4 u; t_f16x8 v; t_bf16x8 w; };
     for (int step = 0; step < nsteps; ++step) {
         __syncthreads();                                        // every wave has read the previous stage's fragments
-        TL_STORE_A(0) TL_STORE_A(1) TL_STORE_A(2) TL_STORE_A(3) TL_STORE_A(4)
+        TL_STORE_A(0) TL_STORE_A(1) TL_STORE_A(2) TL_STORE_A(3) TL_STORE_A(4) TL_STORE_A(5)
+        Bs[tid] = rb0;
+        if (wb1) Bs[tid + TL_THREADS] = rb1;
         __syncthreads();
         const bool more = step + 1 < nsteps;
         if (more) TL_LOAD_HEAD(step + 1)
-        const uint4 *bsh = Bs + (step * 2) * BH + h4 * 16 + l16, *bsl = bsh + BH;
+        const uint4 *bsh = Bs + h4 * 16 + l16, *bsl = bsh + TL_BH;
         FR bh[3], bl[SPLIT ? 3 : 1];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             bh[q].u = bsh[(4 * q) * 16];
             if constexpr (SPLIT) bl[q].u = bsl[(4 * q) * 16];
         }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-#pragma unroll
-            for (int m = 0; m < TL_MT; ++m) {
-                FR ah, al;
-                ah.u = AsH[aslot[m] + toq[q]];
-                if constexpr (SPLIT) al.u = AsL[aslot[m] + toq[q]];
-                // the next stage's global loads go out between the matrix instructions, two tiles apart
-                if (more && q == 0) {
-                    if (m == 0) { TL_LOAD_A(0) } else if (m == 2) { TL_LOAD_A(1) } else if (m == 4) { TL_LOAD_A(2) }
-                    else if (m == 6) { TL_LOAD_A(3) } else if (m == 8) { TL_LOAD_A(4) }
-                }
-                if constexpr (SPLIT) {
-                    c_hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[q].v, c_hi[m], 0, 0, 0);
-                    c_lo[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bl[q].v, c_lo[m], 0, 0, 0);
-                    c_lo[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.v, bh[q].v, c_lo[m], 0, 0, 0);
-                } else if constexpr (PM == 1) {
-                    c_hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.v, bh[q].v, c_hi[m], 0, 0, 0);
-                } else {
-                    c_hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.w, bh[q].w, c_hi[m], 0, 0, 0);
-                }
-            }
+        // one step = a PAIR of row tiles of one tap quad (6 matrix instructions, the two dependent ones of a tile three apart);
+        // the fragments of the next pair are read before the matrix instructions of this one are issued, and one of the next
+        // stage's halo loads goes out per step
+        constexpr int NS = ABL == 2 ? 0 : 3 * (TL_MT / 2);
+        if constexpr (ABL == 2) { if (more) { TL_LOAD_A(0) TL_LOAD_A(1) TL_LOAD_A(2) TL_LOAD_A(3) TL_LOAD_A(4) TL_LOAD_A(5) } c_hi[0][0] += bh[0].v[0] + bh[1].v[1] + bh[2].v[2]; if constexpr (SPLIT) c_lo[0][0] += bl[0].v[0]; }
+        FR ah[2][2], al[SPLIT ? 2 : 1][2];
+#define TL_FRAG(s_)                                                                               \
+        {                                                                                         \
+            const int q_ = (s_) / (TL_MT / 2), m_ = 2 * ((s_) % (TL_MT / 2));                     \
+            ah[(s_) & 1][0].u = AsH[aslot[m_] + toq[q_]];                                         \
+            ah[(s_) & 1][1].u = AsH[aslot[m_ + 1] + toq[q_]];                                     \
+            if constexpr (SPLIT) { al[(s_) & 1][0].u = AsL[aslot[m_] + toq[q_]]; al[(s_) & 1][1].u = AsL[aslot[m_ + 1] + toq[q_]]; } \
         }
+        if constexpr (ABL != 2) TL_FRAG(0)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int q = s / (TL_MT / 2), m = 2 * (s % (TL_MT / 2)), r = s & 1;
+            if (s + 1 < NS) TL_FRAG(s + 1)
+            if (more) {
+                if (s == 0) { TL_LOAD_A(0) } else if (s == 2) { TL_LOAD_A(1) } else if (s == 4) { TL_LOAD_A(2) }
+                else if (s == 6) { TL_LOAD_A(3) } else if (s == 8) { TL_LOAD_A(4) } else if (s == 10) { TL_LOAD_A(5) }
+            }
+            if constexpr (SPLIT) {
+                c_hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r][0].v, bh[q].v, c_hi[m], 0, 0, 0);
+                c_lo[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r][0].v, bl[q].v, c_lo[m], 0, 0, 0);
+                c_hi[m + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r][1].v, bh[q].v, c_hi[m + 1], 0, 0, 0);
+                c_lo[m + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r][1].v, bl[q].v, c_lo[m + 1], 0, 0, 0);
+                c_lo[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r][0].v, bh[q].v, c_lo[m], 0, 0, 0);
+                c_lo[m + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r][1].v, bh[q].v, c_lo[m + 1], 0, 0, 0);
+            } else if constexpr (PM == 1) {
+                c_hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r][0].v, bh[q].v, c_hi[m], 0, 0, 0);
+                c_hi[m + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r][1].v, bh[q].v, c_hi[m + 1], 0, 0, 0);
+            } else {
+                c_hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r][0].w, bh[q].w, c_hi[m], 0, 0, 0);
+                c_hi[m + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r][1].w, bh[q].w, c_hi[m + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef TL_FRAG
     }
 #undef TL_LOAD_HEAD
 #undef TL_LOAD_A
@@ -229,10 +262,11 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     // C/D of 16x16: column = lane & 15, row = 4 * (lane >> 4) + register.  Position p = (zy * 32 + px) holds its 16 columns
     // at P[p * PSTRIDE ..]; the four lane groups of a store land 80 floats apart = 16 banks: conflict-free.
     float *P = (float *)tl_smem;
+    if constexpr (ABL == 4) { if (c_hi[0][0] == 123.456f) a.out[tid] = c_hi[1][1] + c_hi[9][3]; return; }
     __syncthreads();                                            // the last fragments are read: the halo / weight LDS is free
 #pragma unroll
     for (int m = 0; m < TL_MT; ++m) {
-        const int zy = 5 * wave + (m >> 1);
+        const int zy = TL_ZYW * wave + (m >> 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = zy * TL_PX + 16 * (m & 1) + 4 * h4 + i;
@@ -244,45 +278,37 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     }
     __syncthreads();
     // out[z][y][x][o] = bias[o] + sum over dx of P[(z, y, px = x - x0 + dx)][dx * nout + o]  (px = 0 is x0 - 1: a position
-    // outside the volume staged zeros, so its partial sums are the convolution's zero padding).  510 threads walk the
-    // (zy, x, o) elements with a stride of 510 = 0 mod nout*..: a thread's output channel is fixed (stride % nout == 0 below).
+    // outside the volume staged zeros, so its partial sums are the convolution's zero padding).  Thread f < 30 * nout owns
+    // element f = (x - x0) * nout + o of every output row of the tile: consecutive lanes store consecutive floats.
     const int nout = a.nout;
-    const int rowf = TL_TX * nout;                              // floats per output row of the tile
-    const int stride = (TL_THREADS / nout) * nout;
-    const int total = TL_TZ * TL_TY * rowf;
+    const int rowf = TL_TX * nout;
     float s = 0.f, q = 0.f;
-    const int o = tid % nout;
-    const float bsv = a.bias[o];
-    if (tid < stride) {
-        for (int e = tid; e < total; e += stride) {
-            const int zy = e / rowf, f = e % rowf, j = f / nout;          // (f % nout == o)
-            const int z = z0 + zy / TL_TY, y = y0 + zy % TL_TY, x = x0 + j;
-            if (z < D && y < H && x < W) {
-                const float *pr = &P[(zy * TL_PX + j) * TL_PSTRIDE + o];
-                const float v = bsv + pr[0] + pr[TL_PSTRIDE + nout] + pr[2 * TL_PSTRIDE + 2 * nout];
-                a.out[((int64_t)b * M + ((int64_t)z * H + y) * W + x) * nout + o] = v;
-                s += v;
-                q += v * v;
+    if (tid < rowf) {
+        const int j = tid / nout, o = tid - j * nout, x = x0 + j;
+        const float bsv = a.bias[o];
+        const float *pr = &P[j * TL_PSTRIDE + o];
+        if (x < W) {
+#pragma unroll 4
+            for (int zy = 0; zy < TL_TZ * TL_TY; ++zy) {
+                const int z = z0 + zy / TL_TY, y = y0 + zy % TL_TY;
+                if (z < D && y < H) {
+                    const float *pz = pr + zy * (TL_PX * TL_PSTRIDE);
+                    const float v = bsv + pz[0] + pz[TL_PSTRIDE + nout] + pz[2 * TL_PSTRIDE + 2 * nout];
+                    a.out[((int64_t)b * M + ((int64_t)z * H + y) * W + x0) * nout + tid] = v;
+                    s += v;
+                    q += v * v;
+                }
             }
         }
     }
-    // deterministic reduction: per-thread partials -> 16 groups per channel -> one sum per channel, fixed order
-    float *red = P + TL_ROWS * TL_PSTRIDE;                       // behind the partial-sum tile (102 400 B + 4 096 + 1 280)
-    float *red2 = red + 2 * TL_THREADS;
+    // deterministic reduction: the 30 threads of a channel in fixed order
+    float *red = P + TL_ROWS * TL_PSTRIDE;                       // behind the partial-sum tile
     red[2 * tid] = s;
     red[2 * tid + 1] = q;
     __syncthreads();
-    if (tid < 16 * nout) {
-        const int oo = tid % nout, grp = tid / nout;
-        float ss = 0.f, qq = 0.f;
-        for (int t = oo + nout * grp; t < stride; t += 16 * nout) { ss += red[2 * t]; qq += red[2 * t + 1]; }
-        red2[2 * tid] = ss;
-        red2[2 * tid + 1] = qq;
-    }
-    __syncthreads();
     if (tid < nout && a.psum) {
         float ss = 0.f, qq = 0.f;
-        for (int g = 0; g < 16; ++g) { ss += red2[2 * (tid + nout * g)]; qq += red2[2 * (tid + nout * g) + 1]; }
+        for (int t = tid; t < rowf; t += nout) { ss += red[2 * t]; qq += red[2 * t + 1]; }
         const int64_t oi = ((int64_t)b * tiles_per_chunk + tile) * nout + tid;
         a.psum[oi] = ss;
         a.psq[oi] = qq;
@@ -298,8 +324,9 @@ int conv_tail_tiles(const Level &l)
 // LDS bytes of the kernel for `cin` input channels in precision mode pm; 0 if the layer does not fit
 size_t conv_tail_lds(int cin, int pm)
 {
-    const size_t stage = (size_t)((pm == 0 ? 2 : 1) * TL_SLOTS + (cin / 8) * 2 * 12 * 16) * 16;
-    const size_t epi = (size_t)(TL_ROWS * TL_PSTRIDE + 2 * TL_THREADS + 2 * 16 * 8) * sizeof(float);
+    (void)cin;
+    const size_t stage = (size_t)((pm == 0 ? 2 : 1) * TL_SLOTS + 2 * TL_BH) * 16;
+    const size_t epi = (size_t)(TL_ROWS * TL_PSTRIDE + 2 * TL_THREADS) * sizeof(float);
     const size_t lds = stage > epi ? stage : epi;
     return lds <= 160 * 1024 ? lds : 0;
 }
@@ -328,6 +355,14 @@ int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
         ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->tail_attr_done = true;
     }
+#ifdef ISX_TAIL_DEV
+    const int abl = getenv("ISX_TAIL_ABLATE") ? atoi(getenv("ISX_TAIL_ABLATE")) : 0;
+    if (pm == 0 && abl == 1) conv_tail_kernel<0, 1><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+    else if (pm == 0 && abl == 2) conv_tail_kernel<0, 2><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+    else if (pm == 0 && abl == 3) conv_tail_kernel<0, 3><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+    else if (pm == 0 && abl == 4) conv_tail_kernel<0, 4><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+    else
+#endif
     if (pm == 0) conv_tail_kernel<0><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
     else if (pm == 1) conv_tail_kernel<1><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
     else conv_tail_kernel<2><<<grid, TL_THREADS, lds, ctx->stream>>>(a);

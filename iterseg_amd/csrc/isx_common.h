@@ -70,7 +70,7 @@ struct isx_tune {
     int up_per_source = 1;          // ISX_UP_PER_SOURCE: 0 = the transposed convolutions one thread per OUTPUT voxel (rounds 1-2)
     int h2_core16 = 1;              // ISX_H2_CORE16: bit 0 the 27-tap split-f16 / f16 / bf16 convolutions (r3: conv stage 826 -> 788 ms per frame), bit 1
                                     // the 9-tap tail layer (no gain: 808.6 vs 810.6 ms, off) on v_mfma_f32_16x16x32; 0: 32x32x16 everywhere (rounds 1-2)
-    int planar = 1;                 // ISX_PLANAR: the first convolution of a module writes [C/8][voxel][8] for the second one (inference, reduced-precision kernels)
+    int planar = 2;                 // ISX_PLANAR (2: + the skip / pooled / up-sampled tensors, r4): the first convolution of a module writes [C/8][voxel][8] for the second one (inference, reduced-precision kernels)
     int h2_nw8 = 1;                 // ISX_H2_NW8: 1 = 512-thread work-groups (eight waves on ONE weight slab, 256 voxels) for the layers with
                                     // Cout % 64 == 0: half the slab traffic per voxel, same results -- and the same time (r3: 93.0 vs 92.8 ms per launch set)
     int up_on_read = 0;             // ISX_UP_ON_READ: 1 = the tail layer up-samples up3 while staging it instead of reading a materialised tensor.

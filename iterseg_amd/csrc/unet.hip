@@ -469,21 +469,33 @@ __device__ __forceinline__ void put_channels(float *dst, const float4 (&v)[G], b
     else *(float4 *)dst = v[0];
 }
 
+// src_planar / dst_planar: the tensor is [chunk][C/8][voxel][8] instead of [chunk][voxel][C] (UNetState::planar).  With a planar
+// source the thread is (chunk, 8-channel plane, output voxel, half plane) -- consecutive lanes read and write consecutive
+// 16-byte pieces of one plane -- instead of (chunk, output voxel, channel quad).
 __global__ void pool_kernel(const float *__restrict__ src, const float *__restrict__ scale,
                             const float *__restrict__ shift, int C, int D, int H, int W, int kz, int Do, int Ho,
-                            int Wo, float *__restrict__ dst, int64_t total)
+                            int Wo, float *__restrict__ dst, int64_t total, int src_planar, int dst_planar)
 {
     // 32-bit index arithmetic throughout (total < 2^32 is checked by the launcher): the 64-bit divisions this kernel
     // started with cost more than its memory traffic
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)total) return;
     const uint32_t CG = (uint32_t)C / (4 * G);
-    const int c0 = (int)(i % CG) * 4 * G;
-    const uint32_t v = i / CG;
     const uint32_t Mo32 = (uint32_t)Do * Ho * Wo;
     const int64_t Mo = Mo32, M = (int64_t)D * H * W;
-    const int b = (int)(v / Mo32);
-    const uint32_t m = v % Mo32;
+    int c0, b;
+    uint32_t m;
+    if (src_planar) {
+        const uint32_t v = i >> 1, pl = (v / Mo32) % (CG >> 1);
+        c0 = (int)(pl * 8 + (i & 1) * 4);
+        m = v % Mo32;
+        b = (int)(v / (Mo32 * (CG >> 1)));
+    } else {
+        c0 = (int)(i % CG) * 4 * G;
+        const uint32_t v = i / CG;
+        b = (int)(v / Mo32);
+        m = v % Mo32;
+    }
     const int x = (int)(m % (uint32_t)Wo), y = (int)((m / (uint32_t)Wo) % (uint32_t)Ho), z = (int)(m / ((uint32_t)Wo * Ho));
     float4 vs[G], vh[G], best[G];
 #pragma unroll
@@ -492,6 +504,8 @@ __global__ void pool_kernel(const float *__restrict__ src, const float *__restri
         vh[g] = *(const float4 *)&shift[(int64_t)b * C + c0 + 4 * g];
         best[g] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
+    const float *sp = src_planar ? src + ((int64_t)b * (C >> 3) + (c0 >> 3)) * M * 8 + (c0 & 7) : src + (int64_t)b * M * C + c0;
+    const int sC = src_planar ? 8 : C;
     for (int i0 = 0; i0 < kz; ++i0)
         for (int j = 0; j < 2; ++j)
             for (int k = 0; k < 2; ++k) {
@@ -499,7 +513,7 @@ __global__ void pool_kernel(const float *__restrict__ src, const float *__restri
                 if (zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    float4 t = *(const float4 *)&src[((int64_t)b * M + ((int64_t)zz * H + yy) * W + xx) * C + c0 + 4 * g];
+                    float4 t = *(const float4 *)&sp[(((int64_t)zz * H + yy) * W + xx) * sC + 4 * g];
                     t.x = fmaxf(fmaf(t.x, vs[g].x, vh[g].x), 0.f);
                     t.y = fmaxf(fmaf(t.y, vs[g].y, vh[g].y), 0.f);
                     t.z = fmaxf(fmaf(t.z, vs[g].z, vh[g].z), 0.f);
@@ -510,7 +524,8 @@ __global__ void pool_kernel(const float *__restrict__ src, const float *__restri
                     best[g].w = fmaxf(best[g].w, t.w);
                 }
             }
-    put_channels(&dst[((int64_t)b * Mo + m) * C + c0], best, false);
+    float *dp = dst_planar ? &dst[(((int64_t)b * (C >> 3) + (c0 >> 3)) * Mo + m) * 8 + (c0 & 7)] : &dst[((int64_t)b * Mo + m) * C + c0];
+    put_channels(dp, best, false);
 }
 
 // out[z, y, x, c] = act(in[z/kz, (y+off)/2, (x+off)/2, c]) * w[(z%kz, (y+off)%2, (x+off)%2)][c] + bias[c]
@@ -554,24 +569,34 @@ __global__ void upsample_kernel(const float *__restrict__ src, const float *__re
 // 3.7 TB/s against 5.6 TB/s for pool_kernel).  thread = (coarse voxel, 4 G channels).
 __global__ void upsample_src_kernel(const float *__restrict__ src, const float *__restrict__ scale, const float *__restrict__ shift,
                                     int C, int D, int H, int W, int off, const float *__restrict__ w, const float *__restrict__ bias,
-                                    int Ho, int Wo, float *__restrict__ dst, int64_t total)
+                                    int Ho, int Wo, float *__restrict__ dst, int64_t total, int src_planar, int dst_planar)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)total) return;
     const uint32_t CG = (uint32_t)C / (4 * G);
-    const int c0 = (int)(i % CG) * 4 * G;
-    const uint32_t v = i / CG;
     const uint32_t M32 = (uint32_t)D * H * W;
     const int64_t M = M32, Mo = (int64_t)D * Ho * Wo;
-    const int b = (int)(v / M32);
-    const uint32_t m = v % M32;
+    int c0, b;
+    uint32_t m;
+    if (dst_planar) {                  // thread = (chunk, 8-channel plane, coarse voxel, half plane): see pool_kernel
+        const uint32_t v = i >> 1, pl = (v / M32) % (CG >> 1);
+        c0 = (int)(pl * 8 + (i & 1) * 4);
+        m = v % M32;
+        b = (int)(v / (M32 * (CG >> 1)));
+    } else {
+        c0 = (int)(i % CG) * 4 * G;
+        const uint32_t v = i / CG;
+        b = (int)(v / M32);
+        m = v % M32;
+    }
     const int xs = (int)(m % (uint32_t)W), ys = (int)((m / (uint32_t)W) % (uint32_t)H), z = (int)(m / ((uint32_t)W * H));
     float4 t[G], bv[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const float4 vs = *(const float4 *)&scale[(int64_t)b * C + c0 + 4 * g];
         const float4 vh = *(const float4 *)&shift[(int64_t)b * C + c0 + 4 * g];
-        t[g] = *(const float4 *)&src[((int64_t)b * M + m) * C + c0 + 4 * g];
+        t[g] = src_planar ? *(const float4 *)&src[(((int64_t)b * (C >> 3) + (c0 >> 3)) * M + m) * 8 + (c0 & 7) + 4 * g]
+                          : *(const float4 *)&src[((int64_t)b * M + m) * C + c0 + 4 * g];
         t[g].x = fmaxf(fmaf(t[g].x, vs.x, vh.x), 0.f); t[g].y = fmaxf(fmaf(t[g].y, vs.y, vh.y), 0.f);
         t[g].z = fmaxf(fmaf(t[g].z, vs.z, vh.z), 0.f); t[g].w = fmaxf(fmaf(t[g].w, vs.w, vh.w), 0.f);
         bv[g] = *(const float4 *)&bias[c0 + 4 * g];
@@ -589,7 +614,9 @@ __global__ void upsample_src_kernel(const float *__restrict__ src, const float *
                 o[g] = make_float4(fmaf(t[g].x, wv.x, bv[g].x), fmaf(t[g].y, wv.y, bv[g].y), fmaf(t[g].z, wv.z, bv[g].z),
                                    fmaf(t[g].w, wv.w, bv[g].w));
             }
-            put_channels(&dst[((int64_t)b * Mo + ((int64_t)z * Ho + y) * Wo + x) * C + c0], o, true);
+            const int64_t vo = ((int64_t)z * Ho + y) * Wo + x;
+            float *dp = dst_planar ? &dst[(((int64_t)b * (C >> 3) + (c0 >> 3)) * Mo + vo) * 8 + (c0 & 7)] : &dst[((int64_t)b * Mo + vo) * C + c0];
+            put_channels(dp, o, true);
         }
 }
 
@@ -1562,22 +1589,40 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
     auto planar_ok = [&](int li_reader, const Level &l, int li_writer) {
         return ctx->tune.planar && !u->train && u->cv[li_writer].cout % 8 == 0 && conv_takes_h2(ctx, li_reader, l, B, bn_bound(li_writer));
     };
+    // ISX_PLANAR >= 2: the skip tensors (second convolution of c0..c3: read by the pooling and by the decoder's first convolution
+    // of that level) and the tensors that feed / leave up1..up3 are planar as well, whenever every reader can take one -- the
+    // tail layer reads both its sources that way (conv_tail.hip: on row-major sources it re-fetched every 128-byte line of its
+    // halo once per K stage from beyond L2)
+    auto skip_planar_ok = [&](int mi) {
+        if (ctx->tune.planar < 2 || ctx->tune.up_fold || ctx->tune.up_on_read || u->train || mi > 3 || u->cv[2 * mi + 1].cout % 8) return false;
+        const int k = 3 - mi;                                     // the decoder module that reads this skip tensor beside up_k
+        for (int f = 0; f < u->nforks; ++f) {
+            const int li_in = (k == 0) ? 9 : dec_layer(f, k - 1, 1);
+            const float up_bound = bn_bound(li_in) * u->up[k].wmax + u->up[k].bmax;
+            if (!conv_takes_h2(ctx, dec_layer(f, k, 0), lv[mi], B, std::max(up_bound, bn_bound(2 * mi + 1)))) return false;
+        }
+        return true;
+    };
     // ---- encoder ----------------------------------------------------------------------------
     for (int mi = 0; mi <= 4; ++mi) {
         const Level &l = lv[mi];
         Src in = (mi == 0) ? Src{u->x0, nullptr, nullptr, 1}
                            : Src{u->pool[mi - 1], nullptr, nullptr, MOD_COUT[mi - 1], bn_bound(2 * (mi - 1) + 1)};
+        if (mi > 0) in.planar = u->pool_planar[mi - 1];
         ISX_TRY(run_conv(ctx, 2 * mi, l, B, in, none, nullptr, planar_ok(2 * mi + 1, l, 2 * mi)));
-        ISX_TRY(run_conv(ctx, 2 * mi + 1, l, B, act(2 * mi), none));
+        ISX_TRY(run_conv(ctx, 2 * mi + 1, l, B, act(2 * mi), none, nullptr, skip_planar_ok(mi)));
         if (mi < 4) {
             ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
             const Level &lo = lv[mi + 1];
             const ConvBN &L = u->cv[2 * mi + 1];
             int64_t total = (int64_t)B * lo.M * (L.cout / 4);
             ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
+            // a planar skip tensor is pooled plane by plane, into a planar tensor if the next module's first convolution reads one
+            const bool sp = u->planar[2 * mi + 1];
+            u->pool_planar[mi] = sp && conv_takes_h2(ctx, 2 * (mi + 1), lo, B, bn_bound(2 * mi + 1));
             pool_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[2 * mi + 1], L.scale, L.shift, L.cout, l.D, l.H,
                                                                 l.W, mi == 3 ? 2 : 1, lo.D, lo.H, lo.W, u->pool[mi],
-                                                                total);
+                                                                total, sp ? 1 : 0, u->pool_planar[mi] ? 1 : 0);
             ISX_CHECK_LAUNCH();
         }
     }
@@ -1628,17 +1673,24 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                 ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
                 const int64_t total_src = (int64_t)B * ls.M * (U.C / 4);
                 const bool per_src = U.kz == 1 && ctx->tune.up_per_source && total_src < (int64_t)0xFFFFFFFFll;
+                ISX_REQUIRE(per_src || !u->planar[li_in], "internal: a planar tensor reached the per-output transposed convolution");
+                u->ups_planar[ups_index(f, k)] = per_src && ctx->tune.planar >= 2 && !u->train && U.C % 8 == 0 && !ctx->tune.up_fold && !ctx->tune.up_on_read &&
+                                                     conv_takes_h2(ctx, l0, lo, B, std::max(up_bound, bn_bound(skip_li)));
                 if (per_src)
                     upsample_src_kernel<<<cdiv(total_src, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W,
-                                                                                    k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, upo, total_src);
+                                                                                    k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, upo, total_src,
+                                                                                    u->planar[li_in] ? 1 : 0, u->ups_planar[ups_index(f, k)] ? 1 : 0);
                 else
                 upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D,
                                                                         ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, U.bias, lo.D,
                                                                         lo.H, lo.W, upo, total, 1 /* streaming stores: the 5.4 GB output is far larger than L2 */);
                 ISX_CHECK_LAUNCH();
             }
-            ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound}, act(skip_li), nullptr, planar_ok(l1, lo, l0)));
-            ISX_TRY(run_conv(ctx, l1, lo, B, act(l0), none));
+            ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound, u->ups_planar[ups_index(f, k)]}, act(skip_li), nullptr, planar_ok(l1, lo, l0)));
+            // its output feeds up_{k+1} only (k < 3): planar if that transposed convolution runs per source voxel
+            const bool next_per_src = k < 3 && ctx->tune.planar >= 2 && !u->train && !ctx->tune.up_fold && !ctx->tune.up_on_read && u->up[k + 1].kz == 1 && ctx->tune.up_per_source &&
+                                      u->cv[l1].cout % 8 == 0 && (int64_t)B * lo.M * (u->cv[l1].cout / 4) < (int64_t)0xFFFFFFFFll;
+            ISX_TRY(run_conv(ctx, l1, lo, B, act(l0), none, nullptr, next_per_src));
         }
         {
             ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
@@ -1852,13 +1904,13 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
         }
         if (nm == m) {
             const ConvBN &L = u->cv[li + 1];
-            src = u->raw[li + 1]; sc = L.scale; sh = L.shift; C = L.cout; mode = (mi == 8) ? 3 : 2; level = MOD_LEVEL[mi];
+            src = u->raw[li + 1]; sc = L.scale; sh = L.shift; C = L.cout; mode = (mi == 8) ? 3 : 2; level = MOD_LEVEL[mi]; tap_planar = u->planar[li + 1];
         }
     }
     for (int k = 0; k < 4 && !src; ++k) {
-        if (nm == std::string("d") + std::to_string(k)) { src = u->pool[k]; C = MOD_COUT[k]; level = k + 1; }
+        if (nm == std::string("d") + std::to_string(k)) { src = u->pool[k]; C = MOD_COUT[k]; level = k + 1; tap_planar = u->pool_planar[k]; }
         else if (nm == std::string("up") + std::to_string(k) + ".cropped") {
-            src = u->ups[k]; C = UP_C[k]; level = 3 - k;
+            src = u->ups[k]; C = UP_C[k]; level = 3 - k; tap_planar = u->ups_planar[k];
             if (u->up_folded[k]) {            // not materialised by the folded forward: computed here from the resident coarse tensor
                 const int li_in = (k == 0) ? 9 : dec_layer(0, k - 1, 1);
                 const Level &ls = u->lv[MOD_LEVEL[layer_module(li_in)]], &lo = u->lv[3 - k];

@@ -94,6 +94,7 @@ struct UNetState {
     int last_n = 0;
     UpFoldPacks fold_store[ISX_MAX_LAYERS];   // cv[li].fold points here
     bool up_folded[ISX_MAX_UPS] = {false};     // last forward: ups[i] was NOT materialised (its consumer ran the folded form)
+    bool pool_planar[4] = {false}, ups_planar[ISX_MAX_UPS] = {false};      // last forward: pool[i] / ups[i] are stored planar
     bool planar[ISX_MAX_LAYERS] = {false};   // last forward: raw[li] is stored planar (first convolution of a module whose only reader is the second)
     int arith[ISX_MAX_LAYERS] = {0};  // how each convolution ran in the last forward (ISX_ARITH_*, isx_unet_precision_report)
     struct TrainState *train = nullptr;

@@ -3,7 +3,7 @@ import sys, glob, csv
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-conv = [r for r in rows if "conv_h2" in r["Kernel_Name"] or "conv_first" in r["Kernel_Name"]]
+conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_h2", "conv_first", "conv_tail", "tail_combine", "conv55"))]
 # one forward = conv_first + 17 conv_h2 launches (+ more with folds); take the last forward that starts with the biggest grid of conv_first
 firsts = [i for i, r in enumerate(conv) if "conv_first" in r["Kernel_Name"]]
 big = max(int(conv[i].get("Grid_Size", conv[i].get("Grid_Size_X", 0))) for i in firsts)

@@ -321,28 +321,32 @@ def test_tail_layer_up_sampling_on_read_is_bit_identical(monkeypatch):
 @pytest.mark.parametrize("out", [5, (3, 2)])
 @pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
 def test_planar_intermediate_tensors_change_nothing(monkeypatch, out, precision):
-    """ISX_PLANAR (default on): the first convolution of every module writes its output as [C/8][voxel][8] for the second one,
-    whose halo loads then read whole lines.  Only the memory layout changes: feature maps and every tap
-    (the `cX.conv0` / `cX.batch0` taps are read back through the planar index) are identical bit for bit."""
+    """ISX_PLANAR (default 2): the first convolution of every module writes its output as [C/8][voxel][8] for the second one,
+    whose halo loads then read whole lines; at 2 the skip tensors, the pooled tensors and the tensors
+    into / out of up1..up3 are planar too (pool_kernel / upsample_src_kernel plane by plane; the tail layer reads both its
+    sources that way).  Only the memory layout changes: feature maps and every tap (read back through the planar index) are
+    identical bit for bit."""
     import numpy as np
     from iterseg_amd import weights
     from iterseg_amd.unet import UNet
     sd = weights.generate_state_dict(7, out_channels=out)
     nets = []
-    for v in ("1", "0"):
+    for v in ("2", "1", "0"):
         monkeypatch.setenv("ISX_PLANAR", v)
         u = UNet(1, out, batch=2, precision=precision)
         u.load_state_dict(sd)
         nets.append(u)
     for shape in [(4, 32, 32), (10, 80, 48), (6, 48, 112), (10, 256, 256)]:
         x = np.random.default_rng(11).random((1, 1) + shape, dtype=np.float32)
-        ya, yb = nets[0](x), nets[1](x)
-        assert np.array_equal(ya, yb), shape
+        ya, yb, yc = nets[0](x), nets[1](x), nets[2](x)
+        assert np.array_equal(ya, yc) and np.array_equal(yb, yc), shape
         if np.prod(shape) > 100000:        # (the tap buffer of the wrapper holds 2^24 floats: the full-size chunk compares outputs only)
             continue
-        for name in ("c0.conv0", "c1.conv0", "c1.batch0", "c2.conv0", "c4.conv0", "c4.conv1", "c5_0.conv0", "c6_0.batch0", "c7_0.conv0",
-                     "c8_0.conv0", "c8_0.batch0", "c8_0.conv1", "d1", "up2.cropped"):
-            assert np.array_equal(nets[0].tap(name), nets[1].tap(name)), (shape, name)
+        for name in ("c0.conv0", "c0.conv1", "c0", "c1.conv0", "c1.batch0", "c1", "c2.conv0", "c3", "c4.conv0", "c4.conv1", "c5_0.conv0",
+                     "c5_0.conv1", "c6_0.batch0", "c7_0.conv0", "c7_0.conv1", "c8_0.conv0", "c8_0.batch0", "c8_0.conv1", "d0", "d1", "d2",
+                     "d3", "up0.cropped", "up1.cropped", "up2.cropped", "up3.cropped"):
+            ta = nets[0].tap(name)
+            assert np.array_equal(ta, nets[2].tap(name)) and np.array_equal(nets[1].tap(name), ta), (shape, name)
 
 
 @pytest.mark.gpu
