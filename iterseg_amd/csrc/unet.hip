@@ -469,33 +469,21 @@ __device__ __forceinline__ void put_channels(float *dst, const float4 (&v)[G], b
     else *(float4 *)dst = v[0];
 }
 
-// src_planar / dst_planar: the tensor is [chunk][C/8][voxel][8] instead of [chunk][voxel][C] (UNetState::planar).  With a planar
-// source the thread is (chunk, 8-channel plane, output voxel, half plane) -- consecutive lanes read and write consecutive
-// 16-byte pieces of one plane -- instead of (chunk, output voxel, channel quad).
 __global__ void pool_kernel(const float *__restrict__ src, const float *__restrict__ scale,
                             const float *__restrict__ shift, int C, int D, int H, int W, int kz, int Do, int Ho,
-                            int Wo, float *__restrict__ dst, int64_t total, int src_planar, int dst_planar)
+                            int Wo, float *__restrict__ dst, int64_t total)
 {
     // 32-bit index arithmetic throughout (total < 2^32 is checked by the launcher): the 64-bit divisions this kernel
     // started with cost more than its memory traffic
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)total) return;
     const uint32_t CG = (uint32_t)C / (4 * G);
+    const int c0 = (int)(i % CG) * 4 * G;
+    const uint32_t v = i / CG;
     const uint32_t Mo32 = (uint32_t)Do * Ho * Wo;
     const int64_t Mo = Mo32, M = (int64_t)D * H * W;
-    int c0, b;
-    uint32_t m;
-    if (src_planar) {
-        const uint32_t v = i >> 1, pl = (v / Mo32) % (CG >> 1);
-        c0 = (int)(pl * 8 + (i & 1) * 4);
-        m = v % Mo32;
-        b = (int)(v / (Mo32 * (CG >> 1)));
-    } else {
-        c0 = (int)(i % CG) * 4 * G;
-        const uint32_t v = i / CG;
-        b = (int)(v / Mo32);
-        m = v % Mo32;
-    }
+    const int b = (int)(v / Mo32);
+    const uint32_t m = v % Mo32;
     const int x = (int)(m % (uint32_t)Wo), y = (int)((m / (uint32_t)Wo) % (uint32_t)Ho), z = (int)(m / ((uint32_t)Wo * Ho));
     float4 vs[G], vh[G], best[G];
 #pragma unroll
@@ -504,8 +492,6 @@ __global__ void pool_kernel(const float *__restrict__ src, const float *__restri
         vh[g] = *(const float4 *)&shift[(int64_t)b * C + c0 + 4 * g];
         best[g] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
-    const float *sp = src_planar ? src + ((int64_t)b * (C >> 3) + (c0 >> 3)) * M * 8 + (c0 & 7) : src + (int64_t)b * M * C + c0;
-    const int sC = src_planar ? 8 : C;
     for (int i0 = 0; i0 < kz; ++i0)
         for (int j = 0; j < 2; ++j)
             for (int k = 0; k < 2; ++k) {
@@ -513,7 +499,7 @@ __global__ void pool_kernel(const float *__restrict__ src, const float *__restri
                 if (zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    float4 t = *(const float4 *)&sp[(((int64_t)zz * H + yy) * W + xx) * sC + 4 * g];
+                    float4 t = *(const float4 *)&src[((int64_t)b * M + ((int64_t)zz * H + yy) * W + xx) * C + c0 + 4 * g];
                     t.x = fmaxf(fmaf(t.x, vs[g].x, vh[g].x), 0.f);
                     t.y = fmaxf(fmaf(t.y, vs[g].y, vh[g].y), 0.f);
                     t.z = fmaxf(fmaf(t.z, vs[g].z, vh[g].z), 0.f);
@@ -524,8 +510,50 @@ __global__ void pool_kernel(const float *__restrict__ src, const float *__restri
                     best[g].w = fmaxf(best[g].w, t.w);
                 }
             }
-    float *dp = dst_planar ? &dst[(((int64_t)b * (C >> 3) + (c0 >> 3)) * Mo + m) * 8 + (c0 & 7)] : &dst[((int64_t)b * Mo + m) * C + c0];
-    put_channels(dp, best, false);
+    put_channels(&dst[((int64_t)b * Mo + m) * C + c0], best, false);
+}
+
+// The same pooling over PLANAR tensors, [chunk][C/8][voxel][8] in and out (UNetState::planar): thread = (chunk, 8-channel plane,
+// output voxel) reads the 2 x 32 contiguous bytes of its two source columns per (z, y) row and writes 32 -- consecutive lanes
+// read and write consecutive memory.
+__device__ __forceinline__ void bn_relu4(float4 &t, const float4 &s, const float4 &h)
+{
+    t.x = fmaxf(fmaf(t.x, s.x, h.x), 0.f); t.y = fmaxf(fmaf(t.y, s.y, h.y), 0.f);
+    t.z = fmaxf(fmaf(t.z, s.z, h.z), 0.f); t.w = fmaxf(fmaf(t.w, s.w, h.w), 0.f);
+}
+__global__ void pool_planar_kernel(const float *__restrict__ src, const float *__restrict__ scale, const float *__restrict__ shift,
+                                   int C, int D, int H, int W, int kz, int Do, int Ho, int Wo, float *__restrict__ dst, int64_t total)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)total) return;
+    const uint32_t Mo32 = (uint32_t)Do * Ho * Wo, NP = (uint32_t)C >> 3;
+    const int64_t M = (int64_t)D * H * W;
+    const uint32_t m = i % Mo32, pl = (i / Mo32) % NP;
+    const int b = (int)(i / (Mo32 * NP));
+    const int x = (int)(m % (uint32_t)Wo), y = (int)((m / (uint32_t)Wo) % (uint32_t)Ho), z = (int)(m / ((uint32_t)Wo * Ho));
+    const float4 s0 = *(const float4 *)&scale[(int64_t)b * C + 8 * pl], s1 = *(const float4 *)&scale[(int64_t)b * C + 8 * pl + 4];
+    const float4 h0 = *(const float4 *)&shift[(int64_t)b * C + 8 * pl], h1 = *(const float4 *)&shift[(int64_t)b * C + 8 * pl + 4];
+    float4 b0 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), b1 = b0;
+    const float *sp = src + ((int64_t)b * NP + pl) * M * 8;
+    for (int i0 = 0; i0 < kz; ++i0)
+        for (int j = 0; j < 2; ++j) {
+            const int zz = z * kz + i0, yy = 2 * y - 1 + j;
+            if (zz >= D || yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int xx = 2 * x - 1 + k;
+                if (xx < 0 || xx >= W) continue;
+                const float *pp = &sp[(((int64_t)zz * H + yy) * W + xx) * 8];
+                float4 t0 = *(const float4 *)pp, t1 = *(const float4 *)(pp + 4);
+                bn_relu4(t0, s0, h0);
+                bn_relu4(t1, s1, h1);
+                b0.x = fmaxf(b0.x, t0.x); b0.y = fmaxf(b0.y, t0.y); b0.z = fmaxf(b0.z, t0.z); b0.w = fmaxf(b0.w, t0.w);
+                b1.x = fmaxf(b1.x, t1.x); b1.y = fmaxf(b1.y, t1.y); b1.z = fmaxf(b1.z, t1.z); b1.w = fmaxf(b1.w, t1.w);
+            }
+        }
+    float *dp = &dst[(((int64_t)b * NP + pl) * Mo32 + m) * 8];
+    *(float4 *)dp = b0;
+    *(float4 *)(dp + 4) = b1;
 }
 
 // out[z, y, x, c] = act(in[z/kz, (y+off)/2, (x+off)/2, c]) * w[(z%kz, (y+off)%2, (x+off)%2)][c] + bias[c]
@@ -569,34 +597,24 @@ __global__ void upsample_kernel(const float *__restrict__ src, const float *__re
 // 3.7 TB/s against 5.6 TB/s for pool_kernel).  thread = (coarse voxel, 4 G channels).
 __global__ void upsample_src_kernel(const float *__restrict__ src, const float *__restrict__ scale, const float *__restrict__ shift,
                                     int C, int D, int H, int W, int off, const float *__restrict__ w, const float *__restrict__ bias,
-                                    int Ho, int Wo, float *__restrict__ dst, int64_t total, int src_planar, int dst_planar)
+                                    int Ho, int Wo, float *__restrict__ dst, int64_t total)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)total) return;
     const uint32_t CG = (uint32_t)C / (4 * G);
+    const int c0 = (int)(i % CG) * 4 * G;
+    const uint32_t v = i / CG;
     const uint32_t M32 = (uint32_t)D * H * W;
     const int64_t M = M32, Mo = (int64_t)D * Ho * Wo;
-    int c0, b;
-    uint32_t m;
-    if (dst_planar) {                  // thread = (chunk, 8-channel plane, coarse voxel, half plane): see pool_kernel
-        const uint32_t v = i >> 1, pl = (v / M32) % (CG >> 1);
-        c0 = (int)(pl * 8 + (i & 1) * 4);
-        m = v % M32;
-        b = (int)(v / (M32 * (CG >> 1)));
-    } else {
-        c0 = (int)(i % CG) * 4 * G;
-        const uint32_t v = i / CG;
-        b = (int)(v / M32);
-        m = v % M32;
-    }
+    const int b = (int)(v / M32);
+    const uint32_t m = v % M32;
     const int xs = (int)(m % (uint32_t)W), ys = (int)((m / (uint32_t)W) % (uint32_t)H), z = (int)(m / ((uint32_t)W * H));
     float4 t[G], bv[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const float4 vs = *(const float4 *)&scale[(int64_t)b * C + c0 + 4 * g];
         const float4 vh = *(const float4 *)&shift[(int64_t)b * C + c0 + 4 * g];
-        t[g] = src_planar ? *(const float4 *)&src[(((int64_t)b * (C >> 3) + (c0 >> 3)) * M + m) * 8 + (c0 & 7) + 4 * g]
-                          : *(const float4 *)&src[((int64_t)b * M + m) * C + c0 + 4 * g];
+        t[g] = *(const float4 *)&src[((int64_t)b * M + m) * C + c0 + 4 * g];
         t[g].x = fmaxf(fmaf(t[g].x, vs.x, vh.x), 0.f); t[g].y = fmaxf(fmaf(t[g].y, vs.y, vh.y), 0.f);
         t[g].z = fmaxf(fmaf(t[g].z, vs.z, vh.z), 0.f); t[g].w = fmaxf(fmaf(t[g].w, vs.w, vh.w), 0.f);
         bv[g] = *(const float4 *)&bias[c0 + 4 * g];
@@ -614,10 +632,45 @@ __global__ void upsample_src_kernel(const float *__restrict__ src, const float *
                 o[g] = make_float4(fmaf(t[g].x, wv.x, bv[g].x), fmaf(t[g].y, wv.y, bv[g].y), fmaf(t[g].z, wv.z, bv[g].z),
                                    fmaf(t[g].w, wv.w, bv[g].w));
             }
-            const int64_t vo = ((int64_t)z * Ho + y) * Wo + x;
-            float *dp = dst_planar ? &dst[(((int64_t)b * (C >> 3) + (c0 >> 3)) * Mo + vo) * 8 + (c0 & 7)] : &dst[((int64_t)b * Mo + vo) * C + c0];
-            put_channels(dp, o, true);
+            put_channels(&dst[((int64_t)b * Mo + ((int64_t)z * Ho + y) * Wo + x) * C + c0], o, true);
         }
+}
+
+// ... and over PLANAR tensors in and out: thread = (chunk, 8-channel plane, coarse voxel) reads 32 contiguous bytes and writes,
+// per output row, the 2 x 32 contiguous bytes of its two columns (consecutive lanes: consecutive memory; plain stores -- the
+// row's two column stores complete each other's lines in L2).
+__global__ void upsample_src_planar_kernel(const float *__restrict__ src, const float *__restrict__ scale, const float *__restrict__ shift,
+                                           int C, int D, int H, int W, int off, const float *__restrict__ w, const float *__restrict__ bias,
+                                           int Ho, int Wo, float *__restrict__ dst, int64_t total)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)total) return;
+    const uint32_t M32 = (uint32_t)D * H * W, NP = (uint32_t)C >> 3;
+    const int64_t Mo = (int64_t)D * Ho * Wo;
+    const uint32_t m = i % M32, pl = (i / M32) % NP;
+    const int b = (int)(i / (M32 * NP));
+    const int xs = (int)(m % (uint32_t)W), ys = (int)((m / (uint32_t)W) % (uint32_t)H), z = (int)(m / ((uint32_t)W * H));
+    const int c0 = (int)pl * 8;
+    const float *pp = &src[(((int64_t)b * NP + pl) * M32 + m) * 8];
+    float4 t0 = *(const float4 *)pp, t1 = *(const float4 *)(pp + 4);
+    bn_relu4(t0, *(const float4 *)&scale[(int64_t)b * C + c0], *(const float4 *)&shift[(int64_t)b * C + c0]);
+    bn_relu4(t1, *(const float4 *)&scale[(int64_t)b * C + c0 + 4], *(const float4 *)&shift[(int64_t)b * C + c0 + 4]);
+    const float4 bv0 = *(const float4 *)&bias[c0], bv1 = *(const float4 *)&bias[c0 + 4];
+    float *dpl = dst + ((int64_t)b * NP + pl) * Mo * 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int y = 2 * ys + j - off;
+        if (y < 0 || y >= Ho) continue;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int x = 2 * xs + k - off;
+            if (x < 0 || x >= Wo) continue;
+            const float4 w0 = *(const float4 *)&w[(int64_t)(j * 2 + k) * C + c0], w1 = *(const float4 *)&w[(int64_t)(j * 2 + k) * C + c0 + 4];
+            float *dp = &dpl[(((int64_t)z * Ho + y) * Wo + x) * 8];
+            *(float4 *)dp = make_float4(fmaf(t0.x, w0.x, bv0.x), fmaf(t0.y, w0.y, bv0.y), fmaf(t0.z, w0.z, bv0.z), fmaf(t0.w, w0.w, bv0.w));
+            *(float4 *)(dp + 4) = make_float4(fmaf(t1.x, w1.x, bv1.x), fmaf(t1.y, w1.y, bv1.y), fmaf(t1.z, w1.z, bv1.z), fmaf(t1.w, w1.w, bv1.w));
+        }
+    }
 }
 
 // Folded up-convolution (UpFoldPacks): the class convolutions treat every coarse voxel as the source of BOTH fine rows /
@@ -1601,7 +1654,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             const float up_bound = bn_bound(li_in) * u->up[k].wmax + u->up[k].bmax;
             if (!conv_takes_h2(ctx, dec_layer(f, k, 0), lv[mi], B, std::max(up_bound, bn_bound(2 * mi + 1)))) return false;
         }
-        return true;
+        return conv_takes_h2(ctx, 2 * (mi + 1), lv[mi + 1], B, bn_bound(2 * mi + 1));       // the pooled tensor's reader
     };
     // ---- encoder ----------------------------------------------------------------------------
     for (int mi = 0; mi <= 4; ++mi) {
@@ -1617,12 +1670,17 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             const ConvBN &L = u->cv[2 * mi + 1];
             int64_t total = (int64_t)B * lo.M * (L.cout / 4);
             ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
-            // a planar skip tensor is pooled plane by plane, into a planar tensor if the next module's first convolution reads one
+            // a planar skip tensor is pooled plane by plane into a planar tensor (skip_planar_ok has checked its reader)
             const bool sp = u->planar[2 * mi + 1];
-            u->pool_planar[mi] = sp && conv_takes_h2(ctx, 2 * (mi + 1), lo, B, bn_bound(2 * mi + 1));
+            u->pool_planar[mi] = sp;
+            if (sp) {
+                total = (int64_t)B * lo.M * (L.cout / 8);
+                pool_planar_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[2 * mi + 1], L.scale, L.shift, L.cout, l.D, l.H, l.W,
+                                                                           mi == 3 ? 2 : 1, lo.D, lo.H, lo.W, u->pool[mi], total);
+            } else
             pool_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[2 * mi + 1], L.scale, L.shift, L.cout, l.D, l.H,
                                                                 l.W, mi == 3 ? 2 : 1, lo.D, lo.H, lo.W, u->pool[mi],
-                                                                total, sp ? 1 : 0, u->pool_planar[mi] ? 1 : 0);
+                                                                total);
             ISX_CHECK_LAUNCH();
         }
     }
@@ -1674,12 +1732,14 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                 const int64_t total_src = (int64_t)B * ls.M * (U.C / 4);
                 const bool per_src = U.kz == 1 && ctx->tune.up_per_source && total_src < (int64_t)0xFFFFFFFFll;
                 ISX_REQUIRE(per_src || !u->planar[li_in], "internal: a planar tensor reached the per-output transposed convolution");
-                u->ups_planar[ups_index(f, k)] = per_src && ctx->tune.planar >= 2 && !u->train && U.C % 8 == 0 && !ctx->tune.up_fold && !ctx->tune.up_on_read &&
-                                                     conv_takes_h2(ctx, l0, lo, B, std::max(up_bound, bn_bound(skip_li)));
-                if (per_src)
+                u->ups_planar[ups_index(f, k)] = u->planar[li_in];       // (up_planar_ok has checked the reader of the up-sampled tensor)
+                if (per_src && u->planar[li_in]) {
+                    const int64_t total_pl = (int64_t)B * ls.M * (U.C / 8);
+                    upsample_src_planar_kernel<<<cdiv(total_pl, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W,
+                                                                                          k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, upo, total_pl);
+                } else if (per_src)
                     upsample_src_kernel<<<cdiv(total_src, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W,
-                                                                                    k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, upo, total_src,
-                                                                                    u->planar[li_in] ? 1 : 0, u->ups_planar[ups_index(f, k)] ? 1 : 0);
+                                                                                    k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, upo, total_src);
                 else
                 upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D,
                                                                         ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, U.bias, lo.D,
@@ -1687,9 +1747,15 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                 ISX_CHECK_LAUNCH();
             }
             ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound, u->ups_planar[ups_index(f, k)]}, act(skip_li), nullptr, planar_ok(l1, lo, l0)));
-            // its output feeds up_{k+1} only (k < 3): planar if that transposed convolution runs per source voxel
-            const bool next_per_src = k < 3 && ctx->tune.planar >= 2 && !u->train && !ctx->tune.up_fold && !ctx->tune.up_on_read && u->up[k + 1].kz == 1 && ctx->tune.up_per_source &&
-                                      u->cv[l1].cout % 8 == 0 && (int64_t)B * lo.M * (u->cv[l1].cout / 4) < (int64_t)0xFFFFFFFFll;
+            // its output feeds up_{k+1} only (k < 3): planar if that transposed convolution runs per source voxel and the
+            // convolution behind it reads planar sources
+            bool next_per_src = k < 3 && ctx->tune.planar >= 2 && !u->train && !ctx->tune.up_fold && !ctx->tune.up_on_read &&
+                                u->up[k + 1].kz == 1 && ctx->tune.up_per_source && u->cv[l1].cout % 8 == 0 &&
+                                (int64_t)B * lo.M * (u->cv[l1].cout / 4) < (int64_t)0xFFFFFFFFll;
+            if (next_per_src) {
+                const float nb = bn_bound(l1) * u->up[k + 1].wmax + u->up[k + 1].bmax;
+                next_per_src = conv_takes_h2(ctx, dec_layer(f, k + 1, 0), lv[3 - (k + 1)], B, std::max(nb, bn_bound(2 * (3 - (k + 1)) + 1)));
+            }
             ISX_TRY(run_conv(ctx, l1, lo, B, act(l0), none, nullptr, next_per_src));
         }
         {
