@@ -106,10 +106,25 @@ __device__ __forceinline__ void round8(const float4 &a, const float4 &b, uint4 &
 // 16-lane groups of a wave feed four taps (k = 8 * (lane / 16) + channel), a wave's 32 x BN tile is 2 x BN/16 accumulator
 // tiles of 16 x 16: the same fragment reads, accumulator registers and matrix-pipe cycles per product -- but the chip holds
 // a higher clock under this shape when it runs at its power cap (MI355X_MICROARCH.md, "Shape"), and this kernel does.
+// One 1 KiB piece of a weight slab straight into LDS (global_load_lds_dwordx4: lane i's 16 bytes land at lds_wave_base + 16 i,
+// no register round trip).  Inline assembly on purpose: through the builtin the compiler waits for vmcnt(0) before EVERY later
+// LDS read of the work-group's one shared array (it cannot tell the two slab buffers apart), which would put the DMA's latency
+// in front of the matrix phase it is meant to hide behind.  The wave's vmcnt still counts it, in issue order: it is issued
+// before the halo loads of the same stage, so the wait the compiler places for those covers it (conv_h2_body).
+__device__ __forceinline__ void lds_dma16(const uint4 *g, uint4 *lds_wave_base)
+{
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "m0", "memory");
+}
+
 template <int BN, int TX, int MT, int PM, int NW, int CORE>
 __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 {
     constexpr bool SPLIT = PM == 0;
+    // DMA: the 512-thread kernel on the 16x16x32 core takes its weight slabs by LDS-DMA into two buffers used alternately: the
+    // slab of stage s + 1 is requested at the start of the matrix phase of stage s (no prefetch registers, no LDS stores by the
+    // waves: 7 global loads + 7 ds_write_b128 per lane and stage gone) and is complete before the staging of s + 1 ends
+    constexpr bool DMA = NW == 8 && CORE == 1;
     // (the tail layer's packs hold 12 tap slots for its 9 taps, so that either core can read them)
     constexpr int THREADS = 64 * NW;
     constexpr int ROWS = 32 * NW * MT, TXW = 2 * NW * MT;
@@ -124,8 +139,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     constexpr int SLAB = SPLIT ? 2 * BU : BU;             // uint4 of weights staged per K step (single-product modes: hi only)
     constexpr int NB = (SLAB + THREADS - 1) / THREADS;    // uint4 of weights per thread per stage (14 / 7 / 3; halved without lo)
     constexpr bool BEXACT = SLAB % THREADS == 0;
-    uint4 *Bs = smem4;                                    // [hi: 28][BN] | [lo: 28][BN]
-    uint4 *AsH = smem4 + SLAB;
+    uint4 *Bs = smem4;                                    // [hi: 28][BN] | [lo: 28][BN]  (DMA: two of them)
+    uint4 *AsH = smem4 + (DMA ? 2 : 1) * SLAB;
     uint4 *AsL = AsH + a.slots_max;                       // (SPLIT only)
     int *rowinfo = (int *)(AsH + (SPLIT ? 2 : 1) * a.slots_max);
     float *red = (float *)(rowinfo + ROWS);
@@ -322,6 +337,11 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         case 0: H2_LOAD_A(0) break; case 1: H2_LOAD_A(1) break; case 2: H2_LOAD_A(2) break;        \
         case 3: H2_LOAD_A(3) break; case 4: H2_LOAD_A(4) break; default: break;                   \
     }
+#define H2_DMA_B1(step_, k_)                                                                      \
+    if ((k_) < NB && (BEXACT || THREADS * (k_) + wbase < SLAB))                                   \
+        lds_dma16((const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU) + tid + THREADS * (k_), \
+                  Bs + ((step_) & 1) * SLAB + wbase + THREADS * (k_));
+#define H2_DMA_B(step_) { _Pragma("unroll") for (int k_ = 0; k_ < NB; ++k_) H2_DMA_B1(step_, k_) }
 #define H2_LOAD_B_ALL(step_)                                                                      \
     {                                                                                             \
         ld_wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);            \
@@ -399,12 +419,13 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #endif
     // 16x16x32 core: a stage's weight slab is loaded at the top of its own iteration (its registers are then free during the
     // matrix phase, which keeps its fragments two steps ahead in them) and lands behind the barrier and the halo arithmetic
+    if constexpr (DMA) H2_DMA_B(0)
     if constexpr (CORE == 1) { H2_LOAD_HEAD(0) H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4) }
     else H2_LOAD_STAGE(0)
     H2_T(tk_loop)
     for (int step = 0; step < nsteps; ++step) {
         H2_T(t0)
-        if constexpr (CORE == 1) H2_LOAD_B_ALL(step)
+        if constexpr (CORE == 1 && !DMA) H2_LOAD_B_ALL(step)
         __syncthreads();
         H2_T(t1)
 #ifdef H2_STAGE_STAMPS
@@ -417,8 +438,10 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         (void)st_up; (void)st_cc; (void)sb0; (void)sb1;
         if constexpr (UPA || ISX_H2_ABLATE == 1) { H2_STORE_A_GEN(0) H2_STORE_A_GEN(1) H2_STORE_A_GEN(2) H2_STORE_A_GEN(3) H2_STORE_A_GEN(4) }
         else { H2_STORE_A_FAST(0) H2_STORE_A_FAST(1) H2_STORE_A_FAST(2) H2_STORE_A_FAST(3) H2_STORE_A_FAST(4) }
+        if constexpr (!DMA) {
         H2_STORE_B(0) H2_STORE_B(1) H2_STORE_B(2) H2_STORE_B(3) H2_STORE_B(4) H2_STORE_B(5) H2_STORE_B(6)
         H2_STORE_B(7) H2_STORE_B(8) H2_STORE_B(9) H2_STORE_B(10) H2_STORE_B(11) H2_STORE_B(12) H2_STORE_B(13)
+        } else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the stage's slab have landed (nothing else is in flight here)
         H2_T(t2)
         __syncthreads();
         H2_T(t3)
@@ -435,7 +458,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             // read every fragment right before its use (its register budget is spent on the prefetched stage) and issued the
             // 24 global loads back to back before the first matrix instruction: 2 100-2 800 cycles per stage waiting for room
             // in the load queue with the matrix pipe idle (scratch ISX_H2_STAMP build).
-            const uint4 *bqh = Bs + h4 * BN + l16, *bql = bqh + BU;
+            const uint4 *bqh = Bs + (DMA ? (step & 1) * SLAB : 0) + h4 * BN + l16, *bql = bqh + BU;
             union FR { uint4 u; f16x8 v; bf16x8 w; };
             constexpr int NS = NQUAD * NT16;
             // two row tiles per wave (MT16 = 4: 12 matrix instructions = 192 cycles per step): B one step ahead and the lo halves
@@ -467,6 +490,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                 if (!AL2 && j == 0) H2_FRAG_AL(q)
                 if (j == (NT16 >= 2 ? NT16 - 2 : 0) && q + 1 < NQUAD) { H2_FRAG_AH(q + 1) if constexpr (AL2) H2_FRAG_AL(q + 1) }
                 if (more) { H2_LOAD_SLOT(s) }
+                // (DMA) the next stage's slab, one 1 KiB piece every third step, into the buffer the matrix phase of stage step - 1 read
+                if constexpr (DMA) { if (more && s >= 3 && (s - 3) % 3 == 0) H2_DMA_B1(step + 1, (s - 3) / 3) }
                 if constexpr (SPLIT) {
 #pragma unroll
                     for (int m = 0; m < MT16; ++m) {
@@ -488,6 +513,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                 __builtin_amdgcn_sched_barrier(0);
             }
             static_assert(NS >= 5, "one halo load per step");
+            static_assert(!DMA || 3 + 3 * (NB - 1) < NS, "one slab piece every third step");
 #undef H2_FRAG_AH
 #undef H2_FRAG_AL
 #undef H2_FRAG_B
@@ -540,6 +566,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #undef H2_LOAD_HEAD
 #undef H2_LOAD_SLOT
 #undef H2_LOAD_B_ALL
+#undef H2_DMA_B
+#undef H2_DMA_B1
 #undef H2_AFF
 #undef H2_STORE_A_GEN
 #undef H2_STORE_A_FAST
@@ -559,7 +587,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     // the same order as below, the stored values are the same.
     constexpr int TRS = BN + 4;                                    // floats per row of the LDS tile (16-byte rows, conflict-free both ways)
     const bool t_out = !a.remap && !a.accum && a.store_cols % 4 == 0 &&
-                       (size_t)(SLAB + (SPLIT ? 2 : 1) * a.slots_max) * 16 >= (size_t)ROWS * TRS * sizeof(float);
+                       (size_t)((DMA ? 2 : 1) * SLAB + (SPLIT ? 2 : 1) * a.slots_max) * 16 >= (size_t)ROWS * TRS * sizeof(float);
     if (t_out) {
         float *T = (float *)smem4;
         __syncthreads();                                           // every wave has read its last fragments
@@ -907,7 +935,8 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     ISX_REQUIRE(a.slots_max <= (nw8 ? 1536 : (mt == 2 ? 1280 : 1024)), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     a.ntiles = fold ? 1 : cout / BN;
     const int npair = fold ? 6 : (tx2 ? 6 : 14);          // tap slots / 2 of a weight stage (the tail layer's 9 taps sit in 12 slots)
-    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * (2 * npair * BN + a.slots_max)) * 16 + ((nw8 ? 256 : 128 * mt) + (nw8 ? 8 : 4) * BN * 2) * sizeof(float);
+    const bool dma = nw8 && ctx->tune.h2_core16;              // conv_h2c16nw8_kernel: two weight-slab buffers (LDS-DMA)
+    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * ((dma ? 2 : 1) * 2 * npair * BN + a.slots_max)) * 16 + ((nw8 ? 256 : 128 * mt) + (nw8 ? 8 : 4) * BN * 2) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);

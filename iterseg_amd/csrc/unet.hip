@@ -636,40 +636,38 @@ __global__ void upsample_src_kernel(const float *__restrict__ src, const float *
         }
 }
 
-// ... and over PLANAR tensors in and out: thread = (chunk, 8-channel plane, coarse voxel) reads 32 contiguous bytes and writes,
-// per output row, the 2 x 32 contiguous bytes of its two columns (consecutive lanes: consecutive memory; plain stores -- the
-// row's two column stores complete each other's lines in L2).
+// ... and over PLANAR tensors in and out: thread = (chunk, 8-channel plane, z, coarse row, FINE column, half plane) loads 16
+// bytes (the two fine columns of a coarse voxel read the same bytes: L1), applies BatchNorm + ReLU once and writes its two
+// output rows -- consecutive lanes store consecutive 16-byte pieces, so every store instruction writes whole lines and can
+// stream.  (One thread per coarse voxel writing 32-byte pieces with 32-byte gaps took 1.8 x the row-major kernel's time, and
+// 3.4 x with streaming stores.)
 __global__ void upsample_src_planar_kernel(const float *__restrict__ src, const float *__restrict__ scale, const float *__restrict__ shift,
                                            int C, int D, int H, int W, int off, const float *__restrict__ w, const float *__restrict__ bias,
                                            int Ho, int Wo, float *__restrict__ dst, int64_t total)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)total) return;
-    const uint32_t M32 = (uint32_t)D * H * W, NP = (uint32_t)C >> 3;
-    const int64_t Mo = (int64_t)D * Ho * Wo;
-    const uint32_t m = i % M32, pl = (i / M32) % NP;
-    const int b = (int)(i / (M32 * NP));
-    const int xs = (int)(m % (uint32_t)W), ys = (int)((m / (uint32_t)W) % (uint32_t)H), z = (int)(m / ((uint32_t)W * H));
-    const int c0 = (int)pl * 8;
-    const float *pp = &src[(((int64_t)b * NP + pl) * M32 + m) * 8];
-    float4 t0 = *(const float4 *)pp, t1 = *(const float4 *)(pp + 4);
-    bn_relu4(t0, *(const float4 *)&scale[(int64_t)b * C + c0], *(const float4 *)&shift[(int64_t)b * C + c0]);
-    bn_relu4(t1, *(const float4 *)&scale[(int64_t)b * C + c0 + 4], *(const float4 *)&shift[(int64_t)b * C + c0 + 4]);
-    const float4 bv0 = *(const float4 *)&bias[c0], bv1 = *(const float4 *)&bias[c0 + 4];
-    float *dpl = dst + ((int64_t)b * NP + pl) * Mo * 8;
+    const uint32_t NP = (uint32_t)C >> 3, R = (uint32_t)D * H;      // R: (z, coarse row) pairs
+    const int64_t M = (int64_t)D * H * W, Mo = (int64_t)D * Ho * Wo;
+    const int half = (int)(i & 1u);
+    const uint32_t v = i >> 1;
+    const int xf = (int)(v % (uint32_t)Wo);
+    const uint32_t r = (v / (uint32_t)Wo) % R, pl = (v / ((uint32_t)Wo * R)) % NP;
+    const int b = (int)(v / ((uint32_t)Wo * R * NP));
+    const int ys = (int)(r % (uint32_t)H), z = (int)(r / (uint32_t)H);
+    const int xs = (xf + off) >> 1, k = (xf + off) & 1;
+    const int c0 = (int)pl * 8 + 4 * half;
+    float4 t = *(const float4 *)&src[(((int64_t)b * NP + pl) * M + ((int64_t)z * H + ys) * W + xs) * 8 + 4 * half];
+    bn_relu4(t, *(const float4 *)&scale[(int64_t)b * C + c0], *(const float4 *)&shift[(int64_t)b * C + c0]);
+    const float4 bv = *(const float4 *)&bias[c0];
+    float *dpl = dst + ((int64_t)b * NP + pl) * Mo * 8 + 4 * half;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int y = 2 * ys + j - off;
         if (y < 0 || y >= Ho) continue;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int x = 2 * xs + k - off;
-            if (x < 0 || x >= Wo) continue;
-            const float4 w0 = *(const float4 *)&w[(int64_t)(j * 2 + k) * C + c0], w1 = *(const float4 *)&w[(int64_t)(j * 2 + k) * C + c0 + 4];
-            float *dp = &dpl[(((int64_t)z * Ho + y) * Wo + x) * 8];
-            *(float4 *)dp = make_float4(fmaf(t0.x, w0.x, bv0.x), fmaf(t0.y, w0.y, bv0.y), fmaf(t0.z, w0.z, bv0.z), fmaf(t0.w, w0.w, bv0.w));
-            *(float4 *)(dp + 4) = make_float4(fmaf(t1.x, w1.x, bv1.x), fmaf(t1.y, w1.y, bv1.y), fmaf(t1.z, w1.z, bv1.z), fmaf(t1.w, w1.w, bv1.w));
-        }
+        const float4 wv = *(const float4 *)&w[(int64_t)(j * 2 + k) * C + c0];
+        __builtin_nontemporal_store(f32x4{fmaf(t.x, wv.x, bv.x), fmaf(t.y, wv.y, bv.y), fmaf(t.z, wv.z, bv.z), fmaf(t.w, wv.w, bv.w)},
+                                    (f32x4 *)&dpl[(((int64_t)z * Ho + y) * Wo + xf) * 8]);
     }
 }
 
@@ -1734,7 +1732,8 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                 ISX_REQUIRE(per_src || !u->planar[li_in], "internal: a planar tensor reached the per-output transposed convolution");
                 u->ups_planar[ups_index(f, k)] = u->planar[li_in];       // (up_planar_ok has checked the reader of the up-sampled tensor)
                 if (per_src && u->planar[li_in]) {
-                    const int64_t total_pl = (int64_t)B * ls.M * (U.C / 8);
+                    const int64_t total_pl = (int64_t)B * (U.C / 8) * ls.D * ls.H * lo.W * 2;
+                    ISX_REQUIRE(total_pl < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
                     upsample_src_planar_kernel<<<cdiv(total_pl, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W,
                                                                                           k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, upo, total_pl);
                 } else if (per_src)
