@@ -117,9 +117,15 @@ __device__ __forceinline__ void lds_dma16(const uint4 *g, uint4 *lds_wave_base)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "m0", "memory");
 }
 
-template <int BN, int TX, int MT, int PM, int NW, int CORE>
+// NJ (DMA kernel only): N tiles of BN columns per work-group.  NJ = 2: the halo tile of a K stage is staged ONCE for 2 x 64
+// output columns -- the layers with Cout >= 128 (47 % of the network's FLOPs) otherwise load, normalise, split and store
+// every halo tile once per 64 columns --, the two weight slabs of a stage alternate between the two DMA buffers (the slab
+// sequence g = step * NJ + jj simply continues: slab g + 1 lands while the matrix phase reads slab g), one more barrier per
+// stage for twice the matrix work per stage, 128 accumulator registers.
+template <int BN, int TX, int MT, int PM, int NW, int CORE, int NJ = 1>
 __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 {
+    static_assert(NJ == 1 || (NW == 8 && CORE == 1 && MT == 1 && TX == 3), "N-tile pairs: the LDS-DMA kernel only");
     constexpr bool SPLIT = PM == 0;
     // DMA: the 512-thread kernel on the 16x16x32 core takes its weight slabs by LDS-DMA into two buffers used alternately: the
     // slab of stage s + 1 is requested at the start of the matrix phase of stage s (no prefetch registers, no LDS stores by the
@@ -151,7 +157,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         const int per = gridDim.x >> 3, main = per << 3;
         if (lin < main) lin = (lin & 7) * per + (lin >> 3);
     }
-    const int ntile = lin % a.ntiles;
+    const int ntile = (lin % a.ntiles) * NJ;              // first N tile of this work-group (a.ntiles = Cout / (BN * NJ))
     lin /= a.ntiles;
     const int b = lin / a.tiles_per_chunk, tile = lin % a.tiles_per_chunk;
     const int D = a.D, H = a.H, W = a.W;
@@ -253,14 +259,18 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     const int nsteps = (a.CA + a.CB) >> 3;
     typedef float f32x4c __attribute__((ext_vector_type(4)));
     constexpr int MT16 = 2 * MT, NT16 = BN / 16;
-    f32x4c c_hi[CORE == 1 ? MT16 : 1][CORE == 1 ? NT16 : 1], c_lo[(CORE == 1 && SPLIT) ? MT16 : 1][(CORE == 1 && SPLIT) ? NT16 : 1];
+    f32x4c c_hiN[NJ][CORE == 1 ? MT16 : 1][CORE == 1 ? NT16 : 1], c_loN[NJ][(CORE == 1 && SPLIT) ? MT16 : 1][(CORE == 1 && SPLIT) ? NT16 : 1];
+    auto &c_hi = c_hiN[0];                                   // (every path but the N-tile pair uses tile 0)
+    auto &c_lo = c_loN[0];
     if constexpr (CORE == 1) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
         for (int m = 0; m < MT16; ++m)
 #pragma unroll
             for (int j = 0; j < NT16; ++j) {
-                c_hi[m][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
-                if constexpr (SPLIT) c_lo[m][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
+                c_hiN[jj][m][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
+                if constexpr (SPLIT) c_loN[jj][m][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
             }
     }
     f32x16 acc_hi[CORE == 1 ? 1 : MT][CORE == 1 ? 1 : NT], acc_lo[(SPLIT && CORE == 0) ? MT : 1][(SPLIT && CORE == 0) ? NT : 1];
@@ -337,11 +347,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         case 0: H2_LOAD_A(0) break; case 1: H2_LOAD_A(1) break; case 2: H2_LOAD_A(2) break;        \
         case 3: H2_LOAD_A(3) break; case 4: H2_LOAD_A(4) break; default: break;                   \
     }
-#define H2_DMA_B1(step_, k_)                                                                      \
+// piece k_ of slab g_ of the work-group's slab sequence (g = step * NJ + jj: N tile ntile + g % NJ, K stage g / NJ) -> buffer g & 1
+#define H2_DMA_B1(g_, k_)                                                                         \
     if ((k_) < NB && (BEXACT || THREADS * (k_) + wbase < SLAB))                                   \
-        lds_dma16((const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU) + tid + THREADS * (k_), \
-                  Bs + ((step_) & 1) * SLAB + wbase + THREADS * (k_));
-#define H2_DMA_B(step_) { _Pragma("unroll") for (int k_ = 0; k_ < NB; ++k_) H2_DMA_B1(step_, k_) }
+        lds_dma16((const uint4 *)a.w + ((int64_t)(ntile + (g_) % NJ) * nsteps + (g_) / NJ) * (2 * BU) + tid + THREADS * (k_), \
+                  Bs + ((g_) & 1) * SLAB + wbase + THREADS * (k_));
+#define H2_DMA_B(g_) { _Pragma("unroll") for (int k_ = 0; k_ < NB; ++k_) H2_DMA_B1(g_, k_) }
 #define H2_LOAD_B_ALL(step_)                                                                      \
     {                                                                                             \
         ld_wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);            \
@@ -458,13 +469,24 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             // read every fragment right before its use (its register budget is spent on the prefetched stage) and issued the
             // 24 global loads back to back before the first matrix instruction: 2 100-2 800 cycles per stage waiting for room
             // in the load queue with the matrix pipe idle (scratch ISX_H2_STAMP build).
-            const uint4 *bqh = Bs + (DMA ? (step & 1) * SLAB : 0) + h4 * BN + l16, *bql = bqh + BU;
             union FR { uint4 u; f16x8 v; bf16x8 w; };
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+            const int g = step * NJ + jj;                           // position in the slab sequence (= step unless NJ > 1)
+            const bool more_slab = g + 1 < nsteps * NJ;
+            if (jj > 0) {              // the slab of this N tile has landed (every wave's pieces), and every wave is done with the previous one
+                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            auto &c_hi = c_hiN[jj];
+            auto &c_lo = c_loN[jj];
+            const uint4 *bqh = Bs + (DMA ? (g & 1) * SLAB : 0) + h4 * BN + l16, *bql = bqh + BU;
             constexpr int NS = NQUAD * NT16;
             // two row tiles per wave (MT16 = 4: 12 matrix instructions = 192 cycles per step): B one step ahead and the lo halves
             // of A read at the start of their own quad (first used 8 matrix instructions later) -- the registers do not go further
-            constexpr int BR = MT16 < 4 ? 3 : 2, BD = BR - 1;
-            constexpr bool AL2 = MT16 < 4;
+            // (the N-tile pair holds 128 accumulator registers: the shallower pipeline of the two-row-tile kernel as well)
+            constexpr int BR = (MT16 < 4 && NJ == 1) ? 3 : 2, BD = BR - 1;
+            constexpr bool AL2 = MT16 < 4 && NJ == 1;
             FR ah[2][MT16], al[(SPLIT && AL2) ? 2 : 1][SPLIT ? MT16 : 1], bh[BR], bl[SPLIT ? BR : 1];
 #define H2_FRAG_AH(q_)                                                                            \
             { _Pragma("unroll") for (int m = 0; m < MT16; ++m) ah[(q_) & 1][m].u = AsH[aslot16[m] + toq[q_]]; }
@@ -489,9 +511,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                 if (s + BD < NS) H2_FRAG_B(s + BD)
                 if (!AL2 && j == 0) H2_FRAG_AL(q)
                 if (j == (NT16 >= 2 ? NT16 - 2 : 0) && q + 1 < NQUAD) { H2_FRAG_AH(q + 1) if constexpr (AL2) H2_FRAG_AL(q + 1) }
-                if (more) { H2_LOAD_SLOT(s) }
-                // (DMA) the next stage's slab, one 1 KiB piece every third step, into the buffer the matrix phase of stage step - 1 read
-                if constexpr (DMA) { if (more && s >= 3 && (s - 3) % 3 == 0) H2_DMA_B1(step + 1, (s - 3) / 3) }
+                if (more && jj == 0) { H2_LOAD_SLOT(s) }
+                // (DMA) the next slab of the sequence, one 1 KiB piece every third step, into the buffer the previous matrix phase read
+                if constexpr (DMA) { if (more_slab && s >= 3 && (s - 3) % 3 == 0) H2_DMA_B1(g + 1, (s - 3) / 3) }
                 if constexpr (SPLIT) {
 #pragma unroll
                     for (int m = 0; m < MT16; ++m) {
@@ -514,6 +536,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             }
             static_assert(NS >= 5, "one halo load per step");
             static_assert(!DMA || 3 + 3 * (NB - 1) < NS, "one slab piece every third step");
+            }   // jj
 #undef H2_FRAG_AH
 #undef H2_FRAG_AL
 #undef H2_FRAG_B
@@ -590,11 +613,14 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                        (size_t)((DMA ? 2 : 1) * SLAB + (SPLIT ? 2 : 1) * a.slots_max) * 16 >= (size_t)ROWS * TRS * sizeof(float);
     if (t_out) {
         float *T = (float *)smem4;
-        __syncthreads();                                           // every wave has read its last fragments
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+        const int ntile_j = ntile + jj;
+        __syncthreads();                                           // every wave has read its last fragments (jj > 0: and stored tile jj - 1)
         if constexpr (CORE == 0) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int ch = ntile * BN + 32 * j + nn;
+                const int ch = ntile_j * BN + 32 * j + nn;
                 const float bsv = a.bias[ch];
                 float s = 0.f, q = 0.f;
 #pragma unroll
@@ -615,7 +641,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         } else {
 #pragma unroll
         for (int j = 0; j < NT16; ++j) {
-            const int ch = ntile * BN + 16 * j + l16;
+            const int ch = ntile_j * BN + 16 * j + l16;
             const float bsv = a.bias[ch];
             float s = 0.f, q = 0.f;
 #pragma unroll
@@ -624,8 +650,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                 for (int i = 0; i < 4; ++i) {
                     const int row = wave * MT * 32 + 16 * m + 4 * h4 + i;
                     float v;
-                    if constexpr (SPLIT) v = fmaf(c_lo[m][j][i], 1.f / H2_SCALE, c_hi[m][j][i]) + bsv;
-                    else v = c_hi[m][j][i] + bsv;
+                    if constexpr (SPLIT) v = fmaf(c_loN[jj][m][j][i], 1.f / H2_SCALE, c_hiN[jj][m][j][i]) + bsv;
+                    else v = c_hiN[jj][m][j][i] + bsv;
                     T[row * TRS + 16 * j + l16] = v;
                     if (rowinfo[row] >= 0) { s += v; q += v * v; }
                 }
@@ -643,13 +669,24 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             const int row = a.out_planar ? (e >> 1) % ROWS : e / C4;
             const int c4 = a.out_planar ? 2 * (e / (2 * ROWS)) + (e & 1) : e % C4;
             const int g = rowinfo[row];
-            const int ch = ntile * BN + 4 * c4;
+            const int ch = ntile_j * BN + 4 * c4;
             if (g >= 0 && ch < a.store_cols) {
                 const f32x4c o = *(const f32x4c *)&T[row * TRS + 4 * c4];
                 f32x4c *op = (f32x4c *)out_at(g, ch);
                 if (a.nt_out) __builtin_nontemporal_store(o, op); else *op = o;
             }
         }
+        if constexpr (NJ > 1) {                                     // this N tile's statistics (the common code below handles NJ = 1)
+            if (tid < BN && !a.no_stats) {
+                float s = 0.f, q = 0.f;
+                for (int wv = 0; wv < NW; ++wv) { s += red[(wv * BN + tid) * 2]; q += red[(wv * BN + tid) * 2 + 1]; }
+                int64_t o = ((int64_t)b * a.tiles_per_chunk + tile) * a.Cout + ntile_j * BN + tid;
+                a.psum[o] = s;
+                a.psq[o] = q;
+            }
+        }
+        }   // jj
+        if constexpr (NJ > 1) return;
     } else
     if constexpr (CORE == 1) {
         // C/D of 16x16: column = lane & 15, row = 4 * (lane >> 4) + register
@@ -757,6 +794,13 @@ template <int PM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8_kernel(const ConvArgs a)
 {
     conv_h2_body<64, 3, 1, PM, 8, 1>(a);
+}
+
+// ... with two N tiles per work-group (Cout % 128 == 0: the halo tile of a K stage staged once for 128 output columns)
+template <int PM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8x2_kernel(const ConvArgs a)
+{
+    conv_h2_body<64, 3, 1, PM, 8, 1, 2>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -933,9 +977,12 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         else mt = 1;                   // very narrow levels: the 256-position halo does not fit the staging plan
     }
     ISX_REQUIRE(a.slots_max <= (nw8 ? 1536 : (mt == 2 ? 1280 : 1024)), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
-    a.ntiles = fold ? 1 : cout / BN;
-    const int npair = fold ? 6 : (tx2 ? 6 : 14);          // tap slots / 2 of a weight stage (the tail layer's 9 taps sit in 12 slots)
     const bool dma = nw8 && ctx->tune.h2_core16;              // conv_h2c16nw8_kernel: two weight-slab buffers (LDS-DMA)
+    // N-tile pairs (conv_h2c16nw8x2_kernel): plain output, Cout % 128 == 0, and a launch that still fills the chip
+    const int nj = (dma && ctx->tune.h2_nj2 && !a.remap && !a.accum && cout % 128 == 0 && a.store_cols % 4 == 0 &&
+                    (ctx->tune.h2_nj2 == 2 || (int64_t)B * a.tiles_per_chunk * (cout / 128) >= 512)) ? 2 : 1;
+    a.ntiles = fold ? 1 : cout / (BN * nj);
+    const int npair = fold ? 6 : (tx2 ? 6 : 14);          // tap slots / 2 of a weight stage (the tail layer's 9 taps sit in 12 slots)
     const size_t lds = (size_t)((pm == 0 ? 2 : 1) * ((dma ? 2 : 1) * 2 * npair * BN + a.slots_max)) * 16 + ((nw8 ? 256 : 128 * mt) + (nw8 ? 8 : 4) * BN * 2) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
@@ -957,6 +1004,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8x2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8x2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -977,7 +1027,11 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     else if (core16 && BN == 64) ISX_H2_GO16(64, 3, 1);
     else if (core16 && mt == 2) ISX_H2_GO16(32, 3, 2);
     else if (core16) ISX_H2_GO16(32, 3, 1);
-    else if (nw8 && ctx->tune.h2_core16) {
+    else if (nw8 && ctx->tune.h2_core16 && nj == 2) {
+        if (pm == 0) conv_h2c16nw8x2_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
+        else if (pm == 1) conv_h2c16nw8x2_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
+        else conv_h2c16nw8x2_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);
+    } else if (nw8 && ctx->tune.h2_core16) {
         if (pm == 0) conv_h2c16nw8_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
         else if (pm == 1) conv_h2c16nw8_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
         else conv_h2c16nw8_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);

@@ -78,6 +78,7 @@ struct isx_tune {
     int wgrad_wgs = 4096;           // ISX_WGRAD_WGS: work-groups a matrix-core weight gradient aims for (its split count: fewer = fewer partials to write and reduce)
     int thin_wgrad = 1;             // ISX_THIN_WGRAD: 0 = the 1 -> 32 and 5 -> 5 layers' weight gradients on the padded matrix-core tiles (round 2)
     int bf16_wgrad = 1;             // ISX_BF16_WGRAD: 0 = precision "bf16" keeps fp32 products in the weight gradients (round 2's form)
+    int h2_nj2 = 1;                 // ISX_H2_NJ2: 1 = two 64-column N tiles per work-group of the LDS-DMA kernel for Cout % 128 == 0 (2: always, tests)
     int tail_onepass = 1;           // ISX_TAIL_ONEPASS: 0 = the tail layer as conv_h2_kernel<32, 1> + tail_combine_kernel (rounds 1-3)
     int up_fold = 0;                // ISX_UP_FOLD: 1 = up1/up2 folded into their consumers' weights (UpFoldPacks).  Off: measured r3, it removes
                                     // 57 % of the MFMAs of the up-sampled half and still loses 2 % end to end

@@ -164,6 +164,7 @@ isx_ctx *isx_ctx_create(int device)
     if (const char *e = getenv("ISX_H2_FORCE_BN64")) c->tune.h2_force_bn64 = atoi(e);
     if (const char *e = getenv("ISX_CONV_XCD_REMAP")) c->tune.xcd_remap = atoi(e);
     if (const char *e = getenv("ISX_UP_FOLD")) c->tune.up_fold = atoi(e);
+    if (const char *e = getenv("ISX_H2_NJ2")) c->tune.h2_nj2 = atoi(e);
     if (const char *e = getenv("ISX_TAIL_ONEPASS")) c->tune.tail_onepass = atoi(e);
     if (const char *e = getenv("ISX_BF16_WGRAD")) c->tune.bf16_wgrad = atoi(e);
     if (const char *e = getenv("ISX_WGRAD_WGS")) c->tune.wgrad_wgs = std::max(18, atoi(e));
