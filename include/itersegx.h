@@ -58,6 +58,9 @@ int isx_ctx_device(const isx_ctx *ctx);
 /* Bytes currently held by the context's device workspace cache. */
 int64_t isx_ctx_workspace_bytes(const isx_ctx *ctx);
 void isx_ctx_release_workspace(isx_ctx *ctx);
+/* Development / test hook: the ISX_* environment knobs (kernel variants, the flood's stress modes) are read ONCE, at
+ * isx_ctx_create; this reads them again for an existing context.  No reference counterpart (the reference has no knobs). */
+int isx_ctx_reload_knobs(isx_ctx *ctx);
 
 /* Kernel timing by class, measured with HIP events on the context's stream
  * (bench.py's roofline numbers).  Classes: see ISX_PROF_*.  enable=0 stops and clears. */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "isx_ctx_device": (C.c_int, [_vp]),
     "isx_ctx_workspace_bytes": (_i64, [_vp]),
     "isx_ctx_release_workspace": (None, [_vp]),
+    "isx_ctx_reload_knobs": (C.c_int, [_vp]),
     "isx_prof_enable": (C.c_int, [_vp, C.c_int]),
     "isx_prof_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), _i64p]),
     "isx_make_chunks": (_i64, [_i64p, _i64p, _i64p, _i32p, _i64]),
@@ -172,6 +173,10 @@ class Context:
 
     def release_workspace(self):
         self.lib.isx_ctx_release_workspace(self._h)
+
+    def reload_knobs(self):
+        """Re-read the ISX_* environment knobs (they are read once, at creation): tests' stress modes."""
+        check(self.lib.isx_ctx_reload_knobs(self._h))
 
     def set_flood_shard(self, rank=0, world=1):
         """Flood only the mask components of ``rank`` out of ``world`` (isx_ws_set_shard); (0, 1) = all."""

@@ -46,6 +46,12 @@ struct TailArgs {
     int D, H, W, nout;
     int nzt, nyt, nxt;     // tiles per chunk = nzt * nyt * nxt
     int xcd_remap;
+    // UP kernels: source A is the COARSE input of the transposed convolution in front of this layer (up3, kz = 1), up-sampled
+    // while it is staged -- slot voxel (z, y, x) reads (z, (y + uoff) >> 1, (x + uoff) >> 1) of a (D, uH, uW) tensor, BatchNorm +
+    // ReLU as usual, then * upw[parity][c] + upb[c] (UpConv::w / bias; parity = ((y + uoff) & 1) * 2 + ((x + uoff) & 1)): what
+    // upsample_src_kernel would have written to a 4 x larger tensor (5.4 GB per 64-chunk launch set) and this kernel read back
+    int uH, uW, uoff;
+    const float *upw, *upb;
 };
 
 static constexpr int TL_TZ = 5, TL_TY = 4, TL_TX = 30, TL_PX = 32;           // output tile; PX = TX + 2 positions per halo row
@@ -78,7 +84,14 @@ __device__ __forceinline__ uint32_t tl_pack_bf16_rn(float x, float y)
 
 // ABL (development builds, -DISX_TAIL_DEV, timing only -- wrong results): 1 no staging arithmetic, 2 no matrix phase, 3 no halo
 // loads, 4 no epilogue
-template <int PM, int ABL = 0>
+// 1 KiB of weights straight into LDS (see lds_dma16 in conv_h2.hip for why this is inline assembly)
+__device__ __forceinline__ void tl_lds_dma16(const uint4 *g, uint4 *lds_wave_base)
+{
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "m0", "memory");
+}
+
+template <int PM, int ABL = 0, bool UP = false>
 __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void conv_tail_kernel(const TailArgs a)
 {
     constexpr bool SPLIT = PM == 0;
@@ -88,7 +101,10 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     // tile (ROWS x PSTRIDE floats) and the reduction scratch alias it after the last stage
     uint4 *AsH = tl_smem;
     uint4 *AsL = AsH + TL_SLOTS;
-    uint4 *Bs = AsH + (SPLIT ? 2 : 1) * TL_SLOTS;
+    uint4 *Bs = AsH + (SPLIT ? 2 : 1) * TL_SLOTS;             // two buffers of (hi|lo) x 12 x 16, filled by LDS-DMA alternately
+    float *upws = (float *)(Bs + 4 * TL_BH);                  // (UP) [4 parities][CA] weights + [CA] bias of the transposed convolution
+    int *gvs = (int *)(upws + 5 * 64);                        // per halo slot: voxel index (-1: outside the volume = zero padding)
+    int *gus = gvs + TL_SLOTS;                                // (UP) per halo slot: coarse voxel | parity << 28
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, h4 = lane >> 4;
     int lin = blockIdx.x;
@@ -111,13 +127,41 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
         return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
     };
-    const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + TL_THREADS), gv2 = slot_voxel(tid + 2 * TL_THREADS),
-              gv3 = slot_voxel(tid + 3 * TL_THREADS), gv4 = slot_voxel(tid + 4 * TL_THREADS), gv5 = slot_voxel(tid + 5 * TL_THREADS);
-    // this thread's share of a stage's weights: uint4 e = tid (and 256 + tid for tid < 128) of the [hi|lo][12][16] block,
-    // read from the 32-column pack  [Cin/8][hi|lo][12 tap slots][32 columns]
+    // (in LDS, not in registers: twelve registers the split kernel does not have; a thread reads back only what it wrote)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int sl = tid + TL_THREADS * k;
+        if (sl < TL_SLOTS) {
+            const int g = slot_voxel(sl);
+            gvs[sl] = g;
+            if constexpr (UP) {          // the slot's coarse voxel | parity << 28
+                int u = 0;
+                if (g >= 0) {
+                    const int z = g / (H * W), y = (g / W) % H + a.uoff, x = g % W + a.uoff;
+                    u = ((z * a.uH + (y >> 1)) * a.uW + (x >> 1)) | ((((y & 1) << 1) | (x & 1)) << 28);
+                }
+                gus[sl] = u;
+            }
+        }
+    }
+    const int64_t Mup = UP ? (int64_t)D * a.uH * a.uW : 0;
+    if constexpr (UP) {
+        for (int e = tid; e < 5 * a.CA; e += TL_THREADS) upws[e] = e < 4 * a.CA ? a.upw[e] : a.upb[e - 4 * a.CA];
+    }
+    bool stage_up = false, st_up = false;
+    int up_cc = 0, st_cc = 0;
+    // this thread's share of a stage's weights: uint4 e = tid (and 256 + tid for waves 0, 1) of the [hi|lo][12][16] block, read from
+    // the 32-column pack  [Cin/8][hi|lo][12 tap slots][32 columns]  straight into LDS (global_load_lds_dwordx4: no registers)
     auto wsrc = [&](int e) __attribute__((always_inline)) -> int { return ((e / TL_BH) * 12 + ((e % TL_BH) >> 4)) * 32 + (e & 15); };
     const int wo0 = wsrc(tid), wo1 = wsrc(tid + TL_THREADS);
-    const bool wb1 = SPLIT && tid < 2 * TL_BH - TL_THREADS;
+    const bool wb1 = SPLIT && wave < (2 * TL_BH - TL_THREADS) / 64;
+#define TL_DMA_B(step_)                                                                           \
+    {                                                                                             \
+        const uint4 *wst = a.w + (int64_t)(step_) * (2 * 12 * 32);                                \
+        uint4 *bd = Bs + ((step_) & 1) * (2 * TL_BH) + 64 * wave;                                 \
+        tl_lds_dma16(wst + wo0, bd);                                                              \
+        if (wb1) tl_lds_dma16(wst + wo1, bd + TL_THREADS);                                        \
+    }
 
     // ---- accumulators: row tile m of this wave = halo row zy = ZYW * wave + m / 2 (z-local * TY + y-local), x half m & 1 ----
     t_f32x4 c_hi[TL_MT], c_lo[SPLIT ? TL_MT : 1];
@@ -139,7 +183,6 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     }
 
     float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, ra5, rc5, vs0, vs1, vh0, vh1;
-    uint4 rb0, rb1;
     float relu_lo = 0.f;
     const float *ld_src = nullptr;
     int ld_C = 0;
@@ -160,15 +203,16 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
             vh0 = make_float4(0.f, 0.f, 0.f, 0.f); vh1 = vh0;                                     \
             relu_lo = -__builtin_inff();                                                          \
         }                                                                                         \
-        if (planar) { ld_src = src + ((int64_t)b * (C >> 3) + (cc >> 3)) * M * 8; ld_C = 8; }     \
-        else { ld_src = src + (int64_t)b * M * C + cc; ld_C = C; }                                \
-        const uint4 *wst = a.w + (int64_t)(step_) * (2 * 12 * 32);                                \
-        rb0 = wst[wo0];                                                                           \
-        if (wb1) rb1 = wst[wo1];                                                                  \
+        stage_up = UP && c0 < a.CA;                                                               \
+        up_cc = cc;                                                                               \
+        const int64_t Ms = stage_up ? Mup : M;                                                    \
+        if (planar) { ld_src = src + ((int64_t)b * (C >> 3) + (cc >> 3)) * Ms * 8; ld_C = 8; }    \
+        else { ld_src = src + (int64_t)b * Ms * C + cc; ld_C = C; }                               \
     }
 #define TL_LOAD_A(k)                                                                              \
-    if (ABL != 3 && gv##k != -2) {                                                                            \
-        const float *pp = &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];                       \
+    if (ABL != 3 && (k < 5 || wave == 0)) {                                                       \
+        const int gl_ = (UP && stage_up) ? (gus[tid + TL_THREADS * k] & 0x0FFFFFFF) : gvs[tid + TL_THREADS * k]; \
+        const float *pp = &ld_src[(int64_t)(gl_ > 0 ? gl_ : 0) * ld_C];                           \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }
@@ -179,34 +223,41 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     if (k < 5 || wave == 0) {                                                                     \
         float4 v = ra##k, w = rc##k;                                                              \
         if constexpr (ABL != 1) { TL_AFFL(v, vs0, vh0) TL_AFFL(w, vs1, vh1) }                     \
+        const int gs_ = gvs[tid + TL_THREADS * k];                                                \
+        if (UP && st_up) {                                                                        \
+            const float *uw = &upws[((unsigned)gus[tid + TL_THREADS * k] >> 28) * a.CA + st_cc], *ub = &upws[4 * a.CA + st_cc]; \
+            const float4 u0 = *(const float4 *)uw, u1 = *(const float4 *)(uw + 4);                \
+            const float4 b0 = *(const float4 *)ub, b1 = *(const float4 *)(ub + 4);                \
+            v.x = fmaf(v.x, u0.x, b0.x); v.y = fmaf(v.y, u0.y, b0.y); v.z = fmaf(v.z, u0.z, b0.z); v.w = fmaf(v.w, u0.w, b0.w); \
+            w.x = fmaf(w.x, u1.x, b1.x); w.y = fmaf(w.y, u1.y, b1.y); w.z = fmaf(w.z, u1.z, b1.z); w.w = fmaf(w.w, u1.w, b1.w); \
+        }                                                                                         \
         uint4 hi, lo = make_uint4(0u, 0u, 0u, 0u);                                                \
         if constexpr (ABL == 1) { hi = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)); \
                                   lo = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)); } else \
         if constexpr (SPLIT) split8(v, w, hi, lo);                                                \
         else if constexpr (PM == 1) { hi.x = tl_pack_f16_rn(v.x, v.y); hi.y = tl_pack_f16_rn(v.z, v.w); hi.z = tl_pack_f16_rn(w.x, w.y); hi.w = tl_pack_f16_rn(w.z, w.w); } \
         else { hi.x = tl_pack_bf16_rn(v.x, v.y); hi.y = tl_pack_bf16_rn(v.z, v.w); hi.z = tl_pack_bf16_rn(w.x, w.y); hi.w = tl_pack_bf16_rn(w.z, w.w); } \
-        const bool dead = gv##k < 0;                                                              \
+        const bool dead = gs_ < 0;                                                                \
         hi.x = dead ? 0u : hi.x; hi.y = dead ? 0u : hi.y; hi.z = dead ? 0u : hi.z; hi.w = dead ? 0u : hi.w; \
         if constexpr (SPLIT) { lo.x = dead ? 0u : lo.x; lo.y = dead ? 0u : lo.y; lo.z = dead ? 0u : lo.z; lo.w = dead ? 0u : lo.w; } \
-        if (gv##k != -2) {                                                                        \
-            AsH[tid + TL_THREADS * k] = hi;                                                       \
-            if constexpr (SPLIT) AsL[tid + TL_THREADS * k] = lo;                                  \
-        }                                                                                         \
+        AsH[tid + TL_THREADS * k] = hi;                                                           \
+        if constexpr (SPLIT) AsL[tid + TL_THREADS * k] = lo;                                      \
     }
 
     if constexpr (ABL == 3) { ra0 = rc0 = ra1 = rc1 = ra2 = rc2 = ra3 = rc3 = ra4 = rc4 = ra5 = rc5 = make_float4(0.5f, 0.25f, 0.125f, 1.f); }
+    TL_DMA_B(0)
     TL_LOAD_HEAD(0)
     TL_LOAD_A(0) TL_LOAD_A(1) TL_LOAD_A(2) TL_LOAD_A(3) TL_LOAD_A(4) TL_LOAD_A(5)
     union FR { uint4 u; t_f16x8 v; t_bf16x8 w; };
     for (int step = 0; step < nsteps; ++step) {
         __syncthreads();                                        // every wave has read the previous stage's fragments
+        st_up = stage_up; st_cc = up_cc;                        // of the stage being stored (the next TL_LOAD_HEAD overwrites them)
         TL_STORE_A(0) TL_STORE_A(1) TL_STORE_A(2) TL_STORE_A(3) TL_STORE_A(4) TL_STORE_A(5)
-        Bs[tid] = rb0;
-        if (wb1) Bs[tid + TL_THREADS] = rb1;
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the stage's weights have landed
         __syncthreads();
         const bool more = step + 1 < nsteps;
-        if (more) TL_LOAD_HEAD(step + 1)
-        const uint4 *bsh = Bs + h4 * 16 + l16, *bsl = bsh + TL_BH;
+        if (more) { TL_DMA_B(step + 1) TL_LOAD_HEAD(step + 1) }
+        const uint4 *bsh = Bs + (step & 1) * (2 * TL_BH) + h4 * 16 + l16, *bsl = bsh + TL_BH;
         FR bh[3], bl[SPLIT ? 3 : 1];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -253,6 +304,7 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         }
 #undef TL_FRAG
     }
+#undef TL_DMA_B
 #undef TL_LOAD_HEAD
 #undef TL_LOAD_A
 #undef TL_AFFL
@@ -325,14 +377,14 @@ int conv_tail_tiles(const Level &l)
 size_t conv_tail_lds(int cin, int pm)
 {
     (void)cin;
-    const size_t stage = (size_t)((pm == 0 ? 2 : 1) * TL_SLOTS + 2 * TL_BH) * 16;
+    const size_t stage = (size_t)((pm == 0 ? 2 : 1) * TL_SLOTS + 4 * TL_BH) * 16 + (5 * 64 + 2 * TL_SLOTS) * sizeof(float);   // + up weights, slot tables
     const size_t epi = (size_t)(TL_ROWS * TL_PSTRIDE + 2 * TL_THREADS) * sizeof(float);
     const size_t lds = stage > epi ? stage : epi;
     return lds <= 160 * 1024 ? lds : 0;
 }
 
 int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_fold, const float *bias, int nout,
-                     float *out, float *psum, float *psq, int pm, int *tiles_used)
+                     float *out, float *psum, float *psq, int pm, int *tiles_used, const H2Extra *ex)
 {
     const int cin = sa.C + sb.C;
     ISX_REQUIRE(nout >= 1 && nout <= 5 && sa.C % 8 == 0 && sb.C % 8 == 0 && cin >= 8, "internal: tail convolution %d -> %d", cin, nout);
@@ -346,6 +398,9 @@ int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     a.D = l.D; a.H = l.H; a.W = l.W; a.nout = nout;
     a.nzt = (l.D + TL_TZ - 1) / TL_TZ; a.nyt = (l.H + TL_TY - 1) / TL_TY; a.nxt = (l.W + TL_TX - 1) / TL_TX;
     a.xcd_remap = ctx->tune.xcd_remap;
+    const bool up = ex && ex->upA;
+    a.uH = up ? ex->uH : 0; a.uW = up ? ex->uW : 0; a.uoff = up ? ex->uoff : 0; a.upw = up ? ex->upw : nullptr; a.upb = up ? ex->upb : nullptr;
+    ISX_REQUIRE(!up || (a.upw && a.upb && sa.C <= 64), "internal: up-sampling on read needs the transposed convolution's weights (<= 64 channels)");
     const int tiles = a.nzt * a.nyt * a.nxt;
     if (tiles_used) *tiles_used = tiles;
     const unsigned grid = (unsigned)(B * tiles);
@@ -353,6 +408,9 @@ int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
         ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_HIP(hipFuncSetAttribute((const void *)conv_tail_kernel<2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->tail_attr_done = true;
     }
 #ifdef ISX_TAIL_DEV
@@ -363,6 +421,11 @@ int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     else if (pm == 0 && abl == 4) conv_tail_kernel<0, 4><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
     else
 #endif
+    if (up) {
+        if (pm == 0) conv_tail_kernel<0, 0, true><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+        else if (pm == 1) conv_tail_kernel<1, 0, true><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+        else conv_tail_kernel<2, 0, true><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
+    } else
     if (pm == 0) conv_tail_kernel<0><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
     else if (pm == 1) conv_tail_kernel<1><<<grid, TL_THREADS, lds, ctx->stream>>>(a);
     else conv_tail_kernel<2><<<grid, TL_THREADS, lds, ctx->stream>>>(a);

@@ -79,14 +79,25 @@ struct isx_tune {
     int thin_wgrad = 1;             // ISX_THIN_WGRAD: 0 = the 1 -> 32 and 5 -> 5 layers' weight gradients on the padded matrix-core tiles (round 2)
     int bf16_wgrad = 1;             // ISX_BF16_WGRAD: 0 = precision "bf16" keeps fp32 products in the weight gradients (round 2's form)
     int h2_nj2 = 1;                 // ISX_H2_NJ2: 1 = two 64-column N tiles per work-group of the LDS-DMA kernel for Cout % 128 == 0 (2: always, tests)
+    int tail_up = 1;                // ISX_TAIL_UP: 0 = up3 materialised by upsample_src_kernel instead of up-sampled while the tail kernel stages it
     int tail_onepass = 1;           // ISX_TAIL_ONEPASS: 0 = the tail layer as conv_h2_kernel<32, 1> + tail_combine_kernel (rounds 1-3)
     int up_fold = 0;                // ISX_UP_FOLD: 1 = up1/up2 folded into their consumers' weights (UpFoldPacks).  Off: measured r3, it removes
                                     // 57 % of the MFMAs of the up-sampled half and still loses 2 % end to end
 };
 
+// ISX_FLOOD_* (the watershed tests' stress modes, tuning runs): a negative field = the library default (csrc/ws.hip).  Read at
+// isx_ctx_create and again by isx_ctx_reload_knobs -- never per call.
+struct isx_flood_tune {
+    long long coop_min = -1, cold_min = -1, group_min = -1, small_max = -1, arena_mb = -1;
+    int run_limit = -1, drain = -1, win = -1, list = -1, bursts = -1, gsteps = -1, gminsteps = -1, gwin = -1, glist = -1, buckets = -1;
+    int gwatchdog = 0, group_stream = 1, stats = 0;
+    std::string trace;              // ISX_FLOOD_TRACE=<file>: development dump of every component's commit order
+};
+
 struct isx_ctx {
     int device = 0;
     isx_tune tune;
+    isx_flood_tune ftune;
     bool tail_attr_done = false;    // ... and of conv_tail_kernel
     bool h2_attr_done = false;      // dynamic-LDS attribute of the conv_h2 kernels set for this context's device
     hipStream_t stream = nullptr;

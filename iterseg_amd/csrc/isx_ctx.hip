@@ -1,9 +1,11 @@
 // isx_ctx.hip -- context lifetime, workspace cache, error string, profiling spans and the
 // chunk-geometry entry point of libitersegx.so.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "isx_common.h"
+#include "unet_state.h"
 
 namespace isx {
 
@@ -134,6 +136,44 @@ int isx_device_count(void)
     return n;
 }
 
+// Development knobs: the environment is read here -- at isx_ctx_create and when a test asks (isx_ctx_reload_knobs) -- and never
+// inside a call.
+static void read_knobs(isx_ctx *c)
+{
+    isx_tune t;
+    if (const char *e = getenv("ISX_H2_MT2")) t.h2_mt2 = atoi(e);
+    if (const char *e = getenv("ISX_H2_FORCE_BN64")) t.h2_force_bn64 = atoi(e);
+    if (const char *e = getenv("ISX_CONV_XCD_REMAP")) t.xcd_remap = atoi(e);
+    if (const char *e = getenv("ISX_UP_FOLD")) t.up_fold = atoi(e);
+    if (const char *e = getenv("ISX_H2_NJ2")) t.h2_nj2 = atoi(e);
+    if (const char *e = getenv("ISX_TAIL_UP")) t.tail_up = atoi(e);
+    if (const char *e = getenv("ISX_TAIL_ONEPASS")) t.tail_onepass = atoi(e);
+    if (const char *e = getenv("ISX_BF16_WGRAD")) t.bf16_wgrad = atoi(e);
+    if (const char *e = getenv("ISX_WGRAD_WGS")) t.wgrad_wgs = std::max(18, atoi(e));
+    if (const char *e = getenv("ISX_THIN_WGRAD")) t.thin_wgrad = atoi(e);
+    if (const char *e = getenv("ISX_UP_ON_READ")) t.up_on_read = atoi(e);
+    if (const char *e = getenv("ISX_PLANAR")) t.planar = atoi(e);
+    if (const char *e = getenv("ISX_H2_NW8")) t.h2_nw8 = atoi(e);
+    if (const char *e = getenv("ISX_H2_CORE16")) t.h2_core16 = atoi(e);
+    if (const char *e = getenv("ISX_UP_PER_SOURCE")) t.up_per_source = atoi(e);
+    if (const char *e = getenv("ISX_CONV_FIRST_NT")) t.conv_first_nt = atoi(e);
+    if (const char *e = getenv("ISX_H2_NT_OUT")) t.h2_nt_out = atoi(e);
+    if (const char *e = getenv("ISX_CONV_MT2_MIN_VOX")) t.mt2_min_vox = atol(e);
+    c->tune = t;
+    isx_flood_tune f;
+    auto ll = [](const char *name, long long &dst) { if (const char *e = getenv(name)) dst = (long long)strtoull(e, nullptr, 10); };
+    auto in = [](const char *name, int &dst) { if (const char *e = getenv(name)) dst = atoi(e); };
+    ll("ISX_FLOOD_COOP_MIN", f.coop_min); ll("ISX_FLOOD_COLD_MIN", f.cold_min); ll("ISX_FLOOD_GROUP_MIN", f.group_min);
+    ll("ISX_FLOOD_SMALL_MAX", f.small_max); ll("ISX_FLOOD_ARENA_MB", f.arena_mb);
+    in("ISX_FLOOD_RUN_LIMIT", f.run_limit); in("ISX_FLOOD_DRAIN", f.drain); in("ISX_FLOOD_WIN", f.win); in("ISX_FLOOD_LIST", f.list);
+    in("ISX_FLOOD_BURSTS", f.bursts); in("ISX_FLOOD_GSTEPS", f.gsteps); in("ISX_FLOOD_GMINSTEPS", f.gminsteps); in("ISX_FLOOD_GWIN", f.gwin);
+    in("ISX_FLOOD_GLIST", f.glist); in("ISX_FLOOD_BUCKETS", f.buckets); in("ISX_FLOOD_GWATCHDOG", f.gwatchdog);
+    in("ISX_FLOOD_GROUP_STREAM", f.group_stream);
+    f.stats = getenv("ISX_FLOOD_STATS") != nullptr;
+    if (const char *e = getenv("ISX_FLOOD_TRACE")) f.trace = e;
+    c->ftune = f;
+}
+
 isx_ctx *isx_ctx_create(int device)
 {
     int n = 0;
@@ -160,23 +200,7 @@ isx_ctx *isx_ctx_create(int device)
         }
     }
     isx_ctx *c = new isx_ctx();
-    if (const char *e = getenv("ISX_H2_MT2")) c->tune.h2_mt2 = atoi(e);
-    if (const char *e = getenv("ISX_H2_FORCE_BN64")) c->tune.h2_force_bn64 = atoi(e);
-    if (const char *e = getenv("ISX_CONV_XCD_REMAP")) c->tune.xcd_remap = atoi(e);
-    if (const char *e = getenv("ISX_UP_FOLD")) c->tune.up_fold = atoi(e);
-    if (const char *e = getenv("ISX_H2_NJ2")) c->tune.h2_nj2 = atoi(e);
-    if (const char *e = getenv("ISX_TAIL_ONEPASS")) c->tune.tail_onepass = atoi(e);
-    if (const char *e = getenv("ISX_BF16_WGRAD")) c->tune.bf16_wgrad = atoi(e);
-    if (const char *e = getenv("ISX_WGRAD_WGS")) c->tune.wgrad_wgs = std::max(18, atoi(e));
-    if (const char *e = getenv("ISX_THIN_WGRAD")) c->tune.thin_wgrad = atoi(e);
-    if (const char *e = getenv("ISX_UP_ON_READ")) c->tune.up_on_read = atoi(e);
-    if (const char *e = getenv("ISX_PLANAR")) c->tune.planar = atoi(e);
-    if (const char *e = getenv("ISX_H2_NW8")) c->tune.h2_nw8 = atoi(e);
-    if (const char *e = getenv("ISX_H2_CORE16")) c->tune.h2_core16 = atoi(e);
-    if (const char *e = getenv("ISX_UP_PER_SOURCE")) c->tune.up_per_source = atoi(e);
-    if (const char *e = getenv("ISX_CONV_FIRST_NT")) c->tune.conv_first_nt = atoi(e);
-    if (const char *e = getenv("ISX_H2_NT_OUT")) c->tune.h2_nt_out = atoi(e);
-    if (const char *e = getenv("ISX_CONV_MT2_MIN_VOX")) c->tune.mt2_min_vox = atol(e);
+    read_knobs(c);
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         isx::set_error("hipStreamCreate failed");
@@ -185,6 +209,14 @@ isx_ctx *isx_ctx_create(int device)
     }
     c->stream = c->own_stream;
     return c;
+}
+
+int isx_ctx_reload_knobs(isx_ctx *c)
+{
+    ISX_REQUIRE(c, "null context");
+    read_knobs(c);
+    if (c->unet) c->unet->tune = c->tune;
+    return ISX_OK;
 }
 
 void isx_ctx_destroy(isx_ctx *c)

@@ -1467,10 +1467,10 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         ISX_REQUIRE(fold_h2 || !ex, "internal: up-sampling on read needs the reduced-precision tail kernel");
         ISX_REQUIRE(fold_h2 || !(sa.planar || sb.planar), "internal: a planar source reached a convolution that does not read it");
         // one pass: x-shift in LDS, no partial-sum tensor, all weights resident (conv_tail.hip)
-        const bool one_pass = fold_h2 && !ex && ctx->tune.tail_onepass && conv_tail_lds(cin, pm) != 0;
+        const bool one_pass = fold_h2 && ctx->tune.tail_onepass && conv_tail_lds(cin, pm) != 0;
         if (one_pass) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
-            ISX_TRY(launch_conv_tail(ctx, l, B, sa, sb, wf, L.bias, L.cout, u->raw[li], L.psum, L.psq, pm, &stat_tiles));
+            ISX_TRY(launch_conv_tail(ctx, l, B, sa, sb, wf, L.bias, L.cout, u->raw[li], L.psum, L.psq, pm, &stat_tiles, ex));
         } else if (fold_h2) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wf, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
@@ -1708,14 +1708,16 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                 const ConvBN &L0 = u->cv[l0f];
                 const bool bf = u->precision == ISX_PRECISION_BF16;
                 const float bnd = bn_bound(li_in) * U.wmax + U.bmax;
-                const bool on_read = ctx->tune.up_on_read && U.kz == 1 && U.C % 8 == 0 && use_fold(L0.cin, L0.cout) && !u->train &&
+                const bool on_read = (ctx->tune.up_on_read || (ctx->tune.tail_up && ctx->tune.tail_onepass)) && U.kz == 1 && U.C % 8 == 0 && U.C <= 64 &&
+                                     use_fold(L0.cin, L0.cout) && !u->train &&
                                      u->precision != ISX_PRECISION_FP32 && (bf ? L0.w_bf_32 : L0.w_h2_32) &&
                                      (bf || std::max(bnd, bn_bound(skipf)) < 6.0e4f) && conv_mt(ctx->tune, lo, u->wbatch, 32) == 1;
                 if (on_read) {
                     H2Extra ex;
                     ex.upA = 1; ex.uH = ls.H; ex.uW = ls.W; ex.uoff = k == 3 ? 1 : 0; ex.upw = U.w; ex.upb = U.bias;
                     u->up_folded[ups_index(f, k)] = true;
-                    ISX_TRY(run_conv(ctx, l0f, lo, B, Src{u->raw[li_in], Lin.scale, Lin.shift, U.C, bnd}, act(skipf), &ex));
+                    u->ups_planar[ups_index(f, k)] = false;
+                    ISX_TRY(run_conv(ctx, l0f, lo, B, Src{u->raw[li_in], Lin.scale, Lin.shift, U.C, bnd, u->planar[li_in]}, act(skipf), &ex));
                     ISX_TRY(run_conv(ctx, dec_layer(f, k, 1), lo, B, act(l0f), none));
                     continue;
                 }
@@ -1982,6 +1984,12 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
                 const UpConv &U = u->up[k];
                 const ConvBN &Lin = u->cv[li_in];
                 const int64_t total = (int64_t)u->last_n * lo.M * (U.C / 4);
+                if (u->planar[li_in]) {            // (a planar coarse tensor: the planar kernel, into a planar tap)
+                    const int64_t total_pl = (int64_t)u->last_n * (U.C / 8) * ls.D * ls.H * lo.W * 2;
+                    upsample_src_planar_kernel<<<cdiv(total_pl, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W,
+                                                                                          k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, u->ups[k], total_pl);
+                    tap_planar = true;
+                } else
                 upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz,
                                                                            k == 3 ? 1 : 0, U.w, U.bias, lo.D, lo.H, lo.W, u->ups[k], total, 0);
                 ISX_CHECK_LAUNCH();

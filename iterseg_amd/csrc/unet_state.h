@@ -179,8 +179,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
 // one-pass thin tail convolution (conv_tail.hip)
 int conv_tail_tiles(const Level &l);
 size_t conv_tail_lds(int cin, int pm);
+struct H2Extra;
 int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_fold, const float *bias, int nout,
-                     float *out, float *psum, float *psq, int pm, int *tiles_used);
+                     float *out, float *psum, float *psq, int pm, int *tiles_used, const H2Extra *ex = nullptr);
 void pack_h2_taps(const float *w, int cout, int cin, int ntap, int ntap_pad, int bn, std::vector<uint16_t> &out, int pm);
 int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch);
 int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3]);

@@ -1101,11 +1101,8 @@ __device__ __forceinline__ void cold_append(Cold &c, bool has, unsigned long lon
 // all map to bucket b (plateaus: every residual of a commit burst has the same value).  One state update and at most one new
 // segment for the whole batch instead of one cold_append per 64 elements (the work-group kernel's flush of ~350 residuals per
 // sub-round was 6 calls of ~5 k cycles each on one wave while seven waited).  `ascending`: src is in key order.
-// src == nullptr: only the bookkeeping -- the caller's lanes write the n elements themselves: element j goes to pool slot
-// where[0] + j for j < where[1], to where[2] + (j - where[1]) beyond (where: three words, written by lane 0).
 __device__ __forceinline__ void cold_append_bucket(Cold &c, const HeapEnt *src, int n, uint32_t b, bool ascending,
-                                                   unsigned long long first_key, unsigned long long last_key, int lane,
-                                                   uint32_t *where = nullptr)
+                                                   unsigned long long first_key, unsigned long long last_key, int lane)
 {
     uint32_t tail, cnt, tn = 0, tcap = 0;
     bool unsorted;
@@ -1168,12 +1165,10 @@ __device__ __forceinline__ void cold_append_bucket(Cold &c, const HeapEnt *src, 
             atomicOr(&c.bm1()[b >> 12], 1ull << ((b >> 6) & 63));
         }
     }
-    if (src)
-        for (uint32_t j = (uint32_t)lane; j < (uint32_t)n; j += 64u) {
-            const uint32_t slot = j < free_tail ? tail + 1u + tn + j : my_off + 1u + (j - free_tail);
-            c.pool()[slot] = src[j];
-        }
-    if (where && lane == 0) { where[0] = tail + 1u + tn; where[1] = free_tail; where[2] = my_off + 1u; }
+    for (uint32_t j = (uint32_t)lane; j < (uint32_t)n; j += 64u) {
+        const uint32_t slot = j < free_tail ? tail + 1u + tn + j : my_off + 1u + (j - free_tail);
+        c.pool()[slot] = src[j];
+    }
     c.cb = b;
     c.cb_tail = need_new ? my_off : tail;
     c.cb_tn = need_new ? need_new : tn + (uint32_t)n;
@@ -1443,438 +1438,6 @@ __device__ __forceinline__ int cold_drain(Cold &c, HeapEnt *srun, int *hist, int
     return taken;
 }
 
-__global__ __launch_bounds__(64) void flood_wave_kernel(
-    const float *__restrict__ aff, const uint8_t *__restrict__ mask, uint32_t *__restrict__ out,
-    uint32_t *__restrict__ claim, const unsigned long long *__restrict__ keys, uint32_t n_seeds,
-    const uint32_t *__restrict__ comp_first, const unsigned long long *__restrict__ comp_off, uint32_t n_comp,
-    HeapEnt *__restrict__ heap_pool, const unsigned long long *__restrict__ arena_off, HeapEnt *__restrict__ arena,
-    int64_t PY, int64_t PX, int64_t PN, float s0, float s1, float s2, unsigned long long coop_min_size, int run_limit,
-    int drain_n, float bk_lo, float bk_inv, unsigned long long *stats, int shard_rank, int shard_world)
-{
-    __shared__ HeapEnt srun[COOP_SCAP];          // .pad carries the element's label
-    __shared__ HeapEnt stage[6 * 64];            // elements of this round bound for the cold tier
-    __shared__ int hist[64];
-    const uint32_t c = blockIdx.x;
-    const int lane = threadIdx.x;
-    if (c >= n_comp) return;
-    if (!comp_owned(comp_off, c, n_comp, shard_rank, shard_world)) return;
-    const uint32_t first = comp_first[c];
-    const uint32_t end = (c + 1 < n_comp) ? comp_first[c + 1] : n_seeds;
-    if ((uint32_t)(keys[first] >> 32) == NO_PARENT) return;
-    const unsigned long long csize = comp_off[c + 1] - comp_off[c];
-    if (csize < coop_min_size) return;
-    HeapEnt *heap = heap_pool + comp_off[c];
-    const uint32_t ns = end - first;
-
-    const int64_t SZ = PY * PX, SY = PX;
-    const int64_t noff[6] = {-SZ, -SY, -1, 1, SY, SZ};
-    const int ax[6] = {0, 1, 2, 2, 1, 0};
-    const float sc[3] = {s0, s1, s2};
-    const unsigned long long ZKEY = (unsigned long long)0x80000000u << 32;
-    constexpr int SMASK = COOP_SCAP - 1;
-    constexpr int ROUND_MAX = 6 * 64;            // most elements one round can add
-
-    // ---- cold tier (large components only): arena views + clean metadata ----------------------------------
-    Cold cold;
-    cold.on = arena_off && (arena_off[c + 1] > arena_off[c]);
-    cold.failed = false;
-    cold.bump = 0;
-    cold.count = 0;
-    cold.low = COLD_NBK;
-    cold.fifo_drains = 0;
-#ifdef ISX_FLOOD_PROF
-    for (int i = 0; i < 8; ++i) cold.tk[i] = 0;
-    cold.n_groups = 0;
-#endif
-    cold.cb = COLD_NONE;
-    cold.pool_cap = 0;
-    cold.vlo = bk_lo;
-    cold.vinv = bk_inv;
-    if (cold.on) {
-        HeapEnt *base = arena + arena_off[c];
-        cold.base = (uint32_t *)base;
-        cold.pool_cap = (uint32_t)(arena_off[c + 1] - arena_off[c] - COLD_META_ENTS);
-        for (int i = lane; i < COLD_NBK; i += 64) { cold.bhead()[i] = COLD_NONE; cold.btail()[i] = COLD_NONE; cold.bcount()[i] = 0; cold.bmeta()[i] = 0; }
-        for (int i = lane; i < COLD_NBK / 64; i += 64) cold.bm0()[i] = 0ull;
-        if (lane < COLD_NBK / 4096) cold.bm1()[lane] = 0ull;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-
-    // queue: registers (rk key, ri voxel, rl label; lanes < rcount valid, ascending) then the LDS run, then cold
-    unsigned long long rk = ~0ull;
-    uint32_t ri = 0, rl = 0;
-    int rcount = 0, shead = 0, scount = 0;
-    uint32_t age = ns - 1;                       // seeds carry ages 0..ns-1 in index order; pushes continue
-    uint32_t epoch = 0;
-    const uint32_t hot_cap = 64u + (uint32_t)run_limit;          // run_limit <= COOP_SCAP - ROUND_MAX (host-checked)
-    bool serial = (ns > hot_cap) && !cold.on;
-    bool started = false;
-    int stage_from = 0, stage_to = 0;       // staged elements that never reached a bucket (arena exhausted)
-#ifdef ISX_FLOOD_PROF
-    // phase timers (shader clock): tk_acc[i] = cycles between tick i-1 and tick i, tick 0 closes the previous round
-    unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk_prev = __builtin_readcyclecounter();
-#define FLOOD_TICK(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); tk_acc[i] += t_ - tk_prev; tk_prev = t_; } while (0)
-#else
-#define FLOOD_TICK(i) do { } while (0)
-#endif
-    unsigned long long st_rounds = 0, st_pops = 0, st_reg = 0, st_run = 0, st_cold = 0, st_drain = 0, st_evict = 0, st_shift = 0, st_oob = 0;
-
-    if (!serial) {
-        started = true;
-        rcount = ns < 64u ? (int)ns : 64;
-        if (lane < rcount) {
-            rk = ZKEY | (unsigned long long)lane;
-            ri = (uint32_t)(keys[first + lane] & 0xFFFFFFFFull);
-            rl = out[ri];
-        }
-        const uint32_t in_run = ns > hot_cap ? hot_cap : ns;
-        for (uint32_t j = 64 + lane; j < in_run; j += 64) {
-            HeapEnt e;
-            e.key = ZKEY | (unsigned long long)j;
-            e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull);
-            e.pad = out[e.idx];
-            srun[j - 64] = e;
-        }
-        scount = in_run > 64u ? (int)(in_run - 64u) : 0;
-        for (uint32_t j0 = in_run; j0 < ns && !cold.failed; j0 += 64) {       // seeds beyond the hot tiers start cold
-            const uint32_t j = j0 + lane;
-            const bool has = j < ns;
-            const uint32_t vi = has ? (uint32_t)(keys[first + j] & 0xFFFFFFFFull) : 0u;
-            cold_append(cold, has, ZKEY | (unsigned long long)j, vi, has ? out[vi] : 0u, lane);
-        }
-        if (cold.failed) { serial = true; started = false; }     // restart from the seeds on the serial heap
-    }
-
-    while (!serial && rcount > 0) {
-        if (scount > run_limit) {
-            // the run is full: evict its largest elements to their buckets (or leave the wave path)
-            if (!cold.on) { serial = true; break; }
-            const int ev = scount - run_limit / 2, keep = scount - ev;
-            st_evict += (unsigned long long)ev;
-            int done = 0;                     // ascending, so that a bucket's list stays in key order (FIFO drains)
-            while (done < ev) {
-                const int m = ev - done < 64 ? ev - done : 64;
-                const bool has = lane < m;
-                HeapEnt e;
-                e.key = 0; e.idx = 0; e.pad = 0;
-                if (has) e = srun[(shead + keep + done + lane) & SMASK];
-                cold_append(cold, has, e.key, e.idx, e.pad, lane);
-                if (cold.failed) break;       // this batch is still in the run, the earlier ones are not
-                done += m;
-            }
-            if (cold.failed) {
-                // close the gap [keep, keep + done) so that the run again holds exactly what is not in the arena
-                for (int j0 = keep + done; j0 < scount; j0 += 64) {
-                    const bool mv = j0 + lane < scount;
-                    u32x4 e = {0u, 0u, 0u, 0u};
-                    if (mv) e = run_ld(srun, (shead + j0 + lane) & SMASK);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (mv) run_st(srun, (shead + j0 + lane - done) & SMASK, e);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                scount -= done;
-                serial = true;
-                break;
-            }
-            scount = keep;
-        }
-        ++epoch;
-        ++st_rounds;
-        FLOOD_TICK(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // last round's label stores are in L2
-        FLOOD_TICK(1);
-        const bool act = lane < rcount;
-        // idle lanes look at rank 0's voxel (an interior mask voxel): their loads below are unconditional and
-        // must stay inside the padded volume
-        const uint32_t ri0 = rdlane(ri, 0);            // outside the select: a shuffle in a ternary arm runs divergent
-        const int64_t idx = act ? (int64_t)ri : (int64_t)ri0;
-        // ---- every lane looks at its six neighbours as if it were popped now -------------------------
-        // mask, label and edge value of all six neighbours are loaded unconditionally and together: one memory
-        // round trip instead of three dependent ones (the padded border keeps every address in bounds)
-        bool cand[6];
-        float val[6];
-        int64_t nbv[6];
-        uint8_t mk[6];
-        uint32_t lb[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            nbv[k] = idx + noff[k];
-            if (nbv[k] < 0 || nbv[k] >= PN) { nbv[k] = idx; ++st_oob; }    // cannot happen (padded border); never fault
-            mk[k] = mask[nbv[k]];
-            lb[k] = __hip_atomic_load(&out[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val[k] = aff[(int64_t)ax[k] * PN + (k < 3 ? idx : nbv[k])];
-        }
-        const uint32_t mytag = (epoch << 6) | (uint32_t)(63 - lane);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            cand[k] = act && mk[k] && lb[k] == 0u;
-            if (cand[k]) atomicMax(&claim[nbv[k]], mytag);
-            val[k] = val[k] * sc[ax[k]] + 0.0f;                          // -0.0 == +0.0 in the order
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every lane's claims are performed
-        FLOOD_TICK(2);
-        // ---- who won what; smallest value each lane would push ------------------------------------------
-        uint32_t wonmask = 0, mymin = 0xFFFFFFFFu;
-        // all six reads are issued together and unconditionally (a load inside the short-circuit condition is waited
-        // for before the next one is issued: six dependent L2 round trips instead of one)
-        uint32_t ctag[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ctag[k] = __hip_atomic_load(&claim[nbv[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (cand[k] && ctag[k] == mytag) {
-                wonmask |= 1u << k;
-                const uint32_t ov = ford(val[k]);
-                mymin = ov < mymin ? ov : mymin;
-            }
-        FLOOD_TICK(3);
-        // exclusive prefix-min over ranks; the first rank whose own value exceeds it ends the batch
-        const uint32_t epm = wave_shr1(wave_prefix_min(mymin), 0xFFFFFFFFu);
-        const unsigned long long vb = __ballot(act && epm < (uint32_t)(rk >> 32));
-        const int ncommit = vb ? (__ffsll((long long)vb) - 1) : rcount;   // >= 1: rank 0 never violates
-        const bool commit = lane < ncommit;
-        // ---- label + ages in (rank, direction) order: the reference's push order ------------------------
-        // exclusive prefix of the push counts from six ballots (scalar work, no cross-lane LDS traffic)
-        const unsigned long long lt_mask = (1ull << lane) - 1ull;
-        uint32_t before_me = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const unsigned long long bk = __ballot(commit && (wonmask & (1u << k)));
-            before_me += (uint32_t)__popcll(bk & lt_mask);
-            total += (uint32_t)__popcll(bk);
-        }
-        uint32_t myage = age + before_me;
-        unsigned long long pkey[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            pkey[k] = 0;
-            if (commit && (wonmask & (1u << k))) {
-                out[nbv[k]] = rl;                                          // label at discovery (watershed.py:153)
-                pkey[k] = ((unsigned long long)ford(val[k]) << 32) | (unsigned long long)(++myage);
-            }
-        }
-        age += total;
-        st_pops += (unsigned long long)ncommit;
-        const uint32_t wm_all = commit ? wonmask : 0u;
-        const uint32_t lab_all = rl;
-        FLOOD_TICK(4);
-        // ---- drop the committed ranks from the front, refill from the LDS run (and the cold tier) ----------
-        {
-            const int src = (lane + ncommit) & 63;
-            const unsigned long long k2 = shfl64(rk, src);
-            const uint32_t i2 = __shfl(ri, src), l2 = __shfl(rl, src);
-            rcount -= ncommit;
-            if (lane < rcount) { rk = k2; ri = i2; rl = l2; } else { rk = ~0ull; ri = 0; rl = 0; }
-            if (scount == 0 && rcount < 64 && cold.on && cold.count > 0) {
-                scount = cold_drain(cold, srun, hist, lane, drain_n);     // sorted, all >= every register element
-                ++st_drain;
-                shead = 0;
-            }
-            int take = 64 - rcount;
-            if (take > scount) take = scount;
-            if (lane >= rcount && lane < rcount + take) {
-                const HeapEnt e = srun[(shead + (lane - rcount)) & SMASK];
-                rk = e.key; ri = e.idx; rl = e.pad;
-            }
-            rcount += take;
-            shead = (shead + take) & SMASK;
-            scount -= take;
-        }
-        FLOOD_TICK(5);
-        // ---- tier decision for all new elements at once ----------------------------------------------------
-        // An element is cold-bound when it does not sort below the hot maximum and its bucket is not below the lowest
-        // non-empty bucket.  Hot insertions of this round cannot change that: the hot maximum only grows by elements
-        // of lower buckets, which sort below every cold-bound element.  So the cold-bound set is staged in parallel,
-        // in (rank, direction) order, and only the hot-bound elements take the serial insert loop below.
-        int nstage = 0;
-        uint32_t cmask = 0;
-        if (cold.on && cold.count > 0) {
-            unsigned long long back0 = 0ull;
-            if (scount > 0) back0 = srun[(shead + scount - 1) & SMASK].key;
-            const unsigned long long reg_last0 = rcount > 0 ? rdlane64(rk, rcount - 1) : 0ull;
-            const unsigned long long hot_max0 = scount > 0 ? back0 : reg_last0;
-            const bool hot_nonempty0 = scount > 0 || rcount > 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if ((wm_all & (1u << k)) && !(hot_nonempty0 && pkey[k] < hot_max0) && cold_bucket(cold, pkey[k]) >= cold.low)
-                    cmask |= 1u << k;
-            uint32_t slot = 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const unsigned long long bk = __ballot((cmask & (1u << k)) != 0u);
-                slot += (uint32_t)__popcll(bk & lt_mask);
-                nstage += __popcll(bk);
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (cmask & (1u << k)) {
-                    HeapEnt e;
-                    e.key = pkey[k]; e.idx = (uint32_t)nbv[k]; e.pad = lab_all;
-                    stage[slot++] = e;
-                }
-            st_cold += (unsigned long long)nstage;
-        }
-        // ---- insert the hot-bound elements (wave-uniform loop over committed lanes x directions) -----------
-        const uint32_t wm_hot = wm_all & ~cmask;
-        for (unsigned long long todo_l = __ballot(wm_hot != 0u); todo_l; todo_l &= todo_l - 1ull) {
-            const int l = __ffsll((long long)todo_l) - 1;
-            const uint32_t wm = rdlane(wm_hot, l);
-            const uint32_t el = rdlane(lab_all, l);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (!(wm & (1u << k))) continue;
-                const unsigned long long ek = rdlane64(pkey[k], l);
-                const uint32_t ei = rdlane((uint32_t)nbv[k], l);
-                // Tier rule (keeps "every cold element sorts after every hot element"): an element stays hot if it sorts
-                // below the current hot maximum, or if nothing in the cold tier can precede it (cold empty, or its
-                // bucket lies below the lowest non-empty bucket); otherwise it goes to its bucket.
-                unsigned long long back = 0ull;
-                if (scount > 0) back = srun[(shead + scount - 1) & SMASK].key;
-                const unsigned long long reg_last = rcount > 0 ? rdlane64(rk, rcount - 1) : 0ull;
-                const unsigned long long hot_max = scount > 0 ? back : reg_last;
-                const bool hot_nonempty = scount > 0 || rcount > 0;
-                const bool below_hot_max = hot_nonempty && ek < hot_max;
-                const bool cold_free = !cold.on || cold.count == 0 || cold_bucket(cold, ek) < cold.low;
-                if (!below_hot_max && !cold_free) {
-                    if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; stage[nstage] = e; }
-                    ++nstage;
-                    ++st_cold;
-                    continue;
-                }
-                if ((rcount < 64 && scount == 0) || (rcount > 0 && ek < reg_last)) {
-                    if (rcount == 64) {                  // full: the maximum moves to the front of the run
-                        shead = (shead - 1) & SMASK;
-                        if (lane == 63) { HeapEnt e; e.key = rk; e.idx = ri; e.pad = rl; srun[shead] = e; }
-                        ++scount;
-                        --rcount;
-                    }
-                    const int pos = __popcll(__ballot(lane < rcount && rk < ek));
-                    const unsigned long long upk = ((unsigned long long)wave_shr1((uint32_t)(rk >> 32), 0u) << 32) | wave_shr1((uint32_t)rk, 0u);
-                    const uint32_t upi = wave_shr1(ri, 0u), upl = wave_shr1(rl, 0u);
-                    if (lane > pos && lane <= rcount) { rk = upk; ri = upi; rl = upl; }
-                    if (lane == pos) { rk = ek; ri = ei; rl = el; }
-                    ++rcount;
-                    ++st_reg;
-                    continue;
-                }
-                ++st_run;
-                // sorted insert into the LDS run (circular: shift the shorter side by one)
-                // position by two 64-wide probes of the sorted run (segment ends, then inside the segment) instead of a
-                // linear count over up to 2048 entries
-                int pos;
-                {
-                    const int stride = (scount + 63) >> 6;                       // <= 32 entries per segment
-                    int e = lane * stride + stride - 1;
-                    if (e > scount - 1) e = scount - 1;
-                    const bool seg_below = lane * stride < scount && srun[(shead + e) & SMASK].key < ek;
-                    const int base = __popcll(__ballot(seg_below)) * stride;     // segments entirely below ek
-                    const int j = base + lane;
-                    const bool in_below = lane < stride && j < scount && srun[(shead + j) & SMASK].key < ek;
-                    pos = base + __popcll(__ballot(in_below));
-                    if (pos > scount) pos = scount;
-                }
-                st_shift += (unsigned long long)(pos >= scount - pos ? scount - pos : pos);
-                if (pos >= scount - pos) {
-                    for (int base = scount - 64; base > pos - 64; base -= 64) {
-                        const int j = base + lane;
-                        const bool mv = j >= pos && j >= 0 && j < scount;
-                        u32x4 e = {0u, 0u, 0u, 0u};          // a vector value, not a struct: stays in registers
-                        if (mv) e = run_ld(srun, (shead + j) & SMASK);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (mv) run_st(srun, (shead + j + 1) & SMASK, e);
-                    }
-                } else {
-                    for (int base = 0; base < pos; base += 64) {
-                        const int j = base + lane;
-                        const bool mv = j < pos;
-                        u32x4 e = {0u, 0u, 0u, 0u};
-                        if (mv) e = run_ld(srun, (shead + j) & SMASK);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (mv) run_st(srun, (shead + j - 1) & SMASK, e);
-                    }
-                    shead = (shead - 1) & SMASK;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) { HeapEnt e; e.key = ek; e.idx = ei; e.pad = el; srun[(shead + pos) & SMASK] = e; }
-                ++scount;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        }
-        FLOOD_TICK(6);
-        // ---- this round's cold-bound elements, 64 at a time ------------------------------------------------
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int s0i = 0; s0i < nstage; s0i += 64) {
-            const bool has = s0i + lane < nstage;
-            HeapEnt e;
-            e.key = 0; e.idx = 0; e.pad = 0;
-            if (has) e = stage[s0i + lane];
-            cold_append(cold, has, e.key, e.idx, e.pad, lane);
-            if (cold.failed) {               // arena exhausted: nothing of this batch was written
-                stage_from = s0i;
-                stage_to = nstage;
-                serial = true;
-                break;
-            }
-        }
-    }
-
-#ifdef ISX_FLOOD_PROF
-    if (stats && lane == 0)
-        for (int i = 0; i < 8; ++i) { atomicAdd(&stats[16 + i], tk_acc[i]); if (i < 4) atomicAdd(&stats[24 + i], cold.tk[i]); }
-    if (stats && lane == 0) atomicAdd(&stats[28], cold.n_groups);
-#endif
-    if (stats && lane == 0) {
-        atomicAdd(&stats[0], st_rounds); atomicAdd(&stats[1], st_pops); atomicAdd(&stats[2], st_reg); atomicAdd(&stats[3], st_run);
-        atomicAdd(&stats[4], st_cold); atomicAdd(&stats[5], st_drain); atomicAdd(&stats[6], st_evict); atomicAdd(&stats[7], st_shift);
-        if (serial) atomicAdd(&stats[8], 1ull);
-        if (st_oob) atomicAdd(&stats[9], st_oob);
-        if (cold.fifo_drains) atomicAdd(&stats[10], (unsigned long long)cold.fifo_drains);
-    }
-    if (serial) {
-        // Exact continuation on one lane: move the whole queue (registers, run, staged, buckets) into the binary heap.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t hn = 0;
-        if (!started) {
-            if (lane == 0)
-                for (uint32_t j = 0; j < ns; ++j) {
-                    HeapEnt e; e.key = ZKEY | (unsigned long long)j; e.idx = (uint32_t)(keys[first + j] & 0xFFFFFFFFull); e.pad = 0;
-                    heap_push(heap, hn, e);
-                }
-        } else {
-            for (int l = 0; l < rcount; ++l) {
-                HeapEnt e; e.key = shfl64(rk, l); e.idx = __shfl(ri, l); e.pad = 0;
-                if (lane == 0) heap_push(heap, hn, e);
-            }
-            if (lane == 0) {
-                for (int j = 0; j < scount; ++j) { HeapEnt e = srun[(shead + j) & SMASK]; e.pad = 0; heap_push(heap, hn, e); }
-                for (int j = stage_from; j < stage_to; ++j) { HeapEnt e = stage[j]; e.pad = 0; heap_push(heap, hn, e); }
-            }
-            if (cold.on) {
-                // gather the buckets
-                while (cold.count > 0) {
-                    const uint32_t b = cold_lowest(cold, lane);
-                    uint32_t seg = cld32(&cold.bhead()[b]);
-                    uint32_t off = cld32(&cold.bmeta()[b]) & ~COLD_UNSORTED;
-                    uint32_t got = 0;
-                    while (seg != COLD_NONE) {
-                        const HeapEnt h = cld_ent(&cold.pool()[seg]);
-                        const uint32_t n = (uint32_t)(h.key >> 32);
-                        if (lane == 0)
-                            for (uint32_t j = off; j < n; ++j) { HeapEnt e = cld_ent(&cold.pool()[seg + 1u + j]); e.pad = 0; heap_push(heap, hn, e); }
-                        got += n - off;
-                        off = 0;
-                        seg = (uint32_t)h.key;
-                    }
-                    cold_mark_empty(cold, b, lane);
-                    cold.count -= got;
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (lane == 0) serial_flood(heap, hn, age, aff, mask, out, PY, PX, PN, s0, s1, s2);
-    }
-}
-
 __global__ void arena_need_kernel(const unsigned long long *comp_cap, uint32_t n_comp, unsigned long long coop_min,
                                   unsigned long long cold_min, unsigned long long *need)
 {
@@ -1950,21 +1513,20 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     // cold arenas for the components large enough to need one (sizes are the heap capacities)
     Scratch<unsigned long long> arena_need(ctx, n_comp + 1), arena_off(ctx, n_comp + 1);
     if (!arena_need.ok() || !arena_off.ok()) return ISX_ERR_NOMEM;
-    unsigned long long coop_min = COOP_MIN_SIZE;
-    if (const char *e = getenv("ISX_FLOOD_COOP_MIN")) coop_min = strtoull(e, nullptr, 10);   // tests: force a path
-    unsigned long long cold_min = COLD_MIN_SIZE;
-    if (const char *e = getenv("ISX_FLOOD_COLD_MIN")) cold_min = strtoull(e, nullptr, 10);
-    int run_limit = COOP_SCAP - 6 * 64, drain_n = COLD_DRAIN;             // tests shrink these to stress the cold tier
-    if (const char *e = getenv("ISX_FLOOD_RUN_LIMIT")) run_limit = atoi(e);
-    if (const char *e = getenv("ISX_FLOOD_DRAIN")) drain_n = atoi(e);
+    // ISX_FLOOD_* knobs (tests' stress modes, tuning runs): read once into the context (isx_ctx_create / isx_ctx_reload_knobs);
+    // a negative field = the library default
+    const isx_flood_tune &ft = ctx->ftune;
+    auto knob = [](long long v, long long dflt) { return v >= 0 ? v : dflt; };
+    unsigned long long coop_min = (unsigned long long)knob(ft.coop_min, COOP_MIN_SIZE);         // tests: force a path
+    unsigned long long cold_min = (unsigned long long)knob(ft.cold_min, COLD_MIN_SIZE);
+    int run_limit = (int)knob(ft.run_limit, COOP_SCAP - 6 * 64), drain_n = (int)knob(ft.drain, COLD_DRAIN);      // tests shrink these to stress the cold tier
     ISX_REQUIRE(run_limit >= 8 && run_limit <= COOP_SCAP - 6 * 64 && drain_n >= 4 && drain_n <= COLD_DRAIN && drain_n <= run_limit,
                 "ISX_FLOOD_RUN_LIMIT / ISX_FLOOD_DRAIN out of range");
     // A component without an arena whose LDS run overflows finishes on the one-lane heap; on structured volumes those
     // mid-size components were the critical path (tiled 512^3 blobs: 263 ms with arenas from 32 768 voxels, 103 ms from
     // 4 096).  An arena costs 7.4 MB of bucket tables whatever the component's size, so the threshold doubles until the
     // arenas fit the budget (a volume of many thousand mid-size components keeps the larger ones only).
-    unsigned long long arena_budget = COLD_ARENA_BUDGET;
-    if (const char *e = getenv("ISX_FLOOD_ARENA_MB")) arena_budget = strtoull(e, nullptr, 10) << 20;
+    const unsigned long long arena_budget = ft.arena_mb >= 0 ? (unsigned long long)ft.arena_mb << 20 : COLD_ARENA_BUDGET;
     unsigned long long arena_total = 0;
     for (;;) {
         arena_need_kernel<<<cdiv(n_comp + 1, TPB), TPB, 0, ctx->stream>>>(comp_cap.p, n_comp, coop_min, cold_min, arena_need.p);
@@ -1973,39 +1535,30 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         ISX_HIP(hipMemcpyAsync(&arena_total, arena_off.p + n_comp, 8, hipMemcpyDeviceToHost, ctx->stream));
         ISX_HIP(hipStreamSynchronize(ctx->stream));
         // never above the round-1 threshold: the large components keep their arenas whatever they cost
-        if (arena_total * sizeof(HeapEnt) <= arena_budget || getenv("ISX_FLOOD_COLD_MIN") || cold_min >= 32768ull) break;
+        if (arena_total * sizeof(HeapEnt) <= arena_budget || ft.cold_min >= 0 || cold_min >= 32768ull) break;
         cold_min *= 2;
     }
     Scratch<HeapEnt> pool(ctx, (size_t)total + 1);
     Scratch<HeapEnt> arena(ctx, (size_t)arena_total + 1);
-    // large components: ISX_FLOOD_MODE=wave selects the round-based kernel of round 1 (kept for A/B runs), default is the
-    // ordered speculative window (ws_flood_window.h)
-    bool window_mode = true;
-    if (const char *e = getenv("ISX_FLOOD_MODE")) window_mode = strcmp(e, "wave") != 0;
-    int wcap = WIN_W, tcap = WIN_T;
-    if (const char *e = getenv("ISX_FLOOD_WIN")) wcap = atoi(e);                      // tests: tiny windows / lists
-    if (const char *e = getenv("ISX_FLOOD_LIST")) tcap = atoi(e);
-    int max_bursts = 3;
-    if (const char *e = getenv("ISX_FLOOD_BURSTS")) max_bursts = atoi(e);
-    int group_bursts = max_bursts & 0x7FF;       // + (ISX_FLOOD_GWATCHDOG << 16): sub-round limit of the work-group kernel (tests of its hand-over)
-    if (const char *e = getenv("ISX_FLOOD_GWATCHDOG")) group_bursts |= (atoi(e) & 0x7FFF) << 16;
+    // large components: the ordered speculative window (ws_flood_window.h); ISX_FLOOD_WIN / ISX_FLOOD_LIST: tiny windows / lists (tests)
+    const int wcap = (int)knob(ft.win, WIN_W), tcap = (int)knob(ft.list, WIN_T);
+    const int max_bursts = (int)knob(ft.bursts, 3);
+    // + (ISX_FLOOD_GWATCHDOG << 16): sub-round limit of the work-group kernel (tests of its hand-over)
+    const int group_bursts = (max_bursts & 0x7FF) | ((ft.gwatchdog & 0x7FFF) << 16);
     // the largest components: one WORK-GROUP each (ws_flood_group.h; window of 512 episodes, lists of up to 192 discoveries).
     // ISX_FLOOD_GROUP_MIN: smallest component for it (0 = never: everything >= coop_min on the single-wave window kernel);
     // ISX_FLOOD_GWIN / ISX_FLOOD_GLIST shrink its window / lists (tests)
-    unsigned long long group_min = GROUP_MIN_SIZE;
-    if (const char *e = getenv("ISX_FLOOD_GROUP_MIN")) group_min = strtoull(e, nullptr, 10);
-    if (group_min == 0 || !window_mode) group_min = ~0ull;
+    unsigned long long group_min = (unsigned long long)knob(ft.group_min, GROUP_MIN_SIZE);
+    if (group_min == 0) group_min = ~0ull;
     if (group_min != ~0ull && group_min < coop_min) group_min = coop_min;
-    int gwcap = GRP_W, gtcap = GRP_T, gsteps = 64;     // ISX_FLOOD_GSTEPS: pops a wave may make between two work-group barriers (1 = one)
-    if (const char *e = getenv("ISX_FLOOD_GSTEPS")) gsteps = atoi(e);
-    int gminsteps = 4;                                  // ISX_FLOOD_GMINSTEPS: steps every wave makes before the front's "ready" stops it
-    if (const char *e = getenv("ISX_FLOOD_GMINSTEPS")) gminsteps = atoi(e);
-    if (const char *e = getenv("ISX_FLOOD_GWIN")) gwcap = atoi(e);
-    if (const char *e = getenv("ISX_FLOOD_GLIST")) gtcap = atoi(e);
+    // ISX_FLOOD_GSTEPS: pops a wave may make between two work-group barriers (1 = one); ISX_FLOOD_GMINSTEPS: steps every wave
+    // makes before the front's "ready" stops it
+    const int gwcap = (int)knob(ft.gwin, GRP_W), gtcap = (int)knob(ft.glist, GRP_T), gsteps = (int)knob(ft.gsteps, 64), gminsteps = (int)knob(ft.gminsteps, 4);
     ISX_REQUIRE(wcap >= 1 && wcap <= WIN_W && tcap >= 6 && tcap <= WIN_T, "ISX_FLOOD_WIN / ISX_FLOOD_LIST out of range");
     ISX_REQUIRE(gwcap >= 1 && gwcap <= GRP_W && gtcap >= 6 && gtcap <= GRP_T && gsteps >= 1 && gsteps <= 255 && gminsteps >= 1 && gminsteps <= 255, "ISX_FLOOD_GWIN / ISX_FLOOD_GLIST / ISX_FLOOD_GSTEPS out of range");
-    Scratch<uint32_t> claim(ctx, (window_mode && !getenv("ISX_FLOOD_TRACE")) ? 1 : (size_t)std::max<unsigned long long>((unsigned long long)PN, 3 * (total + 1)));
-    Scratch<unsigned long long> vstate(ctx, window_mode ? (size_t)PN : 1);
+    const bool trace_on = !ft.trace.empty();        // development: commit order of every component's roots (ISX_FLOOD_TRACE=<file>)
+    Scratch<uint32_t> claim(ctx, trace_on ? (size_t)(3 * (total + 1)) : 1);
+    Scratch<unsigned long long> vstate(ctx, (size_t)PN);
     Scratch<unsigned long long> stats(ctx, 64);
     if (!pool.ok() || !claim.ok() || !arena.ok() || !stats.ok() || !vstate.ok()) return ISX_ERR_NOMEM;
     ISX_HIP(hipMemsetAsync(stats.p, 0, 64 * 8, ctx->stream));
@@ -2028,8 +1581,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         const float rlo = unord(hmm[0]), rhi = unord(hmm[1]);
         const float smin = std::min(s[0], std::min(s[1], s[2])), smax = std::max(s[0], std::max(s[1], s[2]));
         const float vlo = std::min(std::min(rlo * smin, rlo * smax), 0.0f), vhi = std::max(std::max(rhi * smin, rhi * smax), vlo);
-        int nbuckets = 4096;             // (16384 until round 3: fewer, larger drains are cheaper for both kernels; config 2: 2.55 -> 2.43 s)
-        if (const char *e = getenv("ISX_FLOOD_BUCKETS")) nbuckets = atoi(e);
+        const int nbuckets = (int)knob(ft.buckets, 4096);      // (16384 until round 3: fewer, larger drains are cheaper for both kernels; config 2: 2.55 -> 2.43 s)
         ISX_REQUIRE(nbuckets >= 1 && nbuckets <= COLD_NBK, "ISX_FLOOD_BUCKETS out of range");
         bk_lo = vlo;
         bk_inv = (vhi > vlo && std::isfinite(vhi - vlo)) ? (float)nbuckets / (vhi - vlo) : 0.0f;
@@ -2041,7 +1593,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                                                           pshape[1], pshape[2], PN, s[0], s[1], s[2], coop_min,
                                                           ctx->ws_shard_rank, ctx->ws_shard_world);
     ISX_CHECK_LAUNCH();
-    if (window_mode) {
+    {
         flood_state_init_kernel<<<cdiv(PN, TPB), TPB, 0, ctx->stream>>>(mask, out, vstate.p, PN);
         ISX_CHECK_LAUNCH();
         Scratch<unsigned long long> okeys(ctx, n_comp), order(ctx, n_comp);
@@ -2049,7 +1601,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         comp_order_key_kernel<<<cdiv(n_comp, TPB), TPB, 0, ctx->stream>>>(comp_off.p, n_comp, coop_min, okeys.p);
         ISX_CHECK_LAUNCH();
         ISX_TRY(sort_u64(ctx, (const uint64_t *)okeys.p, (uint64_t *)order.p, n_comp));
-        const bool side = !(getenv("ISX_FLOOD_GROUP_STREAM") && atoi(getenv("ISX_FLOOD_GROUP_STREAM")) == 0);
+        const bool side = ft.group_stream != 0;
         if (group_min != ~0ull) {
             // the giants run beside the mid-size components (other CUs): a side stream, joined below
             // (ISX_FLOOD_GROUP_STREAM=0: same stream, one kernel after the other -- structured 512^3 seed 3, one 345 k-voxel
@@ -2058,18 +1610,15 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
             flood_group_kernel<<<n_comp, GRP_W, 0, side ? ctx->aux_streams[0] : ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                                    comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1], pshape[2], PN,
                                                                    s[0], s[1], s[2], group_min, run_limit, drain_n, gwcap, gtcap, group_bursts,
-                                                                   bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world, gsteps | (gminsteps << 8) | ((getenv("ISX_FLOOD_PLATEAU") && atoi(getenv("ISX_FLOOD_PLATEAU")) != 0) ? 0 : 0x10000) |      /* the plateau pass: off unless asked for */
-                                                                   ((getenv("ISX_FLOOD_PLATEAU") && atoi(getenv("ISX_FLOOD_PLATEAU")) == 2) ? 0x8000000 : 0) |    /* 2: + the wide pass */
-                                                                   ((getenv("ISX_FLOOD_PLATEAU_MIN") ? (atoi(getenv("ISX_FLOOD_PLATEAU_MIN")) & 0x3FF) : 0) << 17));
+                                                                   bk_lo, bk_inv, stats.p, ctx->ws_shard_rank, ctx->ws_shard_world, gsteps | (gminsteps << 8));
             ISX_CHECK_LAUNCH();
         }
         // two tiers of the single-wave kernel: components below small_max voxels on the small instantiation (~30 KB of LDS:
         // five per CU instead of one), the others on the large one, side by side on their own streams
-        unsigned long long small_max = WIN_SMALL_MAX;
-        if (const char *e = getenv("ISX_FLOOD_SMALL_MAX")) small_max = strtoull(e, nullptr, 10);      // 0: no small tier
+        unsigned long long small_max = (unsigned long long)knob(ft.small_max, WIN_SMALL_MAX);      // 0: no small tier
         if (small_max < coop_min) small_max = coop_min;
         if (group_min != ~0ull && small_max > group_min) small_max = group_min;
-        uint32_t *trace_p = getenv("ISX_FLOOD_TRACE") ? claim.p : nullptr;
+        uint32_t *trace_p = trace_on ? claim.p : nullptr;
         const bool two = small_max > coop_min && side;
         if (two) ISX_TRY(ctx->aux_fork(1));
         flood_window_kernel<WIN_W, WIN_T, WIN_RCAP, WIN_PEND><<<n_comp, 64, 0, two ? ctx->aux_streams[1] : ctx->stream>>>(
@@ -2089,7 +1638,8 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         if (two) ISX_TRY(ctx->aux_join(1));
         if (group_min != ~0ull && side) ISX_TRY(ctx->aux_join(0));
 
-        if (const char *tp = getenv("ISX_FLOOD_TRACE")) {      // development: commit order of every component's roots
+        if (trace_on) {
+            const char *tp = ft.trace.c_str();
             ISX_HIP(hipStreamSynchronize(ctx->stream));
             std::vector<uint32_t> hl(3 * ((size_t)total + 1)), hf(n_comp);
             std::vector<unsigned long long> ho(n_comp + 1), hk(n_seeds);
@@ -2104,34 +1654,16 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                 fwrite(hl.data(), 4, 3 * ((size_t)total + 1), f); fclose(f);
             }
         }
-    } else {
-        ISX_HIP(hipMemsetAsync(claim.p, 0, (size_t)PN * sizeof(uint32_t), ctx->stream));
-        flood_wave_kernel<<<n_comp, 64, 0, ctx->stream>>>(aff, mask, out, claim.p, keys_sorted.p, n_seeds, comp_first.p,
-                                                          comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
-                                                          pshape[2], PN, s[0], s[1], s[2], coop_min, run_limit, drain_n, bk_lo, bk_inv, stats.p,
-                                                          ctx->ws_shard_rank, ctx->ws_shard_world);
-        ISX_CHECK_LAUNCH();
     }
-    if (window_mode) {
+    {
         unsigned long long hs[64];
         ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         ISX_HIP(hipStreamSynchronize(ctx->stream));
 #ifdef ISX_FLOOD_CHECK          // these slots carry the phase timers in the ISX_FLOOD_PROF build
         if (hs[40]) fprintf(stderr, "[isx flood/window] ORDER CHECK failed first at tag %llu sub-round %llu nw %llu run %llu: key %016llx !< next %016llx at p %llu (1 window, 2 window/run, 3 run: %llu)\n   window tail (last first): %016llx %016llx %016llx %016llx | run head: %016llx %016llx %016llx %016llx | cold %llu fifo drains %llu seeds %llu staged %llu\n   [tier check] last hot insert key %016llx hot_max then %016llx reason %llu (1 below hot max, 2 cold free) nw %llu run %llu\n", hs[40], hs[41], hs[42], hs[43], hs[44], hs[45], hs[46], hs[47], hs[20], hs[21], hs[22], hs[23], hs[24], hs[25], hs[26], hs[27], hs[28], hs[29], hs[30], hs[31], hs[20], hs[21], hs[22], hs[23], hs[24]);
 #endif
-        if (hs[22]) fprintf(stderr, "[isx flood/group] serial continuation requested %llu time(s) and SKIPPED (development flag); last: mode %llu sub-round %llu component size %llu\n",
-                            hs[22], hs[23] & 0xFF, (hs[23] >> 8) & 0xFFFFFF, hs[23] >> 32);
-        if (hs[20]) {
-            fprintf(stderr, "[isx flood/group] GUARD: %llu report(s), site %llu (1-3: voxel index outside the volume, 100+: hand-over sanity, 200: run empty with cold elements, 3xx: order check tag) "
-                            "sub-round %llu where %llu lane %llu keys %016llx %016llx nw|run %016llx\n", hs[20], hs[21], hs[10] & 0xFFFFFFFF, (hs[10] >> 32) & 0xFF, hs[10] >> 40, hs[40], hs[41], hs[42]);
-            set_error("flood group kernel produced an invalid voxel index (internal error)");
-            return ISX_ERR_INTERNAL;
-        }
-        if (hs[16]) {
-            fprintf(stderr, "[isx flood] TIER INVARIANT: %llu run eviction(s) left the hot maximum above the lowest cold bucket\n", hs[16]);
-            set_error("flood tier invariant violated (internal error)");
-            return ISX_ERR_INTERNAL;
-        }
+        // the watchdog dump first: a tripped kernel has overwritten slots 20..31 with its front state (the guard / skip reports
+        // below live in some of the same slots and would be misread)
         if (hs[9] && group_min != ~0ull)
             fprintf(stderr, "[isx flood/group] watchdog state (if it was the work-group kernel): nw %llu run %llu | free chunks %llu reserve %llu free slots %llu dirty %llu forced %llu | front: info %08llx (np %llu npop %llu started %llu idle %llu) mx %08llx resmin %08llx slot %llu key %016llx | next key %016llx qhead %016llx | episodes %llu started %llu idle %llu with-spare %llu chunks-held %llu entries %llu | pops %llu cold %llu\n",
                     hs[24], hs[25], hs[26] & 0xFFFF, (hs[26] >> 16) & 0xFFFF, (hs[26] >> 32) & 0xFFFF, (hs[26] >> 48) & 0xFF, hs[26] >> 56, hs[27] & 0xFFFFFFFF,
@@ -2147,13 +1679,26 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
             set_error("flood watchdog tripped (internal error)");
             return ISX_ERR_INTERNAL;
         }
-        if (!getenv("ISX_FLOOD_STATS")) return ISX_OK;
+        if (hs[22]) fprintf(stderr, "[isx flood/group] serial continuation requested %llu time(s) and SKIPPED (development flag); last: mode %llu sub-round %llu component size %llu\n",
+                            hs[22], hs[23] & 0xFF, (hs[23] >> 8) & 0xFFFFFF, hs[23] >> 32);
+        if (hs[20]) {
+            fprintf(stderr, "[isx flood/group] GUARD: %llu report(s), site %llu (1-3: voxel index outside the volume, 100+: hand-over sanity, 200: run empty with cold elements, 3xx: order check tag) "
+                            "sub-round %llu where %llu lane %llu keys %016llx %016llx nw|run %016llx\n", hs[20], hs[21], hs[10] & 0xFFFFFFFF, (hs[10] >> 32) & 0xFF, hs[10] >> 40, hs[40], hs[41], hs[42]);
+            set_error("flood group kernel produced an invalid voxel index (internal error)");
+            return ISX_ERR_INTERNAL;
+        }
+        if (hs[16]) {
+            fprintf(stderr, "[isx flood] TIER INVARIANT: %llu run eviction(s) left the hot maximum above the lowest cold bucket\n", hs[16]);
+            set_error("flood tier invariant violated (internal error)");
+            return ISX_ERR_INTERNAL;
+        }
+        if (!ft.stats) return ISX_OK;
         fprintf(stderr, "[isx flood/window] sub-rounds %llu pops %llu (%.2f/sub-round) executed %llu (useful %.2f) rows %llu hot_ins %llu mid_ins %llu cold_app %llu drains %llu (prefix %llu) "
                         "evicted %llu squashes %llu (bound %llu) squashed eps %llu forced %llu serial_handover %llu\n",
                 hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[2] ? (double)hs[1] / hs[2] : 0.0, hs[13], hs[3], hs[7], hs[4], hs[5], hs[10],
                 hs[6], hs[11], hs[14], hs[12], hs[15], hs[8]);
         if (group_min != ~0ull)
-            fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu; of the work-group kernel alone: rounds %llu (plateau passes %llu, %llu of them wide, with %llu pops; not tried: started episode %llu, prefix < 32 %llu; not a plateau %llu) pops %llu drains %llu (%llu as the prefix of a list in key order)\n", hs[17], hs[18], hs[29], hs[30], hs[59], hs[31], hs[24], hs[25], hs[23], hs[28], hs[27], hs[26]);
+            fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu; of the work-group kernel alone: rounds %llu pops %llu drains %llu (%llu as the prefix of a list in key order)\n", hs[17], hs[18], hs[63], hs[62], hs[60], hs[61]);
 #ifdef ISX_FLOOD_PROF
         if (group_min != ~0ull)
             fprintf(stderr, "[isx flood/group] cycles/sub-round of lane 0: (S0)->C %.0f | C loop %.0f | wait (S5) %.0f | squash %.0f | to (E0) %.0f | order (E1-E3a) %.0f | verify %.0f | labels %.0f | enqueue %.0f | "
@@ -2162,28 +1707,13 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                     (double)hs[37] / hs[0], (double)hs[38] / hs[0], (double)hs[45] / hs[0], (double)hs[41] / hs[0], (double)hs[42] / hs[0], (double)hs[39] / hs[0], (double)hs[40] / hs[0], (double)hs[46] / hs[0], (double)hs[47] / hs[0]);
         if (group_min != ~0ull)
             fprintf(stderr, "[isx flood/group] bursts cut by: front not ready (rounds) %llu | not started %llu | running %llu | bound %llu | pend full %llu | whole window %llu ; window fill at first burst %.1f ; flushes %llu (one-bucket %llu, 64-element appends %llu)\n",
-                    hs[48], hs[49], hs[50], hs[51], hs[52], hs[53], hs[29] ? (double)hs[54] / hs[29] : 0.0, hs[57], hs[55], hs[56]);
+                    hs[48], hs[49], hs[50], hs[51], hs[52], hs[53], hs[63] ? (double)hs[54] / hs[63] : 0.0, hs[57], hs[55], hs[56]);
         fprintf(stderr, "[isx flood/window] cycles/sub-round: loop+evict %.0f | scan %.0f | trip %.0f | lists %.0f | squash %.0f | commit: decide %.0f labels %.0f enqueue %.0f | refill %.0f\n",
                 (double)hs[32] / hs[0], (double)hs[33] / hs[0], (double)hs[34] / hs[0], (double)hs[35] / hs[0], (double)hs[36] / hs[0],
                 (double)hs[37] / hs[0], (double)hs[38] / hs[0], (double)hs[39] / hs[0], (double)hs[40] / hs[0]);
 #endif
         return ISX_OK;
     }
-    if (getenv("ISX_FLOOD_STATS")) {
-        unsigned long long hs[32];
-        ISX_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-        ISX_HIP(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[isx flood] rounds %llu pops %llu (%.2f/round) reg_ins %llu run_ins %llu (avg shift %.1f) cold_app %llu drains %llu (prefix %llu) evicted %llu serial_handover %llu oob %llu\n",
-                hs[0], hs[1], hs[0] ? (double)hs[1] / hs[0] : 0.0, hs[2], hs[3], hs[3] ? (double)hs[7] / hs[3] : 0.0, hs[4], hs[5], hs[10], hs[6], hs[8], hs[9]);
-#ifdef ISX_FLOOD_PROF
-        fprintf(stderr, "[isx flood] cycles/round: append+loop %.0f | wait-stores %.0f | loads+claims %.0f | claim-read %.0f | scan+label %.0f | refill/drain %.0f | insert %.0f\n",
-                (double)hs[16] / hs[0], (double)hs[17] / hs[0], (double)hs[18] / hs[0], (double)hs[19] / hs[0], (double)hs[20] / hs[0],
-                (double)hs[21] / hs[0], (double)hs[22] / hs[0]);
-        fprintf(stderr, "[isx flood] append cycles/round: wait %.0f | groups %.0f (%.2f groups/round) | leader loads %.0f | bookkeeping+stores %.0f\n",
-                (double)hs[24] / hs[0], (double)hs[25] / hs[0], (double)hs[28] / hs[0], (double)hs[26] / hs[0], (double)hs[27] / hs[0]);
-#endif
-    }
-    return ISX_OK;
 }
 
 // W2 shared by the public entry and the fused path.  keys_sorted must hold `cap` entries.

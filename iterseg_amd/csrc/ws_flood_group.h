@@ -44,10 +44,10 @@ static constexpr unsigned long long GROUP_MIN_SIZE = 262144;   // components fro
 enum { GI_OH, GI_NW, GI_SHEAD, GI_SCOUNT, GI_NSTAGE, GI_NFREECH, GI_NFREESLOT, GI_SERIAL, GI_FORCED, GI_NTOOK, GI_NLOST, GI_NT, GI_NL,
        GI_DIRTY, GI_COLD_COUNT, GI_COLD_LOW, GI_M, GI_NCOMMIT, GI_PENDN, GI_NHOT, GI_NWB, GI_AGEBASE, GI_NPTOT, GI_ANY, GI_TAKE, GI_POS,
        GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_FRONT, GI_LAST, GI_NRELOAD, GI_READY, GI_SORTN, GI_PEND0,
-       GI_WQ, GI_WA, GI_WE, GI_WH, GI_WFAIL, GI_WHERE0, GI_WHERE1, GI_WHERE2, GI_N };
+       GI_N };
 enum { GQ_KSQ, GQ_TMIN, GQ_QHEAD, GQ_KINV, GQ_N };
 enum { GS_SUB, GS_POPS, GS_EXEC, GS_SQ_EPS, GS_SQ_BOUND, GS_SQ_LOST, GS_SLOW, GS_FORCED, GS_RELOAD, GS_RUNINS, GS_WININS, GS_WINEV, GS_COLD,
-       GS_DRAIN, GS_BURST, GS_PLATEAU, GS_PLPOPS, GS_WIDE, GS_PLSTARTED, GS_PLSHORT, GS_PLABORT, GS_C_NOTREADY, GS_C_NOTSTARTED, GS_C_RUNNING, GS_C_BOUND, GS_C_CAP, GS_C_ALL, GS_NWSUM, GS_F_BULK, GS_F_CALLS, GS_F_FLUSHES, GS_N };
+       GS_DRAIN, GS_BURST, GS_C_NOTREADY, GS_C_NOTSTARTED, GS_C_RUNNING, GS_C_BOUND, GS_C_CAP, GS_C_ALL, GS_NWSUM, GS_F_BULK, GS_F_CALLS, GS_F_FLUSHES, GS_N };
 
 // ---- the cold tier, driven by wave 0, OUT OF LINE: cold_append / cold_drain are large, and inlined into the kernel their
 // registers pushed the episode words of the hot loop into scratch memory (a scratch round trip per phase).  The tier's
@@ -137,17 +137,6 @@ __device__ __noinline__ void grp_w0_flush_stage(Cold *cs, HeapEnt *stage, int *s
     *cs = cold;
 }
 
-// room for n elements at the tail of bucket b (wide plateau pass: its lanes write the elements themselves); where -> shI[GI_WHERE0..2]
-__device__ __noinline__ void grp_w0_reserve(Cold *cs, int *shI, uint32_t *lstat, uint32_t b, int n, unsigned long long first_key,
-                                            unsigned long long last_key, int lane)
-{
-    Cold cold = *cs;
-    cold_append_bucket(cold, nullptr, n, b, true, first_key, last_key, lane, (uint32_t *)&shI[GI_WHERE0]);
-    if (cold.failed) { if (lane == 0) shI[GI_WFAIL] = 1; }
-    else if (lane == 0) atomicAdd(&lstat[GS_COLD], (uint32_t)n);
-    grp_publish_cold(cold, shI, lane);
-    *cs = cold;
-}
 
 // the largest run elements go to their buckets (ascending, so that a bucket's list stays FIFO)
 __device__ __noinline__ void grp_w0_run_evict(Cold *cs, HeapEnt *srun, int *shI, uint32_t *lstat, unsigned long long *stats, int keep, int lane)
@@ -371,29 +360,21 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         pub_info[tid] = 0u; pub_res[tid] = 0xFFFFFFFFu; pub_mx[tid] = 0u;      // "not started" is what the commit phase must see
     };
     // every deferred entry (below the bound, unpopped, only in the list) sorts after every register candidate
+    // (written with selects: with an early-return form the compiler merged `++ncand` / `++ndef` into one store through a selected
+    // pointer and kept both counters in scratch memory -- two scratch loads and a store per discovery in the claim loop)
     auto cand_add = [&](uint32_t v, int li, int ad) {
         const unsigned long long nk_ = ((unsigned long long)v << 32) | ((unsigned long long)(uint32_t)li << 16) | (unsigned long long)(uint32_t)ad;
-        if (ndef == 0 && ncand < GRP_CMAX) {
-#pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) ck[k] = nk_;
-            ++ncand;
-            return;
-        }
         int mk = -1; unsigned long long mv = 0ull;
 #pragma unroll
         for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand && (mk < 0 || ck[k] > mv)) { mk = k; mv = ck[k]; }
         const bool below_max = mk >= 0 && nk_ < mv;
-        if (ncand < GRP_CMAX && below_max) {
+        const bool add = ncand < GRP_CMAX && (ndef == 0 || below_max);      // a free register: behind no deferred entry, or below the largest candidate
+        const bool repl = ncand == GRP_CMAX && below_max;                   // full: the largest candidate becomes a deferred entry
+        const int at = add ? ncand : (repl ? mk : -1);
 #pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) ck[k] = nk_;
-            ++ncand;
-            return;
-        }
-        if (ncand == GRP_CMAX && below_max) {
-#pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) ck[k] = nk_;
-        }
-        ++ndef;
+        for (int k = 0; k < GRP_CMAX; ++k) ck[k] = (k == at) ? nk_ : ck[k];
+        ncand += add ? 1 : 0;
+        ndef += add ? 0 : 1;
     };
     // The candidates of lane L's episode rebuilt from its list by the WHOLE wave (three entries per lane): candidates,
     // deferred count and the minimum of the residuals.  Runs when the six registers are used up and discoveries below
@@ -757,337 +738,8 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         if (tid == 0 && stats && shI[GI_SCOUNT] == 0 && cold_on && (shI[GI_COLD_COUNT] > 0 || shI[GI_NSTAGE] > 0)) {
             if (atomicAdd(&stats[20], 1ull) == 0ull) { stats[21] = 200ull; stats[10] = (unsigned long long)st_sub | ((unsigned long long)shI[GI_COLD_COUNT] << 32); }
         }
-        // ---- P: plateau round.  When every root of the window has the same value v and no episode has started, every episode is
-        //         its root's pop and nothing else (the bound of a root is the next root's VALUE, and a discovery cannot sort below a
-        //         root of its own value: it is younger): the sequential flood is a breadth-first sweep in age order.  The whole
-        //         window then commits in ONE pass -- claims (one trip), verification after a barrier (one trip: a voxel two roots
-        //         of this pass claimed belongs to the older one), ages by a prefix sum over the window positions in (position,
-        //         direction) order = the reference's push order (watershed.py:146-158), labels, residuals -- with no discovery
-        //         lists, chunk pool, candidates or commit decision.  A discovery BELOW v (only possible when v is not the smallest
-        //         value of the map) ends the pass before anything is written: the claims are released and the general sub-round
-        //         runs instead.  (Maps whose affinities are zero inside the objects -- the reference's own demo construction --
-        //         spend most of their pops on that plateau: 345 pops per 43 us sub-round on the general path.) ----------------------
-        bool pl_done = false, did_commit = false;
-        const int pl_min = ((kmax >> 17) & 0x3FF) ? ((kmax >> 17) & 0x3FF) : 32;     // shortest prefix worth a pass (ISX_FLOOD_PLATEAU_MIN)
-        // ---- W: the wide plateau pass (ISX_FLOOD_PLATEAU=2).  When the WHOLE hot tier -- window and run -- sits on one value and
-        //         nothing has started, a pass takes the window's roots and up to three run elements per lane (2 048 pops instead
-        //         of 512 for the same chain of memory trips): claims by non-returning atomics, then ONE read per neighbour decides
-        //         (the word holds the smallest claiming key: mine, or not mine); the discoveries of the plateau's own value go
-        //         straight to the tail of its bucket (they sort after everything hot: same value, younger), the others through
-        //         `pend`.  Per-item words live in the discovery-list pool, which is empty when no episode has started. ------------
-        if (!(kmax & 0x10000) && (kmax & 0x8000000) && cold_on && nw >= pl_min && !shI[GI_FORCED]) {
-            const uint32_t v0 = (uint32_t)(okey[ord_at(0)] >> 32);
-            const int sc0 = shI[GI_SCOUNT], sh0 = shI[GI_SHEAD];
-            bool okw = (uint32_t)(okey[ord_at(nw - 1)] >> 32) == v0 && (sc0 == 0 || (uint32_t)(srun[(sh0 + sc0 - 1) & SMASK].key >> 32) == v0);
-            if (okw) okw = !__syncthreads_or(has && started);
-            if (okw) {
-                const int nr = sc0 < 3 * GRP_W ? sc0 : 3 * GRP_W;
-                const int N = nw + nr;
-                unsigned short *iw = (unsigned short *)pvox, *offA = iw + 4 * GRP_W, *offE = offA + 4 * GRP_W, *offH = offE + 4 * GRP_W;
-                static_assert(sizeof(pvox) >= 4 * 4 * GRP_W * sizeof(unsigned short), "item words of the wide pass live in the list pool");
-                auto claim6 = [&](uint32_t rv, unsigned long long kv) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const uint32_t nb = rv + (uint32_t)noff32[k];
-                        if (nb < (uint32_t)PN) (void)__hip_atomic_fetch_min(&state[nb], kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                };
-                if (has) claim6(root, key);
-#pragma unroll
-                for (int k3 = 0; k3 < 3; ++k3) {
-                    const int r = tid + GRP_W * k3;
-                    if (r < nr) { const HeapEnt e = srun[(sh0 + r) & SMASK]; claim6(e.idx, e.key); }
-                }
-                if (tid == 0) { shI[GI_WQ] = N; shI[GI_WFAIL] = 0; }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                                                // (W1) every claim of the pass is in
-                auto verify6 = [&](uint32_t rv, unsigned long long kv, int id) {
-                    unsigned long long st6[6];
-                    float af[6];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const uint32_t nb = rv + (uint32_t)noff32[k];
-                        st6[k] = 0ull; af[k] = 0.f;
-                        if (nb < (uint32_t)PN) {
-                            st6[k] = __hip_atomic_load(&state[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            af[k] = (aff + (int64_t)ax[k] * PN)[k < 3 ? rv : nb];
-                        }
-                    }
-                    uint32_t w = 0;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        if (st6[k] == kv) {
-                            const uint32_t v = ford(af[k] * sc[ax[k]] + 0.0f);
-                            w |= 1u << k;
-                            if (v == v0) w |= 64u << k;
-                            else if (v < v0) w |= 0x1000u;
-                        }
-                    iw[id] = (unsigned short)w;
-                };
-                if (has) verify6(root, key, tid);
-#pragma unroll
-                for (int k3 = 0; k3 < 3; ++k3) {
-                    const int r = tid + GRP_W * k3;
-                    if (r < nr) { const HeapEnt e = srun[(sh0 + r) & SMASK]; verify6(e.idx, e.key, GRP_W + r); }
-                }
-                __syncthreads();                                                // (W2) item words are written
-                // ordered items: q < nw = window position q, else run element q - nw; thread t owns q = 4 t .. 4 t + 3
-                uint32_t ca[4], ce[4], lowq = (uint32_t)N;
-                int idq[4];
-                uint32_t ta = 0, te = 0, th = 0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int q = 4 * tid + u;
-                    ca[u] = ce[u] = 0u; idq[u] = -1;
-                    if (q < N) {
-                        idq[u] = q < nw ? (int)oslot[ord_at(q)] : GRP_W + (q - nw);
-                        const uint32_t w = iw[idq[u]];
-                        ca[u] = (uint32_t)__popc(w & 63u); ce[u] = (uint32_t)__popc((w >> 6) & 63u);
-                        if ((w & 0x1000u) && (uint32_t)q < lowq) lowq = (uint32_t)q;
-                    }
-                    ta += ca[u]; te += ce[u]; th += ca[u] - ce[u];
-                }
-                const uint32_t ia = wave_incl_sum(ta), ie = wave_incl_sum(te), ih = wave_incl_sum(th);
-                if (lane == 63) { wtmp[0][wave] = (int)ia; wtmp[1][wave] = (int)ie; wtmp[2][wave] = (int)ih; }
-                if (lowq < (uint32_t)N) atomicMin(&shI[GI_WQ], (int)lowq + 1);
-                __syncthreads();                                                // (W3)
-                uint32_t ba = ia - ta, be = ie - te, bh = ih - th;
-#pragma unroll
-                for (int w = 0; w < GRP_NWV; ++w) if (w < wave) { ba += (uint32_t)wtmp[0][w]; be += (uint32_t)wtmp[1][w]; bh += (uint32_t)wtmp[2][w]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (idq[u] >= 0) {
-                        offA[idq[u]] = (unsigned short)ba; offE[idq[u]] = (unsigned short)be; offH[idq[u]] = (unsigned short)bh;
-                        if (bh + (ca[u] - ce[u]) > (uint32_t)GRP_PEND) atomicMin(&shI[GI_WQ], 4 * tid + u);      // `pend` is full here
-                    }
-                    ba += ca[u]; be += ce[u]; bh += ca[u] - ce[u];
-                }
-                __syncthreads();                                                // (W4) the cut is known
-                const int ncommit = shI[GI_WQ];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int q = 4 * tid + u;
-                    if (idq[u] >= 0) {
-                        if (q >= ncommit) offA[idq[u]] |= 0x8000u;
-                        if (q == ncommit - 1) {
-                            shI[GI_WA] = (int)((offA[idq[u]] & 0x7FFFu) + ca[u]); shI[GI_WE] = (int)(offE[idq[u]] + ce[u]);
-                            shI[GI_WH] = (int)(offH[idq[u]] + (ca[u] - ce[u]));
-                        }
-                    }
-                }
-                const uint32_t agebase = (uint32_t)shI[GI_AGEBASE];
-                __syncthreads();                                                // (W5)
-                const int WA = shI[GI_WA], WE = shI[GI_WE], WH = shI[GI_WH];
-                // (what is still staged for the buckets is older than anything this pass appends: it goes first)
-                if (wave == 0 && WE > 0 && shI[GI_NSTAGE] > 0) flush_stage_w0();
-                if (wave == 0 && WE > 0 && !shI[GI_SERIAL])
-                    grp_w0_reserve(&scold, shI, lstat, cold_bucket(cold, (unsigned long long)v0 << 32), WE,
-                                   ((unsigned long long)v0 << 32) | (unsigned long long)(agebase + 1u),
-                                   ((unsigned long long)v0 << 32) | (unsigned long long)(agebase + (uint32_t)WA), lane);
-                __syncthreads();                                                // (W6) the bucket's tail is reserved
-                const bool wfail = shI[GI_WFAIL] != 0 || shI[GI_SERIAL] != 0;
-                const uint32_t whA = (uint32_t)shI[GI_WHERE0], whR = (uint32_t)shI[GI_WHERE1], whB = (uint32_t)shI[GI_WHERE2];
-                HeapEnt *cpool = cold.pool();
-                auto commit6 = [&](uint32_t rv, unsigned long long kv, uint32_t lv, int id) -> bool {
-                    const uint32_t w = iw[id], oa = offA[id];
-                    if ((oa & 0x8000u) || wfail) {                              // behind the cut (or no room in the arena): claims back
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) if (w & (1u << k)) atomicCAS(&state[rv + (uint32_t)noff32[k]], kv, ST_FREE);
-                        return false;
-                    }
-                    uint32_t i = 0, je = offE[id], jh = offH[id];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        if (w & (1u << k)) {
-                            const uint32_t nb = rv + (uint32_t)noff32[k];
-                            __hip_atomic_store(&state[nb], (unsigned long long)lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            out[nb] = lv;
-                            HeapEnt r;
-                            r.idx = nb; r.pad = lv;
-                            const unsigned long long age = (unsigned long long)(agebase + oa + i + 1u);
-                            if (w & (64u << k)) {
-                                r.key = ((unsigned long long)v0 << 32) | age;
-                                cpool[je < whR ? whA + je : whB + (je - whR)] = r;
-                                ++je;
-                            } else {
-                                const uint32_t v = ford((aff + (int64_t)ax[k] * PN)[k < 3 ? rv : nb] * sc[ax[k]] + 0.0f);
-                                r.key = ((unsigned long long)v << 32) | age;
-                                pend[jh++] = r;
-                            }
-                            ++i;
-                        }
-                    return true;
-                };
-                uint32_t npop_w = 0;
-                if (has) {
-                    if (commit6(root, key, lab, tid)) {
-                        has = false; ++npop_w;
-                        freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
-                    }
-                }
-#pragma unroll
-                for (int k3 = 0; k3 < 3; ++k3) {
-                    const int r = tid + GRP_W * k3;
-                    if (r < nr) { const HeapEnt e = srun[(sh0 + r) & SMASK]; if (commit6(e.idx, e.key, e.pad, GRP_W + r)) ++npop_w; }
-                }
-                {
-                    const uint32_t pw = rdlane(wave_incl_sum(npop_w), 63);
-                    if (lane == 0 && pw) { atomicAdd(&lstat[GS_POPS], pw); atomicAdd(&lstat[GS_PLPOPS], pw); }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                                                // (W7)
-                if (wfail) { if (tid == 0) shI[GI_SERIAL] = 1; __syncthreads(); continue; }     // the arena is full: serial continuation
-                if (tid == 0) {
-                    const int nwc = ncommit < nw ? ncommit : nw, rc = ncommit - nwc;
-                    shI[GI_AGEBASE] = (int)(agebase + (uint32_t)WA);
-                    shI[GI_OH] = (shI[GI_OH] + nwc) & (GRP_W - 1);
-                    shI[GI_NW] = nw - nwc;
-                    shI[GI_SHEAD] = (sh0 + rc) & SMASK; shI[GI_SCOUNT] = sc0 - rc;
-                    shI[GI_PENDN] = WH; shI[GI_PEND0] = 0;
-                    atomicAdd(&lstat[GS_BURST], 1u); atomicAdd(&lstat[GS_PLATEAU], 1u); atomicAdd(&lstat[GS_WIDE], 1u);
-                }
-                __syncthreads();                                                // (W8)
-                pl_done = did_commit = true;
-                if (!enqueue_batch()) continue;
-            }
-        }
-        if (!pl_done && nw >= pl_min && !(kmax & 0x10000)) {                              // (bit set unless ISX_FLOOD_PLATEAU=1: measured r3 -- blobs 256^3
-                                                                                // 700 -> 660 ms, structured 512^3 seed 1 1340 -> 1440 ms: off by default)
-            // the pass covers the leading roots of value v0 (the window is sorted: they are a prefix); the roots behind them sit
-            // this sub-round out -- a claim of theirs that a plateau root takes over is settled at their commit, as always
-            const uint32_t v0 = (uint32_t)(okey[ord_at(0)] >> 32);
-            const bool mine_p = has && (uint32_t)(key >> 32) == v0;
-            bool okp = !shI[GI_FORCED];
-            if (okp) { okp = !__syncthreads_or(mine_p && started); if (!okp && tid == 0) atomicAdd(&lstat[GS_PLSTARTED], 1u); }
-            int mpre = 0;
-            if (okp) {
-                const unsigned long long inp = __ballot(tid < nw && (uint32_t)(okey[ord_at(tid)] >> 32) == v0);
-                if (lane == 0) wtmp[2][wave] = __popcll(inp);
-                __syncthreads();
-#pragma unroll
-                for (int w = 0; w < GRP_NWV; ++w) mpre += wtmp[2][w];
-                okp = mpre >= pl_min;
-                if (!okp && tid == 0) atomicAdd(&lstat[GS_PLSHORT], 1u);
-            }
-            if (okp) {
-                unsigned long long pold[6];
-                float pval_[6];
-                uint32_t pnb[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { pold[k] = 0ull; pval_[k] = 0.f; pnb[k] = 0u; }
-                if (mine_p) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        pnb[k] = root + (uint32_t)noff32[k];
-                        if (pnb[k] < (uint32_t)PN && root < (uint32_t)PN) {
-                            pold[k] = __hip_atomic_fetch_min(&state[pnb[k]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            pval_[k] = (aff + (int64_t)ax[k] * PN)[k < 3 ? root : pnb[k]];
-                        }
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                                                // (P1) every claim of this pass is in
-                uint32_t pwon = 0, pv[6];
-                int pcnt = 0;
-                bool plow = false;
-                if (has) ci_age[tid] = 0u;
-                if (mine_p) {
-                    unsigned long long st6[6];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        st6[k] = pold[k] > key ? __hip_atomic_load(&state[pnb[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        pv[k] = 0u;
-                        if (pold[k] > key && st6[k] == key) {
-                            pwon |= 1u << k;
-                            pv[k] = ford(pval_[k] * sc[ax[k]] + 0.0f);
-                            plow = plow || pv[k] < v0;
-                            ++pcnt;
-                        }
-                    }
-                    ci_age[tid] = (uint32_t)pcnt | (plow ? 0x80000000u : 0u);      // bit 31: found a voxel BELOW the plateau
-                }
-                __syncthreads();                                                // (P2)
-                {
-                    const int j = tid;
-                    const bool valid = j < mpre;
-                    const int s_ = valid ? (int)oslot[ord_at(j)] : 0;
-                    const uint32_t cw = valid ? ci_age[s_] : 0u;
-                    const uint32_t cj = cw & 0xFFu;
-                    // a root that discovered a voxel below the plateau is the LAST one of this pass: that voxel pops before the
-                    // roots behind it (it comes back as the front of the window), so they wait -- their claims are released
-                    const bool lowj = (cw >> 31) != 0u;
-                    const uint32_t incl = wave_incl_sum(cj);
-                    if (lane == 63) wtmp[0][wave] = (int)incl;
-                    __syncthreads();                                            // (P3)
-                    uint32_t pre = incl - cj;
-#pragma unroll
-                    for (int w = 0; w < GRP_NWV; ++w) if (w < wave) pre += (uint32_t)wtmp[0][w];
-                    const bool fits = valid && pre + cj <= (uint32_t)GRP_PEND;
-                    {
-                        const unsigned long long nfit = ~__ballot(fits), lowb = __ballot(valid && lowj);
-                        if (lane == 0) {
-                            wtmp[1][wave] = nfit ? wave * 64 + __ffsll((long long)nfit) - 1 : (wave + 1) * 64;
-                            wtmp[3][wave] = lowb ? wave * 64 + __ffsll((long long)lowb) - 1 : GRP_W;
-                        }
-                    }
-                    __syncthreads();                                            // (P4)
-                    int ncommit = GRP_W;
-#pragma unroll
-                    for (int w = GRP_NWV - 1; w >= 0; --w) if (wtmp[1][w] < (w + 1) * 64) ncommit = wtmp[1][w];
-                    if (ncommit > mpre) ncommit = mpre;
-#pragma unroll
-                    for (int w = 0; w < GRP_NWV; ++w) if (wtmp[3][w] + 1 < ncommit) ncommit = wtmp[3][w] + 1;
-                    if (j < ncommit) ci_off[s_] = pre;
-                    if (j == ncommit - 1) { shI[GI_PENDN] = (int)(pre + cj); shI[GI_PEND0] = 0; }
-                    const uint32_t agebase = (uint32_t)shI[GI_AGEBASE];
-                    __syncthreads();                                            // (P5) orders are out
-                    bool committed = false;
-                    if (mine_p) {
-                        const uint32_t po = ci_off[tid];
-                        if (po != GRP_NONE) {
-                            uint32_t i = 0;
-#pragma unroll
-                            for (int k = 0; k < 6; ++k)
-                                if (pwon & (1u << k)) {
-                                    __hip_atomic_store(&state[pnb[k]], (unsigned long long)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    out[pnb[k]] = lab;
-                                    HeapEnt r;
-                                    r.key = ((unsigned long long)pv[k] << 32) | (unsigned long long)(agebase + po + i + 1u);
-                                    r.idx = pnb[k]; r.pad = lab;
-                                    pend[po + i] = r;
-                                    ++i;
-                                }
-                            has = false;
-                            committed = true;
-                            ci_off[tid] = GRP_NONE;
-                            freeslot[atomicAdd(&shI[GI_NFREESLOT], 1)] = (unsigned short)tid;
-                        } else {                                                // behind the cut (capacity of `pend`, or a voxel below the plateau): next sub-round
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) if (pwon & (1u << k)) atomicCAS(&state[pnb[k]], key, ST_FREE);
-                        }
-                    }
-                    {
-                        const uint32_t pops_w = (uint32_t)__popcll(__ballot(committed));
-                        if (lane == 0 && pops_w) { atomicAdd(&lstat[GS_POPS], pops_w); atomicAdd(&lstat[GS_PLPOPS], pops_w); }
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();                                            // (P6)
-                    if (tid == 0) {
-                        shI[GI_AGEBASE] = (int)(agebase + (uint32_t)shI[GI_PENDN]);
-                        shI[GI_OH] = (shI[GI_OH] + ncommit) & (GRP_W - 1);
-                        shI[GI_NW] = nw - ncommit;
-                        atomicAdd(&lstat[GS_BURST], 1u);
-                        atomicAdd(&lstat[GS_PLATEAU], 1u);
-                    }
-                    __syncthreads();                                            // (P7)
-                    pl_done = did_commit = true;
-                    if (!enqueue_batch()) continue;
-                }
-            }
-        }
-        if (!pl_done) {
+        bool did_commit = false;
+        {
         const unsigned long long qhead = shQ[GQ_QHEAD];                         // published by lane 0 at the end of the last sub-round
         const int lastslot = shI[GI_LAST], frontslot = shI[GI_FRONT];
         const bool dirty = shI[GI_DIRTY] != 0;
@@ -1564,18 +1216,12 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         atomicAdd(&stats[14], (unsigned long long)lstat[GS_SQ_BOUND]);
         atomicAdd(&stats[15], (unsigned long long)lstat[GS_FORCED]);
         atomicAdd(&stats[19], (unsigned long long)lstat[GS_SLOW]);
-        atomicAdd(&stats[27], (unsigned long long)lstat[GS_DRAIN]);
-        atomicAdd(&stats[26], (unsigned long long)scold.fifo_drains);
-        atomicAdd(&stats[28], (unsigned long long)lstat[GS_POPS]);
-        atomicAdd(&stats[29], (unsigned long long)st_sub);
+        atomicAdd(&stats[60], (unsigned long long)lstat[GS_DRAIN]);        // (60..63: the watchdog dumps own 20..31)
+        atomicAdd(&stats[61], (unsigned long long)scold.fifo_drains);
+        atomicAdd(&stats[62], (unsigned long long)lstat[GS_POPS]);
+        atomicAdd(&stats[63], (unsigned long long)st_sub);
         atomicAdd(&stats[17], (unsigned long long)lstat[GS_BURST]);
         atomicAdd(&stats[18], (unsigned long long)lstat[GS_RELOAD]);
-        atomicAdd(&stats[30], (unsigned long long)lstat[GS_PLATEAU]);
-        atomicAdd(&stats[31], (unsigned long long)lstat[GS_PLPOPS]);
-        atomicAdd(&stats[59], (unsigned long long)lstat[GS_WIDE]);
-        atomicAdd(&stats[24], (unsigned long long)lstat[GS_PLSTARTED]);
-        atomicAdd(&stats[25], (unsigned long long)lstat[GS_PLSHORT]);
-        atomicAdd(&stats[23], (unsigned long long)lstat[GS_PLABORT]);
         if (shI[GI_SERIAL]) atomicAdd(&stats[8], 1ull);
 #ifdef ISX_FLOOD_PROF
         for (int i = 0; i < 10; ++i) atomicAdd(&stats[48 + i], (unsigned long long)lstat[GS_C_NOTREADY + i]);

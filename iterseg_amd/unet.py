@@ -199,7 +199,7 @@ class UNet:
 
     def tap(self, name):
         """Named intermediate of chunk 0 of the last forward, as a (C, D, H, W) numpy array."""
-        cap = 1 << 24
+        cap = 1 << 25                        # the largest tensor of a (10, 256, 256) chunk: 32 channels at full resolution
         buf = np.empty(cap, np.float32)
         shp = (C.c_int64 * 4)()
         _lib.check(self.ctx.lib.isx_unet_tap_host(self.ctx.handle, name.encode(), buf.ctypes.data_as(C.c_void_p),

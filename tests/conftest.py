@@ -28,3 +28,24 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+@pytest.fixture
+def flood_knobs():
+    """Sets ISX_* environment knobs for one test: the library reads them once per context (isx_ctx_create), so the process-wide
+    watershed context is told to read them again (isx_ctx_reload_knobs) -- and once more after they are restored."""
+    from iterseg_amd import watershed as ws
+    saved = {}
+
+    def apply(env):
+        for k, v in env.items():
+            saved.setdefault(k, os.environ.get(k))
+            os.environ[k] = v
+        ws.get_context().reload_knobs()
+    yield apply
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    ws.get_context().reload_knobs()

@@ -85,7 +85,7 @@ def _properties(lab, mask, seeds):
 
 
 @pytest.mark.parametrize("n", [512, 1024])
-def test_large_volume_properties_and_flood_path_agreement(unet, n, monkeypatch):
+def test_large_volume_properties_and_flood_path_agreement(unet, n, flood_knobs):
     """512^3 / 1024^3 with the seeded random-weight U-Net (BASELINE configs 'north star' and 5): the watershed of the HIP
     feature map is deterministic across flood implementations, and has the structural properties of the reference."""
     from iterseg_amd import watershed as ws
@@ -105,7 +105,7 @@ def test_large_volume_properties_and_flood_path_agreement(unet, n, monkeypatch):
     seg, seeds, mask = ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=lab_a)
     assert len(seeds) > 0
     _properties(lab_a, torch.as_tensor(mask, device="cuda"), seeds)
-    monkeypatch.setenv("ISX_FLOOD_COOP_MIN", "100000000")               # every component on the one-lane heap
+    flood_knobs({"ISX_FLOOD_COOP_MIN": "100000000"})                    # every component on the one-lane heap
     lab_b = torch.zeros(pshape, dtype=torch.int32, device="cuda")
     ws.segment_output_image(fm, (0, 1, 2), 4, 3, out=lab_b)
     assert torch.equal(lab_a, lab_b)
@@ -113,7 +113,7 @@ def test_large_volume_properties_and_flood_path_agreement(unet, n, monkeypatch):
 
 
 @pytest.mark.parametrize("cold_min", [None, "200000"])
-def test_structured_512_labels_against_oracle(cold_min, monkeypatch):
+def test_structured_512_labels_against_oracle(cold_min, flood_knobs):
     """The structured 512^3 volume of bench.py's `watershed_structured` leg (eight independently seeded blob tiles, ~10 M
     mask voxels in ~5000 components): whole-volume labels against the C oracle, bit for bit.  This input is the
     reproducer of a lost-residual bug: with three commit bursts per sub-round a component WITHOUT a cold arena can
@@ -124,7 +124,7 @@ def test_structured_512_labels_against_oracle(cold_min, monkeypatch):
     from oracle import watershed as ows
     from tests.synth import blob_feature_map_tiled
     if cold_min:
-        monkeypatch.setenv("ISX_FLOOD_COLD_MIN", cold_min)
+        flood_knobs({"ISX_FLOOD_COLD_MIN": cold_min})
     n = 512
     fm = blob_feature_map_tiled(n, 0, 0.12, 3.0)
     pshape = (n + 2,) * 3

@@ -186,27 +186,12 @@ FLOOD_ENVS = {
     "small-win-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_SMALL_MAX": "100000000", "ISX_FLOOD_WIN": "3",
                        "ISX_FLOOD_LIST": "6", "ISX_FLOOD_RUN_LIMIT": "8", "ISX_FLOOD_DRAIN": "4"},
     "small-shortlist": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "100000000", "ISX_FLOOD_SMALL_MAX": "100000000", "ISX_FLOOD_LIST": "8"},
-    # the work-group kernel's plateau pass (ISX_FLOOD_PLATEAU=1: the leading roots of one value commit in one breadth-first
-    # pass; off by default) for every component, with short prefixes allowed, a tiny hot tier, and a small window
-    "group-plateau": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_PLATEAU": "1",
-                      "ISX_FLOOD_PLATEAU_MIN": "1"},
-    "group-plateau-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_PLATEAU": "1",
-                           "ISX_FLOOD_PLATEAU_MIN": "2", "ISX_FLOOD_RUN_LIMIT": "8", "ISX_FLOOD_DRAIN": "4", "ISX_FLOOD_GWIN": "40"},
-    # ... and its wide form (ISX_FLOOD_PLATEAU=2: window roots + run elements in one pass, discoveries straight to the bucket)
-    "group-plateau-wide": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_PLATEAU": "2",
-                           "ISX_FLOOD_PLATEAU_MIN": "1"},
-    "group-plateau-wide-tiny": {"ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_GROUP_MIN": "1", "ISX_FLOOD_PLATEAU": "2",
-                                "ISX_FLOOD_PLATEAU_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "40", "ISX_FLOOD_DRAIN": "16", "ISX_FLOOD_GWIN": "17"},
-    # the round-based wave kernel of round 1 (kept selectable for A/B runs)
-    "wave-legacy": {"ISX_FLOOD_MODE": "wave", "ISX_FLOOD_COOP_MIN": "1", "ISX_FLOOD_COLD_MIN": "1", "ISX_FLOOD_RUN_LIMIT": "96",
-                    "ISX_FLOOD_DRAIN": "48"},
 }
 
 
 @pytest.fixture(params=list(FLOOD_ENVS))
-def flood_path(request, monkeypatch):
-    for k, v in FLOOD_ENVS[request.param].items():
-        monkeypatch.setenv(k, v)
+def flood_path(request, flood_knobs):
+    flood_knobs(FLOOD_ENVS[request.param])
     return request.param
 
 
