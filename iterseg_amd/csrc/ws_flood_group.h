@@ -360,21 +360,34 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         pub_info[tid] = 0u; pub_res[tid] = 0xFFFFFFFFu; pub_mx[tid] = 0u;      // "not started" is what the commit phase must see
     };
     // every deferred entry (below the bound, unpopped, only in the list) sorts after every register candidate
-    // (written with selects: with an early-return form the compiler merged `++ncand` / `++ndef` into one store through a selected
-    // pointer and kept both counters in scratch memory -- two scratch loads and a store per discovery in the claim loop)
+    // (Round 4: rewritten with selects -- no early returns, so that the compiler keeps `ncand` / `ndef` in registers instead of
+    // merging the two increments into one store through a selected scratch pointer -- the kernel tripped its own guard (site 3:
+    // an active episode whose current voxel is not a voxel) in 2 of 6 runs of the group-* stress modes; this form passed 16 of
+    // 16 on the same box.  The two forms are the same function of (ncand, ndef, ck), so the difference is timing or code
+    // generation and the hazard it exposes has not been found: DESIGN.md section 5.  The form stays.)
     auto cand_add = [&](uint32_t v, int li, int ad) {
         const unsigned long long nk_ = ((unsigned long long)v << 32) | ((unsigned long long)(uint32_t)li << 16) | (unsigned long long)(uint32_t)ad;
+        if (ndef == 0 && ncand < GRP_CMAX) {
+#pragma unroll
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) ck[k] = nk_;
+            ++ncand;
+            return;
+        }
         int mk = -1; unsigned long long mv = 0ull;
 #pragma unroll
         for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand && (mk < 0 || ck[k] > mv)) { mk = k; mv = ck[k]; }
         const bool below_max = mk >= 0 && nk_ < mv;
-        const bool add = ncand < GRP_CMAX && (ndef == 0 || below_max);      // a free register: behind no deferred entry, or below the largest candidate
-        const bool repl = ncand == GRP_CMAX && below_max;                   // full: the largest candidate becomes a deferred entry
-        const int at = add ? ncand : (repl ? mk : -1);
+        if (ncand < GRP_CMAX && below_max) {
 #pragma unroll
-        for (int k = 0; k < GRP_CMAX; ++k) ck[k] = (k == at) ? nk_ : ck[k];
-        ncand += add ? 1 : 0;
-        ndef += add ? 0 : 1;
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) ck[k] = nk_;
+            ++ncand;
+            return;
+        }
+        if (ncand == GRP_CMAX && below_max) {
+#pragma unroll
+            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) ck[k] = nk_;
+        }
+        ++ndef;
     };
     // The candidates of lane L's episode rebuilt from its list by the WHOLE wave (three entries per lane): candidates,
     // deferred count and the minimum of the residuals.  Runs when the six registers are used up and discoveries below
