@@ -14,14 +14,22 @@
 //
 // Precision modes (template parameter PM; isx_unet_set_precision): 0 = the split arithmetic above (the default, fp32-class);
 // 1 = plain f16 operands (round to nearest, one MFMA per product, ~5e-4 relative per operand: the "fp16 U-Net" of BASELINE
-// config 5); 2 = plain bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 range, ~4e-3 per operand: the mixed-precision mode of
+// config 5); 2 = plain bf16 operands (v_mfma_f32_16x16x32_bf16, fp32 range, ~4e-3 per operand: the mixed-precision mode of
 // BASELINE config 4's training).  The single-product modes use only the hi half of each weight stage and of the halo tile
 // (half the LDS traffic and a third of the MFMAs); accumulation, bias and the BatchNorm statistics stay fp32 in every mode.
 //
-// Structure: as conv_mfma_kernel (128 voxels x BN columns per work-group, halo tile of the input in LDS reused by
-// all 27 taps, register prefetch of the next stage, BN+ReLU of the producer and zero padding applied at the LDS
-// store, XCD-aware 1-D grid), with a K stage of 8 input channels: v_mfma_f32_32x32x16_f16 takes k = 8*(lane/32)+j,
-// so lanes 0-31 feed tap 2p and lanes 32-63 tap 2p+1 (j = channel); 14 tap pairs, the 28th tap has zero weights.
+// Structure: a work-group owns 128 MT or 256 output voxels x BN (x NJ) output columns; the halo of its voxels for a K stage of
+// 8 input channels is staged in LDS (BatchNorm + ReLU of the producer, zero padding and the operand split applied at the
+// store) and reused by all 27 taps together with the stage's weight slab; v_mfma_f32_16x16x32_f16 takes k = 8 * (lane / 16)
+// + channel, so the four 16-lane groups of a wave feed four taps: 28 tap slots = 7 tap quads (the 28th tap has zero weights).
+// The matrix phase is software-pipelined by hand, the next stage's halo loads go out between its matrix instructions, the
+// output tile leaves through LDS as whole rows, the grid is 1-D and XCD-aware (DESIGN.md section 4 has the measurements
+// behind each of these).  Three kernels share the body:
+//   conv_h2c16_kernel<BN, MT, PM>   4 waves, weight slab through registers; BN = 64 (two work-groups per CU where they fit) or
+//                                   32 columns with MT = 2 row tiles per wave (the Cout = 32 layers);
+//   conv_h2c16nw8_kernel<PM>        8 waves on ONE 64-column weight slab over 256 voxels, slabs by LDS-DMA into two buffers;
+//   conv_h2c16nw8x2_kernel<PM>      the same with two N tiles per work-group (Cout % 128 == 0).
+// The thin tail layer has its own kernel (conv_tail.hip); training in fp32 and the exact-fp32 mode use conv_mfma_kernel (unet.hip).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -49,15 +57,10 @@ __device__ unsigned long long h2_stamp[12];
 #define H2_T(var)
 #define H2_ACC(i, d)
 #endif
-#ifndef ISX_H2_DEADLOADS
-#define ISX_H2_DEADLOADS 0      // development: 1 = issue the halo loads of slots beyond the tile too (as before)
-#endif
 #ifndef ISX_H2_ABLATE
-#define ISX_H2_ABLATE 0          // development: 1 = no staging arithmetic, 2 = no matrix phase, 3 = no halo loads (timing experiments, wrong results)
+#define ISX_H2_ABLATE 0          // development: 2 = no matrix phase, 3 = no halo loads (timing experiments, wrong results)
 #endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // 8 fp32 -> 8 f16 (round to nearest even, clamped) / 8 bf16 (round to nearest even), packed in a uint4
@@ -93,57 +96,42 @@ __device__ __forceinline__ void round8(const float4 &a, const float4 &b, uint4 &
     }
 }
 
-// TX = 3: all 27 taps (14 pairs).  TX = 1: the 9 taps with dx = 0 (5 pairs) -- the folded tail layer, whose three
-// x-taps live in the output columns (see conv_mfma_kernel / tail_combine_kernel).  TX = 2: 3 x 2 x 2 taps (6 pairs) over the
-// rows a.oy[] and columns a.ox[] -- one parity class of a decoder convolution with the transposed convolution folded into
-// its weights (UpFoldPacks, unet_state.h): the tile runs over the COARSE tensor and writes the class's output voxels (a.remap).
-// MT = 32-row tiles per wave (1: 128 voxels per work-group, 2: 256).  With 32 columns, MT = 2 gives the wave a
-// 64 x 32 tile whose six fragment reads feed six MFMAs, like the 32 x 64 tile of the 64-column variant.
-// NW = waves per work-group (4, or 8: a 512-thread work-group over 256 voxels whose eight waves share ONE weight slab -- per
-// voxel half the slab loads, half the slab's LDS stores and half its trips through the vector-memory path of two 4-wave
-// work-groups, at the same registers per wave and the same two waves per SIMD; the tile is the one MT = 2 uses).
-// CORE = 1: v_mfma_f32_16x16x32_f16 / _bf16 instead of 32x32x16 (TX = 3 and 2 only: 28 / 12 taps = 7 / 3 tap quads).  The four
-// 16-lane groups of a wave feed four taps (k = 8 * (lane / 16) + channel), a wave's 32 x BN tile is 2 x BN/16 accumulator
-// tiles of 16 x 16: the same fragment reads, accumulator registers and matrix-pipe cycles per product -- but the chip holds
-// a higher clock under this shape when it runs at its power cap (MI355X_MICROARCH.md, "Shape"), and this kernel does.
 // One 1 KiB piece of a weight slab straight into LDS (global_load_lds_dwordx4: lane i's 16 bytes land at lds_wave_base + 16 i,
 // no register round trip).  Inline assembly on purpose: through the builtin the compiler waits for vmcnt(0) before EVERY later
 // LDS read of the work-group's one shared array (it cannot tell the two slab buffers apart), which would put the DMA's latency
-// in front of the matrix phase it is meant to hide behind.  The wave's vmcnt still counts it, in issue order: it is issued
-// before the halo loads of the same stage, so the wait the compiler places for those covers it (conv_h2_body).
+// in front of the matrix phase it is meant to hide behind.  The wave's vmcnt still counts it, in issue order, and the body
+// waits for vmcnt(0) before the barrier in front of the slab's first use.
 __device__ __forceinline__ void lds_dma16(const uint4 *g, uint4 *lds_wave_base)
 {
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "m0", "memory");
 }
 
-// NJ (DMA kernel only): N tiles of BN columns per work-group.  NJ = 2: the halo tile of a K stage is staged ONCE for 2 x 64
+// MT = 32-row tiles per wave (1: 128 voxels per 4-wave work-group, 2: 256).  With 32 columns, MT = 2 gives the wave a 64 x 32
+// tile whose fragment reads feed as many MFMAs as the 32 x 64 tile of the 64-column variant.
+// NW = waves per work-group (4, or 8: a 512-thread work-group over 256 voxels whose eight waves share ONE weight slab).
+// NJ (NW = 8 only): N tiles of BN columns per work-group.  NJ = 2: the halo tile of a K stage is staged ONCE for 2 x 64
 // output columns -- the layers with Cout >= 128 (47 % of the network's FLOPs) otherwise load, normalise, split and store
 // every halo tile once per 64 columns --, the two weight slabs of a stage alternate between the two DMA buffers (the slab
 // sequence g = step * NJ + jj simply continues: slab g + 1 lands while the matrix phase reads slab g), one more barrier per
 // stage for twice the matrix work per stage, 128 accumulator registers.
-template <int BN, int TX, int MT, int PM, int NW, int CORE, int NJ = 1>
+template <int BN, int MT, int PM, int NW, int NJ = 1>
 __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 {
-    static_assert(NJ == 1 || (NW == 8 && CORE == 1 && MT == 1 && TX == 3), "N-tile pairs: the LDS-DMA kernel only");
+    static_assert(NJ == 1 || (NW == 8 && MT == 1), "N-tile pairs: the LDS-DMA kernel only");
     constexpr bool SPLIT = PM == 0;
-    // DMA: the 512-thread kernel on the 16x16x32 core takes its weight slabs by LDS-DMA into two buffers used alternately: the
-    // slab of stage s + 1 is requested at the start of the matrix phase of stage s (no prefetch registers, no LDS stores by the
-    // waves: 7 global loads + 7 ds_write_b128 per lane and stage gone) and is complete before the staging of s + 1 ends
-    constexpr bool DMA = NW == 8 && CORE == 1;
-    // (the tail layer's packs hold 12 tap slots for its 9 taps, so that either core can read them)
+    // DMA: the 512-thread kernel takes its weight slabs by LDS-DMA into two buffers used alternately: the slab of stage s + 1 is
+    // requested during the matrix phase of stage s (no prefetch registers, no LDS stores by the waves: 7 global loads + 7
+    // ds_write_b128 per lane and stage gone) and is complete before the staging of s + 1 ends
+    constexpr bool DMA = NW == 8;
     constexpr int THREADS = 64 * NW;
     constexpr int ROWS = 32 * NW * MT, TXW = 2 * NW * MT;
-    constexpr int NA = NW == 8 ? 3 : (MT > 1 ? 5 : 4);       // halo slots per thread (1280 / 1024 slots at most: launch_conv_h2)
+    constexpr int NA = NW == 8 ? 3 : (MT > 1 ? 5 : 4);       // halo slots per thread (1536 / 1280 / 1024 slots at most: launch_conv_h2)
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-    constexpr int NT = BN / 32;
-    constexpr bool UPA = TX == 4;                         // TX = 4: the taps of TX = 1 + source A up-sampled on read (see ConvArgs::upw)
-    constexpr int NTAPS = TX == 2 ? 12 : (UPA ? 9 : 9 * TX), NPAIR = (NTAPS + 1) / 2;
-    constexpr int NSLOT = (TX == 1 || UPA) ? 12 : 2 * NPAIR;      // tap slots of a weight stage (28 / 12 / 12)
-    constexpr int NQUAD = (NTAPS + 3) / 4;
+    constexpr int NTAPS = 27, NSLOT = 28, NQUAD = 7;          // tap slots of a weight stage: 7 tap quads, the 28th tap has zero weights
     constexpr int BU = NSLOT * BN;                        // uint4 per half of the weight slab (hi | lo)
     constexpr int SLAB = SPLIT ? 2 * BU : BU;             // uint4 of weights staged per K step (single-product modes: hi only)
-    constexpr int NB = (SLAB + THREADS - 1) / THREADS;    // uint4 of weights per thread per stage (14 / 7 / 3; halved without lo)
+    constexpr int NB = (SLAB + THREADS - 1) / THREADS;    // uint4 of weights per thread per stage (14 / 7; halved without lo)
     constexpr bool BEXACT = SLAB % THREADS == 0;
     uint4 *Bs = smem4;                                    // [hi: 28][BN] | [lo: 28][BN]  (DMA: two of them)
     uint4 *AsH = smem4 + (DMA ? 2 : 1) * SLAB;
@@ -151,7 +139,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     int *rowinfo = (int *)(AsH + (SPLIT ? 2 : 1) * a.slots_max);
     float *red = (float *)(rowinfo + ROWS);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, nn = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int lin = blockIdx.x;
     if (a.xcd_remap) {
         const int per = gridDim.x >> 3, main = per << 3;
@@ -162,7 +150,6 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     const int b = lin / a.tiles_per_chunk, tile = lin % a.tiles_per_chunk;
     const int D = a.D, H = a.H, W = a.W;
     const int64_t M = (int64_t)D * H * W;
-    const int64_t Mout = a.remap ? a.Mout : M;
 
     // ---- tile geometry: identical to conv_mfma_kernel with one row tile per wave ---------------------------
     int PS, RS, S;
@@ -199,18 +186,6 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             int z = z0 + zz;
             if (z < D && p < H * W) g = z * H * W + p;
         }
-        if (a.remap && g >= 0) {
-            // class voxel (z, i, j) of the coarse grid -> output voxel (z, 2i + py - off, 2j + px - off); bits 24..29: which
-            // faces of the output box the voxel lies on (selects the row of the bias table)
-            const int z = g / (H * W), i = (g / W) % H, j = g % W;
-            const int Y = 2 * i + a.rpy - a.roff, X = 2 * j + a.rpx - a.roff;
-            if (Y < 0 || Y >= a.rH || X < 0 || X >= a.rW) g = -1;
-            else {
-                const int cfg = (z == 0 ? 1 : 0) | (z == D - 1 ? 2 : 0) | (Y == 0 ? 4 : 0) | (Y == a.rH - 1 ? 8 : 0) |
-                                (X == 0 ? 16 : 0) | (X == a.rW - 1 ? 32 : 0);
-                g = ((z * a.rH + Y) * a.rW + X) | (cfg << 24);
-            }
-        }
         rowinfo[r] = g;
     }
     auto row_slot = [&](int r) __attribute__((always_inline)) -> int {
@@ -223,13 +198,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         int q = (p / W) * WP + (p % W) + 1;
         return (zz + 1) * PS + (q - qlo);
     };
-    const int aslot0 = row_slot((wave * MT) * 32 + nn);
-    const int aslot1 = MT > 1 ? row_slot((wave * MT + 1) * 32 + nn) : 0;
-    // 16x16x32 core: lane (r = lane & 15, h = lane >> 4) holds row r of a 16-row tile and tap 4 q + h
+    // lane (r = lane & 15, h = lane >> 4) holds row r of a 16-row tile and tap 4 q + h
     const int l16 = lane & 15, h4 = lane >> 4;
-    int aslot16[2 * MT];
+    constexpr int MT16 = 2 * MT, NT16 = BN / 16;
+    int aslot16[MT16];
 #pragma unroll
-    for (int t = 0; t < 2 * MT; ++t) aslot16[t] = CORE == 1 ? row_slot(wave * MT * 32 + 16 * t + l16) : 0;
+    for (int t = 0; t < MT16; ++t) aslot16[t] = row_slot(wave * MT * 32 + 16 * t + l16);
     auto slot_voxel = [&](int s) __attribute__((always_inline)) -> int {
         if (s >= S) return -2;
         int z, y, x;
@@ -246,25 +220,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     };
     const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + THREADS), gv2 = slot_voxel(tid + 2 * THREADS),
               gv3 = NA > 3 ? slot_voxel(tid + 3 * THREADS) : -2, gv4 = NA > 4 ? slot_voxel(tid + 4 * THREADS) : -2;
-    // source A up-sampled on read (UPA): the slot's voxel (z, y, x) of the output grid reads the COARSE voxel
-    // (z, (y + off) >> 1, (x + off) >> 1) of srcA and multiplies by the transposed convolution's weight of its parity
-    auto slot_up = [&](int g) __attribute__((always_inline)) -> int {      // coarse index | parity << 28 (g: voxel index or < 0)
-        if (!UPA || g < 0) return 0;
-        const int z = g / (H * W), y = (g / W) % H + a.uoff, x = g % W + a.uoff;
-        return ((z * a.uH + (y >> 1)) * a.uW + (x >> 1)) | ((((y & 1) << 1) | (x & 1)) << 28);
-    };
-    const int gu0 = slot_up(gv0), gu1 = slot_up(gv1), gu2 = slot_up(gv2), gu3 = slot_up(gv3), gu4 = slot_up(gv4);
-    const int64_t Mup = UPA ? (int64_t)D * a.uH * a.uW : 0;
 
     const int nsteps = (a.CA + a.CB) >> 3;
     typedef float f32x4c __attribute__((ext_vector_type(4)));
-    constexpr int MT16 = 2 * MT, NT16 = BN / 16;
-    f32x4c c_hiN[NJ][CORE == 1 ? MT16 : 1][CORE == 1 ? NT16 : 1], c_loN[NJ][(CORE == 1 && SPLIT) ? MT16 : 1][(CORE == 1 && SPLIT) ? NT16 : 1];
-    auto &c_hi = c_hiN[0];                                   // (every path but the N-tile pair uses tile 0)
-    auto &c_lo = c_loN[0];
-    if constexpr (CORE == 1) {
+    f32x4c c_hiN[NJ][MT16][NT16], c_loN[NJ][SPLIT ? MT16 : 1][SPLIT ? NT16 : 1];
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
+    for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
         for (int m = 0; m < MT16; ++m)
 #pragma unroll
@@ -272,25 +233,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                 c_hiN[jj][m][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
                 if constexpr (SPLIT) c_loN[jj][m][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
             }
-    }
-    f32x16 acc_hi[CORE == 1 ? 1 : MT][CORE == 1 ? 1 : NT], acc_lo[(SPLIT && CORE == 0) ? MT : 1][(SPLIT && CORE == 0) ? NT : 1];
-    if constexpr (CORE == 0) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { acc_hi[m][j][i] = 0.f; if constexpr (SPLIT) acc_lo[m][j][i] = 0.f; }
-    }
 
     // named prefetch registers (arrays that live across the K loop end up in scratch)
     float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
     if (ISX_H2_ABLATE == 3) { ra0 = rc0 = ra1 = rc1 = ra2 = rc2 = ra3 = rc3 = ra4 = rc4 = make_float4(0.5f, 0.25f, 0.125f, 1.f); }   // (no halo loads)
     uint4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rb8, rb9, rb10, rb11, rb12, rb13;
-    bool has_affine = false, stage_up = false;
     float relu_lo = 0.f;                                      // ReLU floor of the stage: 0 behind a BatchNorm, -inf for a source without one
-    float4 vb0 = make_float4(0.f, 0.f, 0.f, 0.f), vb1 = vb0;   // (UPA) bias of the transposed convolution for this stage's channels
-    int up_cc = 0;
     // the stage being loaded: source pointer (chunk b, channel offset included), its row length, the weight slab
     const float *ld_src = nullptr;
     int ld_C = 0;
@@ -300,13 +248,14 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     // were 40-56 % of the halo load instructions
     const int wbase = __builtin_amdgcn_readfirstlane(tid) & ~63;
 #define H2_LOAD_A(k)                                                                              \
-    if constexpr (k < NA && ISX_H2_ABLATE != 3) if (ISX_H2_DEADLOADS || THREADS * k + wbase < S) {  \
-        const float *pp = (UPA && stage_up) ? &ld_src[(int64_t)(gu##k & 0x0FFFFFFF) * ld_C]      \
-                                            : &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];   \
+    if constexpr (k < NA && ISX_H2_ABLATE != 3) if (THREADS * k + wbase < S) {                    \
+        const float *pp = &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];                       \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }
 #define H2_LOAD_B(k) if constexpr (NB > k) { if (BEXACT || tid + THREADS * k < SLAB) rb##k = ld_wsrc[tid + THREADS * k]; }
+// a source without BatchNorm gets scale 1, shift 0 and a ReLU floor of -inf (x * 1 + 0 and max(x, -inf) are exact): the staging
+// below has no branches
 #define H2_LOAD_HEAD(step_)                                                                       \
     {                                                                                             \
         const int c0 = (step_) << 3;                                                              \
@@ -314,34 +263,24 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         int C, cc;                                                                                \
         if (c0 < a.CA) { src = a.srcA; sc = a.scaleA; sh = a.shiftA; C = a.CA; cc = c0; }         \
         else { src = a.srcB; sc = a.scaleB; sh = a.shiftB; C = a.CB; cc = c0 - a.CA; }            \
-        has_affine = sc != nullptr;                                                               \
-        stage_up = UPA && c0 < a.CA;                                                              \
-        if (UPA && stage_up) { up_cc = cc; vb0 = *(const float4 *)&a.upb[cc]; vb1 = *(const float4 *)&a.upb[cc + 4]; } \
+        const bool has_affine = sc != nullptr;                                                    \
         const float *scp = has_affine ? sc : a.bias, *shp = has_affine ? sh : a.bias;             \
         const int64_t so = has_affine ? (int64_t)b * C + cc : 0;                                  \
         vs0 = *(const float4 *)&scp[so]; vs1 = *(const float4 *)&scp[so + 4];                     \
         vh0 = *(const float4 *)&shp[so]; vh1 = *(const float4 *)&shp[so + 4];                     \
-        if (!UPA && !has_affine) {                                                                \
+        if (!has_affine) {                                                                        \
             vs0 = make_float4(1.f, 1.f, 1.f, 1.f); vs1 = vs0;                                     \
             vh0 = make_float4(0.f, 0.f, 0.f, 0.f); vh1 = vh0;                                     \
         }                                                                                         \
         relu_lo = has_affine ? 0.f : -__builtin_inff();                                           \
-        ld_src = src + ((UPA && stage_up) ? (int64_t)b * Mup : (int64_t)b * M) * C + cc;          \
+        ld_src = src + (int64_t)b * M * C + cc;                                                   \
         ld_C = C;                                                                                 \
-        if (!UPA && (c0 < a.CA ? a.planarA : a.planarB)) {     /* [chunk][C/8][voxel][8]: this stage's plane */ \
+        if (c0 < a.CA ? a.planarA : a.planarB) {               /* [chunk][C/8][voxel][8]: this stage's plane */ \
             ld_src = src + ((int64_t)b * (C >> 3) + (cc >> 3)) * M * 8;                           \
             ld_C = 8;                                                                             \
         }                                                                                         \
-        ld_wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  /* packs keep the hi|lo stride in every mode */ \
     }
-#define H2_LOAD_STAGE(step_)                                                                      \
-    {                                                                                             \
-        H2_LOAD_HEAD(step_)                                                                       \
-        H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4)                          \
-        H2_LOAD_B(0) H2_LOAD_B(1) H2_LOAD_B(2) H2_LOAD_B(3) H2_LOAD_B(4) H2_LOAD_B(5) H2_LOAD_B(6) \
-        H2_LOAD_B(7) H2_LOAD_B(8) H2_LOAD_B(9) H2_LOAD_B(10) H2_LOAD_B(11) H2_LOAD_B(12) H2_LOAD_B(13) \
-    }
-// (16x16x32 core) the stage's loads one at a time, between the matrix instructions of step s_ of the matrix phase
+// the stage's halo loads one at a time, between the matrix instructions of step s_ of the matrix phase
 #define H2_LOAD_SLOT(s_)                                                                          \
     switch (s_) {                                                                                 \
         case 0: H2_LOAD_A(0) break; case 1: H2_LOAD_A(1) break; case 2: H2_LOAD_A(2) break;        \
@@ -353,42 +292,20 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         lds_dma16((const uint4 *)a.w + ((int64_t)(ntile + (g_) % NJ) * nsteps + (g_) / NJ) * (2 * BU) + tid + THREADS * (k_), \
                   Bs + ((g_) & 1) * SLAB + wbase + THREADS * (k_));
 #define H2_DMA_B(g_) { _Pragma("unroll") for (int k_ = 0; k_ < NB; ++k_) H2_DMA_B1(g_, k_) }
+// (register path) the stage's weight slab, loaded at the top of its own iteration: its registers are then free during the matrix
+// phase, which keeps its fragments two steps ahead in them, and it lands behind the barrier and the halo arithmetic
 #define H2_LOAD_B_ALL(step_)                                                                      \
     {                                                                                             \
-        ld_wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);            \
+        ld_wsrc = (const uint4 *)a.w + ((int64_t)ntile * nsteps + (step_)) * (2 * BU);  /* packs keep the hi|lo stride in every mode */ \
         H2_LOAD_B(0) H2_LOAD_B(1) H2_LOAD_B(2) H2_LOAD_B(3) H2_LOAD_B(4) H2_LOAD_B(5) H2_LOAD_B(6) \
         H2_LOAD_B(7) H2_LOAD_B(8) H2_LOAD_B(9) H2_LOAD_B(10) H2_LOAD_B(11) H2_LOAD_B(12) H2_LOAD_B(13) \
     }
-#define H2_AFF(v, s_, h_)                                                                         \
-    v.x = fmaxf(fmaf(v.x, s_.x, h_.x), 0.f); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), 0.f);             \
-    v.z = fmaxf(fmaf(v.z, s_.z, h_.z), 0.f); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), 0.f);
-#define H2_STORE_A_GEN(k)                                                                           \
-    if (k < NA && gv##k != -2) {                                                       \
-        float4 v = ra##k, w = rc##k;                                                              \
-        if (has_affine) { H2_AFF(v, vs0, vh0) H2_AFF(w, vs1, vh1) }                               \
-        if (UPA && st_up) {                                                                       \
-            const float *uw = &a.upw[(int64_t)((unsigned)gu##k >> 28) * a.CA + st_cc];           \
-            const float4 u0 = *(const float4 *)uw, u1 = *(const float4 *)(uw + 4);                \
-            v.x = fmaf(v.x, u0.x, sb0.x); v.y = fmaf(v.y, u0.y, sb0.y); v.z = fmaf(v.z, u0.z, sb0.z); v.w = fmaf(v.w, u0.w, sb0.w); \
-            w.x = fmaf(w.x, u1.x, sb1.x); w.y = fmaf(w.y, u1.y, sb1.y); w.z = fmaf(w.z, u1.z, sb1.z); w.w = fmaf(w.w, u1.w, sb1.w); \
-        }                                                                                         \
-        if (gv##k < 0) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }                            \
-        uint4 hi, lo;                                                                             \
-        if (ISX_H2_ABLATE == 1) { hi = make_uint4(__float_as_uint(ra##k.x), __float_as_uint(ra##k.y), __float_as_uint(ra##k.z), __float_as_uint(ra##k.w)); \
-                                  lo = make_uint4(__float_as_uint(rc##k.x), __float_as_uint(rc##k.y), __float_as_uint(rc##k.z), __float_as_uint(rc##k.w)); \
-                                  if constexpr (SPLIT) AsL[tid + THREADS * k] = lo; } else              \
-        if constexpr (SPLIT) { split8(v, w, hi, lo); AsL[tid + THREADS * k] = lo; }               \
-        else round8<PM>(v, w, hi);                                                                \
-        AsH[tid + THREADS * k] = hi;                                                              \
-    }
-// The same store without a branch (every kernel but the up-sampling tail): a source without BatchNorm gets scale 1, shift 0 and
-// a ReLU floor of -inf at H2_LOAD_HEAD (x * 1 + 0 and max(x, -inf) are exact), slots outside the volume select zeros after the
-// split, and only the store itself is predicated.  The branchy form above compiled to 19 exec-mask regions and 128 register
-// moves per stage of the 64-column kernel.
+// BatchNorm + ReLU, the operand split (or rounding), zero padding by select, one predicated store: no branches (the branchy
+// form compiled to 19 exec-mask regions and 128 register moves per stage of the 64-column kernel)
 #define H2_AFFL(v, s_, h_)                                                                        \
     v.x = fmaxf(fmaf(v.x, s_.x, h_.x), relu_lo); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), relu_lo);     \
     v.z = fmaxf(fmaf(v.z, s_.z, h_.z), relu_lo); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), relu_lo);
-#define H2_STORE_A_FAST(k)                                                                        \
+#define H2_STORE_A(k)                                                                             \
     if constexpr (k < NA) {                                                                       \
         float4 v = ra##k, w = rc##k;                                                              \
         H2_AFFL(v, vs0, vh0) H2_AFFL(w, vs1, vh1)                                                 \
@@ -404,51 +321,38 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     }
 #define H2_STORE_B(k) if constexpr (NB > k) { if (BEXACT || tid + THREADS * k < SLAB) Bs[tid + THREADS * k] = rb##k; }
 
-    // LDS offset of tap t relative to the output voxel's slot (tap 27 = padding pair of tap 26: zero weights)
+    // LDS offset of tap t relative to the output voxel's slot (tap 27 = padding of tap 26: zero weights)
     auto tap_off = [&](int t) __attribute__((always_inline)) -> int {
         if (t > NTAPS - 1) t = NTAPS - 1;
-        if (TX == 3) return (t / 9 - 1) * PS + ((t / 3) % 3 - 1) * RS + (t % 3 - 1);
-        if (TX == 2) return (t / 4 - 1) * PS + a.oy[(t >> 1) & 1] * RS + a.ox[t & 1];
-        return (t / 3 - 1) * PS + (t % 3 - 1) * RS;
+        return (t / 9 - 1) * PS + ((t / 3) % 3 - 1) * RS + (t % 3 - 1);
     };
-
-    // (16x16x32 core) the lane's tap offset of every tap quad: the same in every K stage, selected once -- selected inside the
-    // matrix phase, the four-way choice by lane group compiled to divergent branches, one basic block per quad, and nothing
-    // (fragment reads least of all) was scheduled across them
-    int toq[CORE == 1 ? NQUAD : 1];
-    if constexpr (CORE == 1) {
+    // the lane's tap offset of every tap quad: the same in every K stage, selected once -- selected inside the matrix phase, the
+    // four-way choice by lane group compiled to divergent branches, one basic block per quad, and nothing (fragment reads least
+    // of all) was scheduled across them
+    int toq[NQUAD];
 #pragma unroll
-        for (int q = 0; q < NQUAD; ++q) {
-            const int t0 = tap_off(4 * q), t1 = tap_off(4 * q + 1), t2 = tap_off(4 * q + 2), t3 = tap_off(4 * q + 3);
-            toq[q] = (h4 & 2) ? ((h4 & 1) ? t3 : t2) : ((h4 & 1) ? t1 : t0);
-        }
+    for (int q = 0; q < NQUAD; ++q) {
+        const int t0 = tap_off(4 * q), t1 = tap_off(4 * q + 1), t2 = tap_off(4 * q + 2), t3 = tap_off(4 * q + 3);
+        toq[q] = (h4 & 2) ? ((h4 & 1) ? t3 : t2) : ((h4 & 1) ? t1 : t0);
     }
 #ifdef ISX_H2_STAMP
     unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tk_begin = __builtin_readcyclecounter();
     const unsigned long long tr_begin = __builtin_amdgcn_s_memrealtime();
 #endif
-    // 16x16x32 core: a stage's weight slab is loaded at the top of its own iteration (its registers are then free during the
-    // matrix phase, which keeps its fragments two steps ahead in them) and lands behind the barrier and the halo arithmetic
     if constexpr (DMA) H2_DMA_B(0)
-    if constexpr (CORE == 1) { H2_LOAD_HEAD(0) H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4) }
-    else H2_LOAD_STAGE(0)
+    H2_LOAD_HEAD(0) H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4)
     H2_T(tk_loop)
     for (int step = 0; step < nsteps; ++step) {
         H2_T(t0)
-        if constexpr (CORE == 1 && !DMA) H2_LOAD_B_ALL(step)
+        if constexpr (!DMA) H2_LOAD_B_ALL(step)
         __syncthreads();
         H2_T(t1)
 #ifdef H2_STAGE_STAMPS
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         H2_T(t1b)
-        const bool st_up = stage_up;                           // of the stage being stored (the next load overwrites them)
-        const int st_cc = up_cc;
-        const float4 sb0 = vb0, sb1 = vb1;
-        (void)st_up; (void)st_cc; (void)sb0; (void)sb1;
-        if constexpr (UPA || ISX_H2_ABLATE == 1) { H2_STORE_A_GEN(0) H2_STORE_A_GEN(1) H2_STORE_A_GEN(2) H2_STORE_A_GEN(3) H2_STORE_A_GEN(4) }
-        else { H2_STORE_A_FAST(0) H2_STORE_A_FAST(1) H2_STORE_A_FAST(2) H2_STORE_A_FAST(3) H2_STORE_A_FAST(4) }
+        H2_STORE_A(0) H2_STORE_A(1) H2_STORE_A(2) H2_STORE_A(3) H2_STORE_A(4)
         if constexpr (!DMA) {
         H2_STORE_B(0) H2_STORE_B(1) H2_STORE_B(2) H2_STORE_B(3) H2_STORE_B(4) H2_STORE_B(5) H2_STORE_B(6)
         H2_STORE_B(7) H2_STORE_B(8) H2_STORE_B(9) H2_STORE_B(10) H2_STORE_B(11) H2_STORE_B(12) H2_STORE_B(13)
@@ -457,18 +361,16 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         __syncthreads();
         H2_T(t3)
         const bool more = step + 1 < nsteps;
-        if constexpr (CORE == 1) { if (more) H2_LOAD_HEAD(step + 1) }       // its loads go out between the matrix instructions below
-        else { if (more) H2_LOAD_STAGE(step + 1) }
+        if (more) H2_LOAD_HEAD(step + 1)                                   // its loads go out between the matrix instructions below
         __builtin_amdgcn_sched_barrier(0);
         H2_T(t4)
-        if (ISX_H2_ABLATE == 2) { acc_hi[0][0][0] += (float)step; } else
-        if constexpr (CORE == 1) {
+        if (ISX_H2_ABLATE == 2) { c_hiN[0][0][0][0] += (float)step; } else {
             // Software-pipelined by hand, one step = one 16-column tile j of one tap quad q (3 MT16 matrix instructions): the
             // B fragments of step s + 2 and the A fragments of the next quad are read from LDS before the matrix instructions
             // of step s are issued, and one of the next stage's global loads goes out per step.  The compiler's own schedule
             // read every fragment right before its use (its register budget is spent on the prefetched stage) and issued the
             // 24 global loads back to back before the first matrix instruction: 2 100-2 800 cycles per stage waiting for room
-            // in the load queue with the matrix pipe idle (scratch ISX_H2_STAMP build).
+            // in the load queue with the matrix pipe idle (ISX_H2_STAMP build).
             union FR { uint4 u; f16x8 v; bf16x8 w; };
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
@@ -540,41 +442,6 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #undef H2_FRAG_AH
 #undef H2_FRAG_AL
 #undef H2_FRAG_B
-        } else {
-        const uint4 *bph = Bs + hh * BN + nn, *bpl = bph + BU;
-#pragma unroll
-        for (int p = 0; p < NPAIR; ++p) {
-            const int to = hh ? tap_off(2 * p + 1) : tap_off(2 * p);
-            union FR { uint4 u; f16x8 v; bf16x8 w; };
-            FR ah[MT], al[MT];
-            ah[0].u = AsH[aslot0 + to];
-            if constexpr (SPLIT) al[0].u = AsL[aslot0 + to];
-            if constexpr (MT > 1) { ah[1].u = AsH[aslot1 + to]; if constexpr (SPLIT) al[1].u = AsL[aslot1 + to]; }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                FR bh, bl;
-                bh.u = bph[(2 * p) * BN + 32 * j];
-                if constexpr (SPLIT) {
-                    bl.u = bpl[(2 * p) * BN + 32 * j];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        acc_hi[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bh.v, acc_hi[m][j], 0, 0, 0);
-                        acc_lo[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bl.v, acc_lo[m][j], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc_lo[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m].v, bh.v, acc_lo[m][j], 0, 0, 0);
-                } else if constexpr (PM == 1) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc_hi[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m].v, bh.v, acc_hi[m][j], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc_hi[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].w, bh.w, acc_hi[m][j], 0, 0, 0);
-                }
-            }
-        }
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef H2_STAGE_STAMPS
@@ -585,60 +452,32 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     H2_ACC(6, tk_loop - tk_begin)
 #undef H2_LOAD_A
 #undef H2_LOAD_B
-#undef H2_LOAD_STAGE
 #undef H2_LOAD_HEAD
 #undef H2_LOAD_SLOT
 #undef H2_LOAD_B_ALL
 #undef H2_DMA_B
 #undef H2_DMA_B1
-#undef H2_AFF
-#undef H2_STORE_A_GEN
-#undef H2_STORE_A_FAST
 #undef H2_AFFL
+#undef H2_STORE_A
 #undef H2_STORE_B
 
     // element (voxel g, channel ch) of the output tensor, row-major or planar (ConvArgs::out_planar; store_cols = Cout then)
     auto out_at = [&](int g, int ch) __attribute__((always_inline)) -> float * {
-        if (a.out_planar) return &a.out[(((int64_t)b * (a.store_cols >> 3) + (ch >> 3)) * Mout + g) * 8 + (ch & 7)];
-        return &a.out[((int64_t)b * Mout + g) * a.store_cols + ch];
+        if (a.out_planar) return &a.out[(((int64_t)b * (a.store_cols >> 3) + (ch >> 3)) * M + g) * 8 + (ch & 7)];
+        return &a.out[((int64_t)b * M + g) * a.store_cols + ch];
     };
     // ---- epilogue: HI + LO / 2^11 + bias, store, per-tile BN partial sums (valid rows only) ------------------
-    // Plain output (no remap, no accumulation): the tile goes through LDS (free after the last stage) and leaves as
-    // whole rows -- BN consecutive channels of a voxel, one global_store_dwordx4 per lane, four rows per wave instruction --
-    // instead of one dword per lane in 64-byte pieces with the address arithmetic of 32 stores per lane (15-24 k cycles per
-    // work-group in the stamped build: as much as two K stages).  The BatchNorm partial sums are taken from the registers in
-    // the same order as below, the stored values are the same.
+    // The tile goes through LDS (free after the last stage) and leaves as whole rows -- BN consecutive channels of a voxel, one
+    // global_store_dwordx4 per lane, four rows per wave instruction -- instead of one dword per lane in 64-byte pieces with the
+    // address arithmetic of 32 stores per lane (15-24 k cycles per work-group in the stamped build: as much as two K stages).
+    // C/D of 16x16: column = lane & 15, row = 4 * (lane >> 4) + register.
     constexpr int TRS = BN + 4;                                    // floats per row of the LDS tile (16-byte rows, conflict-free both ways)
-    const bool t_out = !a.remap && !a.accum && a.store_cols % 4 == 0 &&
-                       (size_t)((DMA ? 2 : 1) * SLAB + (SPLIT ? 2 : 1) * a.slots_max) * 16 >= (size_t)ROWS * TRS * sizeof(float);
-    if (t_out) {
-        float *T = (float *)smem4;
+    // (the launcher pads slots_max so that the staging buffers -- slabs + halo tile -- hold the ROWS x TRS tile)
+    float *T = (float *)smem4;
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
+    for (int jj = 0; jj < NJ; ++jj) {
         const int ntile_j = ntile + jj;
         __syncthreads();                                           // every wave has read its last fragments (jj > 0: and stored tile jj - 1)
-        if constexpr (CORE == 0) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int ch = ntile_j * BN + 32 * j + nn;
-                const float bsv = a.bias[ch];
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int row = (wave * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        float v;
-                        if constexpr (SPLIT) v = fmaf(acc_lo[m][j][i], 1.f / H2_SCALE, acc_hi[m][j][i]) + bsv;
-                        else v = acc_hi[m][j][i] + bsv;
-                        T[row * TRS + 32 * j + nn] = v;
-                        if (rowinfo[row] >= 0) { s += v; q += v * v; }
-                    }
-                s += __shfl_xor(s, 32);
-                q += __shfl_xor(q, 32);
-                if (hh == 0) { red[(wave * BN + 32 * j + nn) * 2] = s; red[(wave * BN + 32 * j + nn) * 2 + 1] = q; }
-            }
-        } else {
 #pragma unroll
         for (int j = 0; j < NT16; ++j) {
             const int ch = ntile_j * BN + 16 * j + l16;
@@ -659,7 +498,6 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
             if (h4 == 0) { red[(wave * BN + 16 * j + l16) * 2] = s; red[(wave * BN + 16 * j + l16) * 2 + 1] = q; }
         }
-        }
         __syncthreads();
         constexpr int C4 = BN / 4;
 #pragma unroll
@@ -670,91 +508,19 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             const int c4 = a.out_planar ? 2 * (e / (2 * ROWS)) + (e & 1) : e % C4;
             const int g = rowinfo[row];
             const int ch = ntile_j * BN + 4 * c4;
-            if (g >= 0 && ch < a.store_cols) {
+            if (g >= 0) {
                 const f32x4c o = *(const f32x4c *)&T[row * TRS + 4 * c4];
                 f32x4c *op = (f32x4c *)out_at(g, ch);
                 if (a.nt_out) __builtin_nontemporal_store(o, op); else *op = o;
             }
         }
-        if constexpr (NJ > 1) {                                     // this N tile's statistics (the common code below handles NJ = 1)
-            if (tid < BN && !a.no_stats) {
-                float s = 0.f, q = 0.f;
-                for (int wv = 0; wv < NW; ++wv) { s += red[(wv * BN + tid) * 2]; q += red[(wv * BN + tid) * 2 + 1]; }
-                int64_t o = ((int64_t)b * a.tiles_per_chunk + tile) * a.Cout + ntile_j * BN + tid;
-                a.psum[o] = s;
-                a.psq[o] = q;
-            }
-        }
-        }   // jj
-        if constexpr (NJ > 1) return;
-    } else
-    if constexpr (CORE == 1) {
-        // C/D of 16x16: column = lane & 15, row = 4 * (lane >> 4) + register
-#pragma unroll
-        for (int j = 0; j < NT16; ++j) {
-            const int ch = ntile * BN + 16 * j + l16;
-            const float bsv = a.bias[ch];
+        if (tid < BN && !a.no_stats) {
             float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int m = 0; m < MT16; ++m)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = wave * MT * 32 + 16 * m + 4 * h4 + i;
-                    int g = rowinfo[row];
-                    if (g >= 0) {
-                        float bv = bsv;
-                        if (a.remap) { bv = a.bias[(g >> 24) * a.Cout + ch]; g &= 0xFFFFFF; }
-                        float v;
-                        if constexpr (SPLIT) v = fmaf(c_lo[m][j][i], 1.f / H2_SCALE, c_hi[m][j][i]) + bv;
-                        else v = c_hi[m][j][i] + bv;
-                        float *op = out_at(g, ch);
-                        if (a.accum) v += *op;
-                        if (ch < a.store_cols) { if (a.nt_out) __builtin_nontemporal_store(v, op); else *op = v; }
-                        s += v;
-                        q += v * v;
-                    }
-                }
-            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (h4 == 0) { red[(wave * BN + 16 * j + l16) * 2] = s; red[(wave * BN + 16 * j + l16) * 2 + 1] = q; }
+            for (int wv = 0; wv < NW; ++wv) { s += red[(wv * BN + tid) * 2]; q += red[(wv * BN + tid) * 2 + 1]; }
+            int64_t o = ((int64_t)b * a.tiles_per_chunk + tile) * a.Cout + ntile_j * BN + tid;
+            a.psum[o] = s;
+            a.psq[o] = q;
         }
-    } else {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int ch = ntile * BN + 32 * j + nn;
-        const float bsv = a.bias[ch];
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (wave * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                int g = rowinfo[row];
-                if (g >= 0) {
-                    float bv = bsv;
-                    if (a.remap) { bv = a.bias[(g >> 24) * a.Cout + ch]; g &= 0xFFFFFF; }
-                    float v;
-                    if constexpr (SPLIT) v = fmaf(acc_lo[m][j][i], 1.f / H2_SCALE, acc_hi[m][j][i]) + bv;
-                    else v = acc_hi[m][j][i] + bv;
-                    float *op = out_at(g, ch);
-                    if (a.accum) v += *op;
-                    if (ch < a.store_cols) { if (a.nt_out) __builtin_nontemporal_store(v, op); else *op = v; }
-                    s += v;
-                    q += v * v;
-                }
-            }
-        s += __shfl_xor(s, 32);
-        q += __shfl_xor(q, 32);
-        if (hh == 0) { red[(wave * BN + 32 * j + nn) * 2] = s; red[(wave * BN + 32 * j + nn) * 2 + 1] = q; }
-    }
-    }
-    __syncthreads();
-    if (tid < BN && !a.no_stats) {
-        float s = 0.f, q = 0.f;
-        for (int wv = 0; wv < NW; ++wv) { s += red[(wv * BN + tid) * 2]; q += red[(wv * BN + tid) * 2 + 1]; }
-        int64_t o = ((int64_t)b * a.tiles_per_chunk + tile) * a.Cout + ntile * BN + tid;
-        a.psum[o] = s;
-        a.psq[o] = q;
     }
 #if defined(ISX_H2_STAMP) && ISX_H2_STAMP == 2
     if (tid == 0 && (blockIdx.x & 63) == 0) {          // one work-group in 64: two atomics that contend with nothing
@@ -775,38 +541,31 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #endif
 }
 
-template <int BN, int TX, int MT, int PM, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void conv_h2_kernel(const ConvArgs a)
-{
-    conv_h2_body<BN, TX, MT, PM, NW, 0>(a);
-}
-
-// the 27-tap convolution on the 16x16x32 core.  (The accumulators of the 64-column variant come to 258 registers unless the
-// compiler is told that two waves per SIMD are wanted; the 32x32x16 kernels keep their own allocation.)
-template <int BN, int TX, int MT, int PM>
+// four waves, weight slab through registers.  (The accumulators of the 64-column variant come to 258 registers unless the
+// compiler is told that two waves per SIMD are wanted.)
+template <int BN, int MT, int PM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16_kernel(const ConvArgs a)
 {
-    conv_h2_body<BN, TX, MT, PM, 4, 1>(a);
+    conv_h2_body<BN, MT, PM, 4>(a);
 }
 
-// ... and on 512-thread work-groups (eight waves share one weight slab over 256 voxels)
+// 512-thread work-groups (eight waves share one weight slab over 256 voxels), slabs by LDS-DMA
 template <int PM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8_kernel(const ConvArgs a)
 {
-    conv_h2_body<64, 3, 1, PM, 8, 1>(a);
+    conv_h2_body<64, 1, PM, 8>(a);
 }
 
 // ... with two N tiles per work-group (Cout % 128 == 0: the halo tile of a K stage staged once for 128 output columns)
 template <int PM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8x2_kernel(const ConvArgs a)
 {
-    conv_h2_body<64, 3, 1, PM, 8, 1, 2>(a);
+    conv_h2_body<64, 1, PM, 8, 2>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-// 64-column tiles whenever two work-groups still fit into the 160 KB of LDS (weight slab 57 KB + 32 B per halo slot)
 // two row tiles per wave for the 32-column tiles: only for launches that still fill the chip with 256-voxel tiles
 int h2_mt(const isx_tune &tune, const Level &l, int batch)
 {
@@ -824,34 +583,12 @@ bool conv_h2_nw8(const isx_tune &tune, const Level &l, int cout, int batch)
     return sl <= 1536 && (tune.h2_nw8 == 2 || (int64_t)batch * tiles2 * (cout / 64) >= 512);        // 2: always (tests)
 }
 
+// 64-column tiles (4-wave kernel) whenever two work-groups still fit into the 160 KB of LDS (weight slab 57 KB + 32 B per halo slot)
 int conv_h2_bn(const isx_tune &tune, int slots, int cout)
 {
     const size_t lds64 = (size_t)(2 * 28 * 64 + 2 * slots) * 16 + (128 + 4 * 64 * 2) * sizeof(float);
     const int force64 = tune.h2_force_bn64;
     return (cout % 64 == 0 && (force64 || 2 * lds64 <= 160 * 1024)) ? 64 : 32;
-}
-
-// w: [Cout][Cin][ntap] fp32 -> [Cout/BN][Cin/8][hi|lo][ntap_pad taps][BN][8 channels] halves
-// pm = 0: split halves (hi | lo); 1: f16 round-to-nearest in hi; 2: bf16 round-to-nearest in hi (lo stays zero, unused)
-void pack_h2_taps(const float *w, int cout, int cin, int ntap, int ntap_pad, int bn, std::vector<uint16_t> &out, int pm)
-{
-    const int ntiles = cout / bn, nsteps = cin / 8;
-    const size_t half_slab = (size_t)ntap_pad * bn * 8;
-    out.assign((size_t)ntiles * nsteps * 2 * half_slab + 4096, 0);
-    for (int co = 0; co < cout; ++co)
-        for (int ci = 0; ci < cin; ++ci)
-            for (int t = 0; t < ntap; ++t) {
-                _Float16 h, l;
-                split_h2(w[((size_t)co * cin + ci) * ntap + t], h, l);
-                const size_t base = ((size_t)(co / bn) * nsteps + ci / 8) * 2 * half_slab;
-                const size_t e = ((size_t)t * bn + co % bn) * 8 + ci % 8;
-                uint16_t hb, lb;
-                memcpy(&hb, &h, 2);
-                memcpy(&lb, &l, 2);
-                if (pm == 2) { hb = bf16_rne_bits(w[((size_t)co * cin + ci) * ntap + t]); lb = 0; }
-                out[base + e] = hb;
-                out[base + half_slab + e] = lb;
-            }
 }
 
 // w: reference layout [Cout][Cin][27] fp32 -> [Cout/BN][Cin/8][hi|lo][28 taps][BN][8 channels] halves
@@ -930,41 +667,30 @@ int repack_bf16(isx_ctx *ctx, const float *wref, int cout, int cin, int transpos
 
 size_t h2_pack_halves(int cout_p, int cin_p, int bn) { return (size_t)(cout_p / bn) * (cin_p / 8) * 2 * 28 * bn * 8 + 4096; }
 
-// fold != 0: the folded tail layer (TX = 1, 32 columns of which store_cols = 16 are stored, no statistics)
+// The 27-tap convolution of one layer over B chunks.  out_planar: write [chunk][Cout/8][voxel][8] (UNetState::planar).
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used, int pm, const H2Extra *ex)
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int *tiles_used, int pm, int out_planar)
 {
     ConvArgs a;
-    const int tx2 = ex ? ex->tx2 : 0;
-    a.oy[0] = ex ? ex->oy[0] : 0; a.oy[1] = ex ? ex->oy[1] : 0; a.ox[0] = ex ? ex->ox[0] : 0; a.ox[1] = ex ? ex->ox[1] : 0;
-    a.remap = ex ? ex->remap : 0; a.rH = ex ? ex->rH : 0; a.rW = ex ? ex->rW : 0; a.rpy = ex ? ex->rpy : 0; a.rpx = ex ? ex->rpx : 0;
-    a.roff = ex ? ex->roff : 0; a.Mout = ex ? ex->Mout : 0; a.accum = ex ? ex->accum : 0;
     a.nt_out = ctx->tune.h2_nt_out;
-    a.planarA = sa.planar ? 1 : 0; a.planarB = sb.planar ? 1 : 0; a.out_planar = ex ? ex->out_planar : 0;
-    const int upa = ex ? ex->upA : 0;
-    a.uH = ex ? ex->uH : 0; a.uW = ex ? ex->uW : 0; a.uoff = ex ? ex->uoff : 0; a.upw = ex ? ex->upw : nullptr; a.upb = ex ? ex->upb : nullptr;
-    ISX_REQUIRE(!upa || (fold && a.upw && a.upb), "internal: up-sampling on read is built for the folded tail layer");
-    ISX_REQUIRE(!a.out_planar || (!fold && !a.remap && !a.accum && cout % 8 == 0), "internal: planar output of a plain convolution only");
-    ISX_REQUIRE(!(a.planarA && (upa || sa.C % 8)) && !(a.planarB && sb.C % 8), "internal: planar source with %d / %d channels", sa.C, sb.C);
-    ISX_REQUIRE(!(tx2 && fold), "internal: class convolution and folded tail are different kernels");
-    ISX_REQUIRE(!a.remap || a.Mout < (1 << 24), "internal: remapped output of %ld voxels per chunk", (long)a.Mout);
+    a.planarA = sa.planar ? 1 : 0; a.planarB = sb.planar ? 1 : 0; a.out_planar = out_planar;
+    ISX_REQUIRE(!a.out_planar || cout % 8 == 0, "internal: planar output needs Cout %% 8 == 0");
+    ISX_REQUIRE(!(a.planarA && sa.C % 8) && !(a.planarB && sb.C % 8), "internal: planar source with %d / %d channels", sa.C, sb.C);
     a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;
     a.srcB = sb.p; a.scaleB = sb.scale; a.shiftB = sb.shift; a.CB = sb.C;
     a.w = (const float *)w_h2; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
-    a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = fold ? 32 : cout;
+    a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = cout;
     a.mode = conv_mode(l);
     a.tiles_per_chunk = conv_tiles(l, a.mode, 1, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
-    a.store_cols = fold ? 16 : cout;
+    a.store_cols = cout;
     a.no_stats = no_stats;
     a.xcd_remap = xcd_remap;
-    ISX_REQUIRE((fold || cout % 32 == 0) && sa.C % 8 == 0 && sb.C % 8 == 0, "internal: split-f16 conv needs Cout %% 32 == 0, Cin %% 8 == 0");
-    const bool nw8 = !fold && !tx2 && !a.accum && !a.remap && conv_h2_nw8(ctx->tune, l, cout, B);
-    int BN = fold ? 32 : (nw8 ? 64 : conv_h2_bn(ctx->tune, a.slots_max, cout));
+    ISX_REQUIRE(cout % 32 == 0 && sa.C % 8 == 0 && sb.C % 8 == 0, "internal: split-f16 conv needs Cout %% 32 == 0, Cin %% 8 == 0");
+    const bool nw8 = conv_h2_nw8(ctx->tune, l, cout, B);
+    const int BN = nw8 ? 64 : conv_h2_bn(ctx->tune, a.slots_max, cout);
     // 32-column tiles get two row tiles per wave (256-voxel work-groups) when the launch is big enough to fill
     // the chip that way; the partial-sum layout then follows that tiling (mt is fixed per workspace: h2_mt)
-    // (the folded layer stays at one row tile: measured 9.7 ms against 10.9 with two; 16-channel stages for it were
-    // tried as well and lost a wave per SIMD: 11.6-15.2 ms)
-    int mt = (!fold && BN == 32 && h2_mt(ctx->tune, l, ctx->unet->wbatch)) ? 2 : 1;
+    int mt = (BN == 32 && h2_mt(ctx->tune, l, ctx->unet->wbatch)) ? 2 : 1;
     if (nw8) {                          // the tile of MT = 2, one row tile per wave
         int ty, tx, tp, sl;
         a.tiles_per_chunk = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
@@ -977,79 +703,47 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         else mt = 1;                   // very narrow levels: the 256-position halo does not fit the staging plan
     }
     ISX_REQUIRE(a.slots_max <= (nw8 ? 1536 : (mt == 2 ? 1280 : 1024)), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
-    const bool dma = nw8 && ctx->tune.h2_core16;              // conv_h2c16nw8_kernel: two weight-slab buffers (LDS-DMA)
-    // N-tile pairs (conv_h2c16nw8x2_kernel): plain output, Cout % 128 == 0, and a launch that still fills the chip
-    const int nj = (dma && ctx->tune.h2_nj2 && !a.remap && !a.accum && cout % 128 == 0 && a.store_cols % 4 == 0 &&
+    // N-tile pairs (conv_h2c16nw8x2_kernel): Cout % 128 == 0 and a launch that still fills the chip
+    const int nj = (nw8 && ctx->tune.h2_nj2 && cout % 128 == 0 &&
                     (ctx->tune.h2_nj2 == 2 || (int64_t)B * a.tiles_per_chunk * (cout / 128) >= 512)) ? 2 : 1;
-    a.ntiles = fold ? 1 : cout / (BN * nj);
-    const int npair = fold ? 6 : (tx2 ? 6 : 14);          // tap slots / 2 of a weight stage (the tail layer's 9 taps sit in 12 slots)
-    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * ((dma ? 2 : 1) * 2 * npair * BN + a.slots_max)) * 16 + ((nw8 ? 256 : 128 * mt) + (nw8 ? 8 : 4) * BN * 2) * sizeof(float);
+    a.ntiles = cout / (BN * nj);
+    {   // the output tile of the epilogue (rows x (BN + 4) floats) aliases the staging buffers: slabs + halo tile; the halo
+        // part is padded where the single-product modes' smaller buffers would not hold it
+        const size_t rows = nw8 ? 256 : 128 * mt, tile = rows * (BN + 4) * sizeof(float);
+        const size_t per = (pm == 0 ? 2 : 1) * 16, slabs = (size_t)(pm == 0 ? 2 : 1) * (nw8 ? 2 : 1) * 2 * 14 * BN * 16;
+        if (slabs + (size_t)a.slots_max * per < tile) a.slots_max = (int)((tile - slabs + per - 1) / per);
+    }
+    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * ((nw8 ? 2 : 1) * 2 * 14 * BN + a.slots_max)) * 16 + ((nw8 ? 256 : 128 * mt) + (nw8 ? 8 : 4) * BN * 2) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
     bool &attr_done = ctx->h2_attr_done;                  // per context (setting it again from another context is harmless)
-#define ISX_H2_ATTR(BN_, TX_, MT_) \
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<BN_, TX_, MT_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<BN_, TX_, MT_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<BN_, TX_, MT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define ISX_H2_ATTR(K_) ISX_HIP(hipFuncSetAttribute((const void *)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define ISX_H2_ATTR3(K_) ISX_H2_ATTR(K_<0>) ISX_H2_ATTR(K_<1>) ISX_H2_ATTR(K_<2>)
     if (!attr_done) {
-        ISX_H2_ATTR(64, 3, 1) ISX_H2_ATTR(32, 3, 1) ISX_H2_ATTR(32, 3, 2) ISX_H2_ATTR(32, 1, 1) ISX_H2_ATTR(32, 1, 2)
-        ISX_H2_ATTR(64, 2, 1) ISX_H2_ATTR(32, 2, 1) ISX_H2_ATTR(32, 2, 2) ISX_H2_ATTR(32, 4, 1) ISX_H2_ATTR(32, 4, 2)
-#define ISX_H2_ATTR16(BN_, TX_, MT_) \
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, TX_, MT_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, TX_, MT_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16_kernel<BN_, TX_, MT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_H2_ATTR16(64, 3, 1) ISX_H2_ATTR16(32, 3, 1) ISX_H2_ATTR16(32, 3, 2) ISX_H2_ATTR16(32, 1, 1) ISX_H2_ATTR16(32, 1, 2)
-#undef ISX_H2_ATTR16
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8x2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2c16nw8x2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ISX_HIP(hipFuncSetAttribute((const void *)conv_h2_kernel<64, 3, 1, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 2>))
+        ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 2>))
+        ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 2>))
+        ISX_H2_ATTR3(conv_h2c16nw8_kernel) ISX_H2_ATTR3(conv_h2c16nw8x2_kernel)
         attr_done = true;
     }
+#undef ISX_H2_ATTR3
 #undef ISX_H2_ATTR
-#define ISX_H2_GO(BN_, TX_, MT_) \
-    do { if (pm == 0) conv_h2_kernel<BN_, TX_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
-         else if (pm == 1) conv_h2_kernel<BN_, TX_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
-         else conv_h2_kernel<BN_, TX_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
-#define ISX_H2_GO16(BN_, TX_, MT_) \
-    do { if (pm == 0) conv_h2c16_kernel<BN_, TX_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
-         else if (pm == 1) conv_h2c16_kernel<BN_, TX_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
-         else conv_h2c16_kernel<BN_, TX_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
-    const bool core16 = ctx->tune.h2_core16 && !tx2 && !nw8 && !upa && (!fold || (ctx->tune.h2_core16 & 2));
-    if (core16 && fold && mt == 2) ISX_H2_GO16(32, 1, 2);
-    else if (core16 && fold) ISX_H2_GO16(32, 1, 1);
-    else if (core16 && BN == 64) ISX_H2_GO16(64, 3, 1);
-    else if (core16 && mt == 2) ISX_H2_GO16(32, 3, 2);
-    else if (core16) ISX_H2_GO16(32, 3, 1);
-    else if (nw8 && ctx->tune.h2_core16 && nj == 2) {
+#define ISX_H2_GO16(BN_, MT_) \
+    do { if (pm == 0) conv_h2c16_kernel<BN_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
+         else if (pm == 1) conv_h2c16_kernel<BN_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
+         else conv_h2c16_kernel<BN_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
+    if (nw8 && nj == 2) {
         if (pm == 0) conv_h2c16nw8x2_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
         else if (pm == 1) conv_h2c16nw8x2_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
         else conv_h2c16nw8x2_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);
-    } else if (nw8 && ctx->tune.h2_core16) {
+    } else if (nw8) {
         if (pm == 0) conv_h2c16nw8_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
         else if (pm == 1) conv_h2c16nw8_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
         else conv_h2c16nw8_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);
-    } else if (nw8) {
-        if (pm == 0) conv_h2_kernel<64, 3, 1, 0, 8><<<grid, 512, lds, ctx->stream>>>(a);
-        else if (pm == 1) conv_h2_kernel<64, 3, 1, 1, 8><<<grid, 512, lds, ctx->stream>>>(a);
-        else conv_h2_kernel<64, 3, 1, 2, 8><<<grid, 512, lds, ctx->stream>>>(a);
-    } else if (fold && upa && mt == 2) ISX_H2_GO(32, 4, 2);
-    else if (fold && upa) ISX_H2_GO(32, 4, 1);
-    else if (fold && mt == 2) ISX_H2_GO(32, 1, 2);
-    else if (fold) ISX_H2_GO(32, 1, 1);
-    else if (tx2 && BN == 64) ISX_H2_GO(64, 2, 1);
-    else if (tx2 && mt == 2) ISX_H2_GO(32, 2, 2);
-    else if (tx2) ISX_H2_GO(32, 2, 1);
-    else if (BN == 64) ISX_H2_GO(64, 3, 1);
-    else if (mt == 2) ISX_H2_GO(32, 3, 2);
-    else ISX_H2_GO(32, 3, 1);
-#undef ISX_H2_GO
+    } else if (BN == 64) ISX_H2_GO16(64, 1);
+    else if (mt == 2) ISX_H2_GO16(32, 2);
+    else ISX_H2_GO16(32, 1);
 #undef ISX_H2_GO16
     ISX_CHECK_LAUNCH();
 #if defined(ISX_H2_STAMP) && ISX_H2_STAMP == 2
@@ -1072,8 +766,8 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         ISX_HIP(hipMemcpyFromSymbol(hs, HIP_SYMBOL(h2_stamp), sizeof(hs)));
         const double wg = (double)hs[9], st = (double)hs[8];
         if (getenv("ISX_H2_STAMP_PRINT") && wg > 0 && st > 0)
-            fprintf(stderr, "h2stamp B=%d D=%d H=%d W=%d cin=%d cout=%d BN=%d mt=%d fold=%d core16=%d grid=%u stages/wg=%.1f | per stage: bar1 %.0f loadwait %.0f store %.0f bar2 %.0f issue %.0f matrix %.0f | per wg: prologue %.0f epilogue %.0f | clock %.2f GHz\n",
-                    B, l.D, l.H, l.W, sa.C + sb.C, cout, BN, mt, fold, (int)core16, grid, st / wg, hs[0] / st, hs[1] / st, hs[2] / st, hs[3] / st, hs[4] / st,
+            fprintf(stderr, "h2stamp B=%d D=%d H=%d W=%d cin=%d cout=%d BN=%d mt=%d grid=%u stages/wg=%.1f | per stage: bar1 %.0f loadwait %.0f store %.0f bar2 %.0f issue %.0f matrix %.0f | per wg: prologue %.0f epilogue %.0f | clock %.2f GHz\n",
+                    B, l.D, l.H, l.W, sa.C + sb.C, cout, BN, mt, grid, st / wg, hs[0] / st, hs[1] / st, hs[2] / st, hs[3] / st, hs[4] / st,
                     hs[5] / st, hs[6] / wg, hs[7] / wg, hs[11] ? (double)hs[10] / (double)hs[11] * 0.1 : 0.0);
         memset(hs, 0, sizeof(hs));
         ISX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(h2_stamp), hs, sizeof(hs)));

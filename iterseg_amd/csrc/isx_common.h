@@ -68,21 +68,14 @@ struct isx_tune {
     int h2_nt_out = 1;              // ISX_H2_NT_OUT: streaming stores in the epilogue of the split-f16 convolutions (conv stage -2 ms per frame)
     int conv_first_nt = 1;          // ISX_CONV_FIRST_NT: streaming stores for c0.conv0's 5.4 GB output per launch set (34.7 -> 31.5 ms per frame)
     int up_per_source = 1;          // ISX_UP_PER_SOURCE: 0 = the transposed convolutions one thread per OUTPUT voxel (rounds 1-2)
-    int h2_core16 = 1;              // ISX_H2_CORE16: bit 0 the 27-tap split-f16 / f16 / bf16 convolutions (r3: conv stage 826 -> 788 ms per frame), bit 1
-                                    // the 9-tap tail layer (no gain: 808.6 vs 810.6 ms, off) on v_mfma_f32_16x16x32; 0: 32x32x16 everywhere (rounds 1-2)
     int planar = 2;                 // ISX_PLANAR (2: + the skip / pooled / up-sampled tensors, r4): the first convolution of a module writes [C/8][voxel][8] for the second one (inference, reduced-precision kernels)
-    int h2_nw8 = 1;                 // ISX_H2_NW8: 1 = 512-thread work-groups (eight waves on ONE weight slab, 256 voxels) for the layers with
-                                    // Cout % 64 == 0: half the slab traffic per voxel, same results -- and the same time (r3: 93.0 vs 92.8 ms per launch set)
-    int up_on_read = 0;             // ISX_UP_ON_READ: 1 = the tail layer up-samples up3 while staging it instead of reading a materialised tensor.
-                                    // Bit-identical, deletes 16 ms of upsample_kernel per 512^3 frame and costs the tail kernel 36 ms (r3): off
+    int h2_nw8 = 1;                 // ISX_H2_NW8: 1 = 512-thread work-groups (eight waves on ONE weight slab, 256 voxels, slabs by LDS-DMA) for the
+                                    // layers with Cout % 64 == 0 whose launch fills the chip; 0 = the 4-wave kernel everywhere; 2 = always (tests)
     int wgrad_wgs = 4096;           // ISX_WGRAD_WGS: work-groups a matrix-core weight gradient aims for (its split count: fewer = fewer partials to write and reduce)
     int thin_wgrad = 1;             // ISX_THIN_WGRAD: 0 = the 1 -> 32 and 5 -> 5 layers' weight gradients on the padded matrix-core tiles (round 2)
     int bf16_wgrad = 1;             // ISX_BF16_WGRAD: 0 = precision "bf16" keeps fp32 products in the weight gradients (round 2's form)
     int h2_nj2 = 1;                 // ISX_H2_NJ2: 1 = two 64-column N tiles per work-group of the LDS-DMA kernel for Cout % 128 == 0 (2: always, tests)
     int tail_up = 1;                // ISX_TAIL_UP: 0 = up3 materialised by upsample_src_kernel instead of up-sampled while the tail kernel stages it
-    int tail_onepass = 1;           // ISX_TAIL_ONEPASS: 0 = the tail layer as conv_h2_kernel<32, 1> + tail_combine_kernel (rounds 1-3)
-    int up_fold = 0;                // ISX_UP_FOLD: 1 = up1/up2 folded into their consumers' weights (UpFoldPacks).  Off: measured r3, it removes
-                                    // 57 % of the MFMAs of the up-sampled half and still loses 2 % end to end
 };
 
 // ISX_FLOOD_* (the watershed tests' stress modes, tuning runs): a negative field = the library default (csrc/ws.hip).  Read at

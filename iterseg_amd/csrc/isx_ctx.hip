@@ -144,17 +144,13 @@ static void read_knobs(isx_ctx *c)
     if (const char *e = getenv("ISX_H2_MT2")) t.h2_mt2 = atoi(e);
     if (const char *e = getenv("ISX_H2_FORCE_BN64")) t.h2_force_bn64 = atoi(e);
     if (const char *e = getenv("ISX_CONV_XCD_REMAP")) t.xcd_remap = atoi(e);
-    if (const char *e = getenv("ISX_UP_FOLD")) t.up_fold = atoi(e);
     if (const char *e = getenv("ISX_H2_NJ2")) t.h2_nj2 = atoi(e);
     if (const char *e = getenv("ISX_TAIL_UP")) t.tail_up = atoi(e);
-    if (const char *e = getenv("ISX_TAIL_ONEPASS")) t.tail_onepass = atoi(e);
     if (const char *e = getenv("ISX_BF16_WGRAD")) t.bf16_wgrad = atoi(e);
     if (const char *e = getenv("ISX_WGRAD_WGS")) t.wgrad_wgs = std::max(18, atoi(e));
     if (const char *e = getenv("ISX_THIN_WGRAD")) t.thin_wgrad = atoi(e);
-    if (const char *e = getenv("ISX_UP_ON_READ")) t.up_on_read = atoi(e);
     if (const char *e = getenv("ISX_PLANAR")) t.planar = atoi(e);
     if (const char *e = getenv("ISX_H2_NW8")) t.h2_nw8 = atoi(e);
-    if (const char *e = getenv("ISX_H2_CORE16")) t.h2_core16 = atoi(e);
     if (const char *e = getenv("ISX_UP_PER_SOURCE")) t.up_per_source = atoi(e);
     if (const char *e = getenv("ISX_CONV_FIRST_NT")) t.conv_first_nt = atoi(e);
     if (const char *e = getenv("ISX_H2_NT_OUT")) t.h2_nt_out = atoi(e);

@@ -1250,7 +1250,7 @@ static int dgrad(isx_ctx *ctx, int li, float *dst)
     if (u->precision == ISX_PRECISION_BF16 && t->wbf_dg[li] && t->dstride[li] == L.cout && conv_mt(ctx->tune, l, u->wbatch, L.cin) == 1) {
         // bf16 mixed precision: the same operator on the bf16 matrix cores (d(raw) is rounded to bf16 at the LDS store)
         return launch_conv_h2(ctx, l, 1, Src{t->draw[li], nullptr, nullptr, L.cout}, Src{nullptr, nullptr, nullptr, 0}, t->wbf_dg[li],
-                              t->zeros, L.cin, dst, nullptr, nullptr, 1, ctx->tune.xcd_remap, 0, nullptr, 2);
+                              t->zeros, L.cin, dst, nullptr, nullptr, 1, ctx->tune.xcd_remap, nullptr, 2);
     }
     if (t->w_dgrad[li]) {
         // the forward kernel with Cin <-> Cout: "input" = d(raw) (Cout channels), "output" = dX (Cin channels)
@@ -1433,7 +1433,11 @@ int isx_train_bind(isx_ctx *ctx, const int64_t chunk[3], float *params, float *g
             (bn == 64 ? L.w_bf_64 : L.w_bf_32) = p;              // the forward reads the refreshed packs from now on
         }
         if (li != 0 && L.cin % 32 == 0 && L.cout % 8 == 0) {     // dgrad operator: Cout -> Cin
-            const int bn = conv_h2_bn(ctx->tune, slots, L.cin);
+            // the tile width launch_conv_h2 will pick for this operator (batch 1, L.cin output columns): the 512-thread kernel
+            // reads 64-column packs wherever it runs.  (Round 3 packed by conv_h2_bn alone: at patch (10, 256, 256) the
+            // 256 -> 64 layer's data gradient ran on the 512-thread kernel over a 32-column pack -- garbage that no test saw,
+            // the layer-by-layer comparison ran at 64^2 only.)
+            const int bn = conv_h2_nw8(ctx->tune, l, L.cin, 1) ? 64 : conv_h2_bn(ctx->tune, slots, L.cin);
             float *p = nullptr;
             const size_t halves = h2_pack_halves(L.cin, L.cout, bn);
             ISX_TRY(talloc(t, (halves + 1) / 2, &p));

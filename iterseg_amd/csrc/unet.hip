@@ -671,54 +671,6 @@ __global__ void upsample_src_planar_kernel(const float *__restrict__ src, const 
     }
 }
 
-// Folded up-convolution (UpFoldPacks): the class convolutions treat every coarse voxel as the source of BOTH fine rows /
-// columns it up-samples to, but the cropped up-sampled tensor ends inside a coarse cell (the [:-1] crops drop the odd last
-// row and column, the [1:-1] crop the first and last ones): a fine tap that reads such a cropped-away position must see the
-// convolution's zero padding.  This kernel subtracts those "phantom" taps for the voxels on the faces of the output box --
-// one work-group per perimeter voxel, fp32, a fraction of a percent of the layer's work.
-__global__ __launch_bounds__(128) void upfold_phantom_kernel(const float *__restrict__ x, const float *__restrict__ scale,
-                                                             const float *__restrict__ shift, int cu, int D, int Hc, int Wc, int off,
-                                                             const float *__restrict__ upw, const float *__restrict__ wph, int cout,
-                                                             int rH, int rW, float *__restrict__ out)
-{
-    __shared__ float sv[256];
-    const int P = 2 * rW + 2 * (rH - 2);
-    const int q = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int z = q / P, e = q % P;
-    int Y, X;
-    if (e < rW) { Y = 0; X = e; }
-    else if (e < 2 * rW) { Y = rH - 1; X = e - rW; }
-    else { const int e2 = e - 2 * rW; X = (e2 / (rH - 2)) ? rW - 1 : 0; Y = 1 + e2 % (rH - 2); }
-    const int64_t Mc = (int64_t)D * Hc * Wc, Mo = (int64_t)D * rH * rW;
-    float acc0 = 0.f, acc1 = 0.f;
-    bool any = false;
-    for (int t = 0; t < 27; ++t) {
-        const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
-        const int zs = z + dz, ys = Y + dy, xs = X + dx;
-        if (zs < 0 || zs >= D) continue;
-        if (ys >= 0 && ys < rH && xs >= 0 && xs < rW) continue;                  // a real voxel of the up-sampled tensor
-        const int yo = ys + off, xo = xs + off;
-        if (yo < 0 || xo < 0) continue;
-        const int yc = yo >> 1, xc = xo >> 1;
-        if (yc >= Hc || xc >= Wc) continue;                                       // outside the coarse tensor too: zero either way
-        const int kidx = (yo & 1) * 2 + (xo & 1);
-        __syncthreads();
-        for (int c = tid; c < cu; c += 128) {
-            const float v = x[((int64_t)b * Mc + ((int64_t)zs * Hc + yc) * Wc + xc) * cu + c];
-            sv[c] = fmaxf(fmaf(v, scale[(int64_t)b * cu + c], shift[(int64_t)b * cu + c]), 0.f) * upw[(int64_t)kidx * cu + c];
-        }
-        __syncthreads();
-        const float *wt = wph + (int64_t)t * cu * cout;
-        if (tid < cout) { float a = 0.f; for (int c = 0; c < cu; ++c) a = fmaf(sv[c], wt[(int64_t)c * cout + tid], a); acc0 -= a; }
-        if (tid + 128 < cout) { float a = 0.f; for (int c = 0; c < cu; ++c) a = fmaf(sv[c], wt[(int64_t)c * cout + tid + 128], a); acc1 -= a; }
-        any = true;
-    }
-    if (!any) return;
-    float *op = out + ((int64_t)b * Mo + ((int64_t)z * rH + Y) * rW + X) * cout;
-    if (tid < cout) op[tid] += acc0;
-    if (tid + 128 < cout) op[tid + 128] += acc1;
-}
-
 // ------------------------------------------------------------------------------------------
 // Kernels: the thin tail, Cin -> NOUT (<= 8) channels, direct.  One voxel per thread; weights
 // [27][Cin][8] broadcast from LDS.  Two sources like the MFMA kernel (concat of the decoder).
@@ -1178,98 +1130,6 @@ static int commit_weights(isx_ctx *ctx, const int *fork_channels, int nforks)
         for (float v : w->f) U.wmax = std::max(U.wmax, fabsf(v));
         for (float v : bs->f) U.bmax = std::max(U.bmax, fabsf(v));
     }
-    // ---- up1..up3 folded into the first convolution of the decoder module they feed (UpFoldPacks; up0 also up-samples z and
-    //      keeps its own kernel).  Class (py, px) = parity of (Y + off, X + off) of the OUTPUT voxel; the fine tap dy reads the
-    //      up-sampled row Y + dy = coarse row i + floor((py + dy) / 2) with kernel parity (py + dy) & 1. ------------------------
-    for (int f = 0; f < nforks; ++f)
-        for (int k = 1; k < 4; ++k) {
-            const int l0 = dec_layer(f, k, 0);
-            ConvBN &L = u->cv[l0];
-            const UpConv &U = u->up[k];
-            L.fold = nullptr;
-            const int cout = L.cout, cin = L.cin, cu = U.C, cs = cin - cu;
-            if (U.kz != 1 || cu % 8 || cs % 8 || cs <= 0 || cout % 32 || !use_mfma(cin, cout)) continue;
-            const std::vector<float> &W = u->host.at(L.conv + ".weight").f, &bc = u->host.at(L.conv + ".bias").f;
-            const std::vector<float> &uw = u->host.at(U.name + ".weight").f, &ub = u->host.at(U.name + ".bias").f;
-            UpFoldPacks &F = u->fold_store[l0];
-            F = UpFoldPacks();
-            auto upload_halves = [&](const std::vector<uint16_t> &hp, void **dst) -> int {
-                void *d = nullptr;
-                ISX_HIP(hipMalloc(&d, hp.size() * 2));
-                u->wblocks.push_back(d);
-                ISX_HIP(hipMemcpy(d, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
-                *dst = d;
-                return ISX_OK;
-            };
-            std::vector<uint16_t> hp;
-            bool in_range = true;
-            for (int cls = 0; cls < 4 && in_range; ++cls) {
-                const int py = cls >> 1, px = cls & 1;
-                std::vector<float> wc((size_t)cout * cu * 12, 0.f);
-                for (int co = 0; co < cout; ++co)
-                    for (int c = 0; c < cu; ++c)
-                        for (int dz = -1; dz <= 1; ++dz)
-                            for (int dy = -1; dy <= 1; ++dy)
-                                for (int dx = -1; dx <= 1; ++dx) {
-                                    const int sy = py + dy, sx = px + dx;
-                                    const int cyi = (sy < 0 ? -1 : sy >> 1) + (1 - py), cxi = (sx < 0 ? -1 : sx >> 1) + (1 - px);
-                                    const int kidx = (sy & 1) * 2 + (sx & 1);
-                                    wc[((size_t)co * cu + c) * 12 + (dz + 1) * 4 + cyi * 2 + cxi] +=
-                                        W[((size_t)co * cin + c) * 27 + (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] * uw[(size_t)c * 4 + kidx];
-                                }
-                for (float v : wc) if (!(fabsf(v) < 6.0e4f)) in_range = false;
-                if (!in_range) break;
-                for (int bn = 32; bn <= 64; bn += 32) {
-                    if (cout % bn) continue;
-                    for (int pmi = 0; pmi < 2; ++pmi) {
-                        pack_h2_taps(wc.data(), cout, cu, 12, 12, bn, hp, pmi ? 2 : 0);
-                        ISX_TRY(upload_halves(hp, &F.cls[pmi][bn == 64][cls]));
-                    }
-                }
-            }
-            if (!in_range) continue;                              // folded weights outside the f16 range: the unfused form stays
-            {
-                std::vector<float> wsk((size_t)cout * cs * 27);
-                for (int co = 0; co < cout; ++co)
-                    for (int c = 0; c < cs; ++c)
-                        for (int t = 0; t < 27; ++t) wsk[((size_t)co * cs + c) * 27 + t] = W[((size_t)co * cin + cu + c) * 27 + t];
-                for (int bn = 32; bn <= 64; bn += 32) {
-                    if (cout % bn) continue;
-                    for (int pmi = 0; pmi < 2; ++pmi) {
-                        pack_h2_weights(wsk.data(), cout, cs, bn, hp, pmi ? 2 : 0);
-                        ISX_TRY(upload_halves(hp, &F.skip[pmi][bn == 64]));
-                    }
-                }
-            }
-            {
-                // bias of an output voxel = conv bias + sum over the taps whose source lies inside the output box of
-                // (sum_c W[o][c][t] * b_up[c]); configuration bits: z == 0, z == D-1, Y == 0, Y == H-1, X == 0, X == W-1
-                std::vector<double> st((size_t)cout * 27, 0.0);
-                for (int co = 0; co < cout; ++co)
-                    for (int c = 0; c < cu; ++c)
-                        for (int t = 0; t < 27; ++t) st[(size_t)co * 27 + t] += (double)W[((size_t)co * cin + c) * 27 + t] * ub[c];
-                std::vector<float> bt((size_t)64 * cout);
-                for (int cfg = 0; cfg < 64; ++cfg)
-                    for (int co = 0; co < cout; ++co) {
-                        double v = bc[co];
-                        for (int t = 0; t < 27; ++t) {
-                            const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
-                            const bool oob = (dz < 0 && (cfg & 1)) || (dz > 0 && (cfg & 2)) || (dy < 0 && (cfg & 4)) || (dy > 0 && (cfg & 8)) ||
-                                             (dx < 0 && (cfg & 16)) || (dx > 0 && (cfg & 32));
-                            if (!oob) v += st[(size_t)co * 27 + t];
-                        }
-                        bt[(size_t)cfg * cout + co] = (float)v;
-                    }
-                ISX_TRY(dev_upload(u, bt, &F.bias_cfg));
-                std::vector<float> wp((size_t)27 * cu * cout);
-                for (int co = 0; co < cout; ++co)
-                    for (int c = 0; c < cu; ++c)
-                        for (int t = 0; t < 27; ++t) wp[((size_t)t * cu + c) * cout + co] = W[((size_t)co * cin + c) * 27 + t];
-                ISX_TRY(dev_upload(u, wp, &F.wph));
-                ISX_TRY(dev_upload(u, std::vector<float>((size_t)cout, 0.f), &F.zeros));
-            }
-            L.fold = &F;
-        }
     if (u->host.size() != expected) {
         set_error("state_dict: %zu unexpected key(s)", u->host.size() - expected);
         return ISX_ERR_STATE;
@@ -1448,15 +1308,13 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         u->arith[li] = h2 ? ISX_ARITH_REDUCED : (reduced && wh && !in_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
         ISX_REQUIRE(h2 || !(sa.planar || sb.planar), "internal: a planar source reached a convolution that does not read it");
         if (h2) {
-            H2Extra pl;
-            pl.out_planar = (want_planar && !ex && L.cout % 8 == 0) ? 1 : 0;
-            u->planar[li] = pl.out_planar != 0;
-            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, 0, &stat_tiles, pm,
-                                   pl.out_planar ? &pl : ex));
+            const int out_planar = (want_planar && L.cout % 8 == 0) ? 1 : 0;
+            u->planar[li] = out_planar != 0;
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, &stat_tiles, pm, out_planar));
         } else
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
     } else if (use_fold(L.cin, L.cout)) {
-        // pass 1 on the matrix cores: 9 (dz,dy) taps, x-taps folded into 3*cout <= 16 output columns
+        // the x-taps folded into 3*cout <= 16 output columns, 9 (dz,dy) taps on the matrix cores
         const bool bf = u->precision == ISX_PRECISION_BF16;
         const void *wf = bf ? L.w_bf_32 : L.w_h2_32;
         const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
@@ -1466,15 +1324,11 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
                                : (u->precision != ISX_PRECISION_FP32 && !u->train && wf && !fold_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
         ISX_REQUIRE(fold_h2 || !ex, "internal: up-sampling on read needs the reduced-precision tail kernel");
         ISX_REQUIRE(fold_h2 || !(sa.planar || sb.planar), "internal: a planar source reached a convolution that does not read it");
-        // one pass: x-shift in LDS, no partial-sum tensor, all weights resident (conv_tail.hip)
-        const bool one_pass = fold_h2 && ctx->tune.tail_onepass && conv_tail_lds(cin, pm) != 0;
+        // reduced precisions: one pass on the f16 / bf16 matrix cores, x-shift in LDS, no partial-sum tensor (conv_tail.hip)
+        const bool one_pass = fold_h2;
         if (one_pass) {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ISX_TRY(launch_conv_tail(ctx, l, B, sa, sb, wf, L.bias, L.cout, u->raw[li], L.psum, L.psq, pm, &stat_tiles, ex));
-        } else if (fold_h2) {
-            ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
-            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wf, u->zeros32, L.cout, u->ptail, nullptr, nullptr, 1,
-                                   ctx->tune.xcd_remap, 1, nullptr, pm, ex));
         } else {
             ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
             ConvArgs a;
@@ -1553,78 +1407,6 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
     return ISX_OK;
 }
 
-// The first convolution of a decoder module with its transposed convolution folded in (UpFoldPacks): four class
-// convolutions over the coarse tensor write the interleaved quarters of the output (bias included), the phantom taps of the
-// cropped faces are taken back, then the skip half accumulates on top and produces the BatchNorm partial sums.
-// `xin`: the coarse activation (raw + affine), `skip`: the skip tensor, `ls` / `lo`: coarse / output level, off: crop offset.
-static bool upfold_usable(isx_ctx *ctx, int li, const Level &ls, const Level &lo, const Src &xin, const Src &skip)
-{
-    UNetState *u = ctx->unet;
-    const ConvBN &L = u->cv[li];
-    if (!L.fold || !ctx->tune.up_fold || u->train || u->precision == ISX_PRECISION_FP32) return false;
-    if (lo.M >= (1 << 24) || L.cout > 256 || xin.C > 256) return false;
-    if (u->precision != ISX_PRECISION_BF16 && !(std::max(xin.bound, skip.bound) < 6.0e4f)) return false;
-    return conv_mt(ctx->tune, ls, u->wbatch, L.cout) == 1 && conv_mt(ctx->tune, lo, u->wbatch, L.cout) == 1;
-}
-
-static int run_upfold(isx_ctx *ctx, int li, const Level &ls, const Level &lo, int B, Src xin, Src skip, const UpConv &U, int off)
-{
-    UNetState *u = ctx->unet;
-    ConvBN &L = u->cv[li];
-    const UpFoldPacks &F = *L.fold;
-    const Src none{nullptr, nullptr, nullptr, 0};
-    const bool bf = u->precision == ISX_PRECISION_BF16;
-    const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
-    int stat_tiles = L.tiles;
-    {
-        ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
-        int t0, t1, t2, slots;
-        conv_tiles(ls, conv_mode(ls), 1, &t0, &t1, &t2, &slots);
-        const bool c64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64;
-        for (int cls = 0; cls < 4; ++cls) {
-            H2Extra ex;
-            const int py = cls >> 1, px = cls & 1;
-            ex.tx2 = 1;
-            ex.oy[0] = py ? 0 : -1; ex.oy[1] = py ? 1 : 0;
-            ex.ox[0] = px ? 0 : -1; ex.ox[1] = px ? 1 : 0;
-            ex.remap = 1; ex.rH = lo.H; ex.rW = lo.W; ex.rpy = py; ex.rpx = px; ex.roff = off; ex.Mout = lo.M;
-            ISX_TRY(launch_conv_h2(ctx, ls, B, xin, none, F.cls[bf ? 1 : 0][c64 ? 1 : 0][cls], F.bias_cfg, L.cout, u->raw[li], nullptr, nullptr, 1,
-                                   ctx->tune.xcd_remap, 0, nullptr, pm, &ex));
-        }
-    }
-    {
-        ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
-        const int P = 2 * lo.W + 2 * (lo.H - 2);
-        upfold_phantom_kernel<<<dim3((unsigned)(P * lo.D), (unsigned)B), 128, 0, ctx->stream>>>(
-            xin.p, xin.scale, xin.shift, xin.C, ls.D, ls.H, ls.W, off, U.w, F.wph, L.cout, lo.H, lo.W, u->raw[li]);
-        ISX_CHECK_LAUNCH();
-    }
-    {
-        ProfScope ps(ctx, ISX_PROF_CONV_MFMA);
-        int t0, t1, t2, slots;
-        conv_tiles(lo, conv_mode(lo), 1, &t0, &t1, &t2, &slots);
-        const bool s64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64;
-        H2Extra ex;
-        ex.accum = 1;
-        ISX_TRY(launch_conv_h2(ctx, lo, B, skip, none, F.skip[bf ? 1 : 0][s64 ? 1 : 0], F.zeros, L.cout, u->raw[li], L.psum, L.psq, 0,
-                               ctx->tune.xcd_remap, 0, &stat_tiles, pm, &ex));
-    }
-    u->arith[li] = ISX_ARITH_REDUCED;
-    {
-        ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
-        bn_finalize_kernel<<<dim3((unsigned)L.cout, (unsigned)B), 256, 0, ctx->stream>>>(
-            L.psum, L.psq, stat_tiles, L.cout, (double)lo.M, L.gamma, L.beta, L.scale, L.shift, L.bmean, L.bvar, L.invstd,
-            B == 1 ? L.rmean : nullptr, B == 1 ? L.rvar : nullptr);
-        ISX_CHECK_LAUNCH();
-        if (B > 1) {
-            bn_running_kernel<<<cdiv(L.cout, 64), 64, 0, ctx->stream>>>(L.bmean, L.bvar, B, L.cout, L.rmean, L.rvar);
-            ISX_CHECK_LAUNCH();
-        }
-        L.nbt += B;
-    }
-    return ISX_OK;
-}
-
 // Forward B chunks whose rows are already in u->d_table and whose voxels are in u->x0.
 int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3])
 {
@@ -1645,7 +1427,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
     // tail layer reads both its sources that way (conv_tail.hip: on row-major sources it re-fetched every 128-byte line of its
     // halo once per K stage from beyond L2)
     auto skip_planar_ok = [&](int mi) {
-        if (ctx->tune.planar < 2 || ctx->tune.up_fold || ctx->tune.up_on_read || u->train || mi > 3 || u->cv[2 * mi + 1].cout % 8) return false;
+        if (ctx->tune.planar < 2 || u->train || mi > 3 || u->cv[2 * mi + 1].cout % 8) return false;
         const int k = 3 - mi;                                     // the decoder module that reads this skip tensor beside up_k
         for (int f = 0; f < u->nforks; ++f) {
             const int li_in = (k == 0) ? 9 : dec_layer(f, k - 1, 1);
@@ -1695,20 +1477,14 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             float *upo = u->ups[ups_index(f, k)];
             const int l0f = dec_layer(f, k, 0), skipf = 2 * (3 - k) + 1;
             ISX_REQUIRE(ls.D == lo.D || k == 0, "internal: up%d changes the depth", k);
-            if (k > 0 && upfold_usable(ctx, l0f, ls, lo, act(li_in), act(skipf))) {
-                u->up_folded[ups_index(f, k)] = true;
-                ISX_TRY(run_upfold(ctx, l0f, ls, lo, B, act(li_in), act(skipf), U, k == 3 ? 1 : 0));
-                ISX_TRY(run_conv(ctx, dec_layer(f, k, 1), lo, B, act(l0f), none));
-                continue;
-            }
             u->up_folded[ups_index(f, k)] = false;
             {
-                // the tail layer (64 -> n, its own 9-tap kernel) up-samples its first source while staging it: up3 is the
-                // largest transposed convolution (5.4 GB written and read back per 64-chunk launch set at 256^2)
+                // the tail layer (64 -> n, conv_tail.hip) up-samples its first source while staging it: up3 is the largest
+                // transposed convolution (5.4 GB written and read back per 64-chunk launch set at 256^2)
                 const ConvBN &L0 = u->cv[l0f];
                 const bool bf = u->precision == ISX_PRECISION_BF16;
                 const float bnd = bn_bound(li_in) * U.wmax + U.bmax;
-                const bool on_read = (ctx->tune.up_on_read || (ctx->tune.tail_up && ctx->tune.tail_onepass)) && U.kz == 1 && U.C % 8 == 0 && U.C <= 64 &&
+                const bool on_read = ctx->tune.tail_up && U.kz == 1 && U.C % 8 == 0 && U.C <= 64 &&
                                      use_fold(L0.cin, L0.cout) && !u->train &&
                                      u->precision != ISX_PRECISION_FP32 && (bf ? L0.w_bf_32 : L0.w_h2_32) &&
                                      (bf || std::max(bnd, bn_bound(skipf)) < 6.0e4f) && conv_mt(ctx->tune, lo, u->wbatch, 32) == 1;
@@ -1750,7 +1526,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound, u->ups_planar[ups_index(f, k)]}, act(skip_li), nullptr, planar_ok(l1, lo, l0)));
             // its output feeds up_{k+1} only (k < 3): planar if that transposed convolution runs per source voxel and the
             // convolution behind it reads planar sources
-            bool next_per_src = k < 3 && ctx->tune.planar >= 2 && !u->train && !ctx->tune.up_fold && !ctx->tune.up_on_read &&
+            bool next_per_src = k < 3 && ctx->tune.planar >= 2 && !u->train &&
                                 u->up[k + 1].kz == 1 && ctx->tune.up_per_source && u->cv[l1].cout % 8 == 0 &&
                                 (int64_t)B * lo.M * (u->cv[l1].cout / 4) < (int64_t)0xFFFFFFFFll;
             if (next_per_src) {

@@ -19,19 +19,6 @@ struct HostTensor {
     bool is_i64 = false;
 };
 
-// Decoder first convolution with the transposed convolution folded into its weights (inference, reduced precisions;
-// forward_batch / conv_h2.hip).  The up-sampled half of the input is up[c, z, Y, X] = act(x[c, z, (Y+off)>>1, (X+off)>>1])
-// * w_up[c, parity] + b_up[c], so for the output voxels of one parity class (py, px) the 27 fine taps over that half collapse
-// to 3 x 2 x 2 taps over the COARSE tensor with class-specific weights: four 12-tap convolutions at the coarse resolution
-// write the four interleaved quarters of the output, then the skip half (27 taps, fine resolution) accumulates on top.
-struct UpFoldPacks {
-    void *cls[2][2][4] = {};        // [0: split-f16 (hi half = plain f16), 1: bf16][0: 32-, 1: 64-column tiles][class py * 2 + px]
-    void *skip[2][2] = {};          // the skip half of the weights, standard 28-tap packs
-    float *bias_cfg = nullptr;      // [64 border configurations][cout]: conv bias + up-conv bias through the in-bounds taps
-    float *wph = nullptr;           // [27][C_up][cout] fp32 weights of the up half (correction of the phantom taps)
-    float *zeros = nullptr;         // [cout]
-};
-
 struct ConvBN {                 // one Conv3d followed by its BatchNorm3d
     std::string conv, bn;       // state-dict prefixes, e.g. "c0.conv0", "c0.batch0"
     int cin = 0, cout = 0;
@@ -46,7 +33,6 @@ struct ConvBN {                 // one Conv3d followed by its BatchNorm3d
     float *psum = nullptr, *psq = nullptr;          // [B][tiles][cout] partial sums
     int tiles = 0;
     float gmax = 0.f, bmax = 0.f;                   // max |gamma|, max |beta|: |BN output| <= gmax * sqrt(M - 1) + bmax
-    UpFoldPacks *fold = nullptr;                    // decoder first convolutions behind up1..up3 (see UpFoldPacks)
 };
 
 struct UpConv {
@@ -92,8 +78,7 @@ struct UNetState {
     float *wtail = nullptr, *zeros32 = nullptr;
     const int32_t *d_table = nullptr;   // device rows of the launch set in flight
     int last_n = 0;
-    UpFoldPacks fold_store[ISX_MAX_LAYERS];   // cv[li].fold points here
-    bool up_folded[ISX_MAX_UPS] = {false};     // last forward: ups[i] was NOT materialised (its consumer ran the folded form)
+    bool up_folded[ISX_MAX_UPS] = {false};     // last forward: ups[i] was NOT materialised (the tail kernel up-sampled it on read)
     bool pool_planar[4] = {false}, ups_planar[ISX_MAX_UPS] = {false};      // last forward: pool[i] / ups[i] are stored planar
     bool planar[ISX_MAX_LAYERS] = {false};   // last forward: raw[li] is stored planar (first convolution of a module whose only reader is the second)
     int arith[ISX_MAX_LAYERS] = {0};  // how each convolution ran in the last forward (ISX_ARITH_*, isx_unet_precision_report)
@@ -126,29 +111,13 @@ struct ConvArgs {
     int no_stats;          // 1: skip BN partial sums
     int xcd_remap;         // 1: XCD-contiguous tile order (see the kernel)
     int ntiles;            // Cout / BN (the grid is 1-D: [chunk][tile][ntile])
-    // ---- conv_h2_kernel only: the class convolutions of a folded up-convolution (UpFoldPacks) and the accumulating skip half
-    int oy[2], ox[2];      // TX = 2: the two coarse rows / columns of this parity class, relative to the tile voxel (-1, 0 or +1)
-    int remap;             // 1: tile voxel (z, i, j) writes output voxel (z, 2i + rpy - roff, 2j + rpx - roff) of an (D, rH, rW) tensor;
-    int rH, rW, rpy, rpx, roff;   //    bias then is a table [64 border configurations of the OUTPUT voxel][Cout]
-    int64_t Mout;          // voxels per chunk of the output tensor (D*H*W unless remap)
-    int accum;             // 1: add to what `out` already holds (statistics over the sums)
     int nt_out;            // 1: streaming stores for the output tensor
     // planar tensors: [chunk][C / 8][voxel][8 channels] instead of [chunk][voxel][C] -- a K stage's 32 bytes of consecutive voxels
     // are contiguous, so a halo load instruction reads whole lines instead of 64 pieces of 16 bytes (UNetState::planar)
     int planarA, planarB, out_planar;
-    // TX = 4 (folded tail layer only): source A is the COARSE input of a transposed convolution, up-sampled while it is staged:
-    // slot voxel (z, y, x) reads (z, (y + uoff) >> 1, (x + uoff) >> 1) of a (D, uH, uW) tensor, BatchNorm + ReLU as usual, then
-    // * upw[parity][c] + upb[c] (UpConv::w / bias) -- what upsample_kernel would have written to a 4x larger tensor
-    int uH, uW, uoff;
-    const float *upw, *upb;
 };
 
-struct H2Extra {           // optional arguments of launch_conv_h2 (see ConvArgs)
-    int out_planar = 0;
-    int tx2 = 0, oy[2] = {0, 0}, ox[2] = {0, 0};
-    int remap = 0, rH = 0, rW = 0, rpy = 0, rpx = 0, roff = 0;
-    int64_t Mout = 0;
-    int accum = 0;
+struct H2Extra {           // the tail kernel's optional source: up3 up-sampled on read (conv_tail.hip, TailArgs)
     int upA = 0, uH = 0, uW = 0, uoff = 0;
     const float *upw = nullptr, *upb = nullptr;
 };
@@ -174,15 +143,12 @@ void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_
 int repack_bf16(isx_ctx *ctx, const float *wref, int cout, int cin, int transpose, int bn, int cout_p, int cin_p, void *dst);
 size_t h2_pack_halves(int cout_p, int cin_p, int bn);
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int fold, int *tiles_used, int pm = 0,
-                   const H2Extra *ex = nullptr);
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int *tiles_used, int pm = 0, int out_planar = 0);
 // one-pass thin tail convolution (conv_tail.hip)
 int conv_tail_tiles(const Level &l);
 size_t conv_tail_lds(int cin, int pm);
-struct H2Extra;
 int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_fold, const float *bias, int nout,
                      float *out, float *psum, float *psq, int pm, int *tiles_used, const H2Extra *ex = nullptr);
-void pack_h2_taps(const float *w, int cout, int cin, int ntap, int ntap_pad, int bn, std::vector<uint16_t> &out, int pm);
 int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch);
 int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3]);
 int dev_alloc(UNetState *u, size_t floats, float **out);

@@ -268,53 +268,55 @@ def test_reduced_precision_modes_full_size_chunk(mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
-def test_folded_up_convolution_equals_materialised_one(precision, monkeypatch):
-    """ISX_UP_FOLD=1: up1 / up2 (ConvTranspose3d + crop, unet.py:215-242,339-349) folded into the weights of c6.conv0 / c7.conv0
-    -- four 12-tap class convolutions over the coarse tensor, the phantom taps of the cropped faces taken back, the skip half
-    accumulated on top -- against the default form that materialises the up-sampled tensor.  Faces and corners included."""
+def test_tail_kernel_up_sampling_on_read_is_bit_identical(precision, monkeypatch):
+    """ISX_TAIL_UP (default 1): the 64 -> n tail kernel (conv_tail.hip) reads the coarse c7 output and applies up3
+    (ConvTranspose3d + [1:-1] crop, unet.py:237-242,352-354) while it stages its halo tile -- the same arithmetic in the same
+    order as upsample_src_kernel writing the tensor and the kernel reading it back, so the outputs are identical bit for bit;
+    the `up3.cropped` tap of a forward that never wrote the tensor is computed on demand.  Plain and forked networks, planar
+    and row-major coarse tensor."""
     import numpy as np
     from iterseg_amd import weights
     from iterseg_amd.unet import UNet
-    sd = weights.generate_state_dict(3)
-    nets = []
-    for fold in ("1", "0"):
-        monkeypatch.setenv("ISX_UP_FOLD", fold)
-        u = UNet(1, 5, batch=1, precision=precision)
-        u.load_state_dict(sd)
-        nets.append(u)
-    tol = 2e-5 if precision == "split-f16" else 3e-2       # the single-product modes round the folded weights once instead of
-    rng = np.random.default_rng(5)                          # activations and weights separately
-    for shape in [(4, 32, 32), (10, 80, 48)]:
-        x = rng.random((1, 1) + shape, dtype=np.float32)
-        ya, yb = nets[0](x), nets[1](x)
-        assert np.abs(ya - yb).max() <= tol
-        for name in ("c6_0.conv0", "c7_0.conv0"):
-            ta, tb = nets[0].tap(name), nets[1].tap(name)
-            assert np.abs(ta - tb).max() <= tol * max(1.0, np.abs(tb).max()), name
-        # the tap of an up-sampled tensor the folded forward never wrote is computed on demand
-        assert np.abs(nets[0].tap("up1.cropped") - nets[1].tap("up1.cropped")).max() <= tol
+    for out, planar in ((5, "2"), ((3, 2), "2"), (5, "0")):
+        sd = weights.generate_state_dict(2, out_channels=out)
+        monkeypatch.setenv("ISX_PLANAR", planar)
+        nets = []
+        for v in ("1", "0"):
+            monkeypatch.setenv("ISX_TAIL_UP", v)
+            u = UNet(1, out, batch=2, precision=precision)
+            u.load_state_dict(sd)
+            nets.append(u)
+        for shape in [(4, 32, 32), (10, 80, 48)]:
+            x = np.random.default_rng(4).random((1, 1) + shape, dtype=np.float32)
+            ya, yb = nets[0](x), nets[1](x)
+            assert np.array_equal(ya, yb), (out, planar, shape)
+            for name in ("c8_0.conv0", "up3.cropped", "c7_0.conv1"):
+                assert np.array_equal(nets[0].tap(name), nets[1].tap(name)), (out, planar, shape, name)
 
 
 @pytest.mark.gpu
-def test_tail_layer_up_sampling_on_read_is_bit_identical(monkeypatch):
-    """ISX_UP_ON_READ=1: the 64 -> 5 tail layer reads the coarse c7 output and applies up3 (ConvTranspose3d + [1:-1] crop,
-    unet.py:237-242,352-354) while it stages its halo tile -- the same arithmetic in the same order as upsample_kernel, so the
-    outputs are identical bit for bit (measured slower, off by default: DESIGN.md section 4)."""
+@pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
+def test_two_n_tiles_per_work_group_change_nothing(precision, monkeypatch):
+    """ISX_H2_NJ2=2 forces conv_h2c16nw8x2_kernel (the halo tile of a K stage staged once for 2 x 64 output columns, the two
+    weight slabs alternating between the LDS-DMA buffers) onto every layer with Cout % 128 == 0, against the one-tile kernel:
+    the same products in the same order, identical bit for bit."""
     import numpy as np
     from iterseg_amd import weights
     from iterseg_amd.unet import UNet
-    sd = weights.generate_state_dict(2)
+    sd = weights.generate_state_dict(6)
     nets = []
-    for v in ("1", "0"):
-        monkeypatch.setenv("ISX_UP_ON_READ", v)
-        u = UNet(1, 5, batch=1)
+    monkeypatch.setenv("ISX_H2_NW8", "2")
+    for v in ("2", "0"):
+        monkeypatch.setenv("ISX_H2_NJ2", v)
+        u = UNet(1, 5, batch=2, precision=precision)
         u.load_state_dict(sd)
         nets.append(u)
-    x = np.random.default_rng(4).random((1, 1, 10, 80, 48), dtype=np.float32)
-    ya, yb = nets[0](x), nets[1](x)
-    assert np.array_equal(ya, yb)
-    assert np.array_equal(nets[0].tap("c8_0.conv0"), nets[1].tap("c8_0.conv0"))
-    assert np.array_equal(nets[0].tap("up3.cropped"), nets[1].tap("up3.cropped"))      # computed on demand on the first one
+    for shape in [(4, 32, 32), (10, 96, 80), (6, 48, 112)]:
+        x = np.random.default_rng(9).random((1, 1) + shape, dtype=np.float32)
+        ya, yb = nets[0](x), nets[1](x)
+        assert np.array_equal(ya, yb), shape
+        for name in ("c2.conv0", "c2.conv1", "c3.conv1", "c4.conv0", "c5_0.conv0", "c5_0.conv1"):
+            assert np.array_equal(nets[0].tap(name), nets[1].tap(name)), (shape, name)
 
 
 @pytest.mark.gpu
@@ -352,7 +354,8 @@ def test_planar_intermediate_tensors_change_nothing(monkeypatch, out, precision)
 @pytest.mark.gpu
 def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
     """ISX_H2_NW8=2: every layer with Cout % 64 == 0 on 512-thread work-groups (eight waves, one weight slab, 256-voxel tiles
-    -- conv_h2_kernel<64, 3, 1, PM, 8>); the K order of every output is unchanged."""
+    by LDS-DMA -- conv_h2c16nw8_kernel) against the 4-wave kernel everywhere (ISX_H2_NW8=0); the K order of every output is
+    unchanged."""
     import numpy as np
     from iterseg_amd import weights
     from iterseg_amd.unet import UNet
@@ -374,29 +377,3 @@ def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
             assert np.abs(ta - tb).max() <= 2e-5 * max(1.0, np.abs(tb).max()), name
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
-def test_both_matrix_core_shapes_give_the_same_feature_maps(precision, monkeypatch):
-    """ISX_H2_CORE16: 0 = v_mfma_f32_32x32x16 (rounds 1-2), 1 = the 27-tap layers on v_mfma_f32_16x16x32 (default: the chip
-    holds a higher clock under that shape), 3 = the tail layer too.  Same operands and products; the taps of a K stage are
-    summed in groups of four instead of two, so the results agree to rounding."""
-    import numpy as np
-    from iterseg_amd import weights
-    from iterseg_amd.unet import UNet
-    sd = weights.generate_state_dict(5)
-    nets = []
-    for v in ("0", "1", "3"):
-        monkeypatch.setenv("ISX_H2_CORE16", v)
-        u = UNet(1, 5, batch=1, precision=precision)
-        u.load_state_dict(sd)
-        nets.append(u)
-    # (a last-bit difference of a sum can flip the f16 / bf16 rounding of an activation in the next layer)
-    tol = {"split-f16": 3e-6, "f16": 5e-3, "bf16": 3e-2}[precision]
-    for shape in [(4, 32, 32), (10, 80, 96)]:
-        x = np.random.default_rng(8).random((1, 1) + shape, dtype=np.float32)
-        ys = [n(x) for n in nets]
-        assert np.abs(ys[1] - ys[0]).max() <= tol and np.abs(ys[2] - ys[0]).max() <= tol
-        for name in ("c0.conv1", "c2.conv0", "c4.conv1", "c6_0.conv0", "c8_0.conv0"):
-            t0 = nets[0].tap(name)
-            for n in nets[1:]:
-                assert np.abs(n.tap(name) - t0).max() <= 10 * tol * max(1.0, np.abs(t0).max()), name
