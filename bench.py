@@ -96,7 +96,7 @@ DTYPE = {"fp32": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumul
 # cannot collect PMC counters on itself, so it reads the summary that scratch/pmc_traffic_json.py wrote from those
 # passes (committed under profiles/ with the CSVs); without one, or if it was made for another kernel build, traffic
 # is null.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03f_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 TRAFFIC_ALGORITHMIC = 0.05725e9          # every activation read once + written once + weights, per chunk-launch
 
 
@@ -116,10 +116,10 @@ def conv_roofline(precision, mfma_flops, n_chunks, steps, ms_mfma, n_mfma, batch
     r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
          "traffic": traffic, "traffic_source": traffic_src, "traffic_algorithmic": TRAFFIC_ALGORITHMIC * batch,
          "kernel": ("conv_mfma_kernel (fp32 32x32x2 implicit-GEMM conv, 16 of 18 layers)" if precision == "fp32" else
-                    "conv_h2c16nw8_kernel / conv_h2c16_kernel / conv_h2_kernel (split-f16 implicit-GEMM conv on v_mfma_f32_16x16x32_f16, matrix phase software-pipelined; the 9-tap tail layer on 32x32x16; 16 of 18 layers)"),
+                    "conv_h2c16nw8x2_kernel / conv_h2c16nw8_kernel / conv_h2c16_kernel / conv_tail_kernel (split-f16 implicit-GEMM conv on v_mfma_f32_16x16x32_f16: matrix phase software-pipelined, weight slabs by LDS-DMA, two N tiles per work-group for Cout % 128 == 0; the thin tail layer in one pass with up3 up-sampled on read; 16 of 18 layers)"),
          "avg_launch_ms": ms_mfma / max(n_mfma, 1), "launches": n_mfma, "algorithmic_gflop_per_chunk": mfma_flops / 1e9}
     if precision in ("f16", "bf16"):
-        r["kernel"] = f"conv_h2c16nw8_kernel / conv_h2c16_kernel / conv_h2_kernel ({precision} operands, one MFMA per product, 16 of 18 layers)"
+        r["kernel"] = f"conv_h2c16nw8x2_kernel / conv_h2c16nw8_kernel / conv_h2c16_kernel / conv_tail_kernel ({precision} operands, one MFMA per product, 16 of 18 layers)"
         r["note"] = "reduced-precision mode: algorithmic FLOPs = executed MFMA FLOPs x 27/28"
     elif precision != "fp32":
         r["note"] = ("achieved = algorithmic (fp32-equivalent) FLOPs; the split executes 3 f16 MFMAs per product (x 28/27 tap "
@@ -182,11 +182,15 @@ def train_step_leg(sd, patch=(10, 256, 256), steps=5, precision="fp32"):
     dt = (time.perf_counter() - t0) / steps
     fwd, direct = conv_flops_per_chunk(patch)
     return {"patch": list(patch), "ms_per_step": 1e3 * dt, "voxels_per_s": float(np.prod(patch)) / dt, "loss": float(loss),
-            "tflops_of_3x_forward": 3.0 * (fwd + direct) / dt / 1e12, "peak_tflops_fp32_matrix": PEAK_MFMA_F32,
+            "tflops_of_3x_forward": 3.0 * (fwd + direct) / dt / 1e12,
+            # the peak of the pipe the step's convolutions run on: bf16 matrix cores (dense) / fp32 matrix cores
+            "peak_tflops": PEAK_MFMA_F16 if precision == "bf16" else PEAK_MFMA_F32,
+            "frac_of_peak": 3.0 * (fwd + direct) / dt / 1e12 / (PEAK_MFMA_F16 if precision == "bf16" else PEAK_MFMA_F32),
             "precision": precision,
             "note": "forward + BCE + backward (dgrad, wgrad, BatchNorm) + the reference's double Adam update, batch 1"
-                    + ("; bf16 = forward and data-gradient convolutions of the wide layers on the bf16 matrix cores, fp32 master "
-                       "weights / weight gradients / BatchNorm / Adam (BASELINE config 4's arithmetic)" if precision == "bf16" else "")}
+                    + ("; bf16 = forward, data-gradient and weight-gradient convolutions of the wide layers on the bf16 matrix "
+                       "cores, fp32 master weights / BatchNorm / Adam (BASELINE config 4's arithmetic); ~160 launches per step: "
+                       "launch- and tail-bound at batch 1" if precision == "bf16" else "")}
 
 
 def structured_watershed_leg(u, n=512, volume_fraction=0.12, t_unet_ms=None):

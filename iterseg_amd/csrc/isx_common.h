@@ -64,7 +64,6 @@ struct isx_tune {
     int h2_mt2 = 1;                 // ISX_H2_MT2: 0 never, 1 big launches, 2 always -- two row tiles per wave in conv_h2
     int h2_force_bn64 = 0;          // ISX_H2_FORCE_BN64
     int xcd_remap = 1;              // ISX_CONV_XCD_REMAP
-    long mt2_min_vox = 1L << 60;    // ISX_CONV_MT2_MIN_VOX
     int h2_nt_out = 1;              // ISX_H2_NT_OUT: streaming stores in the epilogue of the split-f16 convolutions (conv stage -2 ms per frame)
     int conv_first_nt = 1;          // ISX_CONV_FIRST_NT: streaming stores for c0.conv0's 5.4 GB output per launch set (34.7 -> 31.5 ms per frame)
     int up_per_source = 1;          // ISX_UP_PER_SOURCE: 0 = the transposed convolutions one thread per OUTPUT voxel (rounds 1-2)

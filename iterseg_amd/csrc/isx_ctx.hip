@@ -154,7 +154,6 @@ static void read_knobs(isx_ctx *c)
     if (const char *e = getenv("ISX_UP_PER_SOURCE")) t.up_per_source = atoi(e);
     if (const char *e = getenv("ISX_CONV_FIRST_NT")) t.conv_first_nt = atoi(e);
     if (const char *e = getenv("ISX_H2_NT_OUT")) t.h2_nt_out = atoi(e);
-    if (const char *e = getenv("ISX_CONV_MT2_MIN_VOX")) t.mt2_min_vox = atol(e);
     c->tune = t;
     isx_flood_tune f;
     auto ll = [](const char *name, long long &dst) { if (const char *e = getenv(name)) dst = (long long)strtoull(e, nullptr, 10); };

@@ -1247,7 +1247,7 @@ static int dgrad(isx_ctx *ctx, int li, float *dst)
     TrainState *t = u->train;
     const ConvBN &L = u->cv[li];
     const Level &l = u->lv[MOD_LEVEL[layer_module(li)]];
-    if (u->precision == ISX_PRECISION_BF16 && t->wbf_dg[li] && t->dstride[li] == L.cout && conv_mt(ctx->tune, l, u->wbatch, L.cin) == 1) {
+    if (u->precision == ISX_PRECISION_BF16 && t->wbf_dg[li] && t->dstride[li] == L.cout) {
         // bf16 mixed precision: the same operator on the bf16 matrix cores (d(raw) is rounded to bf16 at the LDS store)
         return launch_conv_h2(ctx, l, 1, Src{t->draw[li], nullptr, nullptr, L.cout}, Src{nullptr, nullptr, nullptr, 0}, t->wbf_dg[li],
                               t->zeros, L.cin, dst, nullptr, nullptr, 1, ctx->tune.xcd_remap, nullptr, 2);
@@ -1493,7 +1493,6 @@ static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dic
     u->d_table = tab.p;
     ISX_TRY(forward_batch(ctx, 1, nullptr, nullptr, nullptr));
     // loss and its gradient with respect to the sigmoid output
-    const ConvBN &LL = u->cv[17];
     const int blocks = (int)((l0.M + 255) / 256);
     float hs[8] = {0};
     double total = 0.0;
@@ -1516,35 +1515,43 @@ static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dic
         }
         ISX_HIP(hipMemcpyAsync(hs, t->lossbuf, C * 4, hipMemcpyDeviceToHost, ctx->stream));
     } else {
-        ISX_REQUIRE(u->nforks == 1, "DiceLoss on a forked network is not built (BCE / MSE / channel-wise losses are)");
+        // every decoder's channels against their slice of the target, like the other losses; the reference applies ONE DiceLoss
+        // to the concatenated output (unet.py:322, custom_loss.py:24-53), so the mean runs over all C channels
         const int64_t plane = (int64_t)l0.H * l0.W;
         ISX_REQUIRE(plane % 256 == 0 && l0.D * 3 * C <= 2048, "internal: DiceLoss needs H*W %% 256 == 0");
-        ISX_REQUIRE((size_t)blocks * C * 3 <= t->part_floats, "internal: partial buffer too small");
-        dice_sums_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[17], LL.scale, LL.shift, y, C, l0.M, t->part);
-        ISX_CHECK_LAUNCH();
-        colsum_group_kernel<<<dim3(3 * C, l0.D), 256, 0, ctx->stream>>>(t->part, (int)(plane / 256), 3 * C, t->lossbuf + 128);
-        ISX_CHECK_LAUNCH();
-        std::vector<float> sums((size_t)l0.D * 3 * C);
-        ISX_HIP(hipMemcpyAsync(sums.data(), t->lossbuf + 128, sums.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        ISX_HIP(hipStreamSynchronize(ctx->stream));
-        DiceCoef k;
-        for (int c = 0; c < C; ++c) {
-            double I = 0, A = 0, Bq = 0, zlog = 0;
-            for (int z = 0; z < l0.D; ++z) {
-                const double i = sums[(size_t)z * 3 * C + 3 * c], a2 = sums[(size_t)z * 3 * C + 3 * c + 1],
-                             b2 = sums[(size_t)z * 3 * C + 3 * c + 2];
-                I += i; A += a2; Bq += b2;
-                zlog += 1.0 - (2.0 * i + 1.0) / (a2 + b2 + 1.0);
+        int c_off = 0;
+        for (int f = 0; f < u->nforks; ++f) {
+            const int lf = dec_layer(f, 3, 1);
+            const ConvBN &Lf = u->cv[lf];
+            const int Cf = Lf.cout;
+            ISX_REQUIRE((size_t)blocks * Cf * 3 <= t->part_floats, "internal: partial buffer too small");
+            dice_sums_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[lf], Lf.scale, Lf.shift, y + (int64_t)c_off * l0.M, Cf, l0.M, t->part);
+            ISX_CHECK_LAUNCH();
+            colsum_group_kernel<<<dim3(3 * Cf, l0.D), 256, 0, ctx->stream>>>(t->part, (int)(plane / 256), 3 * Cf, t->lossbuf + 128);
+            ISX_CHECK_LAUNCH();
+            std::vector<float> sums((size_t)l0.D * 3 * Cf);
+            ISX_HIP(hipMemcpyAsync(sums.data(), t->lossbuf + 128, sums.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+            ISX_HIP(hipStreamSynchronize(ctx->stream));
+            DiceCoef k;
+            for (int c = 0; c < Cf; ++c) {
+                double I = 0, A = 0, Bq = 0, zlog = 0;
+                for (int z = 0; z < l0.D; ++z) {
+                    const double i = sums[(size_t)z * 3 * Cf + 3 * c], a2 = sums[(size_t)z * 3 * Cf + 3 * c + 1],
+                                 b2 = sums[(size_t)z * 3 * Cf + 3 * c + 2];
+                    I += i; A += a2; Bq += b2;
+                    zlog += 1.0 - (2.0 * i + 1.0) / (a2 + b2 + 1.0);
+                }
+                const double S = A + Bq + 1.0;
+                total += (1.0 - (2.0 * I + 1.0) / S) / C;
+                k.ka[c] = (float)(-2.0 / (C * S));
+                k.kb[c] = (float)((2.0 * I + 1.0) / (C * S * S));
+                // the reference's per-channel log applies DiceLoss to (1, Z, Y, X): the z planes act as channels
+                hs[c_off + c] = (float)(zlog / l0.D);
             }
-            const double S = A + Bq + 1.0;
-            total += (1.0 - (2.0 * I + 1.0) / S) / C;
-            k.ka[c] = (float)(-2.0 / (C * S));
-            k.kb[c] = (float)((2.0 * I + 1.0) / (C * S * S));
-            // the reference's per-channel log applies DiceLoss to (1, Z, Y, X): the z planes act as channels
-            hs[c] = (float)(zlog / l0.D);
+            dice_grad_kernel<<<blocks, 256, 0, ctx->stream>>>(y + (int64_t)c_off * l0.M, Cf, l0.M, k, t->gact[lf]);
+            ISX_CHECK_LAUNCH();
+            c_off += Cf;
         }
-        dice_grad_kernel<<<blocks, 256, 0, ctx->stream>>>(y, C, l0.M, k, t->gact[17]);
-        ISX_CHECK_LAUNCH();
     }
     if (do_backward) {
         ISX_TRY(backward(ctx));

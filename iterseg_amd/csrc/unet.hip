@@ -1147,17 +1147,6 @@ int conv_mode(const Level &l)
     return (l.D % 2 == 0) ? 1 : 2;
 }
 
-// Two GEMM row tiles per wave (256 voxels per workgroup): halves the weight-slab staging per voxel and doubles the
-// MFMAs per LDS read, but runs at fewer waves per SIMD.  Measured on MI355X (scratch/layer_eff.py): 3 % slower for
-// the 64-column layers; for the 32-column layers +3 % at level 0 and -5 % at 129^2 (16-wide tiles pad more), a wash
-// end to end.  So it is off; ISX_CONV_MT2_MIN_VOX turns it on for launches above that many voxels.  Decided from
-// the workspace batch so that the partial-sum layout of a layer never changes.
-int conv_mt(const isx_tune &tune, const Level &l, int batch, int cout)
-{
-    (void)cout;
-    return ((int64_t)batch * l.M >= tune.mt2_min_vox) ? 2 : 1;
-}
-
 int conv_tiles(const Level &l, int mode, int mt, int *nty, int *ntx, int *ntp, int *slots)
 {
     if (mode == 0) {
@@ -1181,7 +1170,7 @@ static int layer_tiles(const UNetState *u, int li, const Level &l, int batch)
     const ConvBN &L = u->cv[li];
     if (use_mfma(L.cin, L.cout)) {
         int a, b, c, d;
-        return conv_tiles(l, conv_mode(l), conv_mt(u->tune, l, batch, L.cout > 8 ? L.cout : 32), &a, &b, &c, &d);
+        return conv_tiles(l, conv_mode(l), 1, &a, &b, &c, &d);
     }
     if (L.cin == 1) return (int)((l.M + 127) / 128);
     if (L.cin == 5 && L.cout == 5) return ((l.D + 1) / 2) * ((l.H + 7) / 8) * ((l.W + 15) / 16);     // conv55 tiles
@@ -1245,20 +1234,17 @@ int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const 
     a.w = w_packed; a.bias = bias; a.out = out; a.psum = psum; a.psq = psq;
     a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = cout;
     a.mode = conv_mode(l);
-    const int mt = conv_mt(ctx->tune, l, ctx->unet->wbatch, cout);
-    a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+    a.tiles_per_chunk = conv_tiles(l, a.mode, 1, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
     a.store_cols = cout;
     a.no_stats = no_stats;
     a.xcd_remap = ctx->tune.xcd_remap;
-    ISX_REQUIRE(a.slots_max <= (mt > 1 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
+    ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     ISX_REQUIRE(cout % 32 == 0 && (sa.C + sb.C) % 4 == 0, "internal: MFMA conv needs Cout %% 32 == 0, Cin %% 4 == 0");
     const int BN = (cout % 64 == 0) ? 64 : 32;
-    size_t lds = (size_t)(27 * 4 * BN + a.slots_max * A_STRIDE + 128 * mt + 4 * BN * 2) * sizeof(float);
+    size_t lds = (size_t)(27 * 4 * BN + a.slots_max * A_STRIDE + 128 + 4 * BN * 2) * sizeof(float);
     a.ntiles = cout / BN;
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
-    if (BN == 64 && mt == 2) conv_mfma_kernel<64, 3, 2><<<grid, 256, lds, ctx->stream>>>(a);
-    else if (BN == 64) conv_mfma_kernel<64, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
-    else if (mt == 2) conv_mfma_kernel<32, 3, 2><<<grid, 256, lds, ctx->stream>>>(a);
+    if (BN == 64) conv_mfma_kernel<64, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
     else conv_mfma_kernel<32, 3, 1><<<grid, 256, lds, ctx->stream>>>(a);
     ISX_CHECK_LAUNCH();
     return ISX_OK;
@@ -1277,9 +1263,9 @@ static bool conv_takes_h2(isx_ctx *ctx, int li, const Level &l, int B, float bou
         conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
         const bool b64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64 || conv_h2_nw8(ctx->tune, l, L.cout, B);
         const void *wh = bf ? (b64 ? L.w_bf_64 : L.w_bf_32) : (b64 ? L.w_h2_64 : L.w_h2_32);
-        return (!u->train || bf) && wh && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1;
+        return (!u->train || bf) && wh;
     }
-    if (use_fold(L.cin, L.cout)) return !u->train && (bf ? L.w_bf_32 : L.w_h2_32) && conv_mt(ctx->tune, l, u->wbatch, 32) == 1;
+    if (use_fold(L.cin, L.cout)) return !u->train && (bf ? L.w_bf_32 : L.w_h2_32);
     return false;
 }
 
@@ -1304,7 +1290,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         // training keeps fp32 products except in the bf16 mixed-precision mode (its packs are refreshed every step)
         const bool reduced = u->precision != ISX_PRECISION_FP32 && (!u->train || bf);
         const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
-        const bool h2 = reduced && wh && in_range && conv_mt(ctx->tune, l, u->wbatch, L.cout) == 1;
+        const bool h2 = reduced && wh && in_range;
         u->arith[li] = h2 ? ISX_ARITH_REDUCED : (reduced && wh && !in_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
         ISX_REQUIRE(h2 || !(sa.planar || sb.planar), "internal: a planar source reached a convolution that does not read it");
         if (h2) {
@@ -1319,7 +1305,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         const void *wf = bf ? L.w_bf_32 : L.w_h2_32;
         const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);
         const bool fold_range = bf || std::max(sa.bound, sb.bound) < 6.0e4f;
-        const bool fold_h2 = u->precision != ISX_PRECISION_FP32 && !u->train && wf && fold_range && conv_mt(ctx->tune, l, u->wbatch, 32) == 1;
+        const bool fold_h2 = u->precision != ISX_PRECISION_FP32 && !u->train && wf && fold_range;
         u->arith[li] = fold_h2 ? ISX_ARITH_REDUCED
                                : (u->precision != ISX_PRECISION_FP32 && !u->train && wf && !fold_range ? ISX_ARITH_FP32_RANGE_FALLBACK : ISX_ARITH_FP32);
         ISX_REQUIRE(fold_h2 || !ex, "internal: up-sampling on read needs the reduced-precision tail kernel");
@@ -1337,17 +1323,15 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
             a.w = L.w; a.bias = u->zeros32; a.out = u->ptail; a.psum = nullptr; a.psq = nullptr;
             a.D = l.D; a.H = l.H; a.W = l.W; a.Cout = 32;
             a.mode = conv_mode(l);
-            const int mt = conv_mt(ctx->tune, l, u->wbatch, 32);
-            a.tiles_per_chunk = conv_tiles(l, a.mode, mt, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
+            a.tiles_per_chunk = conv_tiles(l, a.mode, 1, &a.nty, &a.ntx, &a.ntp, &a.slots_max);
             a.store_cols = 16;
             a.no_stats = 1;
             a.xcd_remap = ctx->tune.xcd_remap;
-            ISX_REQUIRE(a.slots_max <= (mt > 1 ? 1280 : 1024), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
-            size_t lds = (size_t)(9 * 4 * 32 + a.slots_max * A_STRIDE + 128 * mt + 4 * 32 * 2) * sizeof(float);
+            ISX_REQUIRE(a.slots_max <= 1024, "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
+            size_t lds = (size_t)(9 * 4 * 32 + a.slots_max * A_STRIDE + 128 + 4 * 32 * 2) * sizeof(float);
             a.ntiles = 1;
             const unsigned grid = (unsigned)(B * a.tiles_per_chunk);
-            if (mt == 2) conv_mfma_kernel<32, 1, 2><<<grid, 256, lds, ctx->stream>>>(a);
-            else conv_mfma_kernel<32, 1, 1><<<grid, 256, lds, ctx->stream>>>(a);
+            conv_mfma_kernel<32, 1, 1><<<grid, 256, lds, ctx->stream>>>(a);
             ISX_CHECK_LAUNCH();
         }
         // pass 2: shifted combine + bias + BN partial sums
@@ -1487,7 +1471,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                 const bool on_read = ctx->tune.tail_up && U.kz == 1 && U.C % 8 == 0 && U.C <= 64 &&
                                      use_fold(L0.cin, L0.cout) && !u->train &&
                                      u->precision != ISX_PRECISION_FP32 && (bf ? L0.w_bf_32 : L0.w_h2_32) &&
-                                     (bf || std::max(bnd, bn_bound(skipf)) < 6.0e4f) && conv_mt(ctx->tune, lo, u->wbatch, 32) == 1;
+                                     (bf || std::max(bnd, bn_bound(skipf)) < 6.0e4f);
                 if (on_read) {
                     H2Extra ex;
                     ex.upA = 1; ex.uH = ls.H; ex.uW = ls.W; ex.uoff = k == 3 ? 1 : 0; ex.upw = U.w; ex.upb = U.bias;

@@ -129,7 +129,6 @@ extern const char *UPS[4];
 bool use_mfma(int cin, int cout);
 bool use_fold(int cin, int cout);
 int conv_mode(const Level &l);
-int conv_mt(const isx_tune &tune, const Level &l, int batch, int cout);
 int conv_tiles(const Level &l, int mode, int mt, int *nty, int *ntx, int *ntp, int *slots);
 // raw launch of the MFMA conv (no BN finalize): used by the forward and by dgrad
 int launch_conv_mfma(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const float *w_packed, const float *bias,

@@ -226,8 +226,6 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
         fork_channels = tuple(int(c) for c in fork_channels)
         if sum(fork_channels) != n_out:
             raise ValueError(f"fork_channels {fork_channels} do not add up to the {n_out} target channels")
-        if loss_function == 'DiceLoss':
-            raise NotImplementedError("DiceLoss on a forked network is not built (BCELoss, WeightedBCE, Channelwise are)")
     trainer = Trainer(sd, out_channels=fork_channels if fork_channels is not None else n_out, patch=patch,
                       seed=kwargs.get('seed', 0), chan_final_activations=chan_final_activations, precision=precision)
     cwise = channelwise_spec(losses, chan_losses, n_out) if loss_function == 'Channelwise' else None

@@ -526,6 +526,34 @@ def test_forked_against_oracle_float64_and_channelwise_loss():
         assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, (k, np.abs(got - ref).max(), np.abs(ref).max())
 
 
+def test_forked_dice_loss_against_oracle_float64():
+    """DiceLoss on a forked network (custom_loss.py:24-53 over the concatenated output of the forks, unet.py:322): loss, the
+    per-channel log and the gradients of every parameter tensor against the float64 autograd of the torch-CPU oracle (whose
+    DiceLoss restatement is pinned by the reference's own values, tests/golden/losses_4x32x32.npz)."""
+    from iterseg_amd import weights
+    from iterseg_amd.train import Trainer
+    from oracle import unet_torch as ou
+    from tests.synth import positive_volume
+    forks, patch = (3, 2), (4, 32, 32)
+    sd = weights.generate_state_dict(8, 1, forks)
+    rng = np.random.default_rng(4)
+    x = positive_volume(patch, 3)
+    y = (rng.random((5,) + patch) < 0.4).astype(np.float32)
+    t = Trainer(sd, out_channels=forks, patch=patch)
+    loss, chan = t._call(x, y, "DiceLoss", None, 0.01, 0, True)
+    p = ou._as_params(sd, requires_grad=True, dtype=torch.float64)
+    yh = ou.unet_forward(p, torch.from_numpy(x)[None, None].double())
+    yy = torch.from_numpy(y)[None].double()
+    ref_loss = ou.loss_fn("DiceLoss", yh, yy)
+    ref_loss.backward()
+    assert abs(loss - float(ref_loss)) < 1e-5
+    assert np.abs(np.asarray(chan) - np.asarray(ou.channel_log("DiceLoss", yh, yy))).max() < 1e-5
+    for k, shape, off in t.layout:
+        ref = p[k].grad.numpy()
+        got = t.grad(k).detach().cpu().numpy().astype(np.float64)
+        assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, (k, np.abs(got - ref).max(), np.abs(ref).max())
+
+
 def test_train_unet_with_fork_channels(tmp_path):
     from iterseg_amd import train
     from iterseg_amd.unet import UNet
