@@ -155,11 +155,14 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     int PS, RS, S;
     int z0, y0 = 0, x0 = 0, p0 = 0, qlo = 0, TZ, TP = 0;
     const int WP = W + 2;
+    // mode 0: the halo box is (2 + 2) x (8 + 2) x (TXW + 2) slots -- compile-time strides (the divisions of the per-slot index
+    // arithmetic below by run-time strides were ~1 000 vector instructions per wave: as much as a K stage's staging)
+    constexpr int RS0 = TXW + 2, PS0 = 10 * RS0;
     if (a.mode == 0) {
         const int nzt = (D + 1) >> 1;
         int zt = tile % nzt, xt = (tile / nzt) % a.ntx, yt = tile / (nzt * a.ntx);
         z0 = zt * 2; y0 = yt * 8; x0 = xt * TXW; TZ = 2;
-        RS = TXW + 2; PS = 10 * RS; S = 4 * PS;
+        RS = RS0; PS = PS0; S = 4 * PS0;
     } else {
         TZ = (a.mode == 1) ? 2 : 1;
         TP = ROWS / TZ;
@@ -191,7 +194,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     auto row_slot = [&](int r) __attribute__((always_inline)) -> int {
         if (a.mode == 0) {
             int zz = r / (8 * TXW), yy = (r / TXW) & 7, xx = r % TXW;
-            return (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
+            return (zz + 1) * PS0 + (yy + 1) * RS0 + (xx + 1);
         }
         int zz = r / TP, p = p0 + r % TP;
         if (p > H * W - 1) p = H * W - 1;
@@ -208,7 +211,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if (s >= S) return -2;
         int z, y, x;
         if (a.mode == 0) {
-            int hz = s / PS, hy = (s / RS) % 10, hx = s % RS;
+            int hz = s / PS0, hy = (s / RS0) % 10, hx = s % RS0;
             z = z0 + hz - 1; y = y0 + hy - 1; x = x0 + hx - 1;
         } else {
             int hz = s / PS, qq = qlo + s % PS + WP;
@@ -249,7 +252,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     const int wbase = __builtin_amdgcn_readfirstlane(tid) & ~63;
 #define H2_LOAD_A(k)                                                                              \
     if constexpr (k < NA && ISX_H2_ABLATE != 3) if (THREADS * k + wbase < S) {                    \
-        const float *pp = &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];                       \
+        /* 32-bit element offset from the stage's (wave-uniform) base: one multiply, then a scalar-base load */ \
+        const float *pp = ld_src + (uint32_t)(gv##k > 0 ? gv##k : 0) * (uint32_t)ld_C;           \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }

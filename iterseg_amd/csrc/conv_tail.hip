@@ -212,7 +212,7 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 #define TL_LOAD_A(k)                                                                              \
     if (ABL != 3 && (k < 5 || wave == 0)) {                                                       \
         const int gl_ = (UP && stage_up) ? (gus[tid + TL_THREADS * k] & 0x0FFFFFFF) : gvs[tid + TL_THREADS * k]; \
-        const float *pp = &ld_src[(int64_t)(gl_ > 0 ? gl_ : 0) * ld_C];                           \
+        const float *pp = ld_src + (uint32_t)(gl_ > 0 ? gl_ : 0) * (uint32_t)ld_C;                \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }

@@ -85,7 +85,7 @@ __global__ void gather_chunks_kernel(const float *__restrict__ vol, int64_t Y, i
 __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x0, const float *__restrict__ w,
                                                          const float *__restrict__ bias, int D, int H, int W,
                                                          float *__restrict__ out, float *__restrict__ psum,
-                                                         float *__restrict__ psq, int blocks_per_chunk, int nt_store)
+                                                         float *__restrict__ psq, int blocks_per_chunk, int nt_store, int planar)
 {
     __shared__ float red[4][32][2];
     const int b = blockIdx.x / blocks_per_chunk, blk = blockIdx.x % blocks_per_chunk;
@@ -128,12 +128,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int f = lane + 64 * k, row = f >> 3, c4 = f & 7;
+        // row-major: store k = rows 8 k .. 8 k + 7, all 32 channels; planar ([chunk][4 planes][voxel][8], UNetState::planar):
+        // store k = plane k, all 32 rows -- 1 KB contiguous either way
+        const int f = lane + 64 * k;
+        const int row = planar ? lane >> 1 : f >> 3, c4 = planar ? 2 * k + (lane & 1) : f & 7;
         if (m0 + row < M) {
             const float4 tv = *(const float4 *)&T[wave][row * 36 + 4 * c4];
             f32x4 tn = {tv.x, tv.y, tv.z, tv.w};
-            if (nt_store) __builtin_nontemporal_store(tn, (f32x4 *)&out[((int64_t)b * M + m0 + row) * 32 + 4 * c4]);
-            else *(float4 *)&out[((int64_t)b * M + m0 + row) * 32 + 4 * c4] = tv;
+            float *op = planar ? &out[(((int64_t)b * 4 + k) * M + m0 + row) * 8 + 4 * (lane & 1)] : &out[((int64_t)b * M + m0 + row) * 32 + 4 * c4];
+            if (nt_store) __builtin_nontemporal_store(tn, (f32x4 *)op);
+            else *(float4 *)op = tv;
         }
     }
     s += __shfl_xor(s, 32);
@@ -561,17 +565,26 @@ __global__ void pool_planar_kernel(const float *__restrict__ src, const float *_
 __global__ void upsample_kernel(const float *__restrict__ src, const float *__restrict__ scale,
                                 const float *__restrict__ shift, int C, int D, int H, int W, int kz, int off,
                                 const float *__restrict__ w, const float *__restrict__ bias, int Do, int Ho, int Wo,
-                                float *__restrict__ dst, int64_t total, int nt_store)
+                                float *__restrict__ dst, int64_t total, int nt_store, int src_planar, int dst_planar)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;       // 32-bit index arithmetic (see pool_kernel)
     if (i >= (uint32_t)total) return;
     const uint32_t CG = (uint32_t)C / (4 * G);
-    const int c0 = (int)(i % CG) * 4 * G;
-    const uint32_t v = i / CG;
     const uint32_t Mo32 = (uint32_t)Do * Ho * Wo;
     const int64_t Mo = Mo32, M = (int64_t)D * H * W;
-    const int b = (int)(v / Mo32);
-    const uint32_t m = v % Mo32;
+    int c0, b;
+    uint32_t m;
+    if (dst_planar) {                  // thread = (chunk, 8-channel plane, output voxel, half plane): consecutive lanes, consecutive memory
+        const uint32_t v = i >> 1, pl = (v / Mo32) % (CG >> 1);
+        c0 = (int)(pl * 8 + (i & 1) * 4);
+        m = v % Mo32;
+        b = (int)(v / (Mo32 * (CG >> 1)));
+    } else {
+        c0 = (int)(i % CG) * 4 * G;
+        const uint32_t v = i / CG;
+        b = (int)(v / Mo32);
+        m = v % Mo32;
+    }
     const int x = (int)(m % (uint32_t)Wo), y = (int)((m / (uint32_t)Wo) % (uint32_t)Ho), z = (int)(m / ((uint32_t)Wo * Ho));
     int zs = z / kz, ys = (y + off) >> 1, xs = (x + off) >> 1;
     int kidx = ((z % kz) * 2 + ((y + off) & 1)) * 2 + ((x + off) & 1);
@@ -580,7 +593,9 @@ __global__ void upsample_kernel(const float *__restrict__ src, const float *__re
     for (int g = 0; g < G; ++g) {
         const float4 vs = *(const float4 *)&scale[(int64_t)b * C + c0 + 4 * g];
         const float4 vh = *(const float4 *)&shift[(int64_t)b * C + c0 + 4 * g];
-        float4 t = *(const float4 *)&src[((int64_t)b * M + ((int64_t)zs * H + ys) * W + xs) * C + c0 + 4 * g];
+        const int64_t ms = ((int64_t)zs * H + ys) * W + xs;
+        float4 t = src_planar ? *(const float4 *)&src[(((int64_t)b * (C >> 3) + (c0 >> 3)) * M + ms) * 8 + (c0 & 7) + 4 * g]
+                              : *(const float4 *)&src[((int64_t)b * M + ms) * C + c0 + 4 * g];
         const float4 wv = *(const float4 *)&w[(int64_t)kidx * C + c0 + 4 * g];
         const float4 bv = *(const float4 *)&bias[c0 + 4 * g];
         t.x = fmaf(fmaxf(fmaf(t.x, vs.x, vh.x), 0.f), wv.x, bv.x);
@@ -589,7 +604,8 @@ __global__ void upsample_kernel(const float *__restrict__ src, const float *__re
         t.w = fmaf(fmaxf(fmaf(t.w, vs.w, vh.w), 0.f), wv.w, bv.w);
         o[g] = t;
     }
-    put_channels(&dst[((int64_t)b * Mo + m) * C + c0], o, nt_store != 0);
+    float *dp = dst_planar ? &dst[(((int64_t)b * (C >> 3) + (c0 >> 3)) * Mo + m) * 8 + (c0 & 7)] : &dst[((int64_t)b * Mo + m) * C + c0];
+    put_channels(dp, o, nt_store != 0);
 }
 
 // The same operator per SOURCE voxel (kz = 1): one load and one BatchNorm + ReLU feed the four outputs a coarse voxel
@@ -1352,8 +1368,9 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
     } else if (L.cin == 1) {
         ProfScope ps(ctx, ISX_PROF_CONV_DIRECT);
         ISX_REQUIRE(L.cout == 32 && !sa.scale, "internal: conv_first shape");
+        u->planar[li] = want_planar;                   // (its only reader is the module's second convolution: planar_ok)
         conv_first_kernel<<<(unsigned)(B * L.tiles), 256, 0, ctx->stream>>>(sa.p, L.w, L.bias, l.D, l.H, l.W, u->raw[li],
-                                                                           L.psum, L.psq, L.tiles, ctx->tune.conv_first_nt);
+                                                                           L.psum, L.psq, L.tiles, ctx->tune.conv_first_nt, want_planar ? 1 : 0);
         ISX_CHECK_LAUNCH();
     } else {
         ProfScope ps(ctx, ISX_PROF_CONV_DIRECT);
@@ -1491,8 +1508,12 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                 ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
                 const int64_t total_src = (int64_t)B * ls.M * (U.C / 4);
                 const bool per_src = U.kz == 1 && ctx->tune.up_per_source && total_src < (int64_t)0xFFFFFFFFll;
-                ISX_REQUIRE(per_src || !u->planar[li_in], "internal: a planar tensor reached the per-output transposed convolution");
-                u->ups_planar[ups_index(f, k)] = u->planar[li_in];       // (up_planar_ok has checked the reader of the up-sampled tensor)
+                // up1..up3 (per source voxel): planar out iff planar in (the producing convolution checked the reader of the
+                // up-sampled tensor); up0 (kz = 2, per output voxel): planar out whenever its reader takes one
+                bool up0_planar = !per_src && ctx->tune.planar >= 2 && !u->train && U.C % 8 == 0;
+                for (int ff = 0; ff < u->nforks && up0_planar; ++ff)         // (up0's tensor is shared by the forks)
+                    up0_planar = conv_takes_h2(ctx, dec_layer(ff, k, 0), lo, B, std::max(up_bound, bn_bound(skip_li)));
+                u->ups_planar[ups_index(f, k)] = per_src ? u->planar[li_in] : up0_planar;
                 if (per_src && u->planar[li_in]) {
                     const int64_t total_pl = (int64_t)B * (U.C / 8) * ls.D * ls.H * lo.W * 2;
                     ISX_REQUIRE(total_pl < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
@@ -1504,7 +1525,8 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                 else
                 upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D,
                                                                         ls.H, ls.W, U.kz, k == 3 ? 1 : 0, U.w, U.bias, lo.D,
-                                                                        lo.H, lo.W, upo, total, 1 /* streaming stores: the 5.4 GB output is far larger than L2 */);
+                                                                        lo.H, lo.W, upo, total, 1 /* streaming stores: the 5.4 GB output is far larger than L2 */,
+                                                                        u->planar[li_in] ? 1 : 0, u->ups_planar[ups_index(f, k)] ? 1 : 0);
                 ISX_CHECK_LAUNCH();
             }
             ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound, u->ups_planar[ups_index(f, k)]}, act(skip_li), nullptr, planar_ok(l1, lo, l0)));
@@ -1751,7 +1773,7 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
                     tap_planar = true;
                 } else
                 upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz,
-                                                                           k == 3 ? 1 : 0, U.w, U.bias, lo.D, lo.H, lo.W, u->ups[k], total, 0);
+                                                                           k == 3 ? 1 : 0, U.w, U.bias, lo.D, lo.H, lo.W, u->ups[k], total, 0, 0, 0);
                 ISX_CHECK_LAUNCH();
             }
         }
