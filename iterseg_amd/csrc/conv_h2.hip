@@ -23,7 +23,7 @@
 // store) and reused by all 27 taps together with the stage's weight slab; v_mfma_f32_16x16x32_f16 takes k = 8 * (lane / 16)
 // + channel, so the four 16-lane groups of a wave feed four taps: 28 tap slots = 7 tap quads (the 28th tap has zero weights).
 // The matrix phase is software-pipelined by hand, the next stage's halo loads go out between its matrix instructions, the
-// output tile leaves through LDS as whole rows, the grid is 1-D and XCD-aware (DESIGN.md section 4 has the measurements
+// output tile leaves through LDS as whole rows, the grid is 1-D and XCD-aware (LOG.md has the measurements
 // behind each of these).  Three kernels share the body:
 //   conv_h2c16_kernel<BN, MT, PM>   4 waves, weight slab through registers; BN = 64 (two work-groups per CU where they fit) or
 //                                   32 columns with MT = 2 row tiles per wave (the Cout = 32 layers);
@@ -374,7 +374,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             // of step s are issued, and one of the next stage's global loads goes out per step.  The compiler's own schedule
             // read every fragment right before its use (its register budget is spent on the prefetched stage) and issued the
             // 24 global loads back to back before the first matrix instruction: 2 100-2 800 cycles per stage waiting for room
-            // in the load queue with the matrix pipe idle (ISX_H2_STAMP build).
+            // in the load queue with the matrix pipe idle (ISX_H2_STAMP build, LOG.md round 3).
             union FR { uint4 u; f16x8 v; bf16x8 w; };
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
