@@ -360,34 +360,21 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         pub_info[tid] = 0u; pub_res[tid] = 0xFFFFFFFFu; pub_mx[tid] = 0u;      // "not started" is what the commit phase must see
     };
     // every deferred entry (below the bound, unpopped, only in the list) sorts after every register candidate
-    // (Round 4: rewritten with selects -- no early returns, so that the compiler keeps `ncand` / `ndef` in registers instead of
-    // merging the two increments into one store through a selected scratch pointer -- the kernel tripped its own guard (site 3:
-    // an active episode whose current voxel is not a voxel) in 2 of 6 runs of the group-* stress modes; this form passed 16 of
-    // 16 on the same box.  The two forms are the same function of (ncand, ndef, ck), so the difference is timing or code
-    // generation and the hazard it exposes has not been found: DESIGN.md section 5.  The form stays.)
+    // (written with selects: with an early-return form the compiler merged `++ncand` / `++ndef` into one store through a selected
+    // pointer and kept both counters in scratch memory -- two scratch loads and a store per discovery in the claim loop)
     auto cand_add = [&](uint32_t v, int li, int ad) {
         const unsigned long long nk_ = ((unsigned long long)v << 32) | ((unsigned long long)(uint32_t)li << 16) | (unsigned long long)(uint32_t)ad;
-        if (ndef == 0 && ncand < GRP_CMAX) {
-#pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) ck[k] = nk_;
-            ++ncand;
-            return;
-        }
         int mk = -1; unsigned long long mv = 0ull;
 #pragma unroll
         for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand && (mk < 0 || ck[k] > mv)) { mk = k; mv = ck[k]; }
         const bool below_max = mk >= 0 && nk_ < mv;
-        if (ncand < GRP_CMAX && below_max) {
+        const bool add = ncand < GRP_CMAX && (ndef == 0 || below_max);      // a free register: behind no deferred entry, or below the largest candidate
+        const bool repl = ncand == GRP_CMAX && below_max;                   // full: the largest candidate becomes a deferred entry
+        const int at = add ? ncand : (repl ? mk : -1);
 #pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand) ck[k] = nk_;
-            ++ncand;
-            return;
-        }
-        if (ncand == GRP_CMAX && below_max) {
-#pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) ck[k] = nk_;
-        }
-        ++ndef;
+        for (int k = 0; k < GRP_CMAX; ++k) ck[k] = (k == at) ? nk_ : ck[k];
+        ncand += add ? 1 : 0;
+        ndef += add ? 0 : 1;
     };
     // The candidates of lane L's episode rebuilt from its list by the WHOLE wave (three entries per lane): candidates,
     // deferred count and the minimum of the residuals.  Runs when the six registers are used up and discoveries below
@@ -797,7 +784,12 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         if (tid == frontslot && has && started && cur == GRP_NONE) shI[GI_READY] = 1;
         GTICK(0);
         for (int step = 0; step < (kmax & 0xFF); ++step) {
-            if (step >= kmin && shI[GI_READY]) break;                           // wave-uniform (one LDS word)
+            // The exit must be taken by the WHOLE wave: other waves set GI_READY while this loop runs, and a plain per-lane read is
+            // only uniform if every lane reads it in the same instruction -- the compiler is free to duplicate the read into the
+            // two arms of `if (active)` below, lanes then see the flag at different times, some leave and the rest go on under a
+            // partial EXEC mask, where the DPP scans of coop_reload read lane 63's stale register (round 4: the group-* stress
+            // modes tripped guard site 3 in 3 of 8 runs with one code generation, 0 of 24 with others).  One lane's value for all:
+            if (step >= kmin && __builtin_amdgcn_readfirstlane(shI[GI_READY])) break;
             bool active = false;
             if (has && cur != GRP_NONE) {
                 bool room = true, need = false;
@@ -838,7 +830,11 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 for (int k = 0; k < 6; ++k) {
                     nbv[k] = cur + (uint32_t)noff32[k];
                     old[k] = 0ull; val[k] = 0.0f;
-                    if (cur >= (uint32_t)PN && stats) { atomicAdd(&stats[20], 1ull); stats[21] = 3ull; }
+                    if (cur >= (uint32_t)PN && stats) {
+                        if (atomicAdd(&stats[20], 1ull) == 0ull) {
+                            stats[21] = 3ull;
+                        }
+                    }
                     if (nbv[k] < (uint32_t)PN && cur < (uint32_t)PN) {
                         old[k] = __hip_atomic_fetch_min(&state[nbv[k]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         val[k] = (aff + (int64_t)ax[k] * PN)[k < 3 ? cur : nbv[k]];
