@@ -155,14 +155,17 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     int PS, RS, S;
     int z0, y0 = 0, x0 = 0, p0 = 0, qlo = 0, TZ, TP = 0;
     const int WP = W + 2;
-    // mode 0: the halo box is (2 + 2) x (8 + 2) x (TXW + 2) slots -- compile-time strides (the divisions of the per-slot index
-    // arithmetic below by run-time strides were ~1 000 vector instructions per wave: as much as a K stage's staging)
-    constexpr int RS0 = TXW + 2, PS0 = 10 * RS0;
+    // mode 0: a box of 2 x TYb x TXb voxels (2 TYb TXb <= ROWS) on a halo of 4 x (TYb + 2) x (TXb + 2) slots: the interior boxes are
+    // 8 x TXW, the edge strips (ConvArgs::sr_*, sb_*) tall and narrow / flat and wide
+    int TYb = 8, TXb = TXW, xlim = W;                            // xlim: the last bottom-strip box stops where the right strip begins
     if (a.mode == 0) {
         const int nzt = (D + 1) >> 1;
-        int zt = tile % nzt, xt = (tile / nzt) % a.ntx, yt = tile / (nzt * a.ntx);
-        z0 = zt * 2; y0 = yt * 8; x0 = xt * TXW; TZ = 2;
-        RS = RS0; PS = PS0; S = 4 * PS0;
+        const int zt = tile % nzt, rest = tile / nzt;
+        z0 = zt * 2; TZ = 2;
+        if (rest < a.nI) { y0 = (rest / a.ntx) * 8; x0 = (rest % a.ntx) * TXW; }
+        else if (rest < a.nI + a.sr_n) { TYb = a.sr_ty; TXb = a.sr_tx; y0 = (rest - a.nI) * a.sr_ty; x0 = a.sr_x0; }
+        else { TYb = a.sb_ty; TXb = a.sb_tx; y0 = a.sb_y0; x0 = (rest - a.nI - a.sr_n) * a.sb_tx; if (a.sr_n) xlim = a.sr_x0; }
+        RS = TXb + 2; PS = (TYb + 2) * RS; S = 4 * PS;
     } else {
         TZ = (a.mode == 1) ? 2 : 1;
         TP = ROWS / TZ;
@@ -181,9 +184,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     if (tid < ROWS) {
         int r = tid, g = -1;
         if (a.mode == 0) {
-            int zz = r / (8 * TXW), yy = (r / TXW) & 7, xx = r % TXW;
+            int zz = r / (TYb * TXb), yy = (r / TXb) % TYb, xx = r % TXb;
             int z = z0 + zz, y = y0 + yy, x = x0 + xx;
-            if (z < D && y < H && x < W) g = (z * H + y) * W + x;
+            if (zz < 2 && z < D && y < H && x < xlim) g = (z * H + y) * W + x;
         } else {
             int zz = r / TP, p = p0 + r % TP;
             int z = z0 + zz;
@@ -193,8 +196,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     }
     auto row_slot = [&](int r) __attribute__((always_inline)) -> int {
         if (a.mode == 0) {
-            int zz = r / (8 * TXW), yy = (r / TXW) & 7, xx = r % TXW;
-            return (zz + 1) * PS0 + (yy + 1) * RS0 + (xx + 1);
+            int zz = r / (TYb * TXb), yy = (r / TXb) % TYb, xx = r % TXb;
+            if (zz > 1) { zz = 1; yy = TYb - 1; xx = TXb - 1; }          // rows beyond the box (strips: 2 TYb TXb < ROWS): any valid slot
+            return (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
         }
         int zz = r / TP, p = p0 + r % TP;
         if (p > H * W - 1) p = H * W - 1;
@@ -211,7 +215,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if (s >= S) return -2;
         int z, y, x;
         if (a.mode == 0) {
-            int hz = s / PS0, hy = (s / RS0) % 10, hx = s % RS0;
+            int hz = s / PS, hy = (s / RS) % (TYb + 2), hx = s % RS;
             z = z0 + hz - 1; y = y0 + hy - 1; x = x0 + hx - 1;
         } else {
             int hz = s / PS, qq = qlo + s % PS + WP;
@@ -705,6 +709,32 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         const int tiles2 = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
         if (sl <= 1280) { a.tiles_per_chunk = tiles2; a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl; }
         else mt = 1;                   // very narrow levels: the 256-position halo does not fit the staging plan
+    }
+    if (a.mode == 0) {
+        // box tiles: interior boxes of 8 x TXW voxels, and edge strips where the remainders of H / W make them cheaper than padded
+        // boxes (129 = 128 + 1: 25 padded boxes per plane pair against 3 strips)
+        const int rows = nw8 ? 256 : 128 * mt, txw = rows / 16, cap = a.slots_max;      // strips never grow the LDS footprint of the launch
+        const int ny = l.H / 8, ry = l.H % 8, nx = l.W / txw, rx = l.W % txw;
+        const int nyp = (l.H + 7) / 8, nxp = (l.W + txw - 1) / txw;
+        a.ntx = nxp; a.nI = nyp * nxp; a.sr_n = a.sb_n = 0;
+        a.sr_ty = a.sr_tx = a.sr_x0 = a.sb_ty = a.sb_tx = a.sb_y0 = 0;
+        if ((ry || rx) && ny > 0 && nx > 0 && ctx->tune.h2_strips) {
+            // right strip: rx columns, all H rows; bottom strip: ry rows, the interior columns
+            int sr_ty = 0, sr_n = 0, sb_tx = 0, sb_n = 0;
+            if (rx) { sr_ty = std::min(rows / (2 * rx), cap / (4 * (rx + 2)) - 2); sr_ty = std::min(sr_ty, l.H); if (sr_ty >= 1) sr_n = (l.H + sr_ty - 1) / sr_ty; }
+            if (ry) { sb_tx = std::min(rows / (2 * ry), cap / (4 * (ry + 2)) - 2); sb_tx = std::min(sb_tx, nx * txw); if (sb_tx >= 1) sb_n = (nx * txw + sb_tx - 1) / sb_tx; }
+            const bool ok = (!rx || sr_n > 0) && (!ry || sb_n > 0);
+            // without a right strip the bottom strip spans the padded interior columns; without a bottom strip the interior rows are padded
+            const int ny_i = ry && sb_n ? ny : nyp, nx_i = rx && sr_n ? nx : nxp;
+            if (ry && sb_n && !(rx && sr_n)) { sb_tx = std::min(sb_tx, l.W); sb_n = (l.W + sb_tx - 1) / sb_tx; }
+            if (ok && ny_i * nx_i + sr_n + sb_n < nyp * nxp) {
+                a.ntx = nx_i; a.nI = ny_i * nx_i;
+                if (rx && sr_n) { a.sr_n = sr_n; a.sr_ty = sr_ty; a.sr_tx = rx; a.sr_x0 = nx * txw; }
+                if (ry && sb_n) { a.sb_n = sb_n; a.sb_ty = ry; a.sb_tx = sb_tx; a.sb_y0 = ny * 8; }
+                a.slots_max = std::max(a.slots_max, std::max(a.sr_n ? 4 * (a.sr_ty + 2) * (a.sr_tx + 2) : 0, a.sb_n ? 4 * (a.sb_ty + 2) * (a.sb_tx + 2) : 0));
+            }
+        }
+        a.tiles_per_chunk = ((l.D + 1) / 2) * (a.nI + a.sr_n + a.sb_n);
     }
     ISX_REQUIRE(a.slots_max <= (nw8 ? 1536 : (mt == 2 ? 1280 : 1024)), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     // N-tile pairs (conv_h2c16nw8x2_kernel): Cout % 128 == 0 and a launch that still fills the chip

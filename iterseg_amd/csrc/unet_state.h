@@ -115,6 +115,11 @@ struct ConvArgs {
     // planar tensors: [chunk][C / 8][voxel][8 channels] instead of [chunk][voxel][C] -- a K stage's 32 bytes of consecutive voxels
     // are contiguous, so a halo load instruction reads whole lines instead of 64 pieces of 16 bytes (UNetState::planar)
     int planarA, planarB, out_planar;
+    // conv_h2 kernels, mode 0: box tiles.  A plane pair is covered by nI interior boxes of 8 x TXW voxels (ntx per row) plus,
+    // where H or W leave a remainder the launcher found cheaper to cover this way than by padded interior boxes, sr_n boxes of
+    // sr_ty x sr_tx voxels down the right edge (x0 = sr_x0, all y) and sb_n boxes of sb_ty x sb_tx along the bottom edge
+    // (y0 = sb_y0, x < sr_x0): at 129^2 a padded tiling spends 17.7 % of its matrix work on the "+1" row and column
+    int nI, sr_n, sr_ty, sr_tx, sr_x0, sb_n, sb_ty, sb_tx, sb_y0;
 };
 
 struct H2Extra {           // the tail kernel's optional source: up3 up-sampled on read (conv_tail.hip, TailArgs)

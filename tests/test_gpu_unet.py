@@ -377,3 +377,31 @@ def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
             assert np.abs(ta - tb).max() <= 2e-5 * max(1.0, np.abs(tb).max()), name
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nw8", ["1", "2", "0"])
+@pytest.mark.parametrize("precision", ["split-f16", "bf16"])
+def test_edge_strip_tiles_change_only_the_statistics_rounding(precision, nw8, monkeypatch):
+    """ISX_H2_STRIPS (default 1): where H or W of a box-tiled level leave a remainder (129 = 8 * 16 + 1), the remainder is
+    covered by tall / flat strip tiles instead of padded 8 x TXW boxes (conv_h2.hip, ConvArgs::sr_* / sb_*).  A voxel's products
+    and their order do not depend on the tile it sits in: the first layer that runs on strips is identical bit for bit; behind
+    it only the float partial sums of the BatchNorm statistics are grouped differently (one per tile, reduced in double)."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(8)
+    nets = []
+    monkeypatch.setenv("ISX_H2_NW8", nw8)
+    for v in ("1", "0"):
+        monkeypatch.setenv("ISX_H2_STRIPS", v)
+        u = UNet(1, 5, batch=1, precision=precision)
+        u.load_state_dict(sd)
+        nets.append(u)
+    # chunks are multiples of 16 in y and x, so the remainders appear from level 1 down (H / 2 + 1): 1 row, 1 or 9 columns
+    for shape in [(4, 176, 192), (2, 192, 208), (2, 352, 368), (10, 256, 256)]:
+        x = np.random.default_rng(11).random((1, 1) + shape, dtype=np.float32)
+        ya, yb = nets[0](x), nets[1](x)
+        assert np.array_equal(nets[0].tap("c1.conv0"), nets[1].tap("c1.conv0")), shape
+        # (bf16: a last-bit change of a BatchNorm scale moves some activations across a bf16 rounding boundary, 2^-9 relative)
+        assert np.abs(ya - yb).max() <= (2e-5 if precision == "split-f16" else 4e-3), (shape, np.abs(ya - yb).max())
