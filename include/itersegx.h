@@ -140,6 +140,17 @@ int isx_unet_set_batch(isx_ctx *ctx, int batch);
 #define ISX_PRECISION_F16 2
 #define ISX_PRECISION_BF16 3
 int isx_unet_set_precision(isx_ctx *ctx, int mode);
+/* Final activation of each decoder's last ConvModule -- UNet(chan_final_activations=[...]) (src/iterseg/unet.py:205-209,
+ * ConvModule.forward :91-106; train_unet hands the list through, train.py:134-141).  One entry per decoder (1 or 2), default
+ * sigmoid.  ISX_FINAL_SOFTMAX is nn.Softmax() with dim=None on the 5-D activation: over the module's channels (dim 1).
+ * ISX_FINAL_NONE is what the reference does for any other string: BatchNorm output unchanged.  Applies to inference
+ * (isx_unet_forward*, isx_predict_volume) and to training (loss and backward). */
+#define ISX_FINAL_SIGMOID 0
+#define ISX_FINAL_RELU 1
+#define ISX_FINAL_TANH 2
+#define ISX_FINAL_NONE 3
+#define ISX_FINAL_SOFTMAX 4
+int isx_unet_set_final_activations(isx_ctx *ctx, const int32_t *acts, int n_forks);
 /* How each convolution of the LAST forward actually ran (layer order: c0.conv0, c0.conv1, c1.conv0 ... c4.conv1,
  * c5_0.conv0 ... c8_0.conv1, then c5_1 ... c8_1 of a second fork): the reduced modes send a layer whose operands could
  * leave the f16 range (bounds from the BatchNorm affine parameters of its producer) to the fp32 kernel, at about half the

@@ -49,6 +49,7 @@ SIGNATURES = {
     "isx_unet_tap_host": (C.c_int, [_vp, C.c_char_p, _vp, _i64, _i64p]),
     "isx_unet_set_batch": (C.c_int, [_vp, C.c_int]),
     "isx_unet_set_precision": (C.c_int, [_vp, C.c_int]),
+    "isx_unet_set_final_activations": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int]),
     "isx_unet_precision_report": (C.c_int, [_vp, _i32p, C.c_int, _i32p]),
     "isx_train_param_count": (_i64, [_vp]),
     "isx_train_bind": (C.c_int, [_vp, _i64p, _vp, _vp, _vp, _vp, _i64]),

@@ -132,8 +132,9 @@ __global__ void repack_up_kernel(const float *__restrict__ wref, int C, int kt, 
 // ------------------------------------------------------------------------------------------------
 // loss + d(loss)/d(y_hat).  kind 0: BCE (mean over all elements, logs clamped at -100 like torch);
 // 1: MSE; 2: weighted BCE (per-channel mean * weight, mean over channels, custom_loss.py:161-185).
-// y_hat is recomputed from raw17 (sigmoid(BN(raw))); target is (C, D, H, W) planar.
-// lossbuf partials: [blocks][C] ; gout: [M][C] channels-last.
+// y_hat is recomputed from raw17 (act(BN(raw)), act = the decoder's final activation, ISX_FINAL_*); target is (C, D, H, W)
+// planar.  lossbuf partials: [blocks][C] ; gout: [M][C] channels-last -- d(loss)/d(y_hat) for the default sigmoid (its
+// derivative is fused into the BatchNorm backward, act_grad), d(loss)/d(BN output) for every other activation.
 // ------------------------------------------------------------------------------------------------
 struct LossSpec {          // loss = sum_c w[c] * sum_m elem_loss_kind[c](yh[m,c], y[c,m])
     int kind[8];           // 0 BCE (log clamped at -100 like torch), 1 squared error
@@ -142,15 +143,40 @@ struct LossSpec {          // loss = sum_c w[c] * sum_m elem_loss_kind[c](yh[m,c
 
 __global__ __launch_bounds__(256) void loss_kernel(const float *__restrict__ raw, const float *__restrict__ scale,
                                                    const float *__restrict__ shift, const float *__restrict__ target,
-                                                   int C, int64_t M, const LossSpec spec,
-                                                   float *__restrict__ gout, float *__restrict__ part)
+                                                   int C, int64_t M, const LossSpec spec, int act,
+                                                   float *__restrict__ gout, float *__restrict__ part, int *__restrict__ bad)
 {
     __shared__ float red[4][8];
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float l[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) l[c] = 0.f;
-    if (m < M)
+    if (m < M && act != ISX_FINAL_SIGMOID) {
+        float yv[8], gv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) yv[c] = c < C ? fmaf(raw[m * C + c], scale[c], shift[c]) : 0.f;
+        final_act_apply(yv, C, act);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            gv[c] = 0.f;
+            if (c < C) {
+                const float yh = yv[c], y = target[(int64_t)c * M + m];
+                if (spec.kind[c] == 1) {
+                    const float d = yh - y;
+                    l[c] = d * d;
+                    gv[c] = 2.f * d * spec.w[c];
+                } else {
+                    if (!(yh >= 0.f && yh <= 1.f)) *bad = 1;            // nn.BCELoss refuses such an input (relu / tanh / no activation)
+                    const float lg = fmaxf(logf(yh), -100.f), lg1 = fmaxf(logf(1.f - yh), -100.f);
+                    l[c] = -(y * lg + (1.f - y) * lg1);
+                    gv[c] = spec.w[c] * (yh - y) / fmaxf((1.f - yh) * yh, 1e-12f);
+                }
+            }
+        }
+        final_act_grad(gv, yv, C, act);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < C) gout[m * C + c] = gv[c];
+    } else if (m < M)
         for (int c = 0; c < C; ++c) {
             float z = fmaf(raw[m * C + c], scale[c], shift[c]);
             float yh = 1.f / (1.f + expf(-z));
@@ -184,16 +210,29 @@ __global__ __launch_bounds__(256) void loss_kernel(const float *__restrict__ raw
 // two z planes and the per-plane sums the reference's per-channel log needs fall out of the same partials.
 __global__ __launch_bounds__(256) void dice_sums_kernel(const float *__restrict__ raw, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, const float *__restrict__ target,
-                                                        int C, int64_t M, float *__restrict__ part)
+                                                        int C, int64_t M, int act, float *__restrict__ part)
 {
     __shared__ float red[4][24];
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float yv[8];
+    if (act != ISX_FINAL_SIGMOID) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) yv[c] = (c < C && m < M) ? fmaf(raw[m * C + c], scale[c], shift[c]) : 0.f;
+        final_act_apply(yv, C, act);
+    }
     for (int c = 0; c < C; ++c) {
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
         if (m < M) {
-            float z = fmaf(raw[m * C + c], scale[c], shift[c]);
-            float yh = 1.f / (1.f + expf(-z));
+            float yh;
+            if (act == ISX_FINAL_SIGMOID) {
+                float z = fmaf(raw[m * C + c], scale[c], shift[c]);
+                yh = 1.f / (1.f + expf(-z));
+            } else {
+                yh = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k == c) yh = yv[k];
+            }
             float y = target[(int64_t)c * M + m];
             v0 = yh * y; v1 = yh; v2 = y;
         }
@@ -222,13 +261,28 @@ __global__ void colsum_group_kernel(const float *__restrict__ part, int per, int
 }
 
 struct DiceCoef { float ka[8], kb[8]; };
-// DiceLoss, pass 2: d loss / d yh[m, c] = y * ka[c] + kb[c]
+// DiceLoss, pass 2: d loss / d yh[m, c] = y * ka[c] + kb[c]; with a final activation other than the sigmoid the kernel goes on
+// to d loss / d (BN output) like loss_kernel does
 __global__ void dice_grad_kernel(const float *__restrict__ target, int C, int64_t M, const DiceCoef k,
+                                 const float *__restrict__ raw, const float *__restrict__ scale, const float *__restrict__ shift, int act,
                                  float *__restrict__ gout)
 {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
-    for (int c = 0; c < C; ++c) gout[m * C + c] = fmaf(target[(int64_t)c * M + m], k.ka[c], k.kb[c]);
+    if (act == ISX_FINAL_SIGMOID) {
+        for (int c = 0; c < C; ++c) gout[m * C + c] = fmaf(target[(int64_t)c * M + m], k.ka[c], k.kb[c]);
+        return;
+    }
+    float yv[8], gv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        yv[c] = c < C ? fmaf(raw[m * C + c], scale[c], shift[c]) : 0.f;
+        gv[c] = c < C ? fmaf(target[(int64_t)c * M + m], k.ka[c], k.kb[c]) : 0.f;
+    }
+    final_act_apply(yv, C, act);
+    final_act_grad(gv, yv, C, act);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < C) gout[m * C + c] = gv[c];
 }
 
 // sums the [blocks][C] partials in double, fixed order: out[c] = per-channel sum
@@ -248,7 +302,7 @@ __global__ void colsum_kernel(const float *__restrict__ part, int blocks, int C,
 }
 
 // ------------------------------------------------------------------------------------------------
-// BN(train) + activation backward.  act: 0 relu, 1 sigmoid.  g may be strided (a channel slice of a wider
+// BN(train) + activation backward.  act: 0 relu, 1 sigmoid, 2 none (g already is the gradient at the BatchNorm output).  g may be strided (a channel slice of a wider
 // tensor): element (m, c) at g[m * gstride + c].
 // pass 1: partials of sum(dz), sum(dz * xhat) per channel -> part[blocks][2C]
 // pass 2: draw = gamma*invstd*(dz - c1 - xhat*c2); partials of sum(draw) -> part[blocks][C]
@@ -256,6 +310,7 @@ __global__ void colsum_kernel(const float *__restrict__ part, int blocks, int C,
 __device__ __forceinline__ float act_grad(float g, float z, int act)
 {
     if (act == 0) return z > 0.f ? g : 0.f;
+    if (act == 2) return g;
     float s = 1.f / (1.f + expf(-z));
     return g * (1.f - s) * s;
 }
@@ -1280,7 +1335,7 @@ static int backward(isx_ctx *ctx)
             const UpConv &U = u->up[k];
             const Level &lo = lv[3 - k];
             // conv1 of the module: g arrives in gact[l1] (the loss wrote it for the last module)
-            ISX_TRY(bn_backward(ctx, l1, t->gact[l1], u->cv[l1].cout, k == 3 ? 1 : 0));
+            ISX_TRY(bn_backward(ctx, l1, t->gact[l1], u->cv[l1].cout, k == 3 ? (u->final_act[f] == ISX_FINAL_SIGMOID ? 1 : 2) : 0));
             ISX_TRY(wgrad(ctx, l1, act(l0), none));
             ISX_TRY(dgrad(ctx, l1, t->gact[l0]));
             // conv0 of the module: input = cat(up_k, act(skip))
@@ -1501,19 +1556,33 @@ static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dic
         // every decoder's channels against their slice of the target (the reference concatenates the forks' outputs and
         // applies one loss to the whole tensor, unet.py:322 + train.py:344-363: the means in spec.w are over all channels)
         int c_off = 0;
+        int *bad = (int *)(t->lossbuf + 2048);
+        bool range_check = false;                         // a BCE term on a decoder whose activation can leave [0, 1]
+        for (int f = 0, c0 = 0; f < u->nforks; c0 += u->fork_channels[f], ++f)
+            if (u->final_act[f] != ISX_FINAL_SIGMOID && u->final_act[f] != ISX_FINAL_SOFTMAX)
+                for (int c = 0; c < u->fork_channels[f]; ++c) range_check = range_check || spec.kind[c0 + c] == 0;
+        if (range_check) ISX_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
         for (int f = 0; f < u->nforks; ++f) {
             const int lf = dec_layer(f, 3, 1);
             const ConvBN &Lf = u->cv[lf];
             LossSpec sp;
             for (int c = 0; c < 8; ++c) { sp.kind[c] = c_off + c < 8 ? spec.kind[c_off + c] : 0; sp.w[c] = c_off + c < 8 ? spec.w[c_off + c] : 0.f; }
             loss_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[lf], Lf.scale, Lf.shift, y + (int64_t)c_off * l0.M, Lf.cout, l0.M, sp,
-                                                         t->gact[lf], t->part);
+                                                         u->final_act[f], t->gact[lf], t->part, bad);
             ISX_CHECK_LAUNCH();
             colsum_kernel<<<Lf.cout, 256, 0, ctx->stream>>>(t->part, blocks, Lf.cout, t->lossbuf + c_off);
             ISX_CHECK_LAUNCH();
             c_off += Lf.cout;
         }
         ISX_HIP(hipMemcpyAsync(hs, t->lossbuf, C * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (range_check) {
+            // torch raises inside nn.BCELoss, before backward: parameters and optimiser state stay as they were
+            int hb = 0;
+            ISX_HIP(hipMemcpyAsync(&hb, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            ISX_HIP(hipStreamSynchronize(ctx->stream));
+            ISX_REQUIRE(!hb, "all elements of input should be between 0 and 1 (BCELoss on a decoder whose final activation is not a "
+                             "sigmoid / softmax)");
+        }
     } else {
         // every decoder's channels against their slice of the target, like the other losses; the reference applies ONE DiceLoss
         // to the concatenated output (unet.py:322, custom_loss.py:24-53), so the mean runs over all C channels
@@ -1525,7 +1594,7 @@ static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dic
             const ConvBN &Lf = u->cv[lf];
             const int Cf = Lf.cout;
             ISX_REQUIRE((size_t)blocks * Cf * 3 <= t->part_floats, "internal: partial buffer too small");
-            dice_sums_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[lf], Lf.scale, Lf.shift, y + (int64_t)c_off * l0.M, Cf, l0.M, t->part);
+            dice_sums_kernel<<<blocks, 256, 0, ctx->stream>>>(u->raw[lf], Lf.scale, Lf.shift, y + (int64_t)c_off * l0.M, Cf, l0.M, u->final_act[f], t->part);
             ISX_CHECK_LAUNCH();
             colsum_group_kernel<<<dim3(3 * Cf, l0.D), 256, 0, ctx->stream>>>(t->part, (int)(plane / 256), 3 * Cf, t->lossbuf + 128);
             ISX_CHECK_LAUNCH();
@@ -1548,7 +1617,8 @@ static int train_step_impl(isx_ctx *ctx, const float *x, const float *y, int dic
                 // the reference's per-channel log applies DiceLoss to (1, Z, Y, X): the z planes act as channels
                 hs[c_off + c] = (float)(zlog / l0.D);
             }
-            dice_grad_kernel<<<blocks, 256, 0, ctx->stream>>>(y + (int64_t)c_off * l0.M, Cf, l0.M, k, t->gact[lf]);
+            dice_grad_kernel<<<blocks, 256, 0, ctx->stream>>>(y + (int64_t)c_off * l0.M, Cf, l0.M, k, u->raw[lf], Lf.scale, Lf.shift, u->final_act[f],
+                                                              t->gact[lf]);
             ISX_CHECK_LAUNCH();
             c_off += Cf;
         }

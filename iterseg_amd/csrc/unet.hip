@@ -915,11 +915,11 @@ __global__ __launch_bounds__(256) void tail_combine_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel: final BatchNorm + sigmoid; writes the chunk output as NCDHW (optional) and/or its centre
-// crop into the (C, Z, Y, X) feature map (process_chunks, predict.py:82-95).
+// Kernel: final BatchNorm + activation (sigmoid unless chan_final_activations says otherwise); writes the chunk output as
+// NCDHW (optional) and/or its centre crop into the (C, Z, Y, X) feature map (process_chunks, predict.py:82-95).
 // ------------------------------------------------------------------------------------------
 __global__ void final_kernel(const float *__restrict__ raw, const float *__restrict__ scale,
-                             const float *__restrict__ shift, int nout, int c_off, int c_total, int cz, int cy, int cx,
+                             const float *__restrict__ shift, int nout, int act, int c_off, int c_total, int cz, int cy, int cx,
                              const int32_t *__restrict__ table, float *__restrict__ out_ncdhw,
                              float *__restrict__ fm, int64_t Z, int64_t Y, int64_t X, int64_t total)
 {
@@ -933,18 +933,31 @@ __global__ void final_kernel(const float *__restrict__ raw, const float *__restr
     const int x = (int)(m % (uint32_t)cx), y = (int)((m / (uint32_t)cx) % (uint32_t)cy), z = (int)(m / ((uint32_t)cx * cy));
     const int32_t *r = table + 9 * b;
     bool in_crop = fm && z >= r[3] && z < r[4] && y >= r[5] && y < r[6] && x >= r[7] && x < r[8];
+    float a[8];
+    if (act != ISX_FINAL_SIGMOID) {                     // (the default keeps its own loop: one channel live at a time)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = c < nout ? fmaf(raw[i * nout + c], scale[b * nout + c], shift[b * nout + c]) : 0.f;
+        final_act_apply(a, nout, act);
+    }
     for (int c = 0; c < nout; ++c) {
-        float v = fmaf(raw[i * nout + c], scale[b * nout + c], shift[b * nout + c]);
-        v = 1.f / (1.f + expf(-v));
+        float v;
+        if (act == ISX_FINAL_SIGMOID) {
+            v = fmaf(raw[i * nout + c], scale[b * nout + c], shift[b * nout + c]);
+            v = 1.f / (1.f + expf(-v));
+        } else {
+            v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k == c) v = a[k];
+        }
         if (out_ncdhw) out_ncdhw[((int64_t)b * c_total + c_off + c) * M + m] = v;        // forks are concatenated (unet.py:322)
         if (in_crop) fm[(((int64_t)(c_off + c) * Z + (r[0] + z)) * Y + (r[1] + y)) * X + (r[2] + x)] = v;
     }
 }
 
 // materialise an intermediate as NCDHW for isx_unet_tap_host (tests): mode 0 raw, 1 affine,
-// 2 affine+relu, 3 affine+sigmoid
+// 2 affine+relu, 3 affine+final activation `act` (row-major source, C <= 8)
 __global__ void tap_kernel(const float *__restrict__ src, const float *__restrict__ scale,
-                           const float *__restrict__ shift, int C, int64_t M, int mode, float *__restrict__ dst, int planar)
+                           const float *__restrict__ shift, int C, int64_t M, int mode, int act, float *__restrict__ dst, int planar)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * C) return;
@@ -953,7 +966,14 @@ __global__ void tap_kernel(const float *__restrict__ src, const float *__restric
     float v = planar ? src[((int64_t)(c >> 3) * M + m) * 8 + (c & 7)] : src[i];      // (UNetState::planar)
     if (mode >= 1) v = fmaf(v, scale[c], shift[c]);
     if (mode == 2) v = fmaxf(v, 0.f);
-    if (mode == 3) v = 1.f / (1.f + expf(-v));
+    if (mode == 3) {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = k < C ? fmaf(src[m * C + k], scale[k], shift[k]) : 0.f;
+        final_act_apply(a, C, act);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k == c) v = a[k];
+    }
     dst[(int64_t)c * M + m] = v;
 }
 
@@ -1547,7 +1567,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             const ConvBN &L = u->cv[lf];
             int64_t total = (int64_t)B * lv[0].M;
             ISX_REQUIRE(total < (int64_t)0xFFFFFFFFll, "internal: launch set too large for 32-bit element indices");
-            final_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[lf], L.scale, L.shift, L.cout, c_off, u->out_channels,
+            final_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[lf], L.scale, L.shift, L.cout, u->final_act[f], c_off, u->out_channels,
                                                                  lv[0].D, lv[0].H, lv[0].W, u->d_table, out_ncdhw, fm,
                                                                  shape ? shape[0] : 0, shape ? shape[1] : 0, shape ? shape[2] : 0, total);
             ISX_CHECK_LAUNCH();
@@ -1687,6 +1707,18 @@ int isx_unet_set_precision(isx_ctx *ctx, int mode)
     return ISX_OK;
 }
 
+int isx_unet_set_final_activations(isx_ctx *ctx, const int32_t *acts, int n_forks)
+{
+    ISX_REQUIRE(ctx && acts && n_forks >= 1 && n_forks <= ISX_MAX_FORKS, "final activations: %d decoders", n_forks);
+    for (int f = 0; f < n_forks; ++f)
+        ISX_REQUIRE(acts[f] >= ISX_FINAL_SIGMOID && acts[f] <= ISX_FINAL_SOFTMAX, "final activation code %d", acts[f]);
+    if (!ctx->unet) { ctx->unet = new UNetState(); ctx->unet->tune = ctx->tune; }
+    ISX_REQUIRE(!ctx->unet->committed || n_forks == ctx->unet->nforks, "final activations for %d decoders, the network has %d", n_forks,
+                ctx->unet->nforks);
+    for (int f = 0; f < ISX_MAX_FORKS; ++f) ctx->unet->final_act[f] = f < n_forks ? acts[f] : ISX_FINAL_SIGMOID;
+    return ISX_OK;
+}
+
 int isx_unet_precision_report(isx_ctx *ctx, int32_t *modes, int cap, int32_t *n_fallback)
 {
     ISX_TRY(check_ready(ctx));
@@ -1741,7 +1773,7 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
     ISX_REQUIRE(u->last_n >= 1, "no forward has run yet");
     std::string nm(name);
     const float *src = nullptr, *sc = nullptr, *sh = nullptr;
-    int C = 0, mode = 0, level = 0;
+    int C = 0, mode = 0, level = 0, tap_act = ISX_FINAL_SIGMOID;
     bool tap_planar = false;
     for (int li = 0; li < u->nlayers && !src; li += 2) {        // module names follow the state dict: c0..c4, c5_0..c8_0, c5_1..c8_1
         const int mi = layer_module(li);
@@ -1754,6 +1786,7 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
         if (nm == m) {
             const ConvBN &L = u->cv[li + 1];
             src = u->raw[li + 1]; sc = L.scale; sh = L.shift; C = L.cout; mode = (mi == 8) ? 3 : 2; level = MOD_LEVEL[mi]; tap_planar = u->planar[li + 1];
+            tap_act = u->final_act[li >= 18 ? 1 : 0];
         }
     }
     for (int k = 0; k < 4 && !src; ++k) {
@@ -1783,7 +1816,7 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
     ISX_REQUIRE(cap_elems >= l.M * C, "tap buffer too small: need %ld floats", (long)(l.M * C));
     Scratch<float> tmp(ctx, (size_t)l.M * C);
     if (!tmp.ok()) return ISX_ERR_NOMEM;
-    tap_kernel<<<cdiv(l.M * C, 256), 256, 0, ctx->stream>>>(src, sc, sh, C, l.M, mode, tmp.p, tap_planar ? 1 : 0);     // chunk 0 of the set
+    tap_kernel<<<cdiv(l.M * C, 256), 256, 0, ctx->stream>>>(src, sc, sh, C, l.M, mode, tap_act, tmp.p, tap_planar ? 1 : 0);     // chunk 0 of the set
     ISX_CHECK_LAUNCH();
     ISX_HIP(hipMemcpyAsync(out, tmp.p, (size_t)l.M * C * 4, hipMemcpyDeviceToHost, ctx->stream));
     ISX_HIP(hipStreamSynchronize(ctx->stream));

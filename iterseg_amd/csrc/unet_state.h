@@ -59,6 +59,7 @@ struct UNetState {
     bool committed = false;
     int out_channels = 5;            // all forks together (the channel count of the output tensor)
     int nforks = 1, fork_channels[ISX_MAX_FORKS] = {5, 0};
+    int final_act[ISX_MAX_FORKS] = {0, 0};       // ISX_FINAL_* per decoder (isx_unet_set_final_activations)
     int nlayers = 18;                // 18, or 26 with two forks
     int batch = 4;
     int precision = ISX_PRECISION_SPLIT_F16;     // arithmetic of the wide inference convolutions (isx_unet_set_precision)
@@ -157,5 +158,42 @@ int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch);
 int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3]);
 int dev_alloc(UNetState *u, size_t floats, float **out);
 void train_destroy(TrainState *t);
+
+// ---- final activation of a decoder (ConvModule.forward, unet.py:91-106; codes ISX_FINAL_*) ---------------------------------
+// v[0, C): the BatchNorm outputs of one voxel -> the activations, in place.  C <= 8.
+__device__ __forceinline__ void final_act_apply(float (&v)[8], int C, int act)
+{
+    if (act == ISX_FINAL_SOFTMAX) {
+        // nn.Softmax() with dim=None: dim 1 of the (N, C, D, H, W) tensor (torch.nn.functional._get_softmax_dim)
+        float mx = v[0], s = 0.f;
+#pragma unroll
+        for (int c = 1; c < 8; ++c) if (c < C) mx = fmaxf(mx, v[c]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < C) { v[c] = expf(v[c] - mx); s += v[c]; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < C) v[c] = v[c] / s;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < C) {
+        const float z = v[c];
+        v[c] = act == ISX_FINAL_SIGMOID ? 1.f / (1.f + expf(-z)) : act == ISX_FINAL_RELU ? fmaxf(z, 0.f) : act == ISX_FINAL_TANH ? tanhf(z) : z;
+    }
+}
+// g[0, C): dL/dy of one voxel -> dL/dz, in place; y: the activations final_act_apply produced
+__device__ __forceinline__ void final_act_grad(float (&g)[8], const float (&y)[8], int C, int act)
+{
+    float dot = 0.f;
+    if (act == ISX_FINAL_SOFTMAX) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < C) dot += g[c] * y[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < C) {
+        const float yy = y[c];
+        g[c] = act == ISX_FINAL_SIGMOID ? g[c] * (1.f - yy) * yy : act == ISX_FINAL_RELU ? (yy > 0.f ? g[c] : 0.f)
+             : act == ISX_FINAL_TANH ? g[c] * (1.f - yy * yy) : act == ISX_FINAL_SOFTMAX ? yy * (g[c] - dot) : g[c];
+    }
+}
 
 }  // namespace isx

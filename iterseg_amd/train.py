@@ -112,7 +112,7 @@ class Trainer:
         self.unet._train_params = (self.layout, self.params, self.grads, self.adam_m, self.adam_v)
 
     # ------------------------------------------------------------------ steps
-    def _call(self, x, y, loss, chan_weights, lr, n_adam, backward, channelwise=None):
+    def _call_lib(self, x, y, loss, chan_weights, lr, n_adam, backward, channelwise=None):
         dev = self.params.device
         if self.unet._train_params is None or self.unet._train_params[1] is not self.params:
             raise RuntimeError("this Trainer's U-Net was re-loaded (load_state_dict opens a new context): build a new "
@@ -140,6 +140,14 @@ class Trainer:
             _lib.check(lib.isx_train_step(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), LOSS_KINDS[loss], cw,
                                           C.c_float(lr), int(n_adam), 1 if backward else 0, out))
         return float(out[0]), [float(v) for v in out[1:]]
+
+    def _call(self, *a, **k):
+        try:
+            return self._call_lib(*a, **k)
+        except ValueError as e:
+            if str(e).startswith("all elements of input should be between 0 and 1"):
+                raise RuntimeError(str(e)) from None       # what nn.BCELoss raises upstream for relu / tanh / unactivated outputs
+            raise
 
     def train_step(self, x, y, lr=0.01, loss="BCELoss", chan_weights=None, double_step=True, group=None,
                    channelwise=None):
@@ -204,10 +212,6 @@ def train_unet(x, vx, y, vy, ids=None, vids=None, out_dir=None, name='my-unet', 
     ``(unet, unet_path)`` like the reference; ``unet_path`` is None when ``out_dir`` is None (the reference
     leaves it unbound there, train.py:177-183)."""
     import pandas as pd
-    nforks = len(fork_channels) if fork_channels is not None else 1
-    if chan_final_activations is not None and list(chan_final_activations) != ['sigmoid'] * nforks:
-        # never accepted-and-ignored: the reference hands it to UNet (train.py:135-141) where it changes the arithmetic
-        raise NotImplementedError(f"chan_final_activations={chan_final_activations!r}: only the default 'sigmoid' is built")
     save_output = out_dir is not None
     print('Output will be saved: ', save_output)
     print('Save directory: ', out_dir)

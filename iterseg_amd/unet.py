@@ -40,21 +40,30 @@ class UNet:
             raise NotImplementedError("at most 8 output channels over all decoders")
         if in_channels != 1 or tuple(down_factors) != (1, 2, 2) or up != 'convolution' or not downsample_1_at_bottom:
             raise NotImplementedError("only the configuration iterseg ships (in=1, (1,2,2), transposed conv) is built")
-        if chan_final_activations is not None and list(chan_final_activations) != ['sigmoid'] * len(self.fork_channels):
-            # unet.py:205-209: one entry per decoder, handed to ConvModule(final=...); only the default is built
-            raise NotImplementedError(f"chan_final_activations={chan_final_activations!r}: only the reference's default "
-                                      "final activation ('sigmoid' for every decoder) is on the accelerated path")
+        # unet.py:205-209: chan_final_activations[i] is handed to ConvModule(final=...) of decoder i (an IndexError upstream too
+        # when the list is shorter than the decoders; surplus entries are never read); ConvModule.forward (unet.py:98-106) knows
+        # 'relu', 'softmax', 'sigmoid', 'tanh' and leaves the BatchNorm output alone for any other string
+        if chan_final_activations is None:
+            chan_final_activations = ['sigmoid'] * len(self.fork_channels)
+        self.final_activations = tuple(chan_final_activations[i] for i in range(len(self.fork_channels)))
         self.in_channels, self.out_channels = in_channels, int(sum(self.fork_channels))
         self._schema_out = self.fork_channels if self.forked else self.out_channels
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.ctx = _lib.Context(self.device)
         _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, int(batch)))
+        self._set_final_activations()
         self._batch = int(batch)
         self._loaded = False
         self._sd = None
         self._train_params = None          # (layout, flat parameter tensor) once a Trainer is bound to this context
         self.precision = "fp32"
         self.set_precision(precision if precision is not None else os.environ.get("ISX_CONV_PRECISION", DEFAULT_PRECISION))
+
+    _FINAL_CODES = {'sigmoid': 0, 'relu': 1, 'tanh': 2, 'softmax': 4}          # ISX_FINAL_*; anything else: 3 (none)
+
+    def _set_final_activations(self):
+        codes = (C.c_int32 * len(self.final_activations))(*[self._FINAL_CODES.get(a, 3) for a in self.final_activations])
+        _lib.check(self.ctx.lib.isx_unet_set_final_activations(self.ctx.handle, codes, len(self.final_activations)))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict, strict=True):
@@ -70,6 +79,7 @@ class UNet:
             self._train_params = None
             self.ctx = _lib.Context(self.device)
             _lib.check(self.ctx.lib.isx_unet_set_batch(self.ctx.handle, self._batch))
+            self._set_final_activations()
             self.set_precision(self.precision)
         lib, h = self.ctx.lib, self.ctx.handle
         for k, v in sd.items():

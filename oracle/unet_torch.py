@@ -154,13 +154,17 @@ def conv_module(p, name, x, final="relu", taps=None):
             x = torch.sigmoid(x)
         elif final == "tanh":
             x = torch.tanh(x)
+        elif final == "softmax":
+            x = F.softmax(x, dim=1)                  # nn.Softmax() with dim=None on a 5-D tensor (unet.py:87,100-101)
+        # any other name: the BatchNorm output (unet.py:98-106 has no else branch)
     if taps is not None:
         taps[name] = x
     return x
 
 
 def unet_forward(p, x, taps=None, final="sigmoid"):
-    """x: (1,1,D,H,W) float32 tensor -> (1,C,D,H,W).  One decoder, or -- when the parameters hold ``c5_1...`` -- the forked
+    """x: (1,1,D,H,W) float32 tensor -> (1,C,D,H,W).  ``final``: one name, or UNet(chan_final_activations=[...])'s list (one per
+    decoder, unet.py:205-209).  One decoder, or -- when the parameters hold ``c5_1...`` -- the forked
     network (unet.py:313-325): every fork runs its own c5_i..c8_i on the shared encoder outputs and transposed convolutions,
     the outputs are concatenated in fork order."""
     c0 = conv_module(p, "c0", x, taps=taps)
@@ -199,7 +203,7 @@ def unet_forward(p, x, taps=None, final="sigmoid"):
         x = torch.cat([x[:, :, :, 1:-1, 1:-1], c0], 1)
         if ftaps is not None:
             ftaps["c8_0.in"] = x
-        outs.append(conv_module(p, f"c8_{i}", x, final=final, taps=ftaps))
+        outs.append(conv_module(p, f"c8_{i}", x, final=final if isinstance(final, str) else final[i], taps=ftaps))
         i += 1
     return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
 

@@ -232,18 +232,75 @@ def test_inference_with_another_chunk_between_training_steps():
     assert torch.equal(a.params, b.params)
 
 
-def test_unsupported_final_activation_is_rejected_not_ignored():
+FINAL_ACT_CASES = {                       # tag -> (out_channels, chan_final_activations, loss)  (gen_stage1d_final_activations.py)
+    "tanh_mse": (5, ["tanh"], "MSELoss"), "relu_mse": (5, ["relu"], "MSELoss"), "none_mse": (5, ["linear"], "MSELoss"),
+    "softmax_bce": (5, ["softmax"], "BCELoss"), "softmax_dice": (5, ["softmax"], "DiceLoss"), "tanh_dice": (5, ["tanh"], "DiceLoss"),
+    "fork_softmax_tanh_mse": ((3, 2), ["softmax", "tanh"], "MSELoss"),
+    "fork_sigmoid_softmax_bce": ((3, 2), ["sigmoid", "softmax"], "BCELoss"),
+}
+
+
+@pytest.mark.parametrize("tag", list(FINAL_ACT_CASES))
+def test_final_activations_forward_loss_gradients_and_update_match_reference(golden, tag):
+    """UNet(chan_final_activations=[...]) (unet.py:98-106, 205-209; train.py:134-141): 'relu', 'softmax' (over the decoder's
+    channels), 'tanh', and an unknown name (= no activation), plain and forked, against the reference's own forward, loss,
+    autograd gradients and double Adam step.  Tolerances of the sigmoid tests above."""
+    from iterseg_amd import weights
+    from iterseg_amd.train import Trainer
+    d = golden("final_activations_4x32x32")
+    oc, acts, loss_name = FINAL_ACT_CASES[tag]
+    sd = weights.generate_state_dict(int(d["weights_seed"][0]), 1, oc)
+    t = Trainer(sd, out_channels=oc, patch=(4, 32, 32), chan_final_activations=acts)
+    loss, _ = t._call(d["x"], d["y"], loss_name, None, 0.01, 0, True)     # backward, no update
+    assert abs(loss - float(d[tag + ".loss"])) < 1e-5 * max(1.0, abs(float(d[tag + ".loss"])))
+    keys = [f[len(tag) + 6:] for f in d.files if f.startswith(tag + ".grad.")]
+    assert len(keys) >= 12
+    for k in keys:
+        ref = d[f"{tag}.grad.{k}"]
+        got = _slice(t.grad(k), k)
+        tol = 2e-3 * np.abs(ref).max() + 1e-6
+        assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), np.abs(ref).max())
+    y = t.unet(d["x"][None, None])
+    y = y.cpu().numpy() if isinstance(y, torch.Tensor) else np.asarray(y)
+    assert np.abs(y - d[tag + ".y_hat"]).max() < 1e-4 * max(1.0, np.abs(d[tag + ".y_hat"]).max())
+    assert np.abs(t.unet.tap("c8_0")[None] - d[tag + ".y_hat"][:, :t.unet.fork_channels[0]]).max() < 1e-4 * max(1.0, np.abs(d[tag + ".y_hat"]).max())
+    # the update (train.py:310: two optimiser steps on one gradient)
+    t2 = Trainer(sd, out_channels=oc, patch=(4, 32, 32), chan_final_activations=acts)
+    t2.train_step(d["x"], d["y"], lr=0.01, loss=loss_name, double_step=True)
+    for k in keys:
+        ref, g = d[f"{tag}.param.{k}"], d[f"{tag}.grad.{k}"]
+        sig = np.abs(g) > 1e-5
+        assert np.abs(_slice(t2.param(k), k) - ref)[sig].max(initial=0) < 2e-4, k
+
+
+def test_bce_on_an_unbounded_final_activation_raises_like_torch(golden):
+    """nn.BCELoss refuses inputs outside [0, 1] (the fixture records the reference's RuntimeError for 'tanh'): same exception,
+    before anything is updated."""
+    from iterseg_amd import weights
+    from iterseg_amd.train import Trainer
+    d = golden("final_activations_4x32x32")
+    assert str(d["tanh_bce.raised"]).startswith("RuntimeError: all elements of input should be between 0 and 1")
+    t = Trainer(weights.generate_state_dict(int(d["weights_seed"][0]), 1, 5), out_channels=5, patch=(4, 32, 32), chan_final_activations=["tanh"])
+    before = t.params.clone()
+    with pytest.raises(RuntimeError, match="all elements of input should be between 0 and 1"):
+        t.train_step(d["x"], d["y"], lr=0.01, loss="BCELoss")
+    assert torch.equal(before, t.params)
+    t.train_step(d["x"], d["y"], lr=0.01, loss="MSELoss")                 # the trainer is still usable
+
+
+def test_train_unet_hands_final_activations_through():
     from iterseg_amd import train
     from tests.synth import positive_volume
     xs = [positive_volume((4, 32, 32), 0)]
     ys = [np.zeros((5, 4, 32, 32), np.float32)]
-    with pytest.raises(NotImplementedError):
-        train.train_unet(xs, xs, ys, ys, epochs=1, chan_final_activations=['tanh'])
-    with pytest.raises(NotImplementedError):                     # one entry per decoder, each must be the default
-        train.train_unet(xs, xs, ys, ys, epochs=1, fork_channels=(3, 2), chan_final_activations=['sigmoid', 'tanh'])
-    with pytest.raises(NotImplementedError):
-        train.train_unet(xs, xs, ys, ys, epochs=1, fork_channels=(3, 2), loss_function='DiceLoss')
-    train.train_unet(xs, xs, ys, ys, epochs=1, chan_final_activations=['sigmoid'], validate=False)
+    with pytest.raises(IndexError):                                   # unet.py:206: chan_final_activations[i] per decoder
+        train.train_unet(xs, xs, ys, ys, epochs=1, fork_channels=(3, 2), chan_final_activations=['sigmoid'])
+    u, _ = train.train_unet(xs, xs, ys, ys, epochs=1, chan_final_activations=['softmax'], loss_function='DiceLoss', validate=False)
+    assert u.final_activations == ('softmax',)
+    y = u(xs[0][None, None])
+    y = y.cpu().numpy() if isinstance(y, torch.Tensor) else np.asarray(y)
+    assert np.abs(y.sum(axis=1) - 1.0).max() < 1e-5
+    train.train_unet(xs, xs, ys, ys, epochs=1, fork_channels=(3, 2), loss_function='DiceLoss', validate=False)
 
 
 def test_two_rank_data_parallel_step():
