@@ -1602,11 +1602,18 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         ISX_CHECK_LAUNCH();
         ISX_TRY(sort_u64(ctx, (const uint64_t *)okeys.p, (uint64_t *)order.p, n_comp));
         const bool side = ft.group_stream != 0;
+        // Between a fork and its join an early return (a failed launch, a failed second fork) would hand the Scratch buffers
+        // below back to the context's cache while kernels queued on a side stream may still use them: on that path the guard
+        // waits for the side streams first.  The normal path joins by events and disarms it.
+        struct SideGuard {
+            isx_ctx *c; bool armed[2] = {false, false};
+            ~SideGuard() { for (int i = 0; i < 2; ++i) if (armed[i] && c->aux_streams[i]) (void)hipStreamSynchronize(c->aux_streams[i]); }
+        } guard{ctx};
         if (group_min != ~0ull) {
             // the giants run beside the mid-size components (other CUs): a side stream, joined below
             // (ISX_FLOOD_GROUP_STREAM=0: same stream, one kernel after the other -- structured 512^3 seed 3, one 345 k-voxel
             // giant among 2 900 mid-size components: 150 ms against 104 ms side by side)
-            if (side) ISX_TRY(ctx->aux_fork());
+            if (side) { ISX_TRY(ctx->aux_fork()); guard.armed[0] = true; }
             flood_group_kernel<<<n_comp, GRP_W, 0, side ? ctx->aux_streams[0] : ctx->stream>>>(order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p,
                                                                    comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1], pshape[2], PN,
                                                                    s[0], s[1], s[2], group_min, run_limit, drain_n, gwcap, gtcap, group_bursts,
@@ -1620,7 +1627,7 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         if (group_min != ~0ull && small_max > group_min) small_max = group_min;
         uint32_t *trace_p = trace_on ? claim.p : nullptr;
         const bool two = small_max > coop_min && side;
-        if (two) ISX_TRY(ctx->aux_fork(1));
+        if (two) { ISX_TRY(ctx->aux_fork(1)); guard.armed[1] = true; }
         flood_window_kernel<WIN_W, WIN_T, WIN_RCAP, WIN_PEND><<<n_comp, 64, 0, two ? ctx->aux_streams[1] : ctx->stream>>>(
             order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p, comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
             pshape[2], PN, s[0], s[1], s[2], small_max, run_limit, drain_n, wcap, tcap, max_bursts, bk_lo, bk_inv, stats.p, ctx->ws_shard_rank,
@@ -1635,8 +1642,8 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
                 ctx->ws_shard_world, trace_p, small_max);
             ISX_CHECK_LAUNCH();
         }
-        if (two) ISX_TRY(ctx->aux_join(1));
-        if (group_min != ~0ull && side) ISX_TRY(ctx->aux_join(0));
+        if (two) { ISX_TRY(ctx->aux_join(1)); guard.armed[1] = false; }
+        if (group_min != ~0ull && side) { ISX_TRY(ctx->aux_join(0)); guard.armed[0] = false; }
 
         if (trace_on) {
             const char *tp = ft.trace.c_str();

@@ -145,13 +145,24 @@ class FramePipe:
     ``close()``."""
 
     def __init__(self, unet, shape, chunk_size, margin, depth=2):
-        self.unet, self.shape, self.depth = unet, tuple(int(s) for s in shape), int(depth)
+        # the U-Net owns the pipe (UNet._frame_pipe) and is held weakly here: no reference cycle, so the 9 GB of device and
+        # pinned memory go when the U-Net goes, not when the cycle collector runs
+        self._unet = weakref.ref(unet)
+        self._lib = unet.ctx.lib
+        self.shape, self.depth = tuple(int(s) for s in shape), int(depth)
         self._h = C.c_void_p()
         self._keep = collections.deque()
         unet._bind_stream()
         _lib.check(unet.ctx.lib.isx_pipe_create(unet.ctx.handle, _lib._dims(self.shape), _lib._dims(chunk_size),
                                                 _lib._dims(margin if not isinstance(margin, int) else (margin,) * 3),
                                                 self.depth, C.byref(self._h)))
+
+    @property
+    def unet(self):
+        u = self._unet()
+        if u is None:
+            raise RuntimeError("the U-Net this frame pipe belonged to is gone")
+        return u
 
     @property
     def in_flight(self):
@@ -174,16 +185,21 @@ class FramePipe:
         _lib.check(rc)
         return out
 
+    def discard(self):
+        """Finish the oldest frame in flight and throw its result away, whatever it was (a frame that is redone through
+        the one-frame path: a NoSeedsError of the void full-size frame must not end the stack)."""
+        scratch = np.empty(self.shape, np.uint32)
+        self._lib.isx_pipe_wait(self._h, scratch.ctypes.data_as(C.c_void_p), 2)
+        self._keep.popleft()
+
     def drain(self):
         """Discard whatever is still in flight (after an error): the pipe is reusable afterwards."""
-        scratch = np.empty(self.shape, np.uint32)
         while self._keep:
-            self.unet.ctx.lib.isx_pipe_wait(self._h, scratch.ctypes.data_as(C.c_void_p), 2)
-            self._keep.popleft()
+            self.discard()
 
     def close(self):
         if self._h:
-            self.unet.ctx.lib.isx_pipe_destroy(self._h)
+            self._lib.isx_pipe_destroy(self._h)
             self._h = C.c_void_p()
             self._keep.clear()
 
@@ -289,7 +305,7 @@ def _pipelined_frames(data, chunk_size, margin, output_labels, config):
     def finish():
         t0, redo = pending.popleft()
         if redo is not None:                      # rare: the frame lost all-zero planes, its pipelined result is void
-            pipe.wait()
+            pipe.discard()
             output_labels[t0, ...] = segment_single_volume(redo, chunk_size, config, margin, affinity_watershed_for_chunks)
         elif direct and output_labels[t0].flags.c_contiguous:
             pipe.wait(out=output_labels[t0])      # uint32 labels < 2^31: the bits are the int32 values

@@ -166,7 +166,16 @@ class UNet:
     def _bind_stream(self):
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _require_idle(self):
+        """The context belongs to the frame pipe's compute thread while frames are in flight (segmentation._pipelined_frames
+        hands results out between yields): a forward from the consumer's side would race with it."""
+        cached = getattr(self, "_frame_pipe", None)
+        if cached is not None and cached[1].in_flight:
+            raise RuntimeError("this U-Net has frames in flight in a frame pipe (segmentation_loop is mid-stack): finish or "
+                               "drain the pipe before calling the U-Net directly")
+
     def forward_chunks(self, volume, starts, chunk):
+        self._require_idle()
         """volume: CUDA float32 (Z,Y,X); starts: (n,3) ints -> CUDA (n, C, cz, cy, cx)."""
         assert self._loaded, 'Please ensure a unet is loaded and supplied'
         self._bind_stream()
@@ -195,6 +204,7 @@ class UNet:
     def predict_volume(self, volume, chunk_size, margin, feature_map=None, first=0, count=None):
         """P2-P4 on device: CUDA (Z,Y,X) volume -> CUDA (C,Z,Y,X) feature map (crops stitched)."""
         assert self._loaded, 'Please ensure a unet is loaded and supplied'
+        self._require_idle()
         self._bind_stream()
         tab = _lib.make_chunks_table(volume.shape, chunk_size, margin)
         if feature_map is None:

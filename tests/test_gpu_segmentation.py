@@ -264,3 +264,24 @@ def test_frame_pipe_direct_use_and_errors(unet):
     assert cur2[0, 0, 0] == 12345
     cur2[0, 0, 0] = 0
     assert np.array_equal(cur2, cur)
+
+
+def test_unet_refuses_direct_calls_while_its_frame_pipe_is_busy(unet):
+    """The context is the pipe's while frames are in flight (segmentation_loop yields between frames): a forward from the
+    consumer's side raises instead of racing; ``discard`` finishes a frame whatever its status; the pipe holds the U-Net
+    weakly (no cycle keeping 9 GB of slots alive)."""
+    import gc
+    from iterseg_amd import segmentation as seg
+    from tests.synth import positive_volume
+    v = positive_volume((8, 40, 48), 21)
+    pipe = seg._pipe_for(unet, v.shape, CHUNK, MARGIN)
+    assert seg._pipe_for(unet, v.shape, CHUNK, MARGIN) is pipe and pipe.unet is unet
+    pipe.submit(v)
+    x = v[None, None, :, :32, :32]
+    with pytest.raises(RuntimeError, match="frames in flight"):
+        unet(x)
+    pipe.discard()
+    assert pipe.in_flight == 0
+    assert unet(x).shape == (1, 5, 8, 32, 32)
+    assert not any(r is pipe for r in gc.get_referrers(unet))
+    unet._drop_pipe()
