@@ -28,6 +28,22 @@ def _slice(t, k):
     return a.reshape(a.shape[0], -1)[:, :64]
 
 
+def _weights_off_the_relu_kinks(out_channels, x, first_seed, margin=2e-6):
+    """Seeded weights for which no BatchNorm output of the float64 oracle forward lies within `margin` of zero.  Such a voxel's
+    ReLU mask is decided by the fp32 summation order of the convolution in front of it, and one flipped voxel moves gradients by
+    ~1e-2 of their maximum (LOG.md, round 4: `c7_0.batch0.bias`): a gradient comparison must not sit on that discontinuity."""
+    from iterseg_amd import weights
+    from oracle import unet_torch as ou
+    for seed in range(first_seed, first_seed + 40):
+        sd = weights.generate_state_dict(seed, 1, out_channels)
+        taps = {}
+        with torch.no_grad():
+            ou.unet_forward(ou._as_params(sd, dtype=torch.float64), torch.from_numpy(x)[None, None].double(), taps=taps)
+        if min(float(v.abs().min()) for k, v in taps.items() if ".batch" in k) > margin:
+            return sd
+    raise AssertionError("no seed with a margin")
+
+
 def test_layout_matches_schema():
     from iterseg_amd import weights
     from iterseg_amd.train import trainable_layout
@@ -592,9 +608,9 @@ def test_forked_dice_loss_against_oracle_float64():
     from oracle import unet_torch as ou
     from tests.synth import positive_volume
     forks, patch = (3, 2), (4, 32, 32)
-    sd = weights.generate_state_dict(8, 1, forks)
-    rng = np.random.default_rng(4)
     x = positive_volume(patch, 3)
+    sd = _weights_off_the_relu_kinks(forks, x, first_seed=8)
+    rng = np.random.default_rng(4)
     y = (rng.random((5,) + patch) < 0.4).astype(np.float32)
     t = Trainer(sd, out_channels=forks, patch=patch)
     loss, chan = t._call(x, y, "DiceLoss", None, 0.01, 0, True)
