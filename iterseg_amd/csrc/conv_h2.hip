@@ -157,15 +157,19 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     const int WP = W + 2;
     // mode 0: a box of 2 x TYb x TXb voxels (2 TYb TXb <= ROWS) on a halo of 4 x (TYb + 2) x (TXb + 2) slots: the interior boxes are
     // 8 x TXW, the edge strips (ConvArgs::sr_*, sb_*) tall and narrow / flat and wide
+    // (the N-tile-pair kernel sits at the register limit -- run-time box sizes cost it 35 more spilled registers and 6 % -- and its
+    // layers, Cout % 128 == 0, are below the box-tiled levels for every chunk shape iterseg uses: it keeps the padded boxes)
+    constexpr bool STRIPS = NJ == 1;
     int TYb = 8, TXb = TXW, xlim = W;                            // xlim: the last bottom-strip box stops where the right strip begins
     if (a.mode == 0) {
         const int nzt = (D + 1) >> 1;
         const int zt = tile % nzt, rest = tile / nzt;
         z0 = zt * 2; TZ = 2;
-        if (rest < a.nI) { y0 = (rest / a.ntx) * 8; x0 = (rest % a.ntx) * TXW; }
+        if (!STRIPS || rest < a.nI) { y0 = (rest / a.ntx) * 8; x0 = (rest % a.ntx) * TXW; }
         else if (rest < a.nI + a.sr_n) { TYb = a.sr_ty; TXb = a.sr_tx; y0 = (rest - a.nI) * a.sr_ty; x0 = a.sr_x0; }
         else { TYb = a.sb_ty; TXb = a.sb_tx; y0 = a.sb_y0; x0 = (rest - a.nI - a.sr_n) * a.sb_tx; if (a.sr_n) xlim = a.sr_x0; }
-        RS = TXb + 2; PS = (TYb + 2) * RS; S = 4 * PS;
+        if constexpr (STRIPS) { RS = TXb + 2; PS = (TYb + 2) * RS; } else { RS = TXW + 2; PS = 10 * (TXW + 2); }
+        S = 4 * PS;
     } else {
         TZ = (a.mode == 1) ? 2 : 1;
         TP = ROWS / TZ;
@@ -184,7 +188,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     if (tid < ROWS) {
         int r = tid, g = -1;
         if (a.mode == 0) {
-            int zz = r / (TYb * TXb), yy = (r / TXb) % TYb, xx = r % TXb;
+            int zz, yy, xx;
+            if constexpr (STRIPS) { zz = r / (TYb * TXb); yy = (r / TXb) % TYb; xx = r % TXb; }
+            else { zz = r / (8 * TXW); yy = (r / TXW) & 7; xx = r % TXW; }
             int z = z0 + zz, y = y0 + yy, x = x0 + xx;
             if (zz < 2 && z < D && y < H && x < xlim) g = (z * H + y) * W + x;
         } else {
@@ -196,6 +202,10 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     }
     auto row_slot = [&](int r) __attribute__((always_inline)) -> int {
         if (a.mode == 0) {
+            if constexpr (!STRIPS) {
+                const int zz = r / (8 * TXW), yy = (r / TXW) & 7, xx = r % TXW;
+                return (zz + 1) * (10 * (TXW + 2)) + (yy + 1) * (TXW + 2) + (xx + 1);
+            }
             int zz = r / (TYb * TXb), yy = (r / TXb) % TYb, xx = r % TXb;
             if (zz > 1) { zz = 1; yy = TYb - 1; xx = TXb - 1; }          // rows beyond the box (strips: 2 TYb TXb < ROWS): any valid slot
             return (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
@@ -215,7 +225,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if (s >= S) return -2;
         int z, y, x;
         if (a.mode == 0) {
-            int hz = s / PS, hy = (s / RS) % (TYb + 2), hx = s % RS;
+            int hz, hy, hx;
+            if constexpr (STRIPS) { hz = s / PS; hy = (s / RS) % (TYb + 2); hx = s % RS; }
+            else { hz = s / (10 * (TXW + 2)); hy = (s / (TXW + 2)) % 10; hx = s % (TXW + 2); }
             z = z0 + hz - 1; y = y0 + hy - 1; x = x0 + hx - 1;
         } else {
             int hz = s / PS, qq = qlo + s % PS + WP;
@@ -718,7 +730,8 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         const int nyp = (l.H + 7) / 8, nxp = (l.W + txw - 1) / txw;
         a.ntx = nxp; a.nI = nyp * nxp; a.sr_n = a.sb_n = 0;
         a.sr_ty = a.sr_tx = a.sr_x0 = a.sb_ty = a.sb_tx = a.sb_y0 = 0;
-        if ((ry || rx) && ny > 0 && nx > 0 && ctx->tune.h2_strips) {
+        const bool may_pair = nw8 && ctx->tune.h2_nj2 && cout % 128 == 0;       // conv_h2c16nw8x2_kernel: padded boxes only (STRIPS)
+        if ((ry || rx) && ny > 0 && nx > 0 && ctx->tune.h2_strips && !may_pair) {
             // right strip: rx columns, all H rows; bottom strip: ry rows, the interior columns
             int sr_ty = 0, sr_n = 0, sb_tx = 0, sb_n = 0;
             if (rx) { sr_ty = std::min(rows / (2 * rx), cap / (4 * (rx + 2)) - 2); sr_ty = std::min(sr_ty, l.H); if (sr_ty >= 1) sr_n = (l.H + sr_ty - 1) / sr_ty; }

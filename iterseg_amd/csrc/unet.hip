@@ -412,8 +412,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
                                                           const float *__restrict__ beta, float *__restrict__ scale,
                                                           float *__restrict__ shift, float *__restrict__ bmean,
                                                           float *__restrict__ bvar, float *__restrict__ invstd_out,
-                                                          float *__restrict__ rmean, float *__restrict__ rvar,
-                                                          uint32_t *__restrict__ done)
+                                                          float *__restrict__ rmean, float *__restrict__ rvar)
 {
     __shared__ double rs[256], rq[256];
     const int c = blockIdx.x, b = blockIdx.y;
@@ -442,28 +441,25 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
         invstd_out[b * C + c] = invstd;
         const float ub = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
         bvar[b * C + c] = ub;
-        // running statistics: the chunks of a launch set update them one after the other, like the reference's chunk loop
-        // (predict.py:82-95).  The block of channel c that arrives LAST does it for all of them, in chunk order (a separate
-        // 17 us kernel per layer before: 18 launches per set).
-        const int B = (int)gridDim.y;
-        if (B == 1) {
+        if (rmean) {          // a single chunk (gridDim.y == 1, the training step): bn_running_kernel's update, done here
             rmean[c] = (1.f - BN_MOMENTUM) * rmean[c] + BN_MOMENTUM * (float)mean;
             rvar[c] = (1.f - BN_MOMENTUM) * rvar[c] + BN_MOMENTUM * ub;
-        } else {
-            __threadfence();                                    // this block's bmean / bvar before its arrival
-            if (atomicAdd(&done[c], 1u) == (uint32_t)B - 1u) {
-                __threadfence();
-                done[c] = 0u;                                   // ready for the next layer's launch (stream order)
-                float m = rmean[c], v = rvar[c];
-                for (int bb = 0; bb < B; ++bb) {
-                    m = (1.f - BN_MOMENTUM) * m + BN_MOMENTUM * __hip_atomic_load(&bmean[bb * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v = (1.f - BN_MOMENTUM) * v + BN_MOMENTUM * __hip_atomic_load(&bvar[bb * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                rmean[c] = m;
-                rvar[c] = v;
-            }
         }
     }
+}
+
+// running statistics: chunks update them one after the other, like the reference's chunk loop
+__global__ void bn_running_kernel(const float *bmean, const float *bvar, int B, int C, float *rmean, float *rvar)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float m = rmean[c], v = rvar[c];
+    for (int b = 0; b < B; ++b) {
+        m = (1.f - BN_MOMENTUM) * m + BN_MOMENTUM * bmean[b * C + c];
+        v = (1.f - BN_MOMENTUM) * v + BN_MOMENTUM * bvar[b * C + c];
+    }
+    rmean[c] = m;
+    rvar[c] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1162,7 +1158,6 @@ static int commit_weights(isx_ctx *ctx, const int *fork_channels, int nforks)
         }
     }
     ISX_TRY(dev_upload(u, std::vector<float>(32, 0.f), &u->zeros32));
-    { float *z256 = nullptr; ISX_TRY(dev_upload(u, std::vector<float>(256, 0.f), &z256)); u->bn_done = (uint32_t *)z256; }
     for (int k = 0; k < 4; ++k) {
         UpConv &U = u->up[k];
         U.name = UPS[k];
@@ -1432,8 +1427,12 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
         bn_finalize_kernel<<<dim3((unsigned)L.cout, (unsigned)B), 256, 0, ctx->stream>>>(
             L.psum, L.psq, stat_tiles, L.cout, (double)l.M, L.gamma, L.beta, L.scale, L.shift, L.bmean, L.bvar, L.invstd,
-            L.rmean, L.rvar, u->bn_done);
+            B == 1 ? L.rmean : nullptr, B == 1 ? L.rvar : nullptr);
         ISX_CHECK_LAUNCH();
+        if (B > 1) {
+            bn_running_kernel<<<cdiv(L.cout, 64), 64, 0, ctx->stream>>>(L.bmean, L.bvar, B, L.cout, L.rmean, L.rvar);
+            ISX_CHECK_LAUNCH();
+        }
         L.nbt += B;
     }
     return ISX_OK;

@@ -77,7 +77,6 @@ struct UNetState {
     float *ups[ISX_MAX_UPS] = {nullptr};      // ups_index(fork, k)
     float *ptail = nullptr;           // [B][M0][16] partial sums of the folded tail layer
     float *wtail = nullptr, *zeros32 = nullptr;
-    uint32_t *bn_done = nullptr;      // [256] arrival counters of bn_finalize_kernel (zero between launches)
     const int32_t *d_table = nullptr;   // device rows of the launch set in flight
     int last_n = 0;
     bool up_folded[ISX_MAX_UPS] = {false};     // last forward: ups[i] was NOT materialised (the tail kernel up-sampled it on read)
