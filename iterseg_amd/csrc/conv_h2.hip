@@ -268,8 +268,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     const int wbase = __builtin_amdgcn_readfirstlane(tid) & ~63;
 #define H2_LOAD_A(k)                                                                              \
     if constexpr (k < NA && ISX_H2_ABLATE != 3) if (THREADS * k + wbase < S) {                    \
-        /* 32-bit element offset from the stage's (wave-uniform) base: one multiply, then a scalar-base load */ \
-        const float *pp = ld_src + (uint32_t)(gv##k > 0 ? gv##k : 0) * (uint32_t)ld_C;           \
+        /* (a 32-bit element offset here -- one multiply, scalar-base load -- costs the N-tile-pair kernel 37 more spilled registers) */ \
+        const float *pp = &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];                       \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }
