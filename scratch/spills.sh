@@ -1,7 +1,7 @@
 # VGPR / SGPR spill counts and scratch bytes per lane of every kernel in a HIP source: bash scratch/spills.sh iterseg_amd/csrc/conv_h2.hip
 set -e
 SRC=$(readlink -f ${1:-iterseg_amd/csrc/conv_h2.hip}); INC=$(dirname $(dirname $(dirname $SRC)))/include
-cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o /tmp/spills.s $SRC -I$INC
+cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o /tmp/spills.s $SRC -I$INC 2>/dev/null
 python3 - <<'PY'
 import re
 s = open('/tmp/spills.s').read()
