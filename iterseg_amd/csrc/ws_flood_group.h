@@ -328,15 +328,22 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     uint32_t mx = 0, resmin = 0xFFFFFFFFu;
     int ncand = 0, ndef = 0;
     // register candidates: value << 32 | discovery index << 16 | pool address -- one 64-bit compare orders them like the
-    // reference orders its heap entries of one episode (value, then push order)
-    unsigned long long ck[GRP_CMAX];
+    // reference orders its heap entries of one episode (value, then push order).  Kept SORTED ascending, free registers hold
+    // ~0 (sorts last): the next pop is ck[0], an insertion is one compare per register and a shift by selects, the largest
+    // candidate is `cmax` (= ck[ncand - 1]; 0 when there is none).  (Unsorted registers with a minimum / maximum search per
+    // pop / discovery cost 205 + 6 x 71 instructions of the ~850 a step executes: the step loop is instruction-bound, LOG.md.)
+    unsigned long long ck[GRP_CMAX], cmax = 0ull;
     int chlast = -1, spare = -1;
+    auto cand_clear = [&]() {
 #pragma unroll
-    for (int k = 0; k < GRP_CMAX; ++k) ck[k] = ~0ull;
+        for (int k = 0; k < GRP_CMAX; ++k) ck[k] = ~0ull;
+        ncand = 0; ndef = 0; cmax = 0ull;
+    };
+    cand_clear();
 
     auto ep_fresh = [&]() {
         started = false; cur = root; curv = 0; cur_addr = -1; cur_li = -1; np = 0; npop = 0; mx = 0; resmin = 0xFFFFFFFFu;
-        ncand = 0; ndef = 0; chlast = -1; spare = -1;
+        cand_clear(); chlast = -1; spare = -1;
     };
     auto free_chunks = [&]() {                       // pushes only: never in a phase that allocates (uses np: call before ep_fresh)
         const int nc = (np + GRP_CH - 1) / GRP_CH;
@@ -359,22 +366,27 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         ep_fresh();
         pub_info[tid] = 0u; pub_res[tid] = 0xFFFFFFFFu; pub_mx[tid] = 0u;      // "not started" is what the commit phase must see
     };
-    // every deferred entry (below the bound, unpopped, only in the list) sorts after every register candidate
-    // (written with selects: with an early-return form the compiler merged `++ncand` / `++ndef` into one store through a selected
-    // pointer and kept both counters in scratch memory -- two scratch loads and a store per discovery in the claim loop)
+    // every deferred entry (below the bound, unpopped, only in the list) sorts after every register candidate: a discovery enters
+    // the registers if it sorts below the largest candidate, or if a register is free and nothing is deferred; what falls off
+    // the end of a full set becomes a deferred entry.  (Selects only: with an early-return form the compiler merged `++ncand` /
+    // `++ndef` into one store through a selected pointer and kept both counters in scratch memory.)
     auto cand_add = [&](uint32_t v, int li, int ad) {
         const unsigned long long nk_ = ((unsigned long long)v << 32) | ((unsigned long long)(uint32_t)li << 16) | (unsigned long long)(uint32_t)ad;
-        int mk = -1; unsigned long long mv = 0ull;
+        const bool full = ncand == GRP_CMAX;
+        const bool ins = (ncand > 0 && nk_ < cmax) || (!full && ndef == 0);
+        bool lt[GRP_CMAX];
 #pragma unroll
-        for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand && (mk < 0 || ck[k] > mv)) { mk = k; mv = ck[k]; }
-        const bool below_max = mk >= 0 && nk_ < mv;
-        const bool add = ncand < GRP_CMAX && (ndef == 0 || below_max);      // a free register: behind no deferred entry, or below the largest candidate
-        const bool repl = ncand == GRP_CMAX && below_max;                   // full: the largest candidate becomes a deferred entry
-        const int at = add ? ncand : (repl ? mk : -1);
+        for (int k = 0; k < GRP_CMAX; ++k) lt[k] = ins && nk_ < ck[k];
 #pragma unroll
-        for (int k = 0; k < GRP_CMAX; ++k) ck[k] = (k == at) ? nk_ : ck[k];
-        ncand += add ? 1 : 0;
-        ndef += add ? 0 : 1;
+        for (int k = GRP_CMAX - 1; k >= 0; --k) {
+            const unsigned long long below = k > 0 ? ck[k - 1] : 0ull;
+            const bool shift = k > 0 && lt[k - 1];                 // the new key sorts before ck[k - 1]: that one moves up
+            ck[k] = shift ? below : (lt[k] ? nk_ : ck[k]);
+        }
+        const bool grew = ins && !full;
+        cmax = ins ? (full ? ck[GRP_CMAX - 1] : (nk_ > cmax ? nk_ : cmax)) : cmax;
+        ncand += grew ? 1 : 0;
+        ndef += grew ? 0 : 1;
     };
     // The candidates of lane L's episode rebuilt from its list by the WHOLE wave (three entries per lane): candidates,
     // deferred count and the minimum of the residuals.  Runs when the six registers are used up and discoveries below
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             const uint32_t vmin = rdlane(wave_prefix_min((uint32_t)(m >> 32)), 63);
             const uint32_t lmin = rdlane(wave_prefix_min((uint32_t)(m >> 32) == vmin ? (uint32_t)m : 0xFFFFFFFFu), 63);
             const unsigned long long best = ((unsigned long long)vmin << 32) | lmin;
-            if (lane == L) ck[r] = vmin != 0xFFFFFFFFu ? best : ~0ull;
+            if (lane == L) { ck[r] = vmin != 0xFFFFFFFFu ? best : ~0ull; if (r == 0) cmax = 0ull; if (vmin != 0xFFFFFFFFu) cmax = best; }      // ascending
             if (vmin != 0xFFFFFFFFu) {
 #pragma unroll
                 for (int u = 0; u < 3; ++u) if (k3[u] == best) k3[u] = ~0ull;
@@ -417,24 +429,21 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     };
     // next pop: the smallest unpopped discovery if it sorts below the bound (never called with ncand == 0 && ndef > 0)
     auto select_next = [&](uint32_t bound) {
-        int mk = -1; unsigned long long mv = ~0ull;
-#pragma unroll
-        for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand && ck[k] < mv) { mk = k; mv = ck[k]; }
-        if (mk >= 0 && (uint32_t)(mv >> 32) < bound) {
+        const unsigned long long mv = ck[0];                        // the smallest candidate (~0: none)
+        if (ncand > 0 && (uint32_t)(mv >> 32) < bound) {
             curv = (uint32_t)(mv >> 32); cur_li = (int)((mv >> 16) & 0xFFFFull); cur_addr = (int)(mv & 0xFFFFull);
             cur = pvox[cur_addr];
-            unsigned long long lastk = ~0ull;
 #pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == ncand - 1) lastk = ck[k];
-#pragma unroll
-            for (int k = 0; k < GRP_CMAX; ++k) if (k == mk) ck[k] = lastk;
+            for (int k = 0; k + 1 < GRP_CMAX; ++k) ck[k] = ck[k + 1];
+            ck[GRP_CMAX - 1] = ~0ull;
             --ncand;
+            if (ncand == 0) cmax = 0ull;
             return;
         }
         // idle: what is left in the registers sorts at or above the bound, and every deferred entry sorts after every
         // register candidate -- the smallest candidate is the smallest of all of them
-        if (mk >= 0 && (uint32_t)(mv >> 32) < resmin) resmin = (uint32_t)(mv >> 32);
-        ncand = 0; ndef = 0;
+        if (ncand > 0 && (uint32_t)(mv >> 32) < resmin) resmin = (uint32_t)(mv >> 32);
+        cand_clear();
         cur = GRP_NONE;
     };
     auto adopt = [&]() {
@@ -753,18 +762,18 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 uint32_t m2 = mx;
                 if (cur != GRP_NONE && cur_li >= 0 && curv > m2) m2 = curv;
                 if (m2 != 0u && m2 >= bound) atomicMin(&shQ[GQ_KSQ], key);
-                // candidates that the lower bound turned into residuals
+                // candidates that the lower bound turned into residuals: a suffix of the sorted registers
 #pragma unroll
                 for (int k = GRP_CMAX - 1; k >= 0; --k) {
                     if (k < ncand && (uint32_t)(ck[k] >> 32) >= bound) {
                         if ((uint32_t)(ck[k] >> 32) < resmin) resmin = (uint32_t)(ck[k] >> 32);
-                        unsigned long long lastk = ~0ull;
-#pragma unroll
-                        for (int q = 0; q < GRP_CMAX; ++q) if (q == ncand - 1) lastk = ck[q];
-                        ck[k] = lastk;
+                        ck[k] = ~0ull;
                         --ncand;
                     }
                 }
+                cmax = 0ull;
+#pragma unroll
+                for (int k = 0; k < GRP_CMAX; ++k) if (k < ncand) cmax = ck[k];
             }
             __syncthreads();                                                    // (S1)
             const unsigned long long ksq = shQ[GQ_KSQ];
@@ -826,16 +835,18 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             uint32_t wonm = 0;
             GTICK(11);
             if (active) {
+                // guard site 3 (always on): the voxel in hand must be a voxel -- checked once, before the six claims it would index
+                const bool cur_ok = cur < (uint32_t)PN;
+                if (!cur_ok && stats) {
+                    if (atomicAdd(&stats[20], 1ull) == 0ull) {
+                        stats[21] = 3ull;
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     nbv[k] = cur + (uint32_t)noff32[k];
                     old[k] = 0ull; val[k] = 0.0f;
-                    if (cur >= (uint32_t)PN && stats) {
-                        if (atomicAdd(&stats[20], 1ull) == 0ull) {
-                            stats[21] = 3ull;
-                        }
-                    }
-                    if (nbv[k] < (uint32_t)PN && cur < (uint32_t)PN) {
+                    if (nbv[k] < (uint32_t)PN && cur_ok) {
                         old[k] = __hip_atomic_fetch_min(&state[nbv[k]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         val[k] = (aff + (int64_t)ax[k] * PN)[k < 3 ? cur : nbv[k]];
                     }
@@ -922,7 +933,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                     const uint32_t v = pval[ch * GRP_CH + (i & (GRP_CH - 1))];
                     if (v != WIN_POPPED && v < rm) rm = v;
                 }
-                cur = GRP_NONE; ncand = 0; ndef = 0; resmin = rm;
+                cur = GRP_NONE; cand_clear(); resmin = rm;
                 pub_res[tid] = rm; pub_info[tid] = (uint32_t)np | ((uint32_t)npop << 8) | (1u << 16) | (1u << 17);
                 atomicAdd(&lstat[GS_FORCED], 1u);
             }
