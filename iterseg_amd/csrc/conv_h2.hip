@@ -171,7 +171,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if constexpr (STRIPS) { RS = TXb + 2; PS = (TYb + 2) * RS; } else { RS = TXW + 2; PS = 10 * (TXW + 2); }
         S = 4 * PS;
     } else {
-        TZ = (a.mode == 1) ? 2 : 1;
+        TZ = a.tz;
         TP = ROWS / TZ;
         const int nzt = (D + TZ - 1) / TZ;
         int zt = tile % nzt, pt = tile / nzt;
@@ -748,6 +748,14 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
             }
         }
         a.tiles_per_chunk = ((l.D + 1) / 2) * (a.nI + a.sr_n + a.sb_n);
+    }
+    a.tz = a.mode == 1 ? 2 : 1;
+    if (a.mode == 2 && l.D > 1 && l.D <= 8 && ctx->tune.h2_tz) {
+        // odd, shallow levels: all planes in one tile when that needs fewer tiles (the rows beyond tz * (rows / tz) stay empty)
+        const int rows = nw8 ? 256 : 128 * mt, cap = nw8 ? 1536 : (mt == 2 ? 1280 : 1024);
+        const int tp = rows / l.D, ntp = (l.H * l.W + tp - 1) / tp;
+        const int lh = tp + 2 * ((tp + l.W - 1) / l.W + 1) + 2 * (l.W + 2) + 2, slots = (l.D + 2) * lh;
+        if (tp >= 8 && ntp < a.tiles_per_chunk && slots <= cap) { a.tz = l.D; a.ntp = ntp; a.tiles_per_chunk = ntp; a.slots_max = slots; }
     }
     ISX_REQUIRE(a.slots_max <= (nw8 ? 1536 : (mt == 2 ? 1280 : 1024)), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     // N-tile pairs (conv_h2c16nw8x2_kernel): Cout % 128 == 0 and a launch that still fills the chip

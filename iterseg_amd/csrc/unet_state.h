@@ -121,6 +121,9 @@ struct ConvArgs {
     // sr_ty x sr_tx voxels down the right edge (x0 = sr_x0, all y) and sb_n boxes of sb_ty x sb_tx along the bottom edge
     // (y0 = sb_y0, x < sr_x0): at 129^2 a padded tiling spends 17.7 % of its matrix work on the "+1" row and column
     int nI, sr_n, sr_ty, sr_tx, sr_x0, sb_n, sb_ty, sb_tx, sb_y0;
+    // conv_h2 kernels, modes 1 / 2 (linearised planes): a tile is tz planes x (rows / tz) positions.  2 / 1 by default; a level with
+    // few, small planes takes all of them (17 x 17 x 5: 6 tiles of 5 x 51 rows instead of 10 of 1 x 256 -- 289 positions fill 1.13 tiles)
+    int tz;
 };
 
 struct H2Extra {           // the tail kernel's optional source: up3 up-sampled on read (conv_tail.hip, TailArgs)

@@ -405,3 +405,29 @@ def test_edge_strip_tiles_change_only_the_statistics_rounding(precision, nw8, mo
         assert np.array_equal(nets[0].tap("c1.conv0"), nets[1].tap("c1.conv0")), shape
         # (bf16: a last-bit change of a BatchNorm scale moves some activations across a bf16 rounding boundary, 2^-9 relative)
         assert np.abs(ya - yb).max() <= (2e-5 if precision == "split-f16" else 4e-3), (shape, np.abs(ya - yb).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nw8", ["1", "2", "0"])
+@pytest.mark.parametrize("precision", ["split-f16", "bf16"])
+def test_all_planes_of_a_shallow_level_in_one_tile_change_only_the_statistics_rounding(precision, nw8, monkeypatch):
+    """ISX_H2_TZ (default 1): a level with an odd, small number of planes (the bottom of the timed chunk: 17 x 17 x 5) tiles all
+    planes x rows / D positions instead of one plane x rows positions -- 6 tiles instead of 10 there (ConvArgs::tz).  Which tile a
+    voxel sits in changes nothing about its products: the first layer of that level is identical bit for bit, behind it only the
+    grouping of the BatchNorm partial sums differs."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(9)
+    nets = []
+    monkeypatch.setenv("ISX_H2_NW8", nw8)
+    for v in ("1", "0"):
+        monkeypatch.setenv("ISX_H2_TZ", v)
+        u = UNet(1, 5, batch=2, precision=precision)
+        u.load_state_dict(sd)
+        nets.append(u)
+    for shape in [(10, 256, 256), (6, 96, 112), (10, 64, 80), (14, 48, 48)]:          # bottom levels 17x17x5, 7x8x3, 5x6x5, 4x4x7
+        x = np.random.default_rng(12).random((1, 1) + shape, dtype=np.float32)
+        ya, yb = nets[0](x), nets[1](x)
+        assert np.array_equal(nets[0].tap("c4.conv0"), nets[1].tap("c4.conv0")), shape
+        assert np.abs(ya - yb).max() <= (2e-5 if precision == "split-f16" else 4e-3), (shape, np.abs(ya - yb).max())
