@@ -779,29 +779,26 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel: the last convolution of the network, 5 -> 5 channels (c8_0.conv1).  2 x 8 x 32 voxels per block, an x-pair per
-// thread; the halo tile (4 x 10 x 34 voxels x 5 channels, BN+ReLU of the producer applied) sits in LDS channel-major
-// (row pitch 35: the reads of a wave -- 4 rows x 16 pairs -- are conflict-free), and the 675 weights are read with
-// uniform addresses, i.e. through the scalar cache into SGPRs.  The layer is bound by its 675 FMAs per voxel: the two
-// voxels of a thread share one accumulator pair per output channel, so every FMA is a v_pk_fma_f32 (vector pair x
-// broadcast SGPR: 2 FMAs per lane per issue; the one-voxel form ran at the scalar-FMA rate, 1.16 ms per 64 chunks), and
-// the four x-positions a pair needs per (dz, dy, channel) are read once for both (90 LDS reads per voxel instead of 135).
+// Kernel: the last convolution of the network, 5 -> 5 channels (c8_0.conv1).  2 x 8 x 16 voxels per block, one per
+// thread; the halo tile (4 x 10 x 18 voxels x 5 channels, BN+ReLU of the producer applied) sits in LDS channel-major
+// so that the 27 x 5 reads of a wave are conflict-free, and the 675 weights are read with uniform addresses, i.e.
+// through the scalar cache into SGPRs (the generic thin kernel re-read them from LDS for every FMA group and
+// bounds-checked every tap: 3.8 ms per 64 chunks; this one is bound by its 675 FMAs per voxel).
 // ------------------------------------------------------------------------------------------
-typedef float f32x2v __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void conv55_kernel(const float *__restrict__ src, const float *__restrict__ scale,
                                                      const float *__restrict__ shift, const float *__restrict__ w,
                                                      const float *__restrict__ bias, int D, int H, int W,
                                                      float *__restrict__ out, float *__restrict__ psum,
                                                      float *__restrict__ psq, int tiles_per_chunk, int nty, int ntx)
 {
-    constexpr int C = 5, RS = 35, PS = 10 * RS, S = 4 * PS, CP = S;      // CP: channel plane pitch (floats)
+    constexpr int C = 5, PS = 180, RS = 18, S = 720, CP = 724;      // CP: channel plane pitch (floats)
     __shared__ float As[C * CP];
     __shared__ float red[4 * 8 * 2];
     const int tid = threadIdx.x;
     const int b = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
     const int nzt = (D + 1) >> 1;
     const int zt = tile % nzt, xt = (tile / nzt) % ntx, yt = tile / (nzt * ntx);
-    const int z0 = zt * 2, y0 = yt * 8, x0 = xt * 32;
+    const int z0 = zt * 2, y0 = yt * 8, x0 = xt * 16;
     const int64_t M = (int64_t)D * H * W;
     float sc[C], sh[C];
 #pragma unroll
@@ -809,51 +806,44 @@ __global__ __launch_bounds__(256) void conv55_kernel(const float *__restrict__ s
     for (int s = tid; s < S; s += 256) {
         const int hz = s / PS, hy = (s / RS) % 10, hx = s % RS;
         const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-        const bool ok = hx < 34 && z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
+        const bool ok = z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
         const float *p = src + ((int64_t)b * M + (ok ? ((int64_t)z * H + y) * W + x : 0)) * C;
 #pragma unroll
         for (int c = 0; c < C; ++c) As[c * CP + s] = ok ? fmaxf(fmaf(p[c], sc[c], sh[c]), 0.f) : 0.f;
     }
     __syncthreads();
-    const int zz = tid >> 7, yy = (tid >> 4) & 7, xp = tid & 15;
-    const int z = z0 + zz, y = y0 + yy, x = x0 + 2 * xp;
-    const bool live0 = z < D && y < H && x < W, live1 = live0 && x + 1 < W;
-    const float *ap = As + (zz + 1) * PS + (yy + 1) * RS + (2 * xp + 1);
-    f32x2v acc[C];
+    const int zz = tid >> 7, yy = (tid >> 4) & 7, xx = tid & 15;
+    const int z = z0 + zz, y = y0 + yy, x = x0 + xx;
+    const bool live = z < D && y < H && x < W;
+    const float *ap = As + (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
+    float acc[C];
 #pragma unroll
-    for (int o = 0; o < C; ++o) { const float bo = bias[o]; acc[o] = (f32x2v){bo, bo}; }
+    for (int o = 0; o < C; ++o) acc[o] = bias[o];
 #pragma unroll
     for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float *a = ap + c * CP + dz * PS + dy * RS;
-                const float a0 = a[-1], a1 = a[0], a2 = a[1], a3 = a[2];
-                const f32x2v pr[3] = {(f32x2v){a0, a1}, (f32x2v){a1, a2}, (f32x2v){a2, a3}};        // the pair's inputs for dx = -1, 0, +1
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int tap = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
+                const int toff = dz * PS + dy * RS + dx;
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int tap = (dz + 1) * 9 + (dy + 1) * 3 + dx;
+                for (int c = 0; c < C; ++c) {
+                    const float v = ap[c * CP + toff];
                     const float *wp = w + (tap * C + c) * 8;          // uniform address: scalar loads
 #pragma unroll
-                    for (int o = 0; o < C; ++o) { const float ww = wp[o]; acc[o] = __builtin_elementwise_fma(pr[dx], (f32x2v){ww, ww}, acc[o]); }
+                    for (int o = 0; o < C; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
                 }
             }
-    // (per voxel the sum runs over taps in (dz, dy, c, dx) order: the one-voxel form summed (dz, dy, dx, c) -- same terms)
-    if (live0) {
+    if (live) {
         float *q = out + ((int64_t)b * M + ((int64_t)z * H + y) * W + x) * C;
 #pragma unroll
-        for (int o = 0; o < C; ++o) q[o] = acc[o].x;
-        if (live1) {
-#pragma unroll
-            for (int o = 0; o < C; ++o) q[C + o] = acc[o].y;
-        }
+        for (int o = 0; o < C; ++o) q[o] = acc[o];
     }
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
     for (int o = 0; o < C; ++o) {
-        const float v0 = live0 ? acc[o].x : 0.f, v1 = live1 ? acc[o].y : 0.f;
-        float sm = v0 + v1, q2 = v0 * v0 + v1 * v1;
+        float sm = live ? acc[o] : 0.f, q2 = live ? acc[o] * acc[o] : 0.f;
         for (int off = 32; off > 0; off >>= 1) { sm += __shfl_xor(sm, off); q2 += __shfl_xor(q2, off); }
         if (lane == 0) { red[(wave * 8 + o) * 2] = sm; red[(wave * 8 + o) * 2 + 1] = q2; }
     }
@@ -1219,7 +1209,7 @@ static int layer_tiles(const UNetState *u, int li, const Level &l, int batch)
         return conv_tiles(l, conv_mode(l), 1, &a, &b, &c, &d);
     }
     if (L.cin == 1) return (int)((l.M + 127) / 128);
-    if (L.cin == 5 && L.cout == 5) return ((l.D + 1) / 2) * ((l.H + 7) / 8) * ((l.W + 31) / 32);     // conv55 tiles
+    if (L.cin == 5 && L.cout == 5) return ((l.D + 1) / 2) * ((l.H + 7) / 8) * ((l.W + 15) / 16);     // conv55 tiles
     const int blocks = (int)((l.M + 255) / 256);      // thin kernel blocks, or combine blocks of the folded layer
     return use_fold(L.cin, L.cout) ? std::max(blocks, conv_tail_tiles(l)) : blocks;        // (or the tiles of the one-pass tail kernel)
 }
@@ -1407,7 +1397,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         if (L.cin == 5 && L.cout == 5 && sa.C == 5 && sb.C == 0 && sa.scale) {
             conv55_kernel<<<(unsigned)(B * L.tiles), 256, 0, ctx->stream>>>(sa.p, sa.scale, sa.shift, L.w, L.bias, l.D, l.H, l.W,
                                                                          u->raw[li], L.psum, L.psq, L.tiles, (l.H + 7) / 8,
-                                                                         (l.W + 31) / 32);
+                                                                         (l.W + 15) / 16);
             ISX_CHECK_LAUNCH();
         } else {
         size_t lds = (size_t)(27 * L.cin * 8 + 64) * sizeof(float);

@@ -203,6 +203,8 @@ def test_segment_stack_with_the_hip_path(unet):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "_stack_worker.py")]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and os.path.isdir(os.path.join(root, "gpurun_out")):
+        open(os.path.join(root, "gpurun_out", "stack_worker_stderr.log"), "w").write(r.stdout + "\n----\n" + r.stderr)
     assert r.returncode == 0, r.stderr[-2000:]
 
 

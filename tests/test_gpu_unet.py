@@ -431,3 +431,18 @@ def test_all_planes_of_a_shallow_level_in_one_tile_change_only_the_statistics_ro
         ya, yb = nets[0](x), nets[1](x)
         assert np.array_equal(nets[0].tap("c4.conv0"), nets[1].tap("c4.conv0")), shape
         assert np.abs(ya - yb).max() <= (2e-5 if precision == "split-f16" else 4e-3), (shape, np.abs(ya - yb).max())
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_gpu_time_slicing():
+    """Two processes share the GPU (as the ranks of the two-rank tests do): every repetition of the chunked predict and of the
+    one-frame plugin path must reproduce its first result bit for bit.  Round 4: a `conv55_kernel` on packed fp32 FMAs
+    (`v_pk_fma_f32` with SGPR weights and an op_sel'd bias pair in the accumulator) passed every single-process test and lost the
+    bias of one channel on 16-lane rows in about a third of the frames once a second process time-sliced the device (LOG.md)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "_determinism_worker.py"), "60"]
+    procs = [subprocess.Popen(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-1500:]
