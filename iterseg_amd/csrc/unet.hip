@@ -101,13 +101,26 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // The voxel's six "has a neighbour on this side" flags once, and per tap a wave-uniform 32-bit offset: the two taps of an
+    // MFMA (lanes 0-31 / 32-63) are compile-time constants selected by the half.  (With the tap index computed per lane the
+    // kernel spent 640 vector instructions per wave -- 1.56 ms of its 1.84 ms per launch set -- on 64-bit index arithmetic and
+    // 14 x 6 bounds comparisons; SQ_INSTS_VALU of the r04e SQ pass.)
+    const bool has[3][3] = {{mv && z > 0, mv, mv && z < D - 1}, {y > 0, true, y < H - 1}, {x > 0, true, x < W - 1}};
+    const int HW = H * W;
 #pragma unroll
     for (int p = 0; p < 14; ++p) {
-        const int t = 2 * p + hh;                           // 0..27
-        const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
-        const int zz = z + dz, yy = y + dy, xx = x + dx;
-        const bool ok = mv && t < 27 && zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const float v = ok ? src[((int64_t)dz * H + dy) * W + dx] : 0.f;
+        float v = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int t = 2 * p + half;                     // compile-time: 0..27
+            if (t < 27) {
+                const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+                const bool ok = has[0][dz + 1] && has[1][dy + 1] && has[2][dx + 1];
+                const int off = dz * HW + dy * W + dx;      // wave-uniform
+                if (hh == half && ok) v = src[off];
+            }
+        }
+        const int t = 2 * p + hh;
         const float wv = t < 27 ? w[t * 32 + nn] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, wv, acc, 0, 0, 0);
     }
