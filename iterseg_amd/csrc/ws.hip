@@ -1707,11 +1707,14 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         if (group_min != ~0ull)
             fprintf(stderr, "[isx flood/group] (both kernels share the counters above) commit bursts %llu list reloads %llu; of the work-group kernel alone: rounds %llu pops %llu drains %llu (%llu as the prefix of a list in key order)\n", hs[17], hs[18], hs[63], hs[62], hs[60], hs[61]);
 #ifdef ISX_FLOOD_PROF
+        // (slots 32-40 are shared with the window kernel's timers: on a volume that uses both kernels build with -DISX_FLOOD_PROF_GROUP_ONLY;
+        //  per round of the work-group kernel, summed over its work-groups)
+        const double gr = hs[63] ? (double)hs[63] : 1.0;
         if (group_min != ~0ull)
             fprintf(stderr, "[isx flood/group] cycles/sub-round of lane 0: (S0)->C %.0f | C loop %.0f | wait (S5) %.0f | squash %.0f | to (E0) %.0f | order (E1-E3a) %.0f | verify %.0f | labels %.0f | enqueue %.0f | "
                             "burst-loop exit %.0f | drain call %.0f | drain sort %.0f | refill %.0f | loop end %.0f || C: claims+loads wait %.0f ; flush %.0f\n",
-                    (double)hs[32] / hs[0], (double)hs[43] / hs[0], (double)hs[34] / hs[0], (double)hs[35] / hs[0], (double)hs[44] / hs[0], (double)hs[33] / hs[0], (double)hs[36] / hs[0],
-                    (double)hs[37] / hs[0], (double)hs[38] / hs[0], (double)hs[45] / hs[0], (double)hs[41] / hs[0], (double)hs[42] / hs[0], (double)hs[39] / hs[0], (double)hs[40] / hs[0], (double)hs[46] / hs[0], (double)hs[47] / hs[0]);
+                    (double)hs[32] / gr, (double)hs[43] / gr, (double)hs[34] / gr, (double)hs[35] / gr, (double)hs[44] / gr, (double)hs[33] / gr, (double)hs[36] / gr,
+                    (double)hs[37] / gr, (double)hs[38] / gr, (double)hs[45] / gr, (double)hs[41] / gr, (double)hs[42] / gr, (double)hs[39] / gr, (double)hs[40] / gr, (double)hs[46] / gr, (double)hs[47] / gr);
         if (group_min != ~0ull)
             fprintf(stderr, "[isx flood/group] bursts cut by: front not ready (rounds) %llu | not started %llu | running %llu | bound %llu | pend full %llu | whole window %llu ; window fill at first burst %.1f ; flushes %llu (one-bucket %llu, 64-element appends %llu)\n",
                     hs[48], hs[49], hs[50], hs[51], hs[52], hs[53], hs[63] ? (double)hs[54] / hs[63] : 0.0, hs[57], hs[55], hs[56]);

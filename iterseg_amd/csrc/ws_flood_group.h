@@ -1229,7 +1229,10 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
 #ifdef ISX_FLOOD_PROF
     // phase timers of the work-group's first lane: 0 bounds (A), 1 claims up to (S3), 2 read-back + lists + next pop, 3 squash + publish,
     // 4 commit decision, 5 labels + residuals, 6 enqueue, 7 refill + drains, 8 loop end
-    if (stats && tid == 0) for (int i = 0; i < 16; ++i) atomicAdd(&stats[32 + i], tk_acc[i]);
+#ifndef ISX_FLOOD_PROF_WAVE
+#define ISX_FLOOD_PROF_WAVE 0
+#endif
+    if (stats && tid == 64 * ISX_FLOOD_PROF_WAVE) for (int i = 0; i < 16; ++i) atomicAdd(&stats[32 + i], tk_acc[i]);        // (development: whose wave's phase timers are reported)
 #endif
 #undef GTICK
     if (stats && tid == 0) {

@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(64) void flood_window_kernel(
         WTICK(8);
     }
 
-#ifdef ISX_FLOOD_PROF
+#if defined(ISX_FLOOD_PROF) && !defined(ISX_FLOOD_PROF_GROUP_ONLY)      // (the work-group kernel's timers share these slots: -DISX_FLOOD_PROF_GROUP_ONLY for a volume that uses both)
     if (stats && lane == 0)
         for (int i = 0; i < 10; ++i) { atomicAdd(&stats[32 + i], tk_acc[i]); if (i < 4) atomicAdd(&stats[44 + i], cold.tk[i]); }
 #endif
