@@ -166,6 +166,7 @@ static void read_knobs(isx_ctx *c)
     in("ISX_FLOOD_BURSTS", f.bursts); in("ISX_FLOOD_GSTEPS", f.gsteps); in("ISX_FLOOD_GMINSTEPS", f.gminsteps); in("ISX_FLOOD_GWIN", f.gwin);
     in("ISX_FLOOD_GLIST", f.glist); in("ISX_FLOOD_BUCKETS", f.buckets); in("ISX_FLOOD_GWATCHDOG", f.gwatchdog);
     in("ISX_FLOOD_GROUP_STREAM", f.group_stream);
+    in("ISX_GAUSS_FUSED", f.gauss_fused);
     f.stats = getenv("ISX_FLOOD_STATS") != nullptr;
     if (const char *e = getenv("ISX_FLOOD_TRACE")) f.trace = e;
     c->ftune = f;

@@ -78,6 +78,62 @@ __global__ void gauss_pass_kernel(const float *__restrict__ in, float *__restric
     out[i] = (float)tmp;
 }
 
+// The y pass and the x pass of one plane in ONE kernel (scipy applies the axes in order, every pass stores float32: the
+// intermediate lives in LDS as float32, so the result is the two-pass one bit for bit).  A block owns 16 x 64 outputs of a plane:
+// the (16 + 2R) x (64 + 2R) input tile is loaded once with clamped coordinates ('nearest'), the y pass runs on 16 x (64 + 2R)
+// positions -- the halo columns are the y pass of the clamped columns, exactly what the x pass of the separate kernels reads at
+// an edge --, the x pass on 16 x 64.  One read and one write of the volume instead of two of each, and 2 x 17 LDS reads per
+// output instead of 2 x 17 cached global loads with 64-bit index arithmetic.  Same operation order as gauss_pass_kernel, products
+// and sums not contracted (scipy's C loop has no fused multiply-add).
+template <int R>
+__global__ __launch_bounds__(256) void gauss_yx_kernel(const float *__restrict__ in, float *__restrict__ out, int Z, int Y, int X, int nty, int ntx)
+{
+#pragma clang fp contract(off)
+    constexpr int TY = 16, TX = 64, IW = TX + 2 * R, IH = TY + 2 * R;
+    __shared__ float tin[IH * IW];
+    __shared__ float mid[TY * IW];
+    const double *w = (R == 8) ? GK_SIGMA2 : GK_SIGMA1;
+    const int tile = blockIdx.x;
+    const int xt = tile % ntx, yt = (tile / ntx) % nty, z = tile / (ntx * nty);
+    const int y0 = yt * TY, x0 = xt * TX;
+    const float *plane = in + (int64_t)z * Y * X;
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i % IW;
+        int yy = y0 + r - R, xx = x0 + c - R;
+        yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
+        xx = xx < 0 ? 0 : (xx > X - 1 ? X - 1 : xx);
+        tin[i] = plane[(int64_t)yy * X + xx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TY * IW; i += 256) {
+        const int r = i / IW, c = i % IW;
+        const float *col = tin + (r + R) * IW + c;
+        double tmp = (double)col[0] * w[0];
+#pragma unroll
+        for (int k = R; k >= 1; --k) {
+            const double s2 = (double)col[-k * IW] + (double)col[k * IW];
+            const double p2 = s2 * w[k];
+            tmp = tmp + p2;
+        }
+        mid[i] = (float)tmp;
+    }
+    __syncthreads();
+    float *oplane = out + (int64_t)z * Y * X;
+    for (int i = threadIdx.x; i < TY * TX; i += 256) {
+        const int r = i / TX, c = i % TX;
+        const int y = y0 + r, x = x0 + c;
+        const float *row = mid + r * IW + c + R;
+        double tmp = (double)row[0] * w[0];
+#pragma unroll
+        for (int k = R; k >= 1; --k) {
+            const double s2 = (double)row[-k] + (double)row[k];
+            const double p2 = s2 * w[k];
+            tmp = tmp + p2;
+        }
+        if (y < Y && x < X) oplane[(int64_t)y * X + x] = (float)tmp;
+    }
+}
+
 static int gaussian_impl(isx_ctx *ctx, const float *img, float *out, const int64_t shape[3],
                          const int32_t sigma[3], float *tmpbuf)
 {
@@ -94,8 +150,20 @@ static int gaussian_impl(isx_ctx *ctx, const float *img, float *out, const int64
     // ping-pong so that the last pass lands in `out`
     const float *src = img;
     int done = 0;
+    const bool fuse_yx = sigma[1] > 0 && sigma[1] == sigma[2] && ctx->ftune.gauss_fused &&
+                         shape[0] * ((shape[1] + 15) / 16) * ((shape[2] + 63) / 64) < (int64_t)0x7FFFFFFF;
+    if (fuse_yx) npass -= 1;
     for (int a = 0; a < 3; ++a) {
         if (sigma[a] == 0) continue;
+        if (fuse_yx && a == 1) {
+            const int nty = (int)((shape[1] + 15) / 16), ntx = (int)((shape[2] + 63) / 64);
+            const unsigned grid = (unsigned)(shape[0] * nty * ntx);
+            float *dst = out;                          // the fused pass is the last one
+            if (sigma[a] == 2) gauss_yx_kernel<8><<<grid, 256, 0, ctx->stream>>>(src, dst, (int)shape[0], (int)shape[1], (int)shape[2], nty, ntx);
+            else gauss_yx_kernel<4><<<grid, 256, 0, ctx->stream>>>(src, dst, (int)shape[0], (int)shape[1], (int)shape[2], nty, ntx);
+            ISX_CHECK_LAUNCH();
+            break;
+        }
         int remaining = npass - done - 1;
         float *dst = (remaining % 2 == 0) ? out : tmpbuf;
         if (sigma[a] == 2)

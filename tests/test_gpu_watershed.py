@@ -287,3 +287,23 @@ def test_segment_output_image_scale_and_absolute_thresh(ws, scale, abs_thresh):
     assert np.array_equal(mask, m)
     assert np.array_equal(np.asarray(seg).astype(np.int64), ref.reshape(m.shape)[1:-1, 1:-1, 1:-1].astype(np.int64))
     assert np.asarray(seg).max() > 0
+
+
+@pytest.mark.parametrize("sigma", [2, (0, 1, 1), (0, 2, 2), 1])
+def test_fused_gaussian_is_the_two_pass_one_bit_for_bit(ws, flood_knobs, sigma):
+    """ISX_GAUSS_FUSED (default 1): the y and the x pass of a plane in one kernel with a float32 intermediate in LDS
+    (`gauss_yx_kernel`) against one kernel per axis -- scipy's axis order and per-pass float32 storage either way; shapes with
+    partial tiles, single rows / columns and planes narrower than the filter (everything clamps, mode 'nearest'), and
+    scipy itself on a small one."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(5)
+    sig = (sigma,) * 3 if np.isscalar(sigma) else sigma
+    for shape in [(9, 70, 130), (3, 16, 64), (5, 17, 65), (4, 5, 3), (2, 1, 200), (6, 33, 1)]:
+        x = rng.random(shape, dtype=np.float32)
+        flood_knobs({"ISX_GAUSS_FUSED": "1"})
+        a = ws.gaussian(x, sig)
+        flood_knobs({"ISX_GAUSS_FUSED": "0"})
+        b = ws.gaussian(x, sig)
+        assert np.array_equal(a, b), (shape, np.abs(a - b).max())
+        ref = ndi.gaussian_filter(x, sig, mode="nearest")
+        assert np.array_equal(a, ref), (shape, np.abs(a - ref).max())
