@@ -348,7 +348,11 @@ __global__ void mask_kernel(const float *__restrict__ img, const float *thresh, 
     int64_t PZ = Z + 2 * pad, PY = Y + 2 * pad, PX = X + 2 * pad;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= PZ * PY * PX) return;
-    int64_t x = i % PX - pad, y = (i / PX) % PY - pad, z = i / (PX * PY) - pad;
+    int64_t x, y, z;
+    if (PZ * PY * PX < (int64_t)0xFFFFFFFFll) {              // (uniform) 32-bit divisions for every volume but the largest
+        const uint32_t i32 = (uint32_t)i, r = i32 / (uint32_t)PX;
+        x = (int64_t)(i32 % (uint32_t)PX) - pad; y = (int64_t)(r % (uint32_t)PY) - pad; z = (int64_t)(r / (uint32_t)PY) - pad;
+    } else { x = i % PX - pad; y = (i / PX) % PY - pad; z = i / (PX * PY) - pad; }
     uint8_t m = 0;
     if (x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z) m = img[(z * Y + y) * X + x] > *thresh;
     mask[i] = m;
@@ -625,13 +629,14 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t *__restrict
 // cross-tile links: voxels on the low x / y / z face of their tile
 __global__ void ccl_seam_kernel(const uint8_t *__restrict__ mask, uint32_t *parent, int64_t PZ, int64_t PY, int64_t PX)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t N = PZ * PY * PX;
+    // (32-bit index arithmetic: the launcher guarantees N < 2^32, and three 64-bit divisions per masked voxel were most of this kernel)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t px = (uint32_t)PX, py = (uint32_t)PY, N = (uint32_t)(PZ * PY * PX);
     if (i >= N || !mask[i]) return;
-    const int64_t x = i % PX, y = (i / PX) % PY, z = i / (PX * PY);
-    if (x > 0 && x % CT_X == 0 && mask[i - 1]) uf_union(parent, (uint32_t)i, (uint32_t)(i - 1));
-    if (y > 0 && y % CT_Y == 0 && mask[i - PX]) uf_union(parent, (uint32_t)i, (uint32_t)(i - PX));
-    if (z > 0 && z % CT_Z == 0 && mask[i - PX * PY]) uf_union(parent, (uint32_t)i, (uint32_t)(i - PX * PY));
+    const uint32_t x = i % px, r = i / px, y = r % py, z = r / py;
+    if (x > 0 && x % CT_X == 0 && mask[i - 1]) uf_union(parent, i, i - 1);
+    if (y > 0 && y % CT_Y == 0 && mask[i - px]) uf_union(parent, i, i - px);
+    if (z > 0 && z % CT_Z == 0 && mask[i - px * py]) uf_union(parent, i, i - px * py);
 }
 
 static int ccl_impl(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], uint32_t *parent,
