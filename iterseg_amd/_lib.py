@@ -13,7 +13,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libitersegx.so")
+# ISX_LIB: development only -- load another build of the library (an ablation / profiling build under scratch/libs/) instead of
+# copying it over the product library, so that an interrupted experiment cannot leave the wrong code installed
+LIB_PATH = os.environ.get("ISX_LIB") or os.path.join(HERE, "libitersegx.so")
 
 ISX_OK = 0
 ISX_ERR_NO_DEVICE, ISX_ERR_HIP, ISX_ERR_ARG, ISX_ERR_NO_SEEDS, ISX_ERR_STATE, ISX_ERR_NOMEM, ISX_ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7

@@ -58,7 +58,9 @@ __device__ unsigned long long h2_stamp[12];
 #define H2_ACC(i, d)
 #endif
 #ifndef ISX_H2_ABLATE
-#define ISX_H2_ABLATE 0          // development: 2 = no matrix phase, 3 = no halo loads (timing experiments, wrong results)
+#define ISX_H2_ABLATE 0          // development (timing experiments, wrong results): 2 = no matrix phase, 3 = no halo loads, 4 = no slab DMA,
+                                 // 6 = matrix instructions on the first fragments only (no fragment reads), 7 = 3 + 4 (no vector-memory
+                                 // instruction in the K loop), 8 = 7 and no staging arithmetic / LDS stores (barriers + matrix phase only)
 #endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -255,7 +257,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 
     // named prefetch registers (arrays that live across the K loop end up in scratch)
     float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
-    if (ISX_H2_ABLATE == 3) { ra0 = rc0 = ra1 = rc1 = ra2 = rc2 = ra3 = rc3 = ra4 = rc4 = make_float4(0.5f, 0.25f, 0.125f, 1.f); }   // (no halo loads)
+    if (ISX_H2_ABLATE == 3 || ISX_H2_ABLATE >= 7) { ra0 = rc0 = ra1 = rc1 = ra2 = rc2 = ra3 = rc3 = ra4 = rc4 = make_float4(0.5f, 0.25f, 0.125f, 1.f); }   // (no halo loads)
     uint4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rb8, rb9, rb10, rb11, rb12, rb13;
     float relu_lo = 0.f;                                      // ReLU floor of the stage: 0 behind a BatchNorm, -inf for a source without one
     // the stage being loaded: source pointer (chunk b, channel offset included), its row length, the weight slab
@@ -267,7 +269,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     // were 40-56 % of the halo load instructions
     const int wbase = __builtin_amdgcn_readfirstlane(tid) & ~63;
 #define H2_LOAD_A(k)                                                                              \
-    if constexpr (k < NA && ISX_H2_ABLATE != 3) if (THREADS * k + wbase < S) {                    \
+    if constexpr (k < NA && ISX_H2_ABLATE != 3 && ISX_H2_ABLATE < 7) if (THREADS * k + wbase < S) {                    \
         /* (a 32-bit element offset here -- one multiply, scalar-base load -- costs the N-tile-pair kernel 37 more spilled registers) */ \
         const float *pp = &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];                       \
         ra##k = *(const float4 *)pp;                                                              \
@@ -308,7 +310,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     }
 // piece k_ of slab g_ of the work-group's slab sequence (g = step * NJ + jj: N tile ntile + g % NJ, K stage g / NJ) -> buffer g & 1
 #define H2_DMA_B1(g_, k_)                                                                         \
-    if ((k_) < NB && (BEXACT || THREADS * (k_) + wbase < SLAB))                                   \
+    if (ISX_H2_ABLATE != 4 && ISX_H2_ABLATE < 7 && (k_) < NB && (BEXACT || THREADS * (k_) + wbase < SLAB))                                   \
         lds_dma16((const uint4 *)a.w + ((int64_t)(ntile + (g_) % NJ) * nsteps + (g_) / NJ) * (2 * BU) + tid + THREADS * (k_), \
                   Bs + ((g_) & 1) * SLAB + wbase + THREADS * (k_));
 #define H2_DMA_B(g_) { _Pragma("unroll") for (int k_ = 0; k_ < NB; ++k_) H2_DMA_B1(g_, k_) }
@@ -326,7 +328,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     v.x = fmaxf(fmaf(v.x, s_.x, h_.x), relu_lo); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), relu_lo);     \
     v.z = fmaxf(fmaf(v.z, s_.z, h_.z), relu_lo); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), relu_lo);
 #define H2_STORE_A(k)                                                                             \
-    if constexpr (k < NA) {                                                                       \
+    if constexpr (k < NA && ISX_H2_ABLATE < 8) {                                                                       \
         float4 v = ra##k, w = rc##k;                                                              \
         H2_AFFL(v, vs0, vh0) H2_AFFL(w, vs1, vh1)                                                 \
         uint4 hi, lo = make_uint4(0u, 0u, 0u, 0u);                                                \
@@ -411,11 +413,11 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             constexpr bool AL2 = MT16 < 4 && NJ == 1;
             FR ah[2][MT16], al[(SPLIT && AL2) ? 2 : 1][SPLIT ? MT16 : 1], bh[BR], bl[SPLIT ? BR : 1];
 #define H2_FRAG_AH(q_)                                                                            \
-            { _Pragma("unroll") for (int m = 0; m < MT16; ++m) ah[(q_) & 1][m].u = AsH[aslot16[m] + toq[q_]]; }
+            if (ISX_H2_ABLATE != 6 || (q_) < 2) { _Pragma("unroll") for (int m = 0; m < MT16; ++m) ah[(q_) & 1][m].u = AsH[aslot16[m] + toq[q_]]; }
 #define H2_FRAG_AL(q_)                                                                            \
-            if constexpr (SPLIT) { _Pragma("unroll") for (int m = 0; m < MT16; ++m) al[AL2 ? ((q_) & 1) : 0][m].u = AsL[aslot16[m] + toq[q_]]; }
+            if constexpr (SPLIT) if (ISX_H2_ABLATE != 6 || (q_) < 2) { _Pragma("unroll") for (int m = 0; m < MT16; ++m) al[AL2 ? ((q_) & 1) : 0][m].u = AsL[aslot16[m] + toq[q_]]; }
 #define H2_FRAG_B(s_)                                                                             \
-            {                                                                                     \
+            if (ISX_H2_ABLATE != 6 || (s_) < BR) {                                                \
                 bh[(s_) % BR].u = bqh[(4 * ((s_) / NT16)) * BN + 16 * ((s_) % NT16)];             \
                 if constexpr (SPLIT) bl[(s_) % BR].u = bql[(4 * ((s_) / NT16)) * BN + 16 * ((s_) % NT16)]; \
             }
