@@ -120,7 +120,12 @@ __device__ __forceinline__ void lds_dma16(const uint4 *g, uint4 *lds_wave_base)
 template <int BN, int MT, int PM, int NW, int NJ = 1>
 __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 {
-    static_assert(NJ == 1 || (NW == 8 && MT == 1), "N-tile pairs: the LDS-DMA kernel only");
+    static_assert(NJ == 1 || NW == 8, "N-tile pairs: the LDS-DMA kernel only");
+    // M512 (NW = 8, MT = 2): 512 output voxels per work-group, a 64 x 64 (x NJ) wave tile.  Per matrix instruction half the weight-slab
+    // bytes of the 256-voxel forms and 2/3 (NJ = 1) or half (NJ = 2) of their fragment reads: the round-5 ablations (LOG.md) put 27 % of
+    // the 27-tap layers' time on the K loop's vector-memory traffic and 12 % on fragment reads, and nothing on how they are scheduled.
+    // Possible since the split mode needs one accumulator per output (128 registers for 64 x 128).
+    constexpr bool M512 = NW == 8 && MT == 2;
     constexpr bool SPLIT = PM == 0;
     // DMA: the 512-thread kernel takes its weight slabs by LDS-DMA into two buffers used alternately: the slab of stage s + 1 is
     // requested during the matrix phase of stage s (no prefetch registers, no LDS stores by the waves: 7 global loads + 7
@@ -139,7 +144,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     uint4 *AsH = smem4 + (DMA ? 2 : 1) * SLAB;
     uint4 *AsL = AsH + a.slots_max;                       // (SPLIT only)
     int *rowinfo = (int *)(AsH + (SPLIT ? 2 : 1) * a.slots_max);
-    float *red = (float *)(rowinfo + ROWS);
+    // per-wave BatchNorm partial sums of the epilogue; M512: behind the epilogue's output tile inside the staging buffers (free by then)
+    float *red = M512 ? (float *)smem4 + ROWS * (BN + 4) : (float *)(rowinfo + ROWS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int lin = blockIdx.x;
@@ -161,7 +167,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     // 8 x TXW, the edge strips (ConvArgs::sr_*, sb_*) tall and narrow / flat and wide
     // (the N-tile-pair kernel sits at the register limit -- run-time box sizes cost it 35 more spilled registers and 6 % -- and its
     // layers, Cout % 128 == 0, are below the box-tiled levels for every chunk shape iterseg uses: it keeps the padded boxes)
-    constexpr bool STRIPS = NJ == 1;
+    constexpr bool STRIPS = NJ == 1 || M512;
     int TYb = 8, TXb = TXW, xlim = W;                            // xlim: the last bottom-strip box stops where the right strip begins
     if (a.mode == 0) {
         const int nzt = (D + 1) >> 1;
@@ -244,16 +250,17 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 
     const int nsteps = (a.CA + a.CB) >> 3;
     typedef float f32x4c __attribute__((ext_vector_type(4)));
-    f32x4c c_hiN[NJ][MT16][NT16], c_loN[NJ][SPLIT ? MT16 : 1][SPLIT ? NT16 : 1];
+    // one accumulator per output in every mode: the split mode adds its three partial products into the same register (the
+    // operands are scaled so that the residual halves are normal numbers: h2_split.h)
+    f32x4c c_hiN[NJ][MT16][NT16];
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
         for (int m = 0; m < MT16; ++m)
 #pragma unroll
-            for (int j = 0; j < NT16; ++j) {
-                c_hiN[jj][m][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
-                if constexpr (SPLIT) c_loN[jj][m][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int j = 0; j < NT16; ++j) c_hiN[jj][m][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    // operand scales of the f16 modes (powers of two; bf16 has the fp32 range and takes none)
+    constexpr float ASC = PM == 2 ? 1.f : H2_SA, OSC = PM == 2 ? 1.f : 1.f / (H2_SA * H2_SW);
 
     // named prefetch registers (arrays that live across the K loop end up in scratch)
     float4 ra0, rc0, ra1, rc1, ra2, rc2, ra3, rc3, ra4, rc4, vs0, vs1, vh0, vh1;
@@ -294,6 +301,10 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             vs0 = make_float4(1.f, 1.f, 1.f, 1.f); vs1 = vs0;                                     \
             vh0 = make_float4(0.f, 0.f, 0.f, 0.f); vh1 = vh0;                                     \
         }                                                                                         \
+        if constexpr (ASC != 1.f) {                                                               \
+            vs0.x *= ASC; vs0.y *= ASC; vs0.z *= ASC; vs0.w *= ASC; vs1.x *= ASC; vs1.y *= ASC; vs1.z *= ASC; vs1.w *= ASC; \
+            vh0.x *= ASC; vh0.y *= ASC; vh0.z *= ASC; vh0.w *= ASC; vh1.x *= ASC; vh1.y *= ASC; vh1.z *= ASC; vh1.w *= ASC; \
+        }                                                                                         \
         relu_lo = has_affine ? 0.f : -__builtin_inff();                                           \
         ld_src = src + (int64_t)b * M * C + cc;                                                   \
         ld_C = C;                                                                                 \
@@ -332,7 +343,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         float4 v = ra##k, w = rc##k;                                                              \
         H2_AFFL(v, vs0, vh0) H2_AFFL(w, vs1, vh1)                                                 \
         uint4 hi, lo = make_uint4(0u, 0u, 0u, 0u);                                                \
-        if constexpr (SPLIT) split8(v, w, hi, lo); else round8<PM>(v, w, hi);                     \
+        if constexpr (SPLIT) split8r(v, w, hi, lo); else round8<PM>(v, w, hi);                     \
         const bool dead = gv##k < 0;                                                              \
         hi.x = dead ? 0u : hi.x; hi.y = dead ? 0u : hi.y; hi.z = dead ? 0u : hi.z; hi.w = dead ? 0u : hi.w; \
         if constexpr (SPLIT) { lo.x = dead ? 0u : lo.x; lo.y = dead ? 0u : lo.y; lo.z = dead ? 0u : lo.z; lo.w = dead ? 0u : lo.w; } \
@@ -403,7 +414,6 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                 __syncthreads();
             }
             auto &c_hi = c_hiN[jj];
-            auto &c_lo = c_loN[jj];
             const uint4 *bqh = Bs + (DMA ? (g & 1) * SLAB : 0) + h4 * BN + l16, *bql = bqh + BU;
             constexpr int NS = NQUAD * NT16;
             // two row tiles per wave (MT16 = 4: 12 matrix instructions = 192 cycles per step): B one step ahead and the lo halves
@@ -440,13 +450,14 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                 if constexpr (DMA) { if (more_slab && s >= 3 && (s - 3) % 3 == 0) H2_DMA_B1(g + 1, (s - 3) / 3) }
                 if constexpr (SPLIT) {
 #pragma unroll
-                    for (int m = 0; m < MT16; ++m) {
+                    for (int m = 0; m < MT16; ++m)
                         c_hi[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[qs][m].v, bh[r].v, c_hi[m][j], 0, 0, 0);
-                        c_lo[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[qs][m].v, bl[r].v, c_lo[m][j], 0, 0, 0);
-                    }
 #pragma unroll
                     for (int m = 0; m < MT16; ++m)
-                        c_lo[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ql][m].v, bh[r].v, c_lo[m][j], 0, 0, 0);
+                        c_hi[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[qs][m].v, bl[r].v, c_hi[m][j], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MT16; ++m)
+                        c_hi[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ql][m].v, bh[r].v, c_hi[m][j], 0, 0, 0);
                 } else if constexpr (PM == 1) {
 #pragma unroll
                     for (int m = 0; m < MT16; ++m)
@@ -510,9 +521,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = wave * MT * 32 + 16 * m + 4 * h4 + i;
-                    float v;
-                    if constexpr (SPLIT) v = fmaf(c_loN[jj][m][j][i], 1.f / H2_SCALE, c_hiN[jj][m][j][i]) + bsv;
-                    else v = c_hiN[jj][m][j][i] + bsv;
+                    const float v = OSC == 1.f ? c_hiN[jj][m][j][i] + bsv : fmaf(c_hiN[jj][m][j][i], OSC, bsv);
                     T[row * TRS + 16 * j + l16] = v;
                     if (rowinfo[row] >= 0) { s += v; q += v * v; }
                 }
@@ -578,6 +587,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     conv_h2_body<64, 1, PM, 8>(a);
 }
 
+// 512 voxels per work-group: a 64 x 64 wave tile (conv_h2c16nw8m_kernel), or 64 x 128 with two N tiles (conv_h2c16nw8mx2_kernel)
+template <int PM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8m_kernel(const ConvArgs a)
+{
+    conv_h2_body<64, 2, PM, 8>(a);
+}
+template <int PM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8mx2_kernel(const ConvArgs a)
+{
+    conv_h2_body<64, 2, PM, 8, 2>(a);
+}
+
 // ... with two N tiles per work-group (Cout % 128 == 0: the halo tile of a K stage staged once for 128 output columns)
 template <int PM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8x2_kernel(const ConvArgs a)
@@ -623,7 +644,7 @@ void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < 27; ++t) {
                 _Float16 h, l;
-                split_h2(w[((size_t)co * cin + ci) * 27 + t], h, l);
+                split_h2r(w[((size_t)co * cin + ci) * 27 + t] * H2_SW, h, l);       // scaled, residual as it is (h2_split.h)
                 const size_t base = ((size_t)(co / bn) * nsteps + ci / 8) * 2 * half_slab;
                 const size_t e = ((size_t)t * bn + co % bn) * 8 + ci % 8;
                 uint16_t hb, lb;
@@ -718,6 +739,25 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         a.tiles_per_chunk = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
         a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl;
     }
+    // 512-voxel work-groups (conv_h2c16nw8m*_kernel): where the launch still fills the chip and the halo of 512 voxels fits the
+    // staging plan and, beside the two slab buffers, the LDS.  Levels whose planes the linearised tiles cannot hold that way
+    // (65^2: 1 608 slots) take box tiles with edge strips instead.
+    bool m512 = false;
+    if (nw8 && ctx->tune.h2_m512) {
+        // (measured, round 5: -9 ... -14 % on the Cout = 64 layers, -2 % on c2 at 65^2; the Cout % 128 == 0 layers of the linearised
+        // levels (33^2) are 2-3 % faster on the 256-voxel N-tile pair; eight waves over 512 voxels x 32 columns lose 6 % to the
+        // four-wave kernel of the Cout = 32 layers)
+        const int mode5 = (a.mode != 0 && l.W >= 48 && l.H >= 16 && l.D % 2 == 0) ? 0 : a.mode;
+        int ty, tx, tp, sl;
+        const int tiles5 = conv_tiles(l, mode5, 4, &ty, &tx, &tp, &sl);
+        const size_t lds5 = (size_t)(pm == 0 ? 2 : 1) * (2 * 2 * 14 * BN + sl) * 16 + 512 * sizeof(int);
+        const bool pair_wins = cout % 128 == 0 && mode5 != 0 && ctx->tune.h2_nj2 && ctx->tune.h2_m512 == 1;
+        if (!pair_wins && sl <= 1536 && lds5 <= 160 * 1024 && (ctx->tune.h2_m512 == 2 || (int64_t)B * tiles5 * (cout / 64) >= 2048)) {
+            m512 = true;
+            a.mode = mode5; a.tiles_per_chunk = tiles5; a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl;
+        }
+    }
+    const int rows_wg = m512 ? 512 : (nw8 ? 256 : 128 * mt);
     if (mt == 2) {
         int ty, tx, tp, sl;
         const int tiles2 = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
@@ -727,12 +767,12 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     if (a.mode == 0) {
         // box tiles: interior boxes of 8 x TXW voxels, and edge strips where the remainders of H / W make them cheaper than padded
         // boxes (129 = 128 + 1: 25 padded boxes per plane pair against 3 strips)
-        const int rows = nw8 ? 256 : 128 * mt, txw = rows / 16, cap = a.slots_max;      // strips never grow the LDS footprint of the launch
+        const int rows = rows_wg, txw = rows / 16, cap = a.slots_max;      // strips never grow the LDS footprint of the launch
         const int ny = l.H / 8, ry = l.H % 8, nx = l.W / txw, rx = l.W % txw;
         const int nyp = (l.H + 7) / 8, nxp = (l.W + txw - 1) / txw;
         a.ntx = nxp; a.nI = nyp * nxp; a.sr_n = a.sb_n = 0;
         a.sr_ty = a.sr_tx = a.sr_x0 = a.sb_ty = a.sb_tx = a.sb_y0 = 0;
-        const bool may_pair = nw8 && ctx->tune.h2_nj2 && cout % 128 == 0;       // conv_h2c16nw8x2_kernel: padded boxes only (STRIPS)
+        const bool may_pair = nw8 && !m512 && ctx->tune.h2_nj2 && cout % 128 == 0;       // conv_h2c16nw8x2_kernel: padded boxes only (STRIPS)
         if ((ry || rx) && ny > 0 && nx > 0 && ctx->tune.h2_strips && !may_pair) {
             // right strip: rx columns, all H rows; bottom strip: ry rows, the interior columns
             int sr_ty = 0, sr_n = 0, sb_tx = 0, sb_n = 0;
@@ -754,23 +794,24 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.tz = a.mode == 1 ? 2 : 1;
     if (a.mode == 2 && l.D > 1 && l.D <= 8 && ctx->tune.h2_tz) {
         // odd, shallow levels: all planes in one tile when that needs fewer tiles (the rows beyond tz * (rows / tz) stay empty)
-        const int rows = nw8 ? 256 : 128 * mt, cap = nw8 ? 1536 : (mt == 2 ? 1280 : 1024);
+        const int rows = rows_wg, cap = nw8 ? 1536 : (mt == 2 ? 1280 : 1024);
         const int tp = rows / l.D, ntp = (l.H * l.W + tp - 1) / tp;
         const int lh = tp + 2 * ((tp + l.W - 1) / l.W + 1) + 2 * (l.W + 2) + 2, slots = (l.D + 2) * lh;
         if (tp >= 8 && ntp < a.tiles_per_chunk && slots <= cap) { a.tz = l.D; a.ntp = ntp; a.tiles_per_chunk = ntp; a.slots_max = slots; }
     }
     ISX_REQUIRE(a.slots_max <= (nw8 ? 1536 : (mt == 2 ? 1280 : 1024)), "internal: halo tile of %d slots does not fit the staging plan", a.slots_max);
     // N-tile pairs (conv_h2c16nw8x2_kernel): Cout % 128 == 0 and a launch that still fills the chip
-    const int nj = (nw8 && ctx->tune.h2_nj2 && cout % 128 == 0 &&
-                    (ctx->tune.h2_nj2 == 2 || (int64_t)B * a.tiles_per_chunk * (cout / 128) >= 512)) ? 2 : 1;
+    // (512-voxel work-groups take one N tile: with two the 64 x 128 wave tile has 55 spilled registers; ISX_H2_M512=3 runs it anyway)
+    const int nj = (m512 && ctx->tune.h2_m512 != 3) ? 1 : ((nw8 && ctx->tune.h2_nj2 && cout % 128 == 0 &&
+                    (ctx->tune.h2_nj2 == 2 || (int64_t)B * a.tiles_per_chunk * (cout / 128) >= 512)) ? 2 : 1);
     a.ntiles = cout / (BN * nj);
     {   // the output tile of the epilogue (rows x (BN + 4) floats) aliases the staging buffers: slabs + halo tile; the halo
         // part is padded where the single-product modes' smaller buffers would not hold it
-        const size_t rows = nw8 ? 256 : 128 * mt, tile = rows * (BN + 4) * sizeof(float);
+        const size_t rows = rows_wg, tile = rows * (BN + 4) * sizeof(float) + (m512 ? 8 * BN * 2 * sizeof(float) : 0);   // (M512: + the partial sums)
         const size_t per = (pm == 0 ? 2 : 1) * 16, slabs = (size_t)(pm == 0 ? 2 : 1) * (nw8 ? 2 : 1) * 2 * 14 * BN * 16;
         if (slabs + (size_t)a.slots_max * per < tile) a.slots_max = (int)((tile - slabs + per - 1) / per);
     }
-    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * ((nw8 ? 2 : 1) * 2 * 14 * BN + a.slots_max)) * 16 + ((nw8 ? 256 : 128 * mt) + (nw8 ? 8 : 4) * BN * 2) * sizeof(float);
+    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * ((nw8 ? 2 : 1) * 2 * 14 * BN + a.slots_max)) * 16 + (rows_wg + (m512 ? 0 : (nw8 ? 8 : 4) * BN * 2)) * sizeof(float);
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
@@ -781,7 +822,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 2>))
         ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 2>))
         ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 2>))
-        ISX_H2_ATTR3(conv_h2c16nw8_kernel) ISX_H2_ATTR3(conv_h2c16nw8x2_kernel)
+        ISX_H2_ATTR3(conv_h2c16nw8_kernel) ISX_H2_ATTR3(conv_h2c16nw8x2_kernel) ISX_H2_ATTR3(conv_h2c16nw8m_kernel) ISX_H2_ATTR3(conv_h2c16nw8mx2_kernel)
         attr_done = true;
     }
 #undef ISX_H2_ATTR3
@@ -790,7 +831,15 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     do { if (pm == 0) conv_h2c16_kernel<BN_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
          else if (pm == 1) conv_h2c16_kernel<BN_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
          else conv_h2c16_kernel<BN_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
-    if (nw8 && nj == 2) {
+    if (m512 && nj == 2) {
+        if (pm == 0) conv_h2c16nw8mx2_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
+        else if (pm == 1) conv_h2c16nw8mx2_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
+        else conv_h2c16nw8mx2_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);
+    } else if (m512) {
+        if (pm == 0) conv_h2c16nw8m_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
+        else if (pm == 1) conv_h2c16nw8m_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
+        else conv_h2c16nw8m_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);
+    } else if (nw8 && nj == 2) {
         if (pm == 0) conv_h2c16nw8x2_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
         else if (pm == 1) conv_h2c16nw8x2_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
         else conv_h2c16nw8x2_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);

@@ -74,6 +74,7 @@ struct isx_tune {
     int thin_wgrad = 1;             // ISX_THIN_WGRAD: 0 = the 1 -> 32 and 5 -> 5 layers' weight gradients on the padded matrix-core tiles (round 2)
     int bf16_wgrad = 1;             // ISX_BF16_WGRAD: 0 = precision "bf16" keeps fp32 products in the weight gradients (round 2's form)
     int h2_nj2 = 1;                 // ISX_H2_NJ2: 1 = two 64-column N tiles per work-group of the LDS-DMA kernel for Cout % 128 == 0 (2: always, tests)
+    int h2_m512 = 1;                // ISX_H2_M512: 1 = 512-voxel work-groups (64 x 64 / 64 x 128 wave tiles) for the 512-thread kernels where the launch fills the chip (2: always, tests; 0: off)
     int h2_tz = 1;                  // ISX_H2_TZ: 0 = one plane per tile on odd levels (rounds 1-3) instead of all planes of a shallow level
     int h2_strips = 1;              // ISX_H2_STRIPS: 0 = padded 8 x TXW boxes only (rounds 1-3) instead of edge strips where H / W leave a remainder
     int tail_up = 1;                // ISX_TAIL_UP: 0 = up3 materialised by upsample_src_kernel instead of up-sampled while the tail kernel stages it

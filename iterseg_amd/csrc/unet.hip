@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "unet_state.h"
+#include "h2_split.h"
 
 namespace isx {
 
@@ -1133,7 +1134,7 @@ static int commit_weights(isx_ctx *ctx, const int *fork_channels, int nforks)
                     (pm == 0 ? L.w_h2_32 : L.w_bf_32) = d;
                 }
             }
-            if (use_mfma(L.cin, cout) && L.cin % 8 == 0 && w_in_range) {       // split-f16 packs (both tile widths: the tile
+            if (use_mfma(L.cin, cout) && L.cin % 8 == 0 && wabs < H2_W_LIMIT) {       // split-f16 packs (both tile widths: the tile
                 std::vector<uint16_t> hp;                       // geometry is only known once a chunk arrives)
                 for (int bn = 32; bn <= 64; bn += 32) {
                     if (cout % bn) continue;
@@ -1308,6 +1309,7 @@ static bool conv_takes_h2(isx_ctx *ctx, int li, const Level &l, int B, float bou
     const bool bf = u->precision == ISX_PRECISION_BF16;
     if (u->precision == ISX_PRECISION_FP32 || !(bf || bound < 6.0e4f)) return false;
     if (use_mfma(L.cin, L.cout)) {
+        if (!bf && !(bound < H2_ACT_LIMIT)) return false;         // the 27-tap kernels scale their operands (h2_split.h)
         int t0, t1, t2, slots;
         conv_tiles(l, conv_mode(l), 1, &t0, &t1, &t2, &slots);
         const bool b64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64 || conv_h2_nw8(ctx->tune, l, L.cout, B);
@@ -1335,7 +1337,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         const bool bf = u->precision == ISX_PRECISION_BF16;
         const bool b64 = conv_h2_bn(ctx->tune, slots, L.cout) == 64 || conv_h2_nw8(ctx->tune, l, L.cout, B);
         const void *wh = bf ? (b64 ? L.w_bf_64 : L.w_bf_32) : (b64 ? L.w_h2_64 : L.w_h2_32);
-        const bool in_range = bf || std::max(sa.bound, sb.bound) < 6.0e4f;    // else operands could leave the f16 range
+        const bool in_range = bf || std::max(sa.bound, sb.bound) < H2_ACT_LIMIT;    // else the scaled operands could leave the f16 range
         // training keeps fp32 products except in the bf16 mixed-precision mode (its packs are refreshed every step)
         const bool reduced = u->precision != ISX_PRECISION_FP32 && (!u->train || bf);
         const int pm = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (bf ? 2 : 1);

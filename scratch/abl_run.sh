@@ -2,13 +2,13 @@
 set -e
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$GRAFT_REPO_ROOT
 O=gpurun_out/abl_$1; mkdir -p $O; shift
-for v in prod "$@"; do
+for v in "$@"; do
   L=$GRAFT_REPO_ROOT/iterseg_amd/libitersegx.so; [ $v = prod ] || L=$GRAFT_REPO_ROOT/scratch/libs/lib_$v.so
   ( cd /tmp && export TMPDIR=/tmp && ISX_LIB=$L rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/p_$v -o t -- python3 $GRAFT_REPO_ROOT/scratch/bench_unet.py 64 > $GRAFT_REPO_ROOT/$O/run_$v.log 2>&1 )
   python3 scratch/trace_layers_seq.py $O/p_$v > $O/seq_$v.txt
   rm -rf $O/p_$v
 done
-python3 - "$O" prod "$@" <<'PY'
+python3 - "$O" "$@" <<'PY'
 import sys
 O = sys.argv[1]; vs = sys.argv[2:]
 cols = [[l.rstrip("\n") for l in open(f"{O}/seq_{v}.txt")] for v in vs]

@@ -380,6 +380,34 @@ def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m512", ["2", "3"])
+@pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
+def test_512_voxel_work_groups_change_only_the_statistics_rounding(precision, m512, monkeypatch):
+    """ISX_H2_M512: the 512-thread kernels over 512 output voxels per work-group (64 x 64 wave tiles, conv_h2c16nw8m_kernel; 3:
+    two N tiles as well, conv_h2c16nw8mx2_kernel) against the 256-voxel forms.  Box-tiled levels (with their edge strips), the
+    linearised levels and the levels that move from linearised to box tiles (W >= 48) are all in the shapes.  A voxel's products
+    and their order do not depend on its tile: the first layer that runs on the larger tiles is identical bit for bit, behind it
+    only the grouping of the BatchNorm partial sums differs."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(10)
+    nets = []
+    monkeypatch.setenv("ISX_H2_NW8", "2")
+    for v in (m512, "0"):
+        monkeypatch.setenv("ISX_H2_M512", v)
+        u = UNet(1, 5, batch=2, precision=precision)
+        u.load_state_dict(sd)
+        nets.append(u)
+    for shape in [(4, 32, 32), (10, 96, 80), (6, 48, 112), (4, 176, 192), (10, 256, 256)]:
+        x = np.random.default_rng(13).random((1, 1) + shape, dtype=np.float32)
+        ya, yb = nets[0](x), nets[1](x)
+        if np.prod(shape) <= 100000:
+            assert np.array_equal(nets[0].tap("c1.conv0"), nets[1].tap("c1.conv0")), shape
+        assert np.abs(ya - yb).max() <= (2e-5 if precision == "split-f16" else 4e-3), (shape, np.abs(ya - yb).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nw8", ["1", "2", "0"])
 @pytest.mark.parametrize("precision", ["split-f16", "bf16"])
 def test_edge_strip_tiles_change_only_the_statistics_rounding(precision, nw8, monkeypatch):
