@@ -298,7 +298,8 @@ int isx_allreduce_grads(isx_ctx *ctx, float *grads, int64_t n);
 int isx_gather_tiles(isx_ctx *ctx, const void *send, void *recv, int64_t bytes_per_rank);
 int isx_allreduce_max_labels(isx_ctx *ctx, int32_t *labels, int64_t n);
 /* skimage.filters.gaussian as used at watershed.py:227 / :234: float32 in/out, per-axis
- * sigma in {0,1,2}, border 'nearest', truncate 4, double accumulation per pass. */
+ * sigma in {0,1,2}, border 'nearest', truncate 4, double accumulation per pass.  img and out must be different buffers
+ * (a pass reads neighbours that the same pass writes): ISX_ERR_ARG otherwise. */
 int isx_ws_gaussian(isx_ctx *ctx, const float *img, float *out, const int64_t shape[3],
                     const int32_t sigma[3]);
 /* skimage.filters.threshold_otsu (256 bins) of a float32 array; *thresh is HOST memory. */

@@ -17,7 +17,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libitersegx.so")
 
-SOURCES = ["isx_ctx.hip", "prims.hip", "ws.hip", "unet.hip", "conv_h2.hip", "conv_tail.hip", "host_pipe.hip", "train.hip", "labels.hip", "train_io.hip", "metrics.hip", "comm.hip"]
+SOURCES = ["isx_ctx.hip", "prims.hip", "ws.hip", "unet.hip", "conv55.hip", "conv_h2.hip", "conv_tail.hip", "host_pipe.hip", "train.hip", "labels.hip", "train_io.hip", "metrics.hip", "comm.hip"]
+# per-source flags: conv55.hip must not contain packed fp32 instructions (see its header)
+EXTRA = {"conv55.hip": ["-fno-slp-vectorize"]}
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"]
@@ -54,7 +56,7 @@ def build(force=False, verbose=False, jobs=4):
     def compile_one(job):
         src, obj = job
         # ISX_EXTRA_HIPCC_FLAGS: development builds only (e.g. -DISX_FLOOD_PROF for the flood's phase timers)
-        cmd = [hipcc] + FLAGS + os.environ.get("ISX_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(os.path.basename(src), []) + os.environ.get("ISX_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -793,85 +793,6 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel: the last convolution of the network, 5 -> 5 channels (c8_0.conv1).  2 x 8 x 16 voxels per block, one per
-// thread; the halo tile (4 x 10 x 18 voxels x 5 channels, BN+ReLU of the producer applied) sits in LDS channel-major
-// so that the 27 x 5 reads of a wave are conflict-free, and the 675 weights are read with uniform addresses, i.e.
-// through the scalar cache into SGPRs (the generic thin kernel re-read them from LDS for every FMA group and
-// bounds-checked every tap: 3.8 ms per 64 chunks; this one is bound by its 675 FMAs per voxel).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv55_kernel(const float *__restrict__ src, const float *__restrict__ scale,
-                                                     const float *__restrict__ shift, const float *__restrict__ w,
-                                                     const float *__restrict__ bias, int D, int H, int W,
-                                                     float *__restrict__ out, float *__restrict__ psum,
-                                                     float *__restrict__ psq, int tiles_per_chunk, int nty, int ntx)
-{
-    constexpr int C = 5, PS = 180, RS = 18, S = 720, CP = 724;      // CP: channel plane pitch (floats)
-    __shared__ float As[C * CP];
-    __shared__ float red[4 * 8 * 2];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
-    const int nzt = (D + 1) >> 1;
-    const int zt = tile % nzt, xt = (tile / nzt) % ntx, yt = tile / (nzt * ntx);
-    const int z0 = zt * 2, y0 = yt * 8, x0 = xt * 16;
-    const int64_t M = (int64_t)D * H * W;
-    float sc[C], sh[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) { sc[c] = scale[(int64_t)b * C + c]; sh[c] = shift[(int64_t)b * C + c]; }
-    for (int s = tid; s < S; s += 256) {
-        const int hz = s / PS, hy = (s / RS) % 10, hx = s % RS;
-        const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-        const bool ok = z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
-        const float *p = src + ((int64_t)b * M + (ok ? ((int64_t)z * H + y) * W + x : 0)) * C;
-#pragma unroll
-        for (int c = 0; c < C; ++c) As[c * CP + s] = ok ? fmaxf(fmaf(p[c], sc[c], sh[c]), 0.f) : 0.f;
-    }
-    __syncthreads();
-    const int zz = tid >> 7, yy = (tid >> 4) & 7, xx = tid & 15;
-    const int z = z0 + zz, y = y0 + yy, x = x0 + xx;
-    const bool live = z < D && y < H && x < W;
-    const float *ap = As + (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
-    float acc[C];
-#pragma unroll
-    for (int o = 0; o < C; ++o) acc[o] = bias[o];
-#pragma unroll
-    for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int tap = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
-                const int toff = dz * PS + dy * RS + dx;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float v = ap[c * CP + toff];
-                    const float *wp = w + (tap * C + c) * 8;          // uniform address: scalar loads
-#pragma unroll
-                    for (int o = 0; o < C; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
-                }
-            }
-    if (live) {
-        float *q = out + ((int64_t)b * M + ((int64_t)z * H + y) * W + x) * C;
-#pragma unroll
-        for (int o = 0; o < C; ++o) q[o] = acc[o];
-    }
-    const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-    for (int o = 0; o < C; ++o) {
-        float sm = live ? acc[o] : 0.f, q2 = live ? acc[o] * acc[o] : 0.f;
-        for (int off = 32; off > 0; off >>= 1) { sm += __shfl_xor(sm, off); q2 += __shfl_xor(q2, off); }
-        if (lane == 0) { red[(wave * 8 + o) * 2] = sm; red[(wave * 8 + o) * 2 + 1] = q2; }
-    }
-    __syncthreads();
-    if (tid < C) {
-        float sm = 0.f, q2 = 0.f;
-        for (int wv = 0; wv < 4; ++wv) { sm += red[(wv * 8 + tid) * 2]; q2 += red[(wv * 8 + tid) * 2 + 1]; }
-        const int64_t o = ((int64_t)b * tiles_per_chunk + tile) * C + tid;
-        psum[o] = sm;
-        psq[o] = q2;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Kernel: second half of the folded tail layer (c8.conv0, Cin -> <= 5 channels).  The MFMA pass
 // (TX = 1) produced P[v][dx*nout + o] = sum over (dz, dy, c) of in[v + (dz,dy,0)][c] * w[o][c][dz][dy][dx];
 // here out[v][o] = bias[o] + sum over dx of P[v + dx*ex][dx*nout + o] (x-neighbours outside the chunk
@@ -1410,10 +1331,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
     } else {
         ProfScope ps(ctx, ISX_PROF_CONV_DIRECT);
         if (L.cin == 5 && L.cout == 5 && sa.C == 5 && sb.C == 0 && sa.scale) {
-            conv55_kernel<<<(unsigned)(B * L.tiles), 256, 0, ctx->stream>>>(sa.p, sa.scale, sa.shift, L.w, L.bias, l.D, l.H, l.W,
-                                                                         u->raw[li], L.psum, L.psq, L.tiles, (l.H + 7) / 8,
-                                                                         (l.W + 15) / 16);
-            ISX_CHECK_LAUNCH();
+            ISX_TRY(launch_conv55(ctx, l, B, sa, L.w, L.bias, u->raw[li], L.psum, L.psq, L.tiles));
         } else {
         size_t lds = (size_t)(27 * L.cin * 8 + 64) * sizeof(float);
         ISX_REQUIRE(lds <= 160 * 1024, "internal: thin conv weights do not fit LDS");

@@ -157,6 +157,9 @@ int conv_tail_tiles(const Level &l);
 size_t conv_tail_lds(int cin, int pm);
 int launch_conv_tail(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_fold, const float *bias, int nout,
                      float *out, float *psum, float *psq, int pm, int *tiles_used, const H2Extra *ex = nullptr);
+// the 5 -> 5 convolution on the vector ALU (conv55.hip: compiled without SLP vectorisation)
+int launch_conv55(isx_ctx *ctx, const Level &l, int B, Src sa, const float *w, const float *bias, float *out, float *psum, float *psq,
+                  int tiles);
 int prepare_workspace(isx_ctx *ctx, int cz, int cy, int cx, int batch);
 int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_t shape[3]);
 int dev_alloc(UNetState *u, size_t floats, float **out);

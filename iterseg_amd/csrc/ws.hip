@@ -718,7 +718,9 @@ __global__ __launch_bounds__(256) void aff_pad_kernel(const float *__restrict__ 
                                                       int64_t X, float *__restrict__ aff)
 {
     const int64_t PZ = Z + 2, PY = Y + 2, PX = X + 2;
-    const int y = (int)blockIdx.x - 1, c = (int)(blockIdx.y / (unsigned)PZ), z = (int)(blockIdx.y % (unsigned)PZ) - 1;
+    // 1-D grid over (channel, z, y): two 32-bit divisions per BLOCK (a 2-D grid capped the depth at 21 843 planes)
+    const unsigned cz = blockIdx.x / (unsigned)PY;
+    const int y = (int)(blockIdx.x % (unsigned)PY) - 1, c = (int)(cz / (unsigned)PZ), z = (int)(cz % (unsigned)PZ) - 1;
     float *row = aff + (((int64_t)c * PZ + (z + 1)) * PY + (y + 1)) * PX;
     const bool inside = z >= 0 && z < Z && y >= 0 && y < Y;
     const float *src = fm + (((int64_t)c * Z + (inside ? z : 0)) * Y + (inside ? y : 0)) * X;
@@ -1877,6 +1879,8 @@ int isx_ws_gaussian(isx_ctx *ctx, const float *img, float *out, const int64_t sh
                     const int32_t sigma[3])
 {
     ISX_REQUIRE(ctx && img && out && shape && sigma, "null argument");
+    // every pass reads neighbours that other work-groups of the same pass write: never in place (itersegx.h)
+    ISX_REQUIRE((const float *)out != img, "isx_ws_gaussian: img and out must be different buffers");
     ISX_HIP(hipSetDevice(ctx->device));
     ProfScope ps(ctx, ISX_PROF_WS_FILTERS);
     int64_t n = shape[0] * shape[1] * shape[2];
@@ -2136,8 +2140,8 @@ int isx_segment_output_image_scaled(isx_ctx *ctx, const float *fm, const int64_t
         if (g > 2048) g = 2048;
         chanmax_kernel<<<dim3(g, 3), TPB, 0, ctx->stream>>>(fm, n, cm.p);
         ISX_CHECK_LAUNCH();
-        ISX_REQUIRE(Y + 2 < (int64_t)0x7FFFFFFF && 3 * (Z + 2) <= 65535, "volume too deep for the padding kernel's grid");
-        aff_pad_kernel<<<dim3((unsigned)(Y + 2), (unsigned)(3 * (Z + 2))), 256, 0, ctx->stream>>>(fm, cm.p, Z, Y, X, aff.p);
+        ISX_REQUIRE(3 * (Z + 2) * (Y + 2) < (int64_t)0x7FFFFFFF, "volume too large for the padding kernel's grid");
+        aff_pad_kernel<<<(unsigned)(3 * (Z + 2) * (Y + 2)), 256, 0, ctx->stream>>>(fm, cm.p, Z, Y, X, aff.p);
         ISX_CHECK_LAUNCH();
     }
     // the filtered mask's components are a subset of the raw mask's: reuse roots and sizes

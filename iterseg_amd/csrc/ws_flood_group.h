@@ -45,6 +45,16 @@ enum { GI_OH, GI_NW, GI_SHEAD, GI_SCOUNT, GI_NSTAGE, GI_NFREECH, GI_NFREESLOT, G
        GI_DIRTY, GI_COLD_COUNT, GI_COLD_LOW, GI_M, GI_NCOMMIT, GI_PENDN, GI_NHOT, GI_NWB, GI_AGEBASE, GI_NPTOT, GI_ANY, GI_TAKE, GI_POS,
        GI_EVICT, GI_NSPILL, GI_REQ, GI_NRES, GI_WB0, GI_FRONT, GI_LAST, GI_NRELOAD, GI_READY, GI_SORTN, GI_PEND0,
        GI_N };
+
+// A control word in LDS that steers a wave-uniform branch.  Other waves may write such a word while this wave runs between two
+// barriers, so it is read through ONE helper: a volatile load (the compiler may not cache it across iterations, hoist it, or
+// duplicate it into the arms of a divergent branch) whose first active lane's value is taken for the whole wave (readfirstlane is
+// convergent).  Round 4: a plain read of GI_READY in the free-running step loop split a wave, and the DPP scans of coop_reload then
+// ran under a partial EXEC mask.  Every read of a GI_* word that decides control flow goes through this.
+__device__ __forceinline__ int grp_flag(const int *shI, int i)
+{
+    return __builtin_amdgcn_readfirstlane(*(const volatile int *)(shI + i));
+}
 enum { GQ_KSQ, GQ_TMIN, GQ_QHEAD, GQ_KINV, GQ_N };
 enum { GS_SUB, GS_POPS, GS_EXEC, GS_SQ_EPS, GS_SQ_BOUND, GS_SQ_LOST, GS_SLOW, GS_FORCED, GS_RELOAD, GS_RUNINS, GS_WININS, GS_WINEV, GS_COLD,
        GS_DRAIN, GS_BURST, GS_C_NOTREADY, GS_C_NOTSTARTED, GS_C_RUNNING, GS_C_BOUND, GS_C_CAP, GS_C_ALL, GS_NWSUM, GS_F_BULK, GS_F_CALLS, GS_F_FLUSHES, GS_N };
@@ -393,6 +403,12 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     // the bound remain in the list only -- a long descent does that every few pops, and one lane walking 190 entries
     // (with every other lane of the work-group waiting at the next barrier) was the single most expensive step.
     auto coop_reload = [&](int L, uint32_t bnd) {
+        // guard site 4 (always on): the wave reductions below are DPP scans and need every lane -- a partial EXEC mask here means the
+        // wave has split somewhere above (round 4), and the candidates rebuilt from such scans are garbage: report, rebuild nothing
+        if (__builtin_amdgcn_read_exec() != ~0ull) {
+            if (stats && atomicAdd(&stats[20], 1ull) == 0ull) stats[21] = 4ull;
+            return;
+        }
         const int slot = (wave << 6) + L;
         const int npL = (int)rdlane((uint32_t)np, L);
         unsigned long long k3[3];
@@ -546,7 +562,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             if (shI[GI_SCOUNT] + P > run_limit || shI[GI_SCOUNT] + P > COOP_SCAP - 8) {
                 if (wave == 0) { int keep = run_limit / 2; if (keep > COOP_SCAP - GRP_W - 8) keep = COOP_SCAP - GRP_W - 8; run_evict_w0(keep); publish_cold(); }
                 __syncthreads();
-                if (shI[GI_SERIAL]) break;                                  // `pend` keeps the batch for the serial continuation
+                if (grp_flag(shI, GI_SERIAL)) break;                                  // `pend` keeps the batch for the serial continuation
             }
             const int nw2 = shI[GI_NW], sc2 = shI[GI_SCOUNT], sh2 = shI[GI_SHEAD];
             const bool hot_ne = nw2 > 0 || sc2 > 0;
@@ -594,7 +610,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                     __syncthreads();
                     if (wave == 0) { run_evict_w0(run_limit / 2); publish_cold(); }
                     __syncthreads();
-                    if (shI[GI_SERIAL]) break;                              // pend[0, NWB) are still to be queued (WB0 = 0)
+                    if (grp_flag(shI, GI_SERIAL)) break;                              // pend[0, NWB) are still to be queued (WB0 = 0)
                 }
                 const int sh3w = shI[GI_SHEAD];
                 unsigned long long ok_ = 0ull; int os_ = 0, np_old = -1;
@@ -692,9 +708,9 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             GTICK(15);
             if (tid == 0 && R > 0) { shI[GI_SCOUNT] = sc3 + R; shI[GI_NHOT] = 0; shI[GI_DIRTY] = 1; atomicAdd(&lstat[GS_RUNINS], (uint32_t)R); }
             __syncthreads();
-            if (shI[GI_SERIAL]) break;
+            if (grp_flag(shI, GI_SERIAL)) break;
         }
-        return !shI[GI_SERIAL];
+        return !grp_flag(shI, GI_SERIAL);
     };
 
     // ================================================= sub-rounds ==================================================================
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
     for (;;) {
         __syncthreads();                                                        // (S0) the previous sub-round is complete
         GTICK(8);
-        if (shI[GI_SERIAL] || shI[GI_NW] == 0) break;
+        if (grp_flag(shI, GI_SERIAL) || shI[GI_NW] == 0) break;
         if (++st_sub > sub_limit) {                                             // watchdog (never expected): finish on the serial heap
             if (tid < 8) wtmp[tid >> 2][tid & 3] = 0;
             __syncthreads();
@@ -720,7 +736,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                 const int fs_ = (int)oslot[ord_at(0)];
                 atomicAdd(&stats[9], 1ull);
                 stats[24] = (unsigned long long)shI[GI_NW]; stats[25] = (unsigned long long)shI[GI_SCOUNT];
-                stats[26] = (unsigned long long)(uint32_t)shI[GI_NFREECH] | ((unsigned long long)(uint32_t)shI[GI_NRES] << 16) | ((unsigned long long)(uint32_t)shI[GI_NFREESLOT] << 32) | ((unsigned long long)(uint32_t)shI[GI_DIRTY] << 48) | ((unsigned long long)(uint32_t)shI[GI_FORCED] << 56);
+                stats[26] = (unsigned long long)(uint32_t)shI[GI_NFREECH] | ((unsigned long long)(uint32_t)shI[GI_NRES] << 16) | ((unsigned long long)(uint32_t)shI[GI_NFREESLOT] << 32) | ((unsigned long long)(uint32_t)shI[GI_DIRTY] << 48) | ((unsigned long long)(uint32_t)grp_flag(shI, GI_FORCED) << 56);
                 stats[27] = (unsigned long long)pub_info[fs_] | ((unsigned long long)pub_mx[fs_] << 32);
                 stats[28] = okey[ord_at(0)];
                 stats[29] = shI[GI_SCOUNT] > 0 ? srun[shI[GI_SHEAD]].key : ~0ull;
@@ -798,7 +814,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             // two arms of `if (active)` below, lanes then see the flag at different times, some leave and the rest go on under a
             // partial EXEC mask, where the DPP scans of coop_reload read lane 63's stale register (round 4: the group-* stress
             // modes tripped guard site 3 in 3 of 8 runs with one code generation, 0 of 24 with others).  One lane's value for all:
-            if (step >= kmin && __builtin_amdgcn_readfirstlane(shI[GI_READY])) break;
+            if (step >= kmin && grp_flag(shI, GI_READY)) break;
             bool active = false;
             if (has && cur != GRP_NONE) {
                 bool room = true, need = false;
@@ -914,12 +930,12 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         }
         GTICK(3);
         // ---- E: commit the idle episodes at the front, in order; bursts as wide as the window ------------------------------------------------
-        bool front_ready = shI[GI_FORCED] != 0 || ((pub_info[frontslot] >> 17) & 1u);
-        const bool forced_front = shI[GI_FORCED] != 0;
+        bool front_ready = grp_flag(shI, GI_FORCED) != 0 || ((pub_info[frontslot] >> 17) & 1u);
+        const bool forced_front = grp_flag(shI, GI_FORCED) != 0;
 #ifdef ISX_FLOOD_PROF
         if (tid == 0) { if (!front_ready) atomicAdd(&lstat[GS_C_NOTREADY], 1u); atomicAdd(&lstat[GS_NWSUM], (uint32_t)shI[GI_NW]); }
 #endif
-        for (int burst = 0; front_ready && burst < (max_bursts & 0xFF) && shI[GI_NW] > 0 && !shI[GI_SERIAL]; ++burst) {
+        for (int burst = 0; front_ready && burst < (max_bursts & 0xFF) && shI[GI_NW] > 0 && !grp_flag(shI, GI_SERIAL); ++burst) {
             const int nwb = shI[GI_NW];
             const unsigned long long qh = shI[GI_SCOUNT] > 0 ? srun[shI[GI_SHEAD]].key : ~0ull;
             // the front episode with a full list (or an empty pool) commits what it has done: the element in hand and every
@@ -1140,7 +1156,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             if (!enqueue_batch()) break;                                        // uniform (set before a barrier every thread has passed)
             GTICK(6);
             check_order(10 + burst);
-            if (ncommit < nwb && !shI[GI_ANY]) break;                           // uniform (GI_ANY: written before E4)
+            if (ncommit < nwb && !grp_flag(shI, GI_ANY)) break;                           // uniform (GI_ANY: written before E4)
             __syncthreads();
             if (tid == 0) shI[GI_ANY] = 0;
         }
@@ -1150,7 +1166,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
             shI[GI_FORCED] = 0; shI[GI_ANY] = 0;
             shQ[GQ_KSQ] = ~0ull; shQ[GQ_KINV] = ~0ull; shI[GI_READY] = 0;
         }
-        if (shI[GI_SERIAL]) continue;
+        if (grp_flag(shI, GI_SERIAL)) continue;
         GTICK(13);
         // ---- G: refill the window from the run (from the buckets when the run is empty) ------------------------------------------------------
         if (did_commit || shI[GI_NW] < wcap) {
@@ -1162,7 +1178,7 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
                     if (wave == 0) grp_w0_drain(&scold, srun, stage, hist, shI, lstat, drain_n, lane);
                     __syncthreads();
                     GTICK(9);
-                    if (shI[GI_SERIAL]) break;
+                    if (grp_flag(shI, GI_SERIAL)) break;
                     // the drained bucket comes unsorted unless its list was in key order: a bitonic sort over ALL waves (one
                     // wave sorting 1024 entries was two thirds of a drain)
                     const int sn = shI[GI_SORTN];
@@ -1255,15 +1271,15 @@ __global__ __launch_bounds__(GRP_W) void flood_group_kernel(
         atomicAdd(&stats[63], (unsigned long long)st_sub);
         atomicAdd(&stats[17], (unsigned long long)lstat[GS_BURST]);
         atomicAdd(&stats[18], (unsigned long long)lstat[GS_RELOAD]);
-        if (shI[GI_SERIAL]) atomicAdd(&stats[8], 1ull);
+        if (grp_flag(shI, GI_SERIAL)) atomicAdd(&stats[8], 1ull);
 #ifdef ISX_FLOOD_PROF
         for (int i = 0; i < 10; ++i) atomicAdd(&stats[48 + i], (unsigned long long)lstat[GS_C_NOTREADY + i]);
 #endif
     }
-    if (shI[GI_SERIAL]) {
+    if (grp_flag(shI, GI_SERIAL)) {
         // Exact continuation on one lane: every queued element (window roots -- their speculative work is dropped, `out`
         // only ever holds committed labels --, run, staged, pending residuals, buckets) goes into the binary heap.
-        const int mode = shI[GI_SERIAL];
+        const int mode = grp_flag(shI, GI_SERIAL);
         if (max_bursts & 0x200) {            // development: no continuation, only report that (and where) it was asked for
             if (tid == 0 && stats) { atomicAdd(&stats[22], 1ull); stats[23] = (unsigned long long)mode | ((unsigned long long)st_sub << 8) | ((unsigned long long)csize << 32); }
             return;

@@ -289,6 +289,20 @@ def test_segment_output_image_scale_and_absolute_thresh(ws, scale, abs_thresh):
     assert np.asarray(seg).max() > 0
 
 
+def test_gaussian_refuses_to_run_in_place(ws):
+    """A Gaussian pass reads neighbours that other work-groups of the same pass write: isx_ws_gaussian with img == out is an
+    argument error (include/itersegx.h), not a silent race."""
+    import ctypes as C
+    import torch
+    from iterseg_amd import _lib
+    from iterseg_amd.watershed import get_context
+    ctx = get_context(0)
+    t = torch.rand((4, 32, 64), device="cuda")
+    sig = (C.c_int32 * 3)(0, 1, 1)
+    rc = ctx.lib.isx_ws_gaussian(ctx.handle, C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), _lib._dims(t.shape), sig)
+    assert rc == _lib.ISX_ERR_ARG
+
+
 @pytest.mark.parametrize("sigma", [2, (0, 1, 1), (0, 2, 2), 1])
 def test_fused_gaussian_is_the_two_pass_one_bit_for_bit(ws, flood_knobs, sigma):
     """ISX_GAUSS_FUSED (default 1): the y and the x pass of a plane in one kernel with a float32 intermediate in LDS
