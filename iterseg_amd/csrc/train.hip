@@ -315,6 +315,117 @@ __device__ __forceinline__ float act_grad(float g, float z, int act)
     return g * (1.f - s) * s;
 }
 
+// The two BatchNorm-backward passes with four channels per lane (16-byte loads and stores): C % 4 == 0 and 16-byte aligned rows.
+// The one-channel-per-lane kernels below them moved 4 bytes per lane and load and ran at a quarter of the HBM rate (round 5:
+// 1.5 ms of the 9.7 ms bf16 step for 2.1 GB).  Per channel the rows are summed in another grouping than in the scalar kernels
+// (a lane owns rows m = rslot (mod nslot) with nslot = 256 / (C / 4)); the sums stay in double and in a fixed order.
+__global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float *__restrict__ g, int gstride,
+                                                             const float *__restrict__ raw, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, int C, int64_t M, int act,
+                                                             int rows_per_block, float *__restrict__ part)
+{
+    extern __shared__ double smd[];                     // [256][4][2]
+    const int L4 = C >> 2, l4 = threadIdx.x % L4, c = 4 * l4;
+    const int rslot = threadIdx.x / L4, nslot = 256 / L4;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (rslot < nslot) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t r1 = r0 + rows_per_block;
+        if (r1 > M) r1 = M;
+        const float4 sc = *(const float4 *)&scale[c], sh = *(const float4 *)&shift[c], mu = *(const float4 *)&mean[c], is = *(const float4 *)&invstd[c];
+        for (int64_t m = r0 + rslot; m < r1; m += 2 * nslot) {
+            float4 xv[2], gv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t mm = m + (int64_t)u * nslot;
+                xv[u] = mm < r1 ? *(const float4 *)&raw[mm * C + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                gv[u] = mm < r1 ? *(const float4 *)&g[mm * gstride + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (m + (int64_t)u * nslot >= r1) break;
+                const float x[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w}, muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float z = fmaf(x[k], scv[k], shv[k]);
+                    const float dz = act_grad(gg[k], z, act);
+                    s1[k] += (double)dz;
+                    s2[k] += (double)dz * (double)((x[k] - muv[k]) * isv[k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { smd[(threadIdx.x * 4 + k) * 2] = s1[k]; smd[(threadIdx.x * 4 + k) * 2 + 1] = s2[k]; }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        const int q = threadIdx.x >> 2, k = threadIdx.x & 3;
+        double a = 0.0, b = 0.0;
+        for (int r = 0; r < nslot; ++r) { a += smd[((r * L4 + q) * 4 + k) * 2]; b += smd[((r * L4 + q) * 4 + k) * 2 + 1]; }
+        part[((int64_t)blockIdx.x * C + threadIdx.x) * 2] = (float)a;
+        part[((int64_t)blockIdx.x * C + threadIdx.x) * 2 + 1] = (float)b;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float *__restrict__ g, int gstride,
+                                                            const float *__restrict__ raw, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd, const float *__restrict__ coef,
+                                                            int C, int64_t M, int act, int rows_per_block,
+                                                            float *__restrict__ draw, int dstride, float *__restrict__ part)
+{
+    extern __shared__ float sm[];                        // [256][4]
+    const int L4 = C >> 2, l4 = threadIdx.x % L4, c = 4 * l4;
+    const int rslot = threadIdx.x / L4, nslot = 256 / L4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rslot < nslot) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t r1 = r0 + rows_per_block;
+        if (r1 > M) r1 = M;
+        const float4 sc4 = *(const float4 *)&scale[c], sh4 = *(const float4 *)&shift[c], mu4 = *(const float4 *)&mean[c], is4 = *(const float4 *)&invstd[c];
+        const float4 ca = *(const float4 *)&coef[2 * c], cb = *(const float4 *)&coef[2 * c + 4];       // {c1, c2} of channels c, c + 1 | c + 2, c + 3
+        const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w}, muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, isv[4] = {is4.x, is4.y, is4.z, is4.w};
+        const float c1v[4] = {ca.x, ca.z, cb.x, cb.z}, c2v[4] = {ca.y, ca.w, cb.y, cb.w};
+        for (int64_t m = r0 + rslot; m < r1; m += 2 * nslot) {
+            float4 xv[2], gv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t mm = m + (int64_t)u * nslot;
+                xv[u] = mm < r1 ? *(const float4 *)&raw[mm * C + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                gv[u] = mm < r1 ? *(const float4 *)&g[mm * gstride + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t mm = m + (int64_t)u * nslot;
+                if (mm >= r1) break;
+                const float x[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+                float d[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float z = fmaf(x[k], scv[k], shv[k]);
+                    const float dz = act_grad(gg[k], z, act);
+                    const float xh = (x[k] - muv[k]) * isv[k];
+                    d[k] = scv[k] * (dz - c1v[k] - xh * c2v[k]);          // sc = gamma * invstd
+                    s1[k] += d[k];
+                }
+                *(float4 *)&draw[mm * dstride + c] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm[threadIdx.x * 4 + k] = s1[k];
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        const int q = threadIdx.x >> 2, k = threadIdx.x & 3;
+        float a = 0.f;
+        for (int r = 0; r < nslot; ++r) a += sm[(r * L4 + q) * 4 + k];
+        part[(int64_t)blockIdx.x * C + threadIdx.x] = a;
+    }
+}
+
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restrict__ g, int gstride,
                                                             const float *__restrict__ raw, const float *__restrict__ scale,
                                                             const float *__restrict__ shift, const float *__restrict__ mean,
@@ -1085,12 +1196,24 @@ static int bn_backward(isx_ctx *ctx, int li, const float *g, int gstride, int ac
     const int rows = 512;
     const int blocks = (int)((l.M + rows - 1) / rows);
     ISX_REQUIRE((size_t)blocks * C * 2 <= t->part_floats, "internal: partial buffer too small");
+    // four channels per lane where the rows allow 16-byte accesses (every layer but the 5-channel ones)
+    const bool v4 = C % 4 == 0 && C <= 1024 && gstride % 4 == 0 && t->dstride[li] % 4 == 0 && ((uintptr_t)g & 15) == 0 &&
+                    ((uintptr_t)t->draw[li] & 15) == 0 && ((uintptr_t)u->raw[li] & 15) == 0;
+    if (v4)
+        bn_bwd_reduce4_kernel<<<blocks, 256, 256 * 8 * sizeof(double), ctx->stream>>>(g, gstride, u->raw[li], L.scale, L.shift, L.bmean,
+                                                                                  L.invstd, C, l.M, act, rows, t->part);
+    else
     bn_bwd_reduce_kernel<<<blocks, 256, 256 * 2 * sizeof(double), ctx->stream>>>(g, gstride, u->raw[li], L.scale, L.shift, L.bmean,
                                                                              L.invstd, C, l.M, act, rows, t->part);
     ISX_CHECK_LAUNCH();
     bn_bwd_finalize_kernel<<<C, 256, 0, ctx->stream>>>(t->part, blocks, C, (double)l.M, t->G + t->off_gamma[li],
                                                      t->G + t->off_beta[li], t->coef);
     ISX_CHECK_LAUNCH();
+    if (v4)
+        bn_bwd_apply4_kernel<<<blocks, 256, 256 * 4 * sizeof(float), ctx->stream>>>(g, gstride, u->raw[li], L.scale, L.shift, L.bmean,
+                                                                                L.invstd, t->coef, C, l.M, act, rows, t->draw[li],
+                                                                                t->dstride[li], t->part);
+    else
     bn_bwd_apply_kernel<<<blocks, 256, 256 * sizeof(float), ctx->stream>>>(g, gstride, u->raw[li], L.scale, L.shift, L.bmean,
                                                                         L.invstd, t->coef, C, l.M, act, rows, t->draw[li],
                                                                         t->dstride[li], t->part);
