@@ -96,7 +96,7 @@ DTYPE = {"fp32": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumul
 # cannot collect PMC counters on itself, so it reads the summary that scratch/pmc_traffic_json.py wrote from those
 # passes (committed under profiles/ with the CSVs); without one, or if it was made for another kernel build, traffic
 # is null.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
 TRAFFIC_ALGORITHMIC = 0.05725e9          # every activation read once + written once + weights, per chunk-launch
 
 
