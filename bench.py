@@ -85,8 +85,9 @@ def cpu_baseline(sd, chunk, margin):
 
 
 DTYPE = {"fp32": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)",
-         "split-f16": "f32 operands split into two f16 halves each (x = x_h + x_l / 2^11), three v_mfma_f32_16x16x32_f16 per K "
-                      "block with separate fp32 accumulators: fp32-class results on the f16 matrix cores",
+         "split-f16": "f32 operands split into two f16 halves each (x = x_h + x_r, operands pre-scaled by powers of two so that the residual "
+                      "is a normal half), three v_mfma_f32_16x16x32_f16 per K block (a_h b_h + a_h b_r + a_r b_h) into one fp32 "
+                      "accumulator: fp32-class results on the f16 matrix cores",
          # reduced-precision characterisation runs only (--precision f16 / bf16): never the default, never the headline
          "f16": "f16 operands (round to nearest), one v_mfma_f32_16x16x32_f16 per K block, fp32 accumulate -- REDUCED precision "
                 "(BASELINE config 5's 'fp16 U-Net'; stated tolerance 4e-3 on the sigmoid maps)",
@@ -116,10 +117,10 @@ def conv_roofline(precision, mfma_flops, n_chunks, steps, ms_mfma, n_mfma, batch
     r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
          "traffic": traffic, "traffic_source": traffic_src, "traffic_algorithmic": TRAFFIC_ALGORITHMIC * batch,
          "kernel": ("conv_mfma_kernel (fp32 32x32x2 implicit-GEMM conv, 16 of 18 layers)" if precision == "fp32" else
-                    "conv_h2c16nw8x2_kernel / conv_h2c16nw8_kernel / conv_h2c16_kernel / conv_tail_kernel (split-f16 implicit-GEMM conv on v_mfma_f32_16x16x32_f16: matrix phase software-pipelined, weight slabs by LDS-DMA, two N tiles per work-group for Cout % 128 == 0; the thin tail layer in one pass with up3 up-sampled on read; 16 of 18 layers)"),
+                    "conv_h2c16nw8m_kernel / conv_h2c16nw8x2_kernel / conv_h2c16_kernel / conv_tail_kernel (split-f16 implicit-GEMM conv on v_mfma_f32_16x16x32_f16: matrix phase software-pipelined, weight slabs by LDS-DMA, 512-voxel work-groups with 64 x 64 wave tiles for Cout = 64 and c2, two N tiles per 256-voxel work-group for Cout % 128 == 0 on the linearised levels; the thin tail layer in one pass with up3 up-sampled on read; 16 of 18 layers)"),
          "avg_launch_ms": ms_mfma / max(n_mfma, 1), "launches": n_mfma, "algorithmic_gflop_per_chunk": mfma_flops / 1e9}
     if precision in ("f16", "bf16"):
-        r["kernel"] = f"conv_h2c16nw8x2_kernel / conv_h2c16nw8_kernel / conv_h2c16_kernel / conv_tail_kernel ({precision} operands, one MFMA per product, 16 of 18 layers)"
+        r["kernel"] = f"conv_h2c16nw8m_kernel / conv_h2c16nw8x2_kernel / conv_h2c16_kernel / conv_tail_kernel ({precision} operands, one MFMA per product, 16 of 18 layers)"
         r["note"] = "reduced-precision mode: algorithmic FLOPs = executed MFMA FLOPs x 27/28"
     elif precision != "fp32":
         r["note"] = ("achieved = algorithmic (fp32-equivalent) FLOPs; the split executes 3 f16 MFMAs per product (x 28/27 tap "
