@@ -117,7 +117,11 @@ __device__ __forceinline__ void lds_dma16(const uint4 *g, uint4 *lds_wave_base)
 // every halo tile once per 64 columns --, the two weight slabs of a stage alternate between the two DMA buffers (the slab
 // sequence g = step * NJ + jj simply continues: slab g + 1 lands while the matrix phase reads slab g), one more barrier per
 // stage for twice the matrix work per stage, 128 accumulator registers.
-template <int BN, int MT, int PM, int NW, int NJ = 1>
+// UP: source A is the COARSE output of the previous decoder module and is up-sampled while it is staged (the depthwise transposed
+// convolution of unet.py:216-242 with kernel = stride = (1, 2, 2): fine voxel (z, y, x) reads coarse ((y + off) >> 1, (x + off) >> 1) and
+// takes the weight of its parity): relu(bn(x)) * w_up[parity][c] + b_up[c], the same fmaf the materialising kernel applies -- bit for
+// bit the same operand --, so the up-sampled tensor (42.6 + 21.6 MB per chunk for up2 / up1) is never written or read.
+template <int BN, int MT, int PM, int NW, int NJ = 1, bool UP = false>
 __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 {
     static_assert(NJ == 1 || NW == 8, "N-tile pairs: the LDS-DMA kernel only");
@@ -146,6 +150,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     int *rowinfo = (int *)(AsH + (SPLIT ? 2 : 1) * a.slots_max);
     // per-wave BatchNorm partial sums of the epilogue; M512: behind the epilogue's output tile inside the staging buffers (free by then)
     float *red = M512 ? (float *)smem4 + ROWS * (BN + 4) : (float *)(rowinfo + ROWS);
+    // (UP) [4 parities + bias][CA] floats, pre-scaled by the activation scale of the f16 modes
+    float *upws = M512 ? (float *)(rowinfo + ROWS) : red + NW * BN * 2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int lin = blockIdx.x;
@@ -247,6 +253,16 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     };
     const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + THREADS), gv2 = slot_voxel(tid + 2 * THREADS),
               gv3 = NA > 3 ? slot_voxel(tid + 3 * THREADS) : -2, gv4 = NA > 4 ? slot_voxel(tid + 4 * THREADS) : -2;
+    // (UP) the slot's coarse voxel | parity << 28, from its fine voxel
+    auto up_code = [&](int g) __attribute__((always_inline)) -> int {
+        if (!UP || g < 0) return 0;
+        const int x = g % W, y = (g / W) % H, z = g / (W * H);
+        const int yo = y + a.uoff, xo = x + a.uoff;
+        return ((z * a.uH + (yo >> 1)) * a.uW + (xo >> 1)) | ((((yo & 1) << 1) | (xo & 1)) << 28);
+    };
+    const int gu0 = up_code(gv0), gu1 = up_code(gv1), gu2 = up_code(gv2), gu3 = up_code(gv3), gu4 = up_code(gv4);
+    bool ld_up = false;                                       // the stage in the prefetch registers is an up-sampled one
+    int ld_cc = 0;
 
     const int nsteps = (a.CA + a.CB) >> 3;
     typedef float f32x4c __attribute__((ext_vector_type(4)));
@@ -278,7 +294,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #define H2_LOAD_A(k)                                                                              \
     if constexpr (k < NA && ISX_H2_ABLATE != 3 && ISX_H2_ABLATE < 7) if (THREADS * k + wbase < S) {                    \
         /* (a 32-bit element offset here -- one multiply, scalar-base load -- costs the N-tile-pair kernel 37 more spilled registers) */ \
-        const float *pp = &ld_src[(int64_t)(gv##k > 0 ? gv##k : 0) * ld_C];                       \
+        const int gl_ = (UP && ld_up) ? (gu##k & 0x0FFFFFFF) : (gv##k > 0 ? gv##k : 0);          \
+        const float *pp = &ld_src[(int64_t)gl_ * ld_C];                                           \
         ra##k = *(const float4 *)pp;                                                              \
         rc##k = *(const float4 *)(pp + 4);                                                        \
     }
@@ -301,15 +318,18 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             vs0 = make_float4(1.f, 1.f, 1.f, 1.f); vs1 = vs0;                                     \
             vh0 = make_float4(0.f, 0.f, 0.f, 0.f); vh1 = vh0;                                     \
         }                                                                                         \
-        if constexpr (ASC != 1.f) {                                                               \
+        ld_up = UP && a.upA && c0 < a.CA;                                                         \
+        ld_cc = cc;                                                                               \
+        if (ASC != 1.f && !ld_up) {                  /* (an up stage is scaled through its up weights) */ \
             vs0.x *= ASC; vs0.y *= ASC; vs0.z *= ASC; vs0.w *= ASC; vs1.x *= ASC; vs1.y *= ASC; vs1.z *= ASC; vs1.w *= ASC; \
             vh0.x *= ASC; vh0.y *= ASC; vh0.z *= ASC; vh0.w *= ASC; vh1.x *= ASC; vh1.y *= ASC; vh1.z *= ASC; vh1.w *= ASC; \
         }                                                                                         \
         relu_lo = has_affine ? 0.f : -__builtin_inff();                                           \
-        ld_src = src + (int64_t)b * M * C + cc;                                                   \
+        const int64_t Ms = ld_up ? (int64_t)D * a.uH * a.uW : M;                                  \
+        ld_src = src + (int64_t)b * Ms * C + cc;                                                  \
         ld_C = C;                                                                                 \
         if (c0 < a.CA ? a.planarA : a.planarB) {               /* [chunk][C/8][voxel][8]: this stage's plane */ \
-            ld_src = src + ((int64_t)b * (C >> 3) + (cc >> 3)) * M * 8;                           \
+            ld_src = src + ((int64_t)b * (C >> 3) + (cc >> 3)) * Ms * 8;                          \
             ld_C = 8;                                                                             \
         }                                                                                         \
     }
@@ -342,6 +362,13 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     if constexpr (k < NA && ISX_H2_ABLATE < 8) {                                                                       \
         float4 v = ra##k, w = rc##k;                                                              \
         H2_AFFL(v, vs0, vh0) H2_AFFL(w, vs1, vh1)                                                 \
+        if (UP && ld_up) {                                                                        \
+            const float *uw = &upws[((unsigned)gu##k >> 28) * a.CA + ld_cc], *ub = &upws[4 * a.CA + ld_cc]; \
+            const float4 u0 = *(const float4 *)uw, u1 = *(const float4 *)(uw + 4);                \
+            const float4 b0 = *(const float4 *)ub, b1 = *(const float4 *)(ub + 4);                \
+            v.x = fmaf(v.x, u0.x, b0.x); v.y = fmaf(v.y, u0.y, b0.y); v.z = fmaf(v.z, u0.z, b0.z); v.w = fmaf(v.w, u0.w, b0.w); \
+            w.x = fmaf(w.x, u1.x, b1.x); w.y = fmaf(w.y, u1.y, b1.y); w.z = fmaf(w.z, u1.z, b1.z); w.w = fmaf(w.w, u1.w, b1.w); \
+        }                                                                                         \
         uint4 hi, lo = make_uint4(0u, 0u, 0u, 0u);                                                \
         if constexpr (SPLIT) split8r(v, w, hi, lo); else round8<PM>(v, w, hi);                     \
         const bool dead = gv##k < 0;                                                              \
@@ -373,6 +400,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     const unsigned long long tk_begin = __builtin_readcyclecounter();
     const unsigned long long tr_begin = __builtin_amdgcn_s_memrealtime();
 #endif
+    if constexpr (UP) if (a.upA)
+        for (int i = tid; i < 5 * a.CA; i += THREADS) upws[i] = (i < 4 * a.CA ? a.upw[i] : a.upb[i - 4 * a.CA]) * ASC;
     if constexpr (DMA) H2_DMA_B(0)
     H2_LOAD_HEAD(0) H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4)
     H2_T(tk_loop)
@@ -599,6 +628,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     conv_h2_body<64, 2, PM, 8, 2>(a);
 }
 
+// ... the two forms that can up-sample their first source while staging it (UP)
+template <int PM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8mu_kernel(const ConvArgs a)
+{
+    conv_h2_body<64, 2, PM, 8, 1, true>(a);
+}
+template <int PM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16u_kernel(const ConvArgs a)
+{
+    conv_h2_body<32, 2, PM, 4, 1, true>(a);
+}
+
 // ... with two N tiles per work-group (Cout % 128 == 0: the halo tile of a K stage staged once for 128 output columns)
 template <int PM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8x2_kernel(const ConvArgs a)
@@ -710,11 +751,62 @@ int repack_bf16(isx_ctx *ctx, const float *wref, int cout, int cin, int transpos
 
 size_t h2_pack_halves(int cout_p, int cin_p, int bn) { return (size_t)(cout_p / bn) * (cin_p / 8) * 2 * 28 * bn * 8 + 4096; }
 
+// Which kernel form a layer's launch takes (the part of launch_conv_h2's decisions that does not depend on the strip / tz geometry):
+// nw8 = 512-thread work-groups, m512 = 512 voxels per work-group (then one N tile), BN / mt of the four-wave kernels.
+struct H2Choice { bool nw8, m512; int BN, mt, mode5, tiles5, slots5; };
+static H2Choice h2_choice(isx_ctx *ctx, const Level &l, int B, int cout, int pm)
+{
+    H2Choice c;
+    int t0, t1, t2, slots1;
+    const int mode = conv_mode(l);
+    conv_tiles(l, mode, 1, &t0, &t1, &t2, &slots1);
+    c.nw8 = conv_h2_nw8(ctx->tune, l, cout, B);
+    c.BN = c.nw8 ? 64 : conv_h2_bn(ctx->tune, slots1, cout);
+    // 32-column tiles get two row tiles per wave (256-voxel work-groups) when the launch is big enough to fill
+    // the chip that way; the partial-sum layout then follows that tiling (mt is fixed per workspace: h2_mt)
+    c.mt = (c.BN == 32 && h2_mt(ctx->tune, l, ctx->unet->wbatch)) ? 2 : 1;
+    if (c.mt == 2) {                    // very narrow levels: the 256-position halo does not fit the staging plan
+        int ty, tx, tp, sl;
+        conv_tiles(l, mode, 2, &ty, &tx, &tp, &sl);
+        if (sl > 1280) c.mt = 1;
+    }
+    // 512-voxel work-groups (conv_h2c16nw8m*_kernel): where the launch still fills the chip and the halo of 512 voxels fits the
+    // staging plan and, beside the two slab buffers, the LDS.  Levels whose planes the linearised tiles cannot hold that way
+    // (65^2: 1 608 slots) take box tiles with edge strips instead.
+    // (measured, round 5: -9 ... -14 % on the Cout = 64 layers, -2 % on c2 at 65^2; the Cout % 128 == 0 layers of the linearised
+    // levels (33^2) are 2-3 % faster on the 256-voxel N-tile pair; eight waves over 512 voxels x 32 columns lose 6 % to the
+    // four-wave kernel of the Cout = 32 layers)
+    c.m512 = false;
+    c.mode5 = (mode != 0 && l.W >= 48 && l.H >= 16 && l.D % 2 == 0) ? 0 : mode;
+    c.tiles5 = c.slots5 = 0;
+    if (c.nw8 && ctx->tune.h2_m512) {
+        int ty, tx, tp, sl;
+        c.tiles5 = conv_tiles(l, c.mode5, 4, &ty, &tx, &tp, &sl);
+        c.slots5 = sl;
+        const size_t lds5 = (size_t)(pm == 0 ? 2 : 1) * (2 * 2 * 14 * c.BN + sl) * 16 + 512 * sizeof(int);
+        const bool pair_wins = cout % 128 == 0 && c.mode5 != 0 && ctx->tune.h2_nj2 && ctx->tune.h2_m512 == 1;
+        c.m512 = !pair_wins && sl <= 1536 && lds5 <= 160 * 1024 && (ctx->tune.h2_m512 == 2 || (int64_t)B * c.tiles5 * (cout / 64) >= 2048);
+    }
+    return c;
+}
+
+// Can this layer's launch up-sample its first source while staging it (H2Extra::upA)?  Only the 512-voxel kernel on one N tile
+// and the four-wave 32-column kernel with two row tiles per wave have that form (conv_h2c16nw8mu_kernel / conv_h2c16u_kernel).
+bool conv_h2_can_up(isx_ctx *ctx, const Level &l, int B, int cout, int pm)
+{
+    const H2Choice c = h2_choice(ctx, l, B, cout, pm);
+    return (c.m512 && ctx->tune.h2_m512 != 3) || (!c.nw8 && c.BN == 32 && c.mt == 2);
+}
+
 // The 27-tap convolution of one layer over B chunks.  out_planar: write [chunk][Cout/8][voxel][8] (UNetState::planar).
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int *tiles_used, int pm, int out_planar)
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int *tiles_used, int pm, int out_planar,
+                   const H2Extra *ex)
 {
     ConvArgs a;
+    const bool up = ex && ex->upA;
+    a.upA = up ? 1 : 0; a.uH = up ? ex->uH : 0; a.uW = up ? ex->uW : 0; a.uoff = up ? ex->uoff : 0;
+    a.upw = up ? ex->upw : nullptr; a.upb = up ? ex->upb : nullptr;
     a.nt_out = ctx->tune.h2_nt_out;
     a.planarA = sa.planar ? 1 : 0; a.planarB = sb.planar ? 1 : 0; a.out_planar = out_planar;
     ISX_REQUIRE(!a.out_planar || cout % 8 == 0, "internal: planar output needs Cout %% 8 == 0");
@@ -729,40 +821,25 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.no_stats = no_stats;
     a.xcd_remap = xcd_remap;
     ISX_REQUIRE(cout % 32 == 0 && sa.C % 8 == 0 && sb.C % 8 == 0, "internal: split-f16 conv needs Cout %% 32 == 0, Cin %% 8 == 0");
-    const bool nw8 = conv_h2_nw8(ctx->tune, l, cout, B);
-    const int BN = nw8 ? 64 : conv_h2_bn(ctx->tune, a.slots_max, cout);
-    // 32-column tiles get two row tiles per wave (256-voxel work-groups) when the launch is big enough to fill
-    // the chip that way; the partial-sum layout then follows that tiling (mt is fixed per workspace: h2_mt)
-    int mt = (BN == 32 && h2_mt(ctx->tune, l, ctx->unet->wbatch)) ? 2 : 1;
+    const H2Choice ch = h2_choice(ctx, l, B, cout, pm);
+    const bool nw8 = ch.nw8, m512 = ch.m512;
+    const int BN = ch.BN, mt = ch.mt;
     if (nw8) {                          // the tile of MT = 2, one row tile per wave
         int ty, tx, tp, sl;
         a.tiles_per_chunk = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
         a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl;
     }
-    // 512-voxel work-groups (conv_h2c16nw8m*_kernel): where the launch still fills the chip and the halo of 512 voxels fits the
-    // staging plan and, beside the two slab buffers, the LDS.  Levels whose planes the linearised tiles cannot hold that way
-    // (65^2: 1 608 slots) take box tiles with edge strips instead.
-    bool m512 = false;
-    if (nw8 && ctx->tune.h2_m512) {
-        // (measured, round 5: -9 ... -14 % on the Cout = 64 layers, -2 % on c2 at 65^2; the Cout % 128 == 0 layers of the linearised
-        // levels (33^2) are 2-3 % faster on the 256-voxel N-tile pair; eight waves over 512 voxels x 32 columns lose 6 % to the
-        // four-wave kernel of the Cout = 32 layers)
-        const int mode5 = (a.mode != 0 && l.W >= 48 && l.H >= 16 && l.D % 2 == 0) ? 0 : a.mode;
+    if (m512) {
         int ty, tx, tp, sl;
-        const int tiles5 = conv_tiles(l, mode5, 4, &ty, &tx, &tp, &sl);
-        const size_t lds5 = (size_t)(pm == 0 ? 2 : 1) * (2 * 2 * 14 * BN + sl) * 16 + 512 * sizeof(int);
-        const bool pair_wins = cout % 128 == 0 && mode5 != 0 && ctx->tune.h2_nj2 && ctx->tune.h2_m512 == 1;
-        if (!pair_wins && sl <= 1536 && lds5 <= 160 * 1024 && (ctx->tune.h2_m512 == 2 || (int64_t)B * tiles5 * (cout / 64) >= 2048)) {
-            m512 = true;
-            a.mode = mode5; a.tiles_per_chunk = tiles5; a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl;
-        }
+        a.mode = ch.mode5;
+        a.tiles_per_chunk = conv_tiles(l, a.mode, 4, &ty, &tx, &tp, &sl);
+        a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl;
     }
     const int rows_wg = m512 ? 512 : (nw8 ? 256 : 128 * mt);
     if (mt == 2) {
         int ty, tx, tp, sl;
-        const int tiles2 = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
-        if (sl <= 1280) { a.tiles_per_chunk = tiles2; a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl; }
-        else mt = 1;                   // very narrow levels: the 256-position halo does not fit the staging plan
+        a.tiles_per_chunk = conv_tiles(l, a.mode, 2, &ty, &tx, &tp, &sl);
+        a.nty = ty; a.ntx = tx; a.ntp = tp; a.slots_max = sl;
     }
     if (a.mode == 0) {
         // box tiles: interior boxes of 8 x TXW voxels, and edge strips where the remainders of H / W make them cheaper than padded
@@ -811,7 +888,12 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         const size_t per = (pm == 0 ? 2 : 1) * 16, slabs = (size_t)(pm == 0 ? 2 : 1) * (nw8 ? 2 : 1) * 2 * 14 * BN * 16;
         if (slabs + (size_t)a.slots_max * per < tile) a.slots_max = (int)((tile - slabs + per - 1) / per);
     }
-    const size_t lds = (size_t)((pm == 0 ? 2 : 1) * ((nw8 ? 2 : 1) * 2 * 14 * BN + a.slots_max)) * 16 + (rows_wg + (m512 ? 0 : (nw8 ? 8 : 4) * BN * 2)) * sizeof(float);
+    size_t lds = (size_t)((pm == 0 ? 2 : 1) * ((nw8 ? 2 : 1) * 2 * 14 * BN + a.slots_max)) * 16 + (rows_wg + (m512 ? 0 : (nw8 ? 8 : 4) * BN * 2)) * sizeof(float);
+    if (up) {
+        ISX_REQUIRE((m512 && nj == 1) || (!nw8 && BN == 32 && mt == 2), "internal: this launch has no up-sampling form (conv_h2_can_up)");
+        ISX_REQUIRE(a.upw && a.upb && sa.C % 8 == 0, "internal: up-sampling on read needs the transposed convolution's weights");
+        lds += (size_t)5 * sa.C * sizeof(float);
+    }
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
     const unsigned grid = (unsigned)(B * a.tiles_per_chunk * a.ntiles);
@@ -822,7 +904,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 2>))
         ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 2>))
         ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 2>))
-        ISX_H2_ATTR3(conv_h2c16nw8_kernel) ISX_H2_ATTR3(conv_h2c16nw8x2_kernel) ISX_H2_ATTR3(conv_h2c16nw8m_kernel) ISX_H2_ATTR3(conv_h2c16nw8mx2_kernel)
+        ISX_H2_ATTR3(conv_h2c16nw8_kernel) ISX_H2_ATTR3(conv_h2c16nw8x2_kernel) ISX_H2_ATTR3(conv_h2c16nw8m_kernel) ISX_H2_ATTR3(conv_h2c16nw8mx2_kernel) ISX_H2_ATTR3(conv_h2c16nw8mu_kernel) ISX_H2_ATTR3(conv_h2c16u_kernel)
         attr_done = true;
     }
 #undef ISX_H2_ATTR3
@@ -831,7 +913,15 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     do { if (pm == 0) conv_h2c16_kernel<BN_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
          else if (pm == 1) conv_h2c16_kernel<BN_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
          else conv_h2c16_kernel<BN_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
-    if (m512 && nj == 2) {
+    if (up && m512) {
+        if (pm == 0) conv_h2c16nw8mu_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
+        else if (pm == 1) conv_h2c16nw8mu_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
+        else conv_h2c16nw8mu_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);
+    } else if (up) {
+        if (pm == 0) conv_h2c16u_kernel<0><<<grid, 256, lds, ctx->stream>>>(a);
+        else if (pm == 1) conv_h2c16u_kernel<1><<<grid, 256, lds, ctx->stream>>>(a);
+        else conv_h2c16u_kernel<2><<<grid, 256, lds, ctx->stream>>>(a);
+    } else if (m512 && nj == 2) {
         if (pm == 0) conv_h2c16nw8mx2_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
         else if (pm == 1) conv_h2c16nw8mx2_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
         else conv_h2c16nw8mx2_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);

@@ -1268,9 +1268,11 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         if (h2) {
             const int out_planar = (want_planar && L.cout % 8 == 0) ? 1 : 0;
             u->planar[li] = out_planar != 0;
-            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, &stat_tiles, pm, out_planar));
-        } else
+            ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, &stat_tiles, pm, out_planar, ex));
+        } else {
+            ISX_REQUIRE(!ex, "internal: up-sampling on read needs the reduced-precision convolution");
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
+        }
     } else if (use_fold(L.cin, L.cout)) {
         // the x-taps folded into 3*cout <= 16 output columns, 9 (dz,dy) taps on the matrix cores
         const bool bf = u->precision == ISX_PRECISION_BF16;
@@ -1455,6 +1457,17 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             const int l0 = dec_layer(f, k, 0), l1 = dec_layer(f, k, 1);   // c5..c8 of this fork
             const int skip_li = 2 * (3 - k) + 1;                   // c3, c2, c1, c0 second conv
             const float up_bound = bn_bound(li_in) * U.wmax + U.bmax;
+            // up1 / up2 (kernel (1, 2, 2)) are up-sampled by their consumer while it stages its halo, where that consumer's launch has
+            // the form for it (conv_h2_can_up: the 512-voxel kernel and the two-row-tile 32-column kernel): the up-sampled tensors
+            // (21.6 + 42.6 MB per chunk) are never written or read, bit-identical operands (conv_h2.hip, UP)
+            const int pm_k = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (u->precision == ISX_PRECISION_BF16 ? 2 : 1);
+            const bool on_read_h2 = ctx->tune.h2_up && U.kz == 1 && U.C % 8 == 0 && !u->train && use_mfma(u->cv[l0].cin, u->cv[l0].cout) &&
+                                    conv_takes_h2(ctx, l0, lo, B, std::max(up_bound, bn_bound(skip_li))) &&
+                                    conv_h2_can_up(ctx, lo, B, u->cv[l0].cout, pm_k);
+            if (on_read_h2) {
+                u->up_folded[ups_index(f, k)] = true;
+                u->ups_planar[ups_index(f, k)] = false;
+            } else
             if (!(f > 0 && k == 0)) {
                 ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
                 int64_t total = (int64_t)B * lo.M * (U.C / 4);
@@ -1482,6 +1495,11 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
                                                                         u->planar[li_in] ? 1 : 0, u->ups_planar[ups_index(f, k)] ? 1 : 0);
                 ISX_CHECK_LAUNCH();
             }
+            if (on_read_h2) {
+                H2Extra ex;
+                ex.upA = 1; ex.uH = ls.H; ex.uW = ls.W; ex.uoff = k == 3 ? 1 : 0; ex.upw = U.w; ex.upb = U.bias;
+                ISX_TRY(run_conv(ctx, l0, lo, B, Src{u->raw[li_in], Lin.scale, Lin.shift, U.C, up_bound, u->planar[li_in]}, act(skip_li), &ex, planar_ok(l1, lo, l0)));
+            } else
             ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound, u->ups_planar[ups_index(f, k)]}, act(skip_li), nullptr, planar_ok(l1, lo, l0)));
             // its output feeds up_{k+1} only (k < 3): planar if that transposed convolution runs per source voxel and the
             // convolution behind it reads planar sources

@@ -124,6 +124,10 @@ struct ConvArgs {
     // conv_h2 kernels, modes 1 / 2 (linearised planes): a tile is tz planes x (rows / tz) positions.  2 / 1 by default; a level with
     // few, small planes takes all of them (17 x 17 x 5: 6 tiles of 5 x 51 rows instead of 10 of 1 x 256 -- 289 positions fill 1.13 tiles)
     int tz;
+    // conv_h2 kernels with UP: source A is up-sampled while it is staged (H2Extra): coarse plane uH x uW, crop offset, the transposed
+    // convolution's weights [4 parities][CA] and bias [CA]
+    int upA, uH, uW, uoff;
+    const float *upw, *upb;
 };
 
 struct H2Extra {           // the tail kernel's optional source: up3 up-sampled on read (conv_tail.hip, TailArgs)
@@ -150,8 +154,11 @@ void pack_h2_weights(const float *w, int cout, int cin, int bn, std::vector<uint
 void pack_h2_fold_weights(const float *w, int cout, int cin, std::vector<uint16_t> &out, int pm);
 int repack_bf16(isx_ctx *ctx, const float *wref, int cout, int cin, int transpose, int bn, int cout_p, int cin_p, void *dst);
 size_t h2_pack_halves(int cout_p, int cin_p, int bn);
+struct H2Extra;
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
-                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int *tiles_used, int pm = 0, int out_planar = 0);
+                   float *out, float *psum, float *psq, int no_stats, int xcd_remap, int *tiles_used, int pm = 0, int out_planar = 0,
+                   const H2Extra *ex = nullptr);
+bool conv_h2_can_up(isx_ctx *ctx, const Level &l, int B, int cout, int pm);
 // one-pass thin tail convolution (conv_tail.hip)
 int conv_tail_tiles(const Level &l);
 size_t conv_tail_lds(int cin, int pm);

@@ -380,6 +380,37 @@ def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("out", [5, (3, 2)])
+@pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
+def test_up_sampling_while_staging_is_bit_identical(monkeypatch, out, precision):
+    """ISX_H2_UP (default 1): up1 / up2 are not materialised -- the first convolution of c6 / c7 reads the coarse output of the
+    previous module and applies the transposed convolution while it stages its halo (conv_h2.hip, UP: conv_h2c16nw8mu_kernel for
+    the 512-voxel form, conv_h2c16u_kernel for the 32-column form).  Same fmaf, same operand: feature maps and taps (the taps of
+    the up-sampled tensors are recomputed from the coarse ones) identical bit for bit, on plain and forked networks."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(12, out_channels=out)
+    nets = []
+    monkeypatch.setenv("ISX_H2_NW8", "2")
+    monkeypatch.setenv("ISX_H2_M512", "2")
+    monkeypatch.setenv("ISX_H2_MT2", "2")
+    for v in ("1", "0"):
+        monkeypatch.setenv("ISX_H2_UP", v)
+        u = UNet(1, out, batch=2, precision=precision)
+        u.load_state_dict(sd)
+        nets.append(u)
+    for shape in [(4, 32, 32), (10, 96, 80), (6, 48, 112), (4, 176, 192), (10, 256, 256)]:
+        x = np.random.default_rng(14).random((1, 1) + shape, dtype=np.float32)
+        ya, yb = nets[0](x), nets[1](x)
+        assert np.array_equal(ya, yb), shape
+        if np.prod(shape) > 100000:
+            continue
+        for name in ("up1.cropped", "up2.cropped", "c6_0.conv0", "c7_0.conv0", "c7_0.conv1", "c8_0.conv0"):
+            assert np.array_equal(nets[0].tap(name), nets[1].tap(name)), (shape, name)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("m512", ["2", "3"])
 @pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
 def test_512_voxel_work_groups_change_only_the_statistics_rounding(precision, m512, monkeypatch):
