@@ -38,7 +38,7 @@ static constexpr int GRP_PEND = 2 * GRP_W;        // residuals of one commit bur
 static constexpr int GRP_STAGE = GRP_W + 64;      // staged cold-bound elements (flushed down to < 64 after every slice)
 static constexpr int GRP_TL = 256;                // take-over / fresh-loss records of one sub-round
 static constexpr uint32_t GRP_NONE = 0xFFFFFFFFu;
-static constexpr unsigned long long GROUP_MIN_SIZE = 262144;   // components from this size flood on the work-group kernel (ISX_FLOOD_GROUP_MIN; 0 = never).  Measured r3:
+static constexpr unsigned long long GROUP_MIN_SIZE = 65536;    // components from this size flood on the work-group kernel (ISX_FLOOD_GROUP_MIN; 0 = never).  Round 5, after round 4's leaner step: structured 512^3 seeds 0 / 4 74 -> 58 / 79 -> 62 ms against 262144 (their largest components, 100-180 k voxels, were the whole stage on the one-wave kernel); 32768 and 16384 measure the same.  Measured r3 (at 262144):
                                                                // config 2 (one 8.3 M chain-like component) 3.01 -> 1.55 s, blobs 256^3 (one 5.4 M) 0.95 -> 0.70 s, structured 512^3 +3..6 %
 
 enum { GI_OH, GI_NW, GI_SHEAD, GI_SCOUNT, GI_NSTAGE, GI_NFREECH, GI_NFREESLOT, GI_SERIAL, GI_FORCED, GI_NTOOK, GI_NLOST, GI_NT, GI_NL,

@@ -14,6 +14,7 @@ for seed in seeds:
         keys = []
         for kv in filter(None, cfg.split(",")):
             k, v = kv.split("="); os.environ[k] = v; keys.append(k)
+        ws.get_context().reload_knobs()              # the library reads its knobs once per context
         ts = []
         for rep in range(3):
             lab.zero_(); torch.cuda.synchronize(); t = time.time()
@@ -23,3 +24,4 @@ for seed in seeds:
         if base is None: base = cur
         print(f"seed {seed} [{cfg or 'default'}] {min(ts)*1e3:.1f} ms  (runs {[round(x*1e3,1) for x in ts]}) same-as-first {same}", flush=True)
         for k in keys: os.environ.pop(k, None)
+        ws.get_context().reload_knobs()
