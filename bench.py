@@ -24,6 +24,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # before the first HIP call: the flood's three streams need a queue each (iterseg_amd/__init__.py)
+
 import numpy as np
 import torch
 

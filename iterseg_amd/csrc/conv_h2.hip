@@ -150,7 +150,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     int *rowinfo = (int *)(AsH + (SPLIT ? 2 : 1) * a.slots_max);
     // per-wave BatchNorm partial sums of the epilogue; M512: behind the epilogue's output tile inside the staging buffers (free by then)
     float *red = M512 ? (float *)smem4 + ROWS * (BN + 4) : (float *)(rowinfo + ROWS);
-    // (UP) [4 parities + bias][CA] floats, pre-scaled by the activation scale of the f16 modes
+    // (UP) [4 ukz parities + bias][CA] floats, pre-scaled by the activation scale of the f16 modes
     float *upws = M512 ? (float *)(rowinfo + ROWS) : red + NW * BN * 2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -258,7 +258,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if (!UP || g < 0) return 0;
         const int x = g % W, y = (g / W) % H, z = g / (W * H);
         const int yo = y + a.uoff, xo = x + a.uoff;
-        return ((z * a.uH + (yo >> 1)) * a.uW + (xo >> 1)) | ((((yo & 1) << 1) | (xo & 1)) << 28);
+        const int zc = a.ukz == 2 ? z >> 1 : z, pz = a.ukz == 2 ? z & 1 : 0;          // (upsample_kernel: zs = z / kz, kidx = ((z % kz) * 2 + py) * 2 + px)
+        return ((zc * a.uH + (yo >> 1)) * a.uW + (xo >> 1)) | (((pz << 2) | ((yo & 1) << 1) | (xo & 1)) << 28);
     };
     const int gu0 = up_code(gv0), gu1 = up_code(gv1), gu2 = up_code(gv2), gu3 = up_code(gv3), gu4 = up_code(gv4);
     bool ld_up = false;                                       // the stage in the prefetch registers is an up-sampled one
@@ -325,7 +326,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             vh0.x *= ASC; vh0.y *= ASC; vh0.z *= ASC; vh0.w *= ASC; vh1.x *= ASC; vh1.y *= ASC; vh1.z *= ASC; vh1.w *= ASC; \
         }                                                                                         \
         relu_lo = has_affine ? 0.f : -__builtin_inff();                                           \
-        const int64_t Ms = ld_up ? (int64_t)D * a.uH * a.uW : M;                                  \
+        const int64_t Ms = ld_up ? (int64_t)(D / a.ukz) * a.uH * a.uW : M;                                  \
         ld_src = src + (int64_t)b * Ms * C + cc;                                                  \
         ld_C = C;                                                                                 \
         if (c0 < a.CA ? a.planarA : a.planarB) {               /* [chunk][C/8][voxel][8]: this stage's plane */ \
@@ -363,7 +364,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         float4 v = ra##k, w = rc##k;                                                              \
         H2_AFFL(v, vs0, vh0) H2_AFFL(w, vs1, vh1)                                                 \
         if (UP && ld_up) {                                                                        \
-            const float *uw = &upws[((unsigned)gu##k >> 28) * a.CA + ld_cc], *ub = &upws[4 * a.CA + ld_cc]; \
+            const float *uw = &upws[((unsigned)gu##k >> 28) * a.CA + ld_cc], *ub = &upws[4 * a.ukz * a.CA + ld_cc]; \
             const float4 u0 = *(const float4 *)uw, u1 = *(const float4 *)(uw + 4);                \
             const float4 b0 = *(const float4 *)ub, b1 = *(const float4 *)(ub + 4);                \
             v.x = fmaf(v.x, u0.x, b0.x); v.y = fmaf(v.y, u0.y, b0.y); v.z = fmaf(v.z, u0.z, b0.z); v.w = fmaf(v.w, u0.w, b0.w); \
@@ -401,7 +402,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     const unsigned long long tr_begin = __builtin_amdgcn_s_memrealtime();
 #endif
     if constexpr (UP) if (a.upA)
-        for (int i = tid; i < 5 * a.CA; i += THREADS) upws[i] = (i < 4 * a.CA ? a.upw[i] : a.upb[i - 4 * a.CA]) * ASC;
+        for (int i = tid; i < (4 * a.ukz + 1) * a.CA; i += THREADS) upws[i] = (i < 4 * a.ukz * a.CA ? a.upw[i] : a.upb[i - 4 * a.ukz * a.CA]) * ASC;
     if constexpr (DMA) H2_DMA_B(0)
     H2_LOAD_HEAD(0) H2_LOAD_A(0) H2_LOAD_A(1) H2_LOAD_A(2) H2_LOAD_A(3) H2_LOAD_A(4)
     H2_T(tk_loop)
@@ -639,6 +640,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 {
     conv_h2_body<32, 2, PM, 4, 1, true>(a);
 }
+template <int PM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_h2c16nw8x2u_kernel(const ConvArgs a)
+{
+    conv_h2_body<64, 1, PM, 8, 2, true>(a);
+}
 
 // ... with two N tiles per work-group (Cout % 128 == 0: the halo tile of a K stage staged once for 128 output columns)
 template <int PM>
@@ -753,7 +759,7 @@ size_t h2_pack_halves(int cout_p, int cin_p, int bn) { return (size_t)(cout_p / 
 
 // Which kernel form a layer's launch takes (the part of launch_conv_h2's decisions that does not depend on the strip / tz geometry):
 // nw8 = 512-thread work-groups, m512 = 512 voxels per work-group (then one N tile), BN / mt of the four-wave kernels.
-struct H2Choice { bool nw8, m512; int BN, mt, mode5, tiles5, slots5; };
+struct H2Choice { bool nw8, m512, pair_sure; int BN, mt, mode5, tiles5, slots5; };
 static H2Choice h2_choice(isx_ctx *ctx, const Level &l, int B, int cout, int pm)
 {
     H2Choice c;
@@ -787,15 +793,24 @@ static H2Choice h2_choice(isx_ctx *ctx, const Level &l, int B, int cout, int pm)
         const bool pair_wins = cout % 128 == 0 && c.mode5 != 0 && ctx->tune.h2_nj2 && ctx->tune.h2_m512 == 1;
         c.m512 = !pair_wins && sl <= 1536 && lds5 <= 160 * 1024 && (ctx->tune.h2_m512 == 2 || (int64_t)B * c.tiles5 * (cout / 64) >= 2048);
     }
+    // the N-tile pair, where no later geometry decision (strips, the all-planes tiles of an odd level) can change the tile count its
+    // "still fills the chip" test looks at: box tiles stay padded for it, linearised even levels have no variants
+    {
+        int ty, tx, tp, sl;
+        const int tiles2 = conv_tiles(l, mode, 2, &ty, &tx, &tp, &sl);
+        c.pair_sure = c.nw8 && !c.m512 && ctx->tune.h2_nj2 && cout % 128 == 0 && mode != 2 &&
+                      (ctx->tune.h2_nj2 == 2 || (int64_t)B * tiles2 * (cout / 128) >= 512);
+    }
     return c;
 }
 
-// Can this layer's launch up-sample its first source while staging it (H2Extra::upA)?  Only the 512-voxel kernel on one N tile
-// and the four-wave 32-column kernel with two row tiles per wave have that form (conv_h2c16nw8mu_kernel / conv_h2c16u_kernel).
+// Can this layer's launch up-sample its first source while staging it (H2Extra::upA)?  The 512-voxel kernel on one N tile, the
+// four-wave 32-column kernel with two row tiles per wave and the 256-voxel N-tile pair have that form (conv_h2c16nw8mu_kernel /
+// conv_h2c16u_kernel / conv_h2c16nw8x2u_kernel).
 bool conv_h2_can_up(isx_ctx *ctx, const Level &l, int B, int cout, int pm)
 {
     const H2Choice c = h2_choice(ctx, l, B, cout, pm);
-    return (c.m512 && ctx->tune.h2_m512 != 3) || (!c.nw8 && c.BN == 32 && c.mt == 2);
+    return (c.m512 && ctx->tune.h2_m512 != 3) || (!c.nw8 && c.BN == 32 && c.mt == 2) || c.pair_sure;
 }
 
 // The 27-tap convolution of one layer over B chunks.  out_planar: write [chunk][Cout/8][voxel][8] (UNetState::planar).
@@ -805,7 +820,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
 {
     ConvArgs a;
     const bool up = ex && ex->upA;
-    a.upA = up ? 1 : 0; a.uH = up ? ex->uH : 0; a.uW = up ? ex->uW : 0; a.uoff = up ? ex->uoff : 0;
+    a.upA = up ? 1 : 0; a.uH = up ? ex->uH : 0; a.uW = up ? ex->uW : 0; a.uoff = up ? ex->uoff : 0; a.ukz = up ? ex->ukz : 1;
     a.upw = up ? ex->upw : nullptr; a.upb = up ? ex->upb : nullptr;
     a.nt_out = ctx->tune.h2_nt_out;
     a.planarA = sa.planar ? 1 : 0; a.planarB = sb.planar ? 1 : 0; a.out_planar = out_planar;
@@ -890,9 +905,9 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     }
     size_t lds = (size_t)((pm == 0 ? 2 : 1) * ((nw8 ? 2 : 1) * 2 * 14 * BN + a.slots_max)) * 16 + (rows_wg + (m512 ? 0 : (nw8 ? 8 : 4) * BN * 2)) * sizeof(float);
     if (up) {
-        ISX_REQUIRE((m512 && nj == 1) || (!nw8 && BN == 32 && mt == 2), "internal: this launch has no up-sampling form (conv_h2_can_up)");
-        ISX_REQUIRE(a.upw && a.upb && sa.C % 8 == 0, "internal: up-sampling on read needs the transposed convolution's weights");
-        lds += (size_t)5 * sa.C * sizeof(float);
+        ISX_REQUIRE((m512 && nj == 1) || (!nw8 && BN == 32 && mt == 2) || (nw8 && !m512 && nj == 2), "internal: this launch has no up-sampling form (conv_h2_can_up)");
+        ISX_REQUIRE(a.upw && a.upb && sa.C % 8 == 0 && (a.ukz == 1 || (a.ukz == 2 && l.D % 2 == 0)), "internal: up-sampling on read needs the transposed convolution's weights");
+        lds += (size_t)(4 * a.ukz + 1) * sa.C * sizeof(float);
     }
     ISX_REQUIRE(lds <= 160 * 1024, "internal: split-f16 conv tile needs %zu bytes of LDS", lds);
     if (tiles_used) *tiles_used = a.tiles_per_chunk;        // layout of the BN partial sums this launch writes
@@ -904,7 +919,7 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
         ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<64, 1, 2>))
         ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 1, 2>))
         ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 0>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 1>)) ISX_H2_ATTR((conv_h2c16_kernel<32, 2, 2>))
-        ISX_H2_ATTR3(conv_h2c16nw8_kernel) ISX_H2_ATTR3(conv_h2c16nw8x2_kernel) ISX_H2_ATTR3(conv_h2c16nw8m_kernel) ISX_H2_ATTR3(conv_h2c16nw8mx2_kernel) ISX_H2_ATTR3(conv_h2c16nw8mu_kernel) ISX_H2_ATTR3(conv_h2c16u_kernel)
+        ISX_H2_ATTR3(conv_h2c16nw8_kernel) ISX_H2_ATTR3(conv_h2c16nw8x2_kernel) ISX_H2_ATTR3(conv_h2c16nw8m_kernel) ISX_H2_ATTR3(conv_h2c16nw8mx2_kernel) ISX_H2_ATTR3(conv_h2c16nw8mu_kernel) ISX_H2_ATTR3(conv_h2c16u_kernel) ISX_H2_ATTR3(conv_h2c16nw8x2u_kernel)
         attr_done = true;
     }
 #undef ISX_H2_ATTR3
@@ -913,7 +928,11 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     do { if (pm == 0) conv_h2c16_kernel<BN_, MT_, 0><<<grid, 256, lds, ctx->stream>>>(a); \
          else if (pm == 1) conv_h2c16_kernel<BN_, MT_, 1><<<grid, 256, lds, ctx->stream>>>(a); \
          else conv_h2c16_kernel<BN_, MT_, 2><<<grid, 256, lds, ctx->stream>>>(a); } while (0)
-    if (up && m512) {
+    if (up && nw8 && !m512) {
+        if (pm == 0) conv_h2c16nw8x2u_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
+        else if (pm == 1) conv_h2c16nw8x2u_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
+        else conv_h2c16nw8x2u_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);
+    } else if (up && m512) {
         if (pm == 0) conv_h2c16nw8mu_kernel<0><<<grid, 512, lds, ctx->stream>>>(a);
         else if (pm == 1) conv_h2c16nw8mu_kernel<1><<<grid, 512, lds, ctx->stream>>>(a);
         else conv_h2c16nw8mu_kernel<2><<<grid, 512, lds, ctx->stream>>>(a);

@@ -1461,7 +1461,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             // the form for it (conv_h2_can_up: the 512-voxel kernel and the two-row-tile 32-column kernel): the up-sampled tensors
             // (21.6 + 42.6 MB per chunk) are never written or read, bit-identical operands (conv_h2.hip, UP)
             const int pm_k = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (u->precision == ISX_PRECISION_BF16 ? 2 : 1);
-            const bool on_read_h2 = ctx->tune.h2_up && U.kz == 1 && U.C % 8 == 0 && !u->train && use_mfma(u->cv[l0].cin, u->cv[l0].cout) &&
+            const bool on_read_h2 = ctx->tune.h2_up && (U.kz == 1 || (U.kz == 2 && ctx->tune.h2_up >= 2 && lo.D % 2 == 0)) && U.C % 8 == 0 && !u->train && use_mfma(u->cv[l0].cin, u->cv[l0].cout) &&
                                     conv_takes_h2(ctx, l0, lo, B, std::max(up_bound, bn_bound(skip_li))) &&
                                     conv_h2_can_up(ctx, lo, B, u->cv[l0].cout, pm_k);
             if (on_read_h2) {
@@ -1497,7 +1497,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             }
             if (on_read_h2) {
                 H2Extra ex;
-                ex.upA = 1; ex.uH = ls.H; ex.uW = ls.W; ex.uoff = k == 3 ? 1 : 0; ex.upw = U.w; ex.upb = U.bias;
+                ex.upA = 1; ex.uH = ls.H; ex.uW = ls.W; ex.uoff = k == 3 ? 1 : 0; ex.ukz = U.kz; ex.upw = U.w; ex.upb = U.bias;
                 ISX_TRY(run_conv(ctx, l0, lo, B, Src{u->raw[li_in], Lin.scale, Lin.shift, U.C, up_bound, u->planar[li_in]}, act(skip_li), &ex, planar_ok(l1, lo, l0)));
             } else
             ISX_TRY(run_conv(ctx, l0, lo, B, Src{upo, nullptr, nullptr, U.C, up_bound, u->ups_planar[ups_index(f, k)]}, act(skip_li), nullptr, planar_ok(l1, lo, l0)));
@@ -1750,14 +1750,14 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
                 const UpConv &U = u->up[k];
                 const ConvBN &Lin = u->cv[li_in];
                 const int64_t total = (int64_t)u->last_n * lo.M * (U.C / 4);
-                if (u->planar[li_in]) {            // (a planar coarse tensor: the planar kernel, into a planar tap)
+                if (u->planar[li_in] && U.kz == 1) {            // (a planar coarse tensor: the planar kernel, into a planar tap)
                     const int64_t total_pl = (int64_t)u->last_n * (U.C / 8) * ls.D * ls.H * lo.W * 2;
                     upsample_src_planar_kernel<<<cdiv(total_pl, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W,
                                                                                           k == 3 ? 1 : 0, U.w, U.bias, lo.H, lo.W, u->ups[k], total_pl);
                     tap_planar = true;
                 } else
                 upsample_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[li_in], Lin.scale, Lin.shift, U.C, ls.D, ls.H, ls.W, U.kz,
-                                                                           k == 3 ? 1 : 0, U.w, U.bias, lo.D, lo.H, lo.W, u->ups[k], total, 0, 0, 0);
+                                                                           k == 3 ? 1 : 0, U.w, U.bias, lo.D, lo.H, lo.W, u->ups[k], total, 0, u->planar[li_in] ? 1 : 0, 0);
                 ISX_CHECK_LAUNCH();
             }
         }

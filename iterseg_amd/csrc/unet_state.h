@@ -126,12 +126,12 @@ struct ConvArgs {
     int tz;
     // conv_h2 kernels with UP: source A is up-sampled while it is staged (H2Extra): coarse plane uH x uW, crop offset, the transposed
     // convolution's weights [4 parities][CA] and bias [CA]
-    int upA, uH, uW, uoff;
-    const float *upw, *upb;
+    int upA, uH, uW, uoff, ukz;            // ukz: the transposed convolution's kernel depth (1; 2 for up0, which up-samples z as well)
+    const float *upw, *upb;                // [4 ukz parities][CA], [CA]
 };
 
 struct H2Extra {           // the tail kernel's optional source: up3 up-sampled on read (conv_tail.hip, TailArgs)
-    int upA = 0, uH = 0, uW = 0, uoff = 0;
+    int upA = 0, uH = 0, uW = 0, uoff = 0, ukz = 1;
     const float *upw = nullptr, *upb = nullptr;
 };
 

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # before the first HIP call (iterseg_amd/__init__.py has the reason)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
