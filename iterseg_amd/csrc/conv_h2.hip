@@ -807,10 +807,19 @@ static H2Choice h2_choice(isx_ctx *ctx, const Level &l, int B, int cout, int pm)
 // Can this layer's launch up-sample its first source while staging it (H2Extra::upA)?  The 512-voxel kernel on one N tile, the
 // four-wave 32-column kernel with two row tiles per wave and the 256-voxel N-tile pair have that form (conv_h2c16nw8mu_kernel /
 // conv_h2c16u_kernel / conv_h2c16nw8x2u_kernel).
-bool conv_h2_can_up(isx_ctx *ctx, const Level &l, int B, int cout, int pm)
+bool conv_h2_can_up(isx_ctx *ctx, const Level &l, int B, int cout, int pm, int ca, int ukz)
 {
     const H2Choice c = h2_choice(ctx, l, B, cout, pm);
-    return (c.m512 && ctx->tune.h2_m512 != 3) || (!c.nw8 && c.BN == 32 && c.mt == 2) || c.pair_sure;
+    const size_t table = (size_t)(4 * ukz + 1) * ca * sizeof(float), per = (pm == 0 ? 2 : 1) * 16;
+    int ty, tx, tp, slots2;
+    conv_tiles(l, conv_mode(l), 2, &ty, &tx, &tp, &slots2);
+    if (c.m512 && ctx->tune.h2_m512 != 3)
+        return (size_t)(pm == 0 ? 2 : 1) * (2 * 2 * 14 * 64) * 16 + (size_t)c.slots5 * per + 512 * sizeof(int) + table <= 160 * 1024;
+    if (!c.nw8 && c.BN == 32 && c.mt == 2)
+        return (size_t)(pm == 0 ? 2 : 1) * (2 * 14 * 32) * 16 + (size_t)slots2 * per + (256 + 4 * 32 * 2) * sizeof(float) + table <= 160 * 1024;
+    if (c.pair_sure)
+        return (size_t)(pm == 0 ? 2 : 1) * (2 * 2 * 14 * 64) * 16 + (size_t)slots2 * per + (256 + 8 * 64 * 2) * sizeof(float) + table <= 160 * 1024;
+    return false;
 }
 
 // The 27-tap convolution of one layer over B chunks.  out_planar: write [chunk][Cout/8][voxel][8] (UNetState::planar).

@@ -77,7 +77,7 @@ struct isx_tune {
     int h2_m512 = 1;                // ISX_H2_M512: 1 = 512-voxel work-groups (64 x 64 / 64 x 128 wave tiles) for the 512-thread kernels where the launch fills the chip (2: always, tests; 0: off)
     int h2_tz = 1;                  // ISX_H2_TZ: 0 = one plane per tile on odd levels (rounds 1-3) instead of all planes of a shallow level
     int h2_strips = 1;              // ISX_H2_STRIPS: 0 = padded 8 x TXW boxes only (rounds 1-3) instead of edge strips where H / W leave a remainder
-    int h2_up = 1;                  // ISX_H2_UP: 0 = up1 / up2 materialised instead of up-sampled while their consumer stages its halo (conv_h2.hip, UP)
+    int h2_up = 2;                  // ISX_H2_UP: 0 = up0 .. up2 materialised instead of up-sampled while their consumer stages its halo (conv_h2.hip, UP); 1 = up1 / up2 only
     int tail_up = 1;                // ISX_TAIL_UP: 0 = up3 materialised by upsample_src_kernel instead of up-sampled while the tail kernel stages it
 };
 

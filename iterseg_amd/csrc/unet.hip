@@ -1463,7 +1463,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             const int pm_k = u->precision == ISX_PRECISION_SPLIT_F16 ? 0 : (u->precision == ISX_PRECISION_BF16 ? 2 : 1);
             const bool on_read_h2 = ctx->tune.h2_up && (U.kz == 1 || (U.kz == 2 && ctx->tune.h2_up >= 2 && lo.D % 2 == 0)) && U.C % 8 == 0 && !u->train && use_mfma(u->cv[l0].cin, u->cv[l0].cout) &&
                                     conv_takes_h2(ctx, l0, lo, B, std::max(up_bound, bn_bound(skip_li))) &&
-                                    conv_h2_can_up(ctx, lo, B, u->cv[l0].cout, pm_k);
+                                    conv_h2_can_up(ctx, lo, B, u->cv[l0].cout, pm_k, U.C, U.kz);
             if (on_read_h2) {
                 u->up_folded[ups_index(f, k)] = true;
                 u->ups_planar[ups_index(f, k)] = false;

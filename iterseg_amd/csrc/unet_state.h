@@ -158,7 +158,7 @@ struct H2Extra;
 int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const void *w_h2, const float *bias, int cout,
                    float *out, float *psum, float *psq, int no_stats, int xcd_remap, int *tiles_used, int pm = 0, int out_planar = 0,
                    const H2Extra *ex = nullptr);
-bool conv_h2_can_up(isx_ctx *ctx, const Level &l, int B, int cout, int pm);
+bool conv_h2_can_up(isx_ctx *ctx, const Level &l, int B, int cout, int pm, int ca, int ukz);
 // one-pass thin tail convolution (conv_tail.hip)
 int conv_tail_tiles(const Level &l);
 size_t conv_tail_lds(int cin, int pm);

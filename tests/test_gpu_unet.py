@@ -395,19 +395,21 @@ def test_up_sampling_while_staging_is_bit_identical(monkeypatch, out, precision)
     monkeypatch.setenv("ISX_H2_NW8", "2")
     monkeypatch.setenv("ISX_H2_M512", "2")
     monkeypatch.setenv("ISX_H2_MT2", "2")
-    for v in ("1", "0"):
+    for v in ("2", "1", "0"):                 # 2 (default): up0 (kernel (2, 2, 2), conv_h2c16nw8x2u_kernel) as well
         monkeypatch.setenv("ISX_H2_UP", v)
+        monkeypatch.setenv("ISX_H2_NJ2", "2")
         u = UNet(1, out, batch=2, precision=precision)
         u.load_state_dict(sd)
         nets.append(u)
     for shape in [(4, 32, 32), (10, 96, 80), (6, 48, 112), (4, 176, 192), (10, 256, 256)]:
         x = np.random.default_rng(14).random((1, 1) + shape, dtype=np.float32)
-        ya, yb = nets[0](x), nets[1](x)
-        assert np.array_equal(ya, yb), shape
+        ya, yb, yc = nets[0](x), nets[1](x), nets[2](x)
+        assert np.array_equal(ya, yc) and np.array_equal(yb, yc), shape
         if np.prod(shape) > 100000:
             continue
-        for name in ("up1.cropped", "up2.cropped", "c6_0.conv0", "c7_0.conv0", "c7_0.conv1", "c8_0.conv0"):
-            assert np.array_equal(nets[0].tap(name), nets[1].tap(name)), (shape, name)
+        for name in ("up0.cropped", "up1.cropped", "up2.cropped", "c5_0.conv0", "c6_0.conv0", "c7_0.conv0", "c7_0.conv1", "c8_0.conv0"):
+            tc = nets[2].tap(name)
+            assert np.array_equal(nets[0].tap(name), tc) and np.array_equal(nets[1].tap(name), tc), (shape, name)
 
 
 @pytest.mark.gpu
