@@ -625,7 +625,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a)
             float4 xvv = make_float4(0.f, 0.f, 0.f, 0.f);
             const int ci = ci0 + 4 * xq;
             if (row < XROWS && u >= 0 && u < M && ci < Cin) {
-                const int x = (int)(u % W), y = (int)((u / W) % H) + dy, z = (int)(u / ((int64_t)W * H)) + dz;
+                // (32-bit: a chunk has far fewer than 2^32 voxels; three 64-bit divisions per loaded row were most of this kernel's vector instructions)
+                const uint32_t uu = (uint32_t)u, hw = (uint32_t)W * (uint32_t)H, zq = uu / hw, rem = uu - zq * hw, yq = rem / (uint32_t)W;
+                const int x = (int)(rem - yq * (uint32_t)W), y = (int)yq + dy, z = (int)zq + dz;
                 if (z >= 0 && z < D && y >= 0 && y < H) {
                     const int64_t g = ((int64_t)z * H + y) * W + x;
                     const bool fromB = ci >= a.CA;
@@ -789,7 +791,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
             float4 xvv = make_float4(0.f, 0.f, 0.f, 0.f);
             const int ci = ci0 + 4 * xq;
             if (row < XROWS && u >= 0 && u < M && ci < Cin) {
-                const int x = (int)(u % W), y = (int)((u / W) % H) + dy, z = (int)(u / ((int64_t)W * H)) + dz;
+                // (32-bit: a chunk has far fewer than 2^32 voxels; three 64-bit divisions per loaded row were most of this kernel's vector instructions)
+                const uint32_t uu = (uint32_t)u, hw = (uint32_t)W * (uint32_t)H, zq = uu / hw, rem = uu - zq * hw, yq = rem / (uint32_t)W;
+                const int x = (int)(rem - yq * (uint32_t)W), y = (int)yq + dy, z = (int)zq + dz;
                 if (z >= 0 && z < D && y >= 0 && y < H) {
                     const int64_t g = ((int64_t)z * H + y) * W + x;
                     const bool fromB = ci >= a.CA;
@@ -1350,6 +1354,7 @@ static int wgrad(isx_ctx *ctx, int li, Src sa, Src sb)
     TrainState *t = u->train;
     const ConvBN &L = u->cv[li];
     const Level &l = u->lv[MOD_LEVEL[layer_module(li)]];
+    ISX_REQUIRE(l.M < (int64_t)0x7FFFFFFF, "internal: weight-gradient kernels index a chunk's voxels in 32 bits");
     if (ctx->tune.thin_wgrad && sb.C == 0 && sa.C == L.cin) {
         // the thin layers at the big levels: dedicated kernels (see above)
         const int rows = 2048;
