@@ -18,8 +18,11 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libitersegx.so")
 
 SOURCES = ["isx_ctx.hip", "prims.hip", "ws.hip", "unet.hip", "conv55.hip", "conv_h2.hip", "conv_tail.hip", "host_pipe.hip", "train.hip", "labels.hip", "train_io.hip", "metrics.hip", "comm.hip"]
-# per-source flags: conv55.hip must not contain packed fp32 instructions (see its header)
-EXTRA = {"conv55.hip": ["-fno-slp-vectorize"]}
+# per-source flags: conv55.hip must not contain packed fp32 instructions (see its header); conv_h2.hip: the SLP vectoriser packed two
+# scalar products of one value into `v_pk_mul_f32 v[8:9], s[66:67], v[8:9] op_sel_hi:[1,0]` -- the destination pair overlapping the
+# source whose low half feeds both results, the shape tests/test_abi.py keeps out of the library -- and packing measures null there
+# (same-call A/B, round 5: 68.45 / 69.63 against 68.69 / 69.32 ms per launch set)
+EXTRA = {"conv55.hip": ["-fno-slp-vectorize"], "conv_h2.hip": ["-fno-slp-vectorize"]}
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"]

@@ -8,7 +8,7 @@ OBJS=""
 for o in $C/_obj/*.o; do
   b=$(basename $o .o); use=$o
   for s in "$@"; do if [ "$s" = "$b.hip" ]; then
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt $FLAGS -c $C/$s -o /tmp/var_$NAME/$b.o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt $(python3 -c "from iterseg_amd import _build; print(' '.join(_build.EXTRA.get('$s', [])))") $FLAGS -c $C/$s -o /tmp/var_$NAME/$b.o
     use=/tmp/var_$NAME/$b.o
   fi; done
   OBJS="$OBJS $use"
