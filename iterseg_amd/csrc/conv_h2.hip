@@ -356,13 +356,21 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     }
 // BatchNorm + ReLU, the operand split (or rounding), zero padding by select, one predicated store: no branches (the branchy
 // form compiled to 19 exec-mask regions and 128 register moves per stage of the 64-column kernel)
-#define H2_AFFL(v, s_, h_)                                                                        \
-    v.x = fmaxf(fmaf(v.x, s_.x, h_.x), relu_lo); v.y = fmaxf(fmaf(v.y, s_.y, h_.y), relu_lo);     \
-    v.z = fmaxf(fmaf(v.z, s_.z, h_.z), relu_lo); v.w = fmaxf(fmaf(v.w, s_.w, h_.w), relu_lo);
+#ifndef ISX_H2_LEAN
+#define ISX_H2_LEAN 1            // split mode, 512-thread kernels: ReLU folded into the split's clamp, residual by v_fma_mix_f32 (2 of ~6.5 vector
+                                 // instructions per staged element less; bit-identical; round 5: -2 ... -7 % on the 512-voxel kernels' layers)
+#endif
+#define H2_AFF(v, s_, h_)                                                                         \
+    v.x = fmaf(v.x, s_.x, h_.x); v.y = fmaf(v.y, s_.y, h_.y); v.z = fmaf(v.z, s_.z, h_.z); v.w = fmaf(v.w, s_.w, h_.w);
+#define H2_RELU(v) v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
+#define H2_AFFL(v, s_, h_) H2_AFF(v, s_, h_) H2_RELU(v)
 #define H2_STORE_A(k)                                                                             \
     if constexpr (k < NA && ISX_H2_ABLATE < 8) {                                                                       \
         float4 v = ra##k, w = rc##k;                                                              \
-        H2_AFFL(v, vs0, vh0) H2_AFFL(w, vs1, vh1)                                                 \
+        constexpr bool LEAN = SPLIT && ISX_H2_LEAN && NW == 8;   /* (the four-wave kernels measure 2 % slower with it) */ \
+        float lo_clamp = -H2_MAX;                                                                 \
+        if (LEAN && !(UP && ld_up)) { H2_AFF(v, vs0, vh0) H2_AFF(w, vs1, vh1) lo_clamp = relu_lo == 0.f ? 0.f : -H2_MAX; } \
+        else { H2_AFFL(v, vs0, vh0) H2_AFFL(w, vs1, vh1) }                                        \
         if (UP && ld_up) {                                                                        \
             const float *uw = &upws[((unsigned)gu##k >> 28) * a.CA + ld_cc], *ub = &upws[4 * a.ukz * a.CA + ld_cc]; \
             const float4 u0 = *(const float4 *)uw, u1 = *(const float4 *)(uw + 4);                \
@@ -371,7 +379,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             w.x = fmaf(w.x, u1.x, b1.x); w.y = fmaf(w.y, u1.y, b1.y); w.z = fmaf(w.z, u1.z, b1.z); w.w = fmaf(w.w, u1.w, b1.w); \
         }                                                                                         \
         uint4 hi, lo = make_uint4(0u, 0u, 0u, 0u);                                                \
-        if constexpr (SPLIT) split8r(v, w, hi, lo); else round8<PM>(v, w, hi);                     \
+        if constexpr (LEAN) split8r_lean(v, w, lo_clamp, hi, lo);                                 \
+        else if constexpr (SPLIT) split8r(v, w, hi, lo); else round8<PM>(v, w, hi);               \
         const bool dead = gv##k < 0;                                                              \
         hi.x = dead ? 0u : hi.x; hi.y = dead ? 0u : hi.y; hi.z = dead ? 0u : hi.z; hi.w = dead ? 0u : hi.w; \
         if constexpr (SPLIT) { lo.x = dead ? 0u : lo.x; lo.y = dead ? 0u : lo.y; lo.z = dead ? 0u : lo.z; lo.w = dead ? 0u : lo.w; } \
@@ -521,6 +530,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #undef H2_DMA_B
 #undef H2_DMA_B1
 #undef H2_AFFL
+#undef H2_AFF
+#undef H2_RELU
 #undef H2_STORE_A
 #undef H2_STORE_B
 

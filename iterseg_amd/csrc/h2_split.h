@@ -61,6 +61,30 @@ __device__ __forceinline__ void split2r(float x, float y, uint32_t &hi, uint32_t
     hi = H.u;
     lo = L.u;
 }
+// ... the staging form: the clamp doubles as the ReLU (lo_clamp = 0 behind a BatchNorm, -H2_MAX for a source without one), the
+// residual is one mixed-precision FMA, fma(half h, -1, x) = x - h rounded once like the subtraction it replaces (v_fma_mix_f32)
+__device__ __forceinline__ void split2r_lean(float x, float y, float lo_clamp, uint32_t &hi, uint32_t &lo)
+{
+    typedef __fp16 h2v __attribute__((ext_vector_type(2)));
+    union { h2v v; uint32_t u; } H, L;
+    x = __builtin_amdgcn_fmed3f(x, lo_clamp, H2_MAX);
+    y = __builtin_amdgcn_fmed3f(y, lo_clamp, H2_MAX);
+    H.v = __builtin_amdgcn_cvt_pkrtz(x, y);
+    float rx, ry;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(H.u), "v"(x));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(H.u), "v"(y));
+    L.v = __builtin_amdgcn_cvt_pkrtz(rx, ry);
+    hi = H.u;
+    lo = L.u;
+}
+__device__ __forceinline__ void split8r_lean(const float4 &a, const float4 &b, float lo_clamp, uint4 &hi, uint4 &lo)
+{
+    split2r_lean(a.x, a.y, lo_clamp, hi.x, lo.x);
+    split2r_lean(a.z, a.w, lo_clamp, hi.y, lo.y);
+    split2r_lean(b.x, b.y, lo_clamp, hi.z, lo.z);
+    split2r_lean(b.z, b.w, lo_clamp, hi.w, lo.w);
+}
+
 __device__ __forceinline__ void split8r(const float4 &a, const float4 &b, uint4 &hi, uint4 &lo)
 {
     split2r(a.x, a.y, hi.x, lo.x);
