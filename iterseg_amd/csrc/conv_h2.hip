@@ -381,13 +381,17 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         uint4 hi, lo = make_uint4(0u, 0u, 0u, 0u);                                                \
         if constexpr (LEAN) split8r_lean(v, w, lo_clamp, hi, lo);                                 \
         else if constexpr (SPLIT) split8r(v, w, hi, lo); else round8<PM>(v, w, hi);               \
-        const bool dead = gv##k < 0;                                                              \
-        hi.x = dead ? 0u : hi.x; hi.y = dead ? 0u : hi.y; hi.z = dead ? 0u : hi.z; hi.w = dead ? 0u : hi.w; \
-        if constexpr (SPLIT) { lo.x = dead ? 0u : lo.x; lo.y = dead ? 0u : lo.y; lo.z = dead ? 0u : lo.z; lo.w = dead ? 0u : lo.w; } \
-        if (gv##k != -2) {                                                                        \
+        /* (a slot outside the volume -- the convolution's zero padding -- is the same slot in every K stage: zeroed once in the  */ \
+        /*  prologue and never written again, instead of eight selects per slot and stage)                                       */ \
+        if (gv##k >= 0) {                                                                         \
             AsH[tid + THREADS * k] = hi;                                                          \
             if constexpr (SPLIT) AsL[tid + THREADS * k] = lo;                                     \
         }                                                                                         \
+    }
+#define H2_ZERO_A(k)                                                                              \
+    if constexpr (k < NA) if (gv##k == -1) {                                                      \
+        AsH[tid + THREADS * k] = make_uint4(0u, 0u, 0u, 0u);                                      \
+        if constexpr (SPLIT) AsL[tid + THREADS * k] = make_uint4(0u, 0u, 0u, 0u);                 \
     }
 #define H2_STORE_B(k) if constexpr (NB > k) { if (BEXACT || tid + THREADS * k < SLAB) Bs[tid + THREADS * k] = rb##k; }
 
@@ -410,6 +414,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     const unsigned long long tk_begin = __builtin_readcyclecounter();
     const unsigned long long tr_begin = __builtin_amdgcn_s_memrealtime();
 #endif
+    H2_ZERO_A(0) H2_ZERO_A(1) H2_ZERO_A(2) H2_ZERO_A(3) H2_ZERO_A(4)
     if constexpr (UP) if (a.upA)
         for (int i = tid; i < (4 * a.ukz + 1) * a.CA; i += THREADS) upws[i] = (i < 4 * a.ukz * a.CA ? a.upw[i] : a.upb[i - 4 * a.ukz * a.CA]) * ASC;
     if constexpr (DMA) H2_DMA_B(0)
@@ -533,6 +538,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #undef H2_AFF
 #undef H2_RELU
 #undef H2_STORE_A
+#undef H2_ZERO_A
 #undef H2_STORE_B
 
     // element (voxel g, channel ch) of the output tensor, row-major or planar (ConvArgs::out_planar; store_cols = Cout then)
