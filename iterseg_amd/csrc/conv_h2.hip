@@ -263,6 +263,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     };
     const int gu0 = up_code(gv0), gu1 = up_code(gv1), gu2 = up_code(gv2), gu3 = up_code(gv3), gu4 = up_code(gv4);
     bool ld_up = false;                                       // the stage in the prefetch registers is an up-sampled one
+    bool ld_pre = false;                                      // ... comes from a pre-split source
     int ld_cc = 0;
 
     const int nsteps = (a.CA + a.CB) >> 3;
@@ -320,6 +321,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
             vh0 = make_float4(0.f, 0.f, 0.f, 0.f); vh1 = vh0;                                     \
         }                                                                                         \
         ld_up = UP && a.upA && c0 < a.CA;                                                         \
+        ld_pre = SPLIT && a.presplitA && c0 < a.CA;                                               \
         ld_cc = cc;                                                                               \
         if (ASC != 1.f && !ld_up) {                  /* (an up stage is scaled through its up weights) */ \
             vs0.x *= ASC; vs0.y *= ASC; vs0.z *= ASC; vs0.w *= ASC; vs1.x *= ASC; vs1.y *= ASC; vs1.z *= ASC; vs1.w *= ASC; \
@@ -367,6 +369,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
 #define H2_STORE_A(k)                                                                             \
     if constexpr (k < NA && ISX_H2_ABLATE < 8) {                                                                       \
         float4 v = ra##k, w = rc##k;                                                              \
+        if (SPLIT && ld_pre) {          /* (a pre-split source: the two 16-byte loads ARE the hi and the residual halves) */ \
+            if (gv##k >= 0) {                                                                     \
+                AsH[tid + THREADS * k] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)); \
+                AsL[tid + THREADS * k] = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)); \
+            }                                                                                     \
+        } else {                                                                                  \
         constexpr bool LEAN = SPLIT && ISX_H2_LEAN && NW == 8;   /* (the four-wave kernels measure 2 % slower with it) */ \
         float lo_clamp = -H2_MAX;                                                                 \
         if (LEAN && !(UP && ld_up)) { H2_AFF(v, vs0, vh0) H2_AFF(w, vs1, vh1) lo_clamp = relu_lo == 0.f ? 0.f : -H2_MAX; } \
@@ -386,6 +394,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if (gv##k >= 0) {                                                                         \
             AsH[tid + THREADS * k] = hi;                                                          \
             if constexpr (SPLIT) AsL[tid + THREADS * k] = lo;                                     \
+        }                                                                                         \
         }                                                                                         \
     }
 #define H2_ZERO_A(k)                                                                              \
@@ -850,6 +859,8 @@ int launch_conv_h2(isx_ctx *ctx, const Level &l, int B, Src sa, Src sb, const vo
     a.upw = up ? ex->upw : nullptr; a.upb = up ? ex->upb : nullptr;
     a.nt_out = ctx->tune.h2_nt_out;
     a.planarA = sa.planar ? 1 : 0; a.planarB = sb.planar ? 1 : 0; a.out_planar = out_planar;
+    a.presplitA = sa.presplit ? 1 : 0;
+    ISX_REQUIRE(!sa.presplit || (pm == 0 && sa.planar && !sa.scale && !(ex && ex->upA)), "internal: a pre-split source reached a launch that cannot copy it");
     ISX_REQUIRE(!a.out_planar || cout % 8 == 0, "internal: planar output needs Cout %% 8 == 0");
     ISX_REQUIRE(!(a.planarA && sa.C % 8) && !(a.planarB && sb.C % 8), "internal: planar source with %d / %d channels", sa.C, sb.C);
     a.srcA = sa.p; a.scaleA = sa.scale; a.shiftA = sa.shift; a.CA = sa.C;

@@ -78,6 +78,7 @@ struct isx_tune {
     int h2_tz = 1;                  // ISX_H2_TZ: 0 = one plane per tile on odd levels (rounds 1-3) instead of all planes of a shallow level
     int h2_strips = 1;              // ISX_H2_STRIPS: 0 = padded 8 x TXW boxes only (rounds 1-3) instead of edge strips where H / W leave a remainder
     int h2_up = 2;                  // ISX_H2_UP: 0 = up0 .. up2 materialised instead of up-sampled while their consumer stages its halo (conv_h2.hip, UP); 1 = up1 / up2 only
+    int h2_presplit = 1;            // ISX_H2_PRESPLIT: 0 = pooled tensors as float values (their reader splits them while staging) instead of pre-split halves
     int tail_up = 1;                // ISX_TAIL_UP: 0 = up3 materialised by upsample_src_kernel instead of up-sampled while the tail kernel stages it
 };
 

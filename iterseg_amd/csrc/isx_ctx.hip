@@ -149,6 +149,7 @@ static void read_knobs(isx_ctx *c)
     if (const char *e = getenv("ISX_H2_TZ")) t.h2_tz = atoi(e);
     if (const char *e = getenv("ISX_H2_M512")) t.h2_m512 = atoi(e);
     if (const char *e = getenv("ISX_TAIL_UP")) t.tail_up = atoi(e);
+    if (const char *e = getenv("ISX_H2_PRESPLIT")) t.h2_presplit = atoi(e);
     if (const char *e = getenv("ISX_H2_UP")) t.h2_up = atoi(e);
     if (const char *e = getenv("ISX_BF16_WGRAD")) t.bf16_wgrad = atoi(e);
     if (const char *e = getenv("ISX_WGRAD_WGS")) t.wgrad_wgs = std::max(18, atoi(e));

@@ -539,8 +539,12 @@ __device__ __forceinline__ void bn_relu4(float4 &t, const float4 &s, const float
     t.x = fmaxf(fmaf(t.x, s.x, h.x), 0.f); t.y = fmaxf(fmaf(t.y, s.y, h.y), 0.f);
     t.z = fmaxf(fmaf(t.z, s.z, h.z), 0.f); t.w = fmaxf(fmaf(t.w, s.w, h.w), 0.f);
 }
+// presplit: the pooled values leave already split for the split-f16 convolution that reads them -- [8 hi halves][8 residual halves]
+// of value * H2_SA in the 32 bytes of a voxel's plane, exactly what that kernel's staging computes from the float values
+// (split8r: the 512-thread kernels' leaner form is the same function of its input) -- so that its staging of this source is a copy.
 __global__ void pool_planar_kernel(const float *__restrict__ src, const float *__restrict__ scale, const float *__restrict__ shift,
-                                   int C, int D, int H, int W, int kz, int Do, int Ho, int Wo, float *__restrict__ dst, int64_t total)
+                                   int C, int D, int H, int W, int kz, int Do, int Ho, int Wo, float *__restrict__ dst, int64_t total,
+                                   int presplit)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)total) return;
@@ -570,6 +574,14 @@ __global__ void pool_planar_kernel(const float *__restrict__ src, const float *_
             }
         }
     float *dp = &dst[(((int64_t)b * NP + pl) * Mo32 + m) * 8];
+    if (presplit) {
+        uint4 hi, lo;
+        split8r(make_float4(b0.x * H2_SA, b0.y * H2_SA, b0.z * H2_SA, b0.w * H2_SA),
+                make_float4(b1.x * H2_SA, b1.y * H2_SA, b1.z * H2_SA, b1.w * H2_SA), hi, lo);
+        *(uint4 *)dp = hi;
+        *(uint4 *)(dp + 4) = lo;
+        return;
+    }
     *(float4 *)dp = b0;
     *(float4 *)(dp + 4) = b1;
 }
@@ -1397,7 +1409,7 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
         const Level &l = lv[mi];
         Src in = (mi == 0) ? Src{u->x0, nullptr, nullptr, 1}
                            : Src{u->pool[mi - 1], nullptr, nullptr, MOD_COUT[mi - 1], bn_bound(2 * (mi - 1) + 1)};
-        if (mi > 0) in.planar = u->pool_planar[mi - 1];
+        if (mi > 0) { in.planar = u->pool_planar[mi - 1]; in.presplit = u->pool_presplit[mi - 1]; }
         ISX_TRY(run_conv(ctx, 2 * mi, l, B, in, none, nullptr, planar_ok(2 * mi + 1, l, 2 * mi)));
         ISX_TRY(run_conv(ctx, 2 * mi + 1, l, B, act(2 * mi), none, nullptr, skip_planar_ok(mi)));
         if (mi < 4) {
@@ -1409,10 +1421,14 @@ int forward_batch(isx_ctx *ctx, int B, float *out_ncdhw, float *fm, const int64_
             // a planar skip tensor is pooled plane by plane into a planar tensor (skip_planar_ok has checked its reader)
             const bool sp = u->planar[2 * mi + 1];
             u->pool_planar[mi] = sp;
+            // pre-split for its reader (skip_planar_ok has checked that the reader runs on the reduced-precision kernel): only in
+            // the split-f16 arithmetic, whose staging would compute exactly these halves
+            u->pool_presplit[mi] = sp && ctx->tune.h2_presplit && u->precision == ISX_PRECISION_SPLIT_F16;
             if (sp) {
                 total = (int64_t)B * lo.M * (L.cout / 8);
                 pool_planar_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[2 * mi + 1], L.scale, L.shift, L.cout, l.D, l.H, l.W,
-                                                                           mi == 3 ? 2 : 1, lo.D, lo.H, lo.W, u->pool[mi], total);
+                                                                           mi == 3 ? 2 : 1, lo.D, lo.H, lo.W, u->pool[mi], total,
+                                                                           u->pool_presplit[mi] ? 1 : 0);
             } else
             pool_kernel<<<cdiv(total, 256), 256, 0, ctx->stream>>>(u->raw[2 * mi + 1], L.scale, L.shift, L.cout, l.D, l.H,
                                                                 l.W, mi == 3 ? 2 : 1, lo.D, lo.H, lo.W, u->pool[mi],
@@ -1741,7 +1757,18 @@ int isx_unet_tap_host(isx_ctx *ctx, const char *name, float *out, int64_t cap_el
         }
     }
     for (int k = 0; k < 4 && !src; ++k) {
-        if (nm == std::string("d") + std::to_string(k)) { src = u->pool[k]; C = MOD_COUT[k]; level = k + 1; tap_planar = u->pool_planar[k]; }
+        if (nm == std::string("d") + std::to_string(k)) {
+            src = u->pool[k]; C = MOD_COUT[k]; level = k + 1; tap_planar = u->pool_planar[k];
+            if (u->pool_presplit[k]) {        // the tensor holds split halves: the float values are pooled again from the resident raw tensor
+                const Level &lf = u->lv[k], &lc = u->lv[k + 1];
+                const ConvBN &Lp = u->cv[2 * k + 1];
+                const int64_t total_p = (int64_t)u->last_n * lc.M * (Lp.cout / 8);
+                pool_planar_kernel<<<cdiv(total_p, 256), 256, 0, ctx->stream>>>(u->raw[2 * k + 1], Lp.scale, Lp.shift, Lp.cout, lf.D, lf.H, lf.W,
+                                                                             k == 3 ? 2 : 1, lc.D, lc.H, lc.W, u->pool[k], total_p, 0);
+                ISX_CHECK_LAUNCH();
+                u->pool_presplit[k] = false;
+            }
+        }
         else if (nm == std::string("up") + std::to_string(k) + ".cropped") {
             src = u->ups[k]; C = UP_C[k]; level = 3 - k; tap_planar = u->ups_planar[k];
             if (u->up_folded[k]) {            // not materialised by the folded forward: computed here from the resident coarse tensor

@@ -81,6 +81,7 @@ struct UNetState {
     int last_n = 0;
     bool up_folded[ISX_MAX_UPS] = {false};     // last forward: ups[i] was NOT materialised (the tail kernel up-sampled it on read)
     bool pool_planar[4] = {false}, ups_planar[ISX_MAX_UPS] = {false};      // last forward: pool[i] / ups[i] are stored planar
+    bool pool_presplit[4] = {false};  // last forward: pool[i] holds its values already split for the split-f16 kernels ([8 hi halves][8 residual halves] per voxel and plane)
     bool planar[ISX_MAX_LAYERS] = {false};   // last forward: raw[li] is stored planar (first convolution of a module whose only reader is the second)
     int arith[ISX_MAX_LAYERS] = {0};  // how each convolution ran in the last forward (ISX_ARITH_*, isx_unet_precision_report)
     struct TrainState *train = nullptr;
@@ -93,7 +94,7 @@ struct TrainState;
 // precision switch after fp32 steps never convolves with stale or zero packs.
 int train_ensure_bf16_packs(isx_ctx *ctx);
 
-struct Src { const float *p; const float *scale; const float *shift; int C; float bound = 0.f; bool planar = false; };   // bound: max |activation| (split-f16 range check)
+struct Src { const float *p; const float *scale; const float *shift; int C; float bound = 0.f; bool planar = false; bool presplit = false; };   // bound: max |activation| (split-f16 range check)
 
 // implicit-GEMM conv on the fp32 matrix cores (unet.hip); see ConvArgs there
 struct ConvArgs {
@@ -116,6 +117,7 @@ struct ConvArgs {
     // planar tensors: [chunk][C / 8][voxel][8 channels] instead of [chunk][voxel][C] -- a K stage's 32 bytes of consecutive voxels
     // are contiguous, so a halo load instruction reads whole lines instead of 64 pieces of 16 bytes (UNetState::planar)
     int planarA, planarB, out_planar;
+    int presplitA;         // source A (planar, no BatchNorm) holds split halves already: its staging is a copy (pool_planar_kernel, UNetState::pool_presplit)
     // conv_h2 kernels, mode 0: box tiles.  A plane pair is covered by nI interior boxes of 8 x TXW voxels (ntx per row) plus,
     // where H or W leave a remainder the launcher found cheaper to cover this way than by padded interior boxes, sr_n boxes of
     // sr_ty x sr_tx voxels down the right edge (x0 = sr_x0, all y) and sb_n boxes of sb_ty x sb_tx along the bottom edge

@@ -380,6 +380,34 @@ def test_512_thread_work_groups_give_the_same_feature_maps(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nw8", ["1", "2", "0"])
+def test_pre_split_pooled_tensors_change_nothing(monkeypatch, nw8):
+    """ISX_H2_PRESPLIT (default 1): in the split-f16 arithmetic the pooling kernel writes its planar output as the halves its
+    reader's staging would compute (8 hi halves + 8 residual halves of value * 8 in the 32 bytes of a voxel's plane), and the reader
+    stages that source by copy.  Same halves, same products: feature maps and taps identical bit for bit (the taps d0..d3 of a
+    pre-split tensor are pooled again from the resident raw tensor)."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    sd = weights.generate_state_dict(15)
+    nets = []
+    monkeypatch.setenv("ISX_H2_NW8", nw8)
+    for v in ("1", "0"):
+        monkeypatch.setenv("ISX_H2_PRESPLIT", v)
+        u = UNet(1, 5, batch=2)
+        u.load_state_dict(sd)
+        nets.append(u)
+    for shape in [(4, 32, 32), (10, 96, 80), (6, 48, 112), (4, 176, 192), (10, 256, 256)]:
+        x = np.random.default_rng(16).random((1, 1) + shape, dtype=np.float32)
+        ya, yb = nets[0](x), nets[1](x)
+        assert np.array_equal(ya, yb), shape
+        if np.prod(shape) > 100000:
+            continue
+        for name in ("d0", "d1", "d2", "d3", "c1.conv0", "c2.conv0", "c3.conv0", "c4.conv0", "c4.conv1"):
+            assert np.array_equal(nets[0].tap(name), nets[1].tap(name)), (shape, name)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("out", [5, (3, 2)])
 @pytest.mark.parametrize("precision", ["split-f16", "f16", "bf16"])
 def test_up_sampling_while_staging_is_bit_identical(monkeypatch, out, precision):
