@@ -109,6 +109,13 @@ __device__ __forceinline__ void lds_dma16(const uint4 *g, uint4 *lds_wave_base)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "m0", "memory");
 }
 
+// n / d for 0 <= n < 2^21 by one multiplication with inv = 1 / d (a 1-ulp reciprocal will do): (n + 0.5) / d lies at least 0.5 / d from
+// every integer, the three roundings move it by less than (n + 0.5) / d * 1.8e-7.  The prologue's row / slot tables are ~30 integer
+// divisions by run-time tile sizes otherwise, ~35 vector instructions each -- as many as the whole K loop of a four-stage layer
+// (c0.conv1, c1.conv0, c7.conv1) issues, on a vector pipe that those layers keep busier than the matrix pipe.
+__device__ __forceinline__ float qinv(int d) { return __builtin_amdgcn_rcpf((float)d); }
+__device__ __forceinline__ int qdiv(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
 // MT = 32-row tiles per wave (1: 128 voxels per 4-wave work-group, 2: 256).  With 32 columns, MT = 2 gives the wave a 64 x 32
 // tile whose fragment reads feed as many MFMAs as the 32 x 64 tile of the 64-column variant.
 // NW = waves per work-group (4, or 8: a 512-thread work-group over 256 voxels whose eight waves share ONE weight slab).
@@ -175,6 +182,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     // layers, Cout % 128 == 0, are below the box-tiled levels for every chunk shape iterseg uses: it keeps the padded boxes)
     constexpr bool STRIPS = NJ == 1 || M512;
     int TYb = 8, TXb = TXW, xlim = W;                            // xlim: the last bottom-strip box stops where the right strip begins
+    float iA, iB, iC, iD;                                        // qdiv reciprocals -- boxes: 1 / TXb, TYb, RS, TYb + 2; linearised: 1 / TP, W, PS, WP
     if (a.mode == 0) {
         const int nzt = (D + 1) >> 1;
         const int zt = tile % nzt, rest = tile / nzt;
@@ -184,6 +192,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         else { TYb = a.sb_ty; TXb = a.sb_tx; y0 = a.sb_y0; x0 = (rest - a.nI - a.sr_n) * a.sb_tx; if (a.sr_n) xlim = a.sr_x0; }
         if constexpr (STRIPS) { RS = TXb + 2; PS = (TYb + 2) * RS; } else { RS = TXW + 2; PS = 10 * (TXW + 2); }
         S = 4 * PS;
+        iA = qinv(TXb); iB = qinv(TYb); iC = qinv(RS); iD = qinv(TYb + 2);
     } else {
         TZ = a.tz;
         TP = ROWS / TZ;
@@ -198,17 +207,18 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         RS = WP;
         PS = qlast + WP + 1 - qlo + 1;
         S = (TZ + 2) * PS;
+        iA = qinv(TP); iB = qinv(W); iC = qinv(PS); iD = qinv(WP);
     }
     if (tid < ROWS) {
         int r = tid, g = -1;
         if (a.mode == 0) {
             int zz, yy, xx;
-            if constexpr (STRIPS) { zz = r / (TYb * TXb); yy = (r / TXb) % TYb; xx = r % TXb; }
+            if constexpr (STRIPS) { const int t = qdiv(r, iA); xx = r - t * TXb; zz = qdiv(t, iB); yy = t - zz * TYb; }
             else { zz = r / (8 * TXW); yy = (r / TXW) & 7; xx = r % TXW; }
             int z = z0 + zz, y = y0 + yy, x = x0 + xx;
             if (zz < 2 && z < D && y < H && x < xlim) g = (z * H + y) * W + x;
         } else {
-            int zz = r / TP, p = p0 + r % TP;
+            int zz = qdiv(r, iA), p = p0 + r - zz * TP;
             int z = z0 + zz;
             if (z < D && p < H * W) g = z * H * W + p;
         }
@@ -220,13 +230,15 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
                 const int zz = r / (8 * TXW), yy = (r / TXW) & 7, xx = r % TXW;
                 return (zz + 1) * (10 * (TXW + 2)) + (yy + 1) * (TXW + 2) + (xx + 1);
             }
-            int zz = r / (TYb * TXb), yy = (r / TXb) % TYb, xx = r % TXb;
+            const int t = qdiv(r, iA);
+            int xx = r - t * TXb, zz = qdiv(t, iB), yy = t - zz * TYb;
             if (zz > 1) { zz = 1; yy = TYb - 1; xx = TXb - 1; }          // rows beyond the box (strips: 2 TYb TXb < ROWS): any valid slot
             return (zz + 1) * PS + (yy + 1) * RS + (xx + 1);
         }
-        int zz = r / TP, p = p0 + r % TP;
+        int zz = qdiv(r, iA), p = p0 + r - zz * TP;
         if (p > H * W - 1) p = H * W - 1;
-        int q = (p / W) * WP + (p % W) + 1;
+        const int py = qdiv(p, iB);
+        int q = py * WP + (p - py * W) + 1;
         return (zz + 1) * PS + (q - qlo);
     };
     // lane (r = lane & 15, h = lane >> 4) holds row r of a 16-row tile and tap 4 q + h
@@ -235,33 +247,34 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
     int aslot16[MT16];
 #pragma unroll
     for (int t = 0; t < MT16; ++t) aslot16[t] = row_slot(wave * MT * 32 + 16 * t + l16);
-    auto slot_voxel = [&](int s) __attribute__((always_inline)) -> int {
+    // a halo slot's voxel (-1: outside the volume = zero padding, -2: beyond the tile's slots) and, for the up-sampling kernels, its
+    // coarse voxel | parity << 28 (upsample_kernel: zs = z / kz, kidx = ((z % kz) * 2 + py) * 2 + px)
+    auto slot_voxel = [&](int s, int &gu) __attribute__((always_inline)) -> int {
+        gu = 0;
         if (s >= S) return -2;
         int z, y, x;
         if (a.mode == 0) {
             int hz, hy, hx;
-            if constexpr (STRIPS) { hz = s / PS; hy = (s / RS) % (TYb + 2); hx = s % RS; }
+            if constexpr (STRIPS) { const int t = qdiv(s, iC); hx = s - t * RS; hz = qdiv(t, iD); hy = t - hz * (TYb + 2); }
             else { hz = s / (10 * (TXW + 2)); hy = (s / (TXW + 2)) % 10; hx = s % (TXW + 2); }
             z = z0 + hz - 1; y = y0 + hy - 1; x = x0 + hx - 1;
         } else {
-            int hz = s / PS, qq = qlo + s % PS + WP;
+            const int hz = qdiv(s, iC), qq = qlo + (s - hz * PS) + WP, yq = qdiv(qq, iD);
             z = z0 + hz - 1;
-            y = qq / WP - 1;
-            x = qq % WP - 1;
+            y = yq - 1;
+            x = qq - yq * WP - 1;
         }
-        return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
+        if (!(z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W)) return -1;
+        if constexpr (UP) {
+            const int yo = y + a.uoff, xo = x + a.uoff;
+            const int zc = a.ukz == 2 ? z >> 1 : z, pz = a.ukz == 2 ? z & 1 : 0;
+            gu = ((zc * a.uH + (yo >> 1)) * a.uW + (xo >> 1)) | (((pz << 2) | ((yo & 1) << 1) | (xo & 1)) << 28);
+        }
+        return (z * H + y) * W + x;
     };
-    const int gv0 = slot_voxel(tid), gv1 = slot_voxel(tid + THREADS), gv2 = slot_voxel(tid + 2 * THREADS),
-              gv3 = NA > 3 ? slot_voxel(tid + 3 * THREADS) : -2, gv4 = NA > 4 ? slot_voxel(tid + 4 * THREADS) : -2;
-    // (UP) the slot's coarse voxel | parity << 28, from its fine voxel
-    auto up_code = [&](int g) __attribute__((always_inline)) -> int {
-        if (!UP || g < 0) return 0;
-        const int x = g % W, y = (g / W) % H, z = g / (W * H);
-        const int yo = y + a.uoff, xo = x + a.uoff;
-        const int zc = a.ukz == 2 ? z >> 1 : z, pz = a.ukz == 2 ? z & 1 : 0;          // (upsample_kernel: zs = z / kz, kidx = ((z % kz) * 2 + py) * 2 + px)
-        return ((zc * a.uH + (yo >> 1)) * a.uW + (xo >> 1)) | (((pz << 2) | ((yo & 1) << 1) | (xo & 1)) << 28);
-    };
-    const int gu0 = up_code(gv0), gu1 = up_code(gv1), gu2 = up_code(gv2), gu3 = up_code(gv3), gu4 = up_code(gv4);
+    int gu0, gu1, gu2, gu3 = 0, gu4 = 0;
+    const int gv0 = slot_voxel(tid, gu0), gv1 = slot_voxel(tid + THREADS, gu1), gv2 = slot_voxel(tid + 2 * THREADS, gu2),
+              gv3 = NA > 3 ? slot_voxel(tid + 3 * THREADS, gu3) : -2, gv4 = NA > 4 ? slot_voxel(tid + 4 * THREADS, gu4) : -2;
     bool ld_up = false;                                       // the stage in the prefetch registers is an up-sampled one
     bool ld_pre = false;                                      // ... comes from a pre-split source
     int ld_cc = 0;

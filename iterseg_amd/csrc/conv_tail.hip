@@ -121,27 +121,29 @@ __global__ __launch_bounds__(TL_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     const int64_t M = (int64_t)D * H * W;
 
     // ---- halo slots of this thread: voxel index, -1 outside the volume (zero padding), -2 beyond the slot list -----------
-    auto slot_voxel = [&](int s) __attribute__((always_inline)) -> int {
+    // (the coarse voxel | parity << 28 of the up-sampling kernels comes from the slot's coordinates, not from three run-time divisions of
+    //  its voxel index: 18 divisions = ~650 vector instructions per thread of a work-group that issues ~5 000 in its K loop)
+    auto slot_voxel = [&](int s, int &u) __attribute__((always_inline)) -> int {
+        u = 0;
         if (s >= TL_SLOTS) return -2;
         const int hz = s / (TL_HY * TL_PX), hy = (s / TL_PX) % TL_HY, hx = s % TL_PX;
         const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-        return (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? (z * H + y) * W + x : -1;
+        if (!(z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W)) return -1;
+        if constexpr (UP) {
+            const int yo = y + a.uoff, xo = x + a.uoff;
+            u = ((z * a.uH + (yo >> 1)) * a.uW + (xo >> 1)) | ((((yo & 1) << 1) | (xo & 1)) << 28);
+        }
+        return (z * H + y) * W + x;
     };
     // (in LDS, not in registers: twelve registers the split kernel does not have; a thread reads back only what it wrote)
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int sl = tid + TL_THREADS * k;
         if (sl < TL_SLOTS) {
-            const int g = slot_voxel(sl);
+            int u;
+            const int g = slot_voxel(sl, u);
             gvs[sl] = g;
-            if constexpr (UP) {          // the slot's coarse voxel | parity << 28
-                int u = 0;
-                if (g >= 0) {
-                    const int z = g / (H * W), y = (g / W) % H + a.uoff, x = g % W + a.uoff;
-                    u = ((z * a.uH + (y >> 1)) * a.uW + (x >> 1)) | ((((y & 1) << 1) | (x & 1)) << 28);
-                }
-                gus[sl] = u;
-            }
+            if constexpr (UP) gus[sl] = u;
         }
     }
     const int64_t Mup = UP ? (int64_t)D * a.uH * a.uW : 0;
