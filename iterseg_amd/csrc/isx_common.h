@@ -88,7 +88,9 @@ struct isx_flood_tune {
     long long coop_min = -1, cold_min = -1, group_min = -1, small_max = -1, arena_mb = -1;
     int run_limit = -1, drain = -1, win = -1, list = -1, bursts = -1, gsteps = -1, gminsteps = -1, gwin = -1, glist = -1, buckets = -1;
     int gwatchdog = 0, group_stream = 1, stats = 0;
-    int gauss_fused = 1;            // ISX_GAUSS_FUSED: 0 = one kernel per axis (rounds 1-3) instead of the fused y + x pass
+    int gauss_fused = 1;            // ISX_GAUSS_FUSED: 0 = one kernel per axis (rounds 1-3) instead of the marching z pass + the fused y + x pass (which also hands Otsu its min / max)
+    int ccl_fused = 1;              // ISX_CCL_FUSED: 0 = ccl_flatten_kernel + ccl_sizes_kernel as two passes (rounds 1-4)
+    int ws_check = 0;               // ISX_WS_CHECK: 1 = derived quantities (the affinities' value range from the channel extrema) are also measured the slow way and must agree (tests)
     std::string trace;              // ISX_FLOOD_TRACE=<file>: development dump of every component's commit order
 };
 

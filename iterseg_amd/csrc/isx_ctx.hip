@@ -170,6 +170,8 @@ static void read_knobs(isx_ctx *c)
     in("ISX_FLOOD_GLIST", f.glist); in("ISX_FLOOD_BUCKETS", f.buckets); in("ISX_FLOOD_GWATCHDOG", f.gwatchdog);
     in("ISX_FLOOD_GROUP_STREAM", f.group_stream);
     in("ISX_GAUSS_FUSED", f.gauss_fused);
+    in("ISX_WS_CHECK", f.ws_check);
+    in("ISX_CCL_FUSED", f.ccl_fused);
     f.stats = getenv("ISX_FLOOD_STATS") != nullptr;
     if (const char *e = getenv("ISX_FLOOD_TRACE")) f.trace = e;
     c->ftune = f;

@@ -48,6 +48,31 @@ __device__ __forceinline__ float funord(uint32_t u)
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
+// Fold a thread's ordered-uint minimum / maximum into the global pair mm[0] / mm[1] (initialised to 0xFFFFFFFF / 0): wave reduction,
+// the block's waves through LDS, then ONE thread touches the global pair -- and issues an atomic only when the block still improves on
+// what is there (a relaxed read first: hundreds of thousands of blocks end on the same two words, and same-address atomics serialise in
+// L2; a stale read only costs a redundant atomic; per wave instead of per block the reads alone cost aff_pad_kernel 0.35 ms).  For
+// producers that already hold every value of a tensor in registers: the separate minmax_kernel pass over it (0.4 ms per 0.5 GB at
+// 512^3) goes away.  Every thread of the block must call it (it has a barrier); blocks of at most 16 waves.
+__device__ __forceinline__ void mm_fold2(uint32_t lo, uint32_t hi, uint32_t *pmin, uint32_t *pmax)
+{
+    __shared__ uint32_t mm_s[32];
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t l2 = __shfl_down(lo, o), h2 = __shfl_down(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { mm_s[2 * wave] = lo; mm_s[2 * wave + 1] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) { const uint32_t l2 = mm_s[2 * w], h2 = mm_s[2 * w + 1]; lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; }
+        if (pmin && lo < __hip_atomic_load(pmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pmin, lo);
+        if (pmax && hi > __hip_atomic_load(pmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(pmax, hi);
+    }
+}
+__device__ __forceinline__ void mm_fold(uint32_t lo, uint32_t hi, uint32_t *mm) { mm_fold2(lo, hi, &mm[0], &mm[1]); }
+
 // ------------------------------------------------------------------------------------
 // W1/W2: separable Gaussian pass (scipy NI_Correlate1D symmetric branch, 'nearest').
 //   tmp = c*w0; for k = R..1: tmp += (in[-k] + in[+k]) * w[k];   all in double; store f32.
@@ -78,6 +103,49 @@ __global__ void gauss_pass_kernel(const float *__restrict__ in, float *__restric
     out[i] = (float)tmp;
 }
 
+// The z pass as a march: a thread owns one (y, x) column of a z segment and keeps the 2 R + 1 planes an output needs (+ 3 planes of
+// prefetch) in a register ring, so every input plane is read ONCE per segment, coalesced along x, instead of 2 R + 1 times through the
+// caches by a thread per voxel (17 x 0.5 GB of L2 traffic at 512^3: 0.95 ms for a pass whose compulsory bytes stream in 0.25).  Same
+// operands in the same order as gauss_pass_kernel -- bit-identical.
+template <int R>
+__global__ __launch_bounds__(256) void gauss_z_kernel(const float *__restrict__ in, float *__restrict__ out, int Z, int Y, int X, int ZS, int nxb)
+{
+#pragma clang fp contract(off)
+    constexpr int P = 3, NSL = 2 * R + 1 + P;
+    const double *w = (R == 8) ? GK_SIGMA2 : GK_SIGMA1;
+    const int xb = blockIdx.x % nxb, y = (blockIdx.x / nxb) % Y, seg = blockIdx.x / (nxb * Y);
+    const int x = xb * 256 + (int)threadIdx.x;
+    if (x >= X) return;
+    const int zs = seg * ZS, ze = zs + ZS < Z ? zs + ZS : Z;
+    const int64_t plane = (int64_t)Y * X;
+    const float *col = in + (int64_t)y * X + x;
+    float *ocol = out + (int64_t)y * X + x;
+    auto ld = [&](int p) __attribute__((always_inline)) -> double {
+        const int q = p < 0 ? 0 : (p > Z - 1 ? Z - 1 : p);                 // mode='nearest'
+        return (double)col[(int64_t)q * plane];
+    };
+    double ring[NSL];                                   // plane p sits in slot (p - (zs - R)) % NSL
+#pragma unroll
+    for (int i = 0; i < NSL - 1; ++i) ring[i] = ld(zs - R + i);
+    for (int t0 = 0; zs + t0 < ze; t0 += NSL) {
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const int z = zs + t0 + j;
+            if (z < ze) {                                                  // (uniform)
+                ring[(j + 2 * R + P) % NSL] = ld(z + R + P);               // the slot of plane z - 1, dead since the last output
+                double tmp = ring[(j + R) % NSL] * w[0];
+#pragma unroll
+                for (int k = R; k >= 1; --k) {
+                    const double s2 = ring[(j + R - k) % NSL] + ring[(j + R + k) % NSL];
+                    const double p2 = s2 * w[k];
+                    tmp = tmp + p2;
+                }
+                ocol[(int64_t)z * plane] = (float)tmp;
+            }
+        }
+    }
+}
+
 // The y pass and the x pass of one plane in ONE kernel (scipy applies the axes in order, every pass stores float32: the
 // intermediate lives in LDS as float32, so the result is the two-pass one bit for bit).  A block owns 16 x 64 outputs of a plane:
 // the (16 + 2R) x (64 + 2R) input tile is loaded once with clamped coordinates ('nearest'), the y pass runs on 16 x (64 + 2R)
@@ -86,7 +154,7 @@ __global__ void gauss_pass_kernel(const float *__restrict__ in, float *__restric
 // output instead of 2 x 17 cached global loads with 64-bit index arithmetic.  Same operation order as gauss_pass_kernel, products
 // and sums not contracted (scipy's C loop has no fused multiply-add).
 template <int R>
-__global__ __launch_bounds__(256) void gauss_yx_kernel(const float *__restrict__ in, float *__restrict__ out, int Z, int Y, int X, int nty, int ntx)
+__global__ __launch_bounds__(256) void gauss_yx_kernel(const float *__restrict__ in, float *__restrict__ out, int Z, int Y, int X, int nty, int ntx, uint32_t *mm)
 {
 #pragma clang fp contract(off)
     constexpr int TY = 16, TX = 64, IW = TX + 2 * R, IH = TY + 2 * R;
@@ -119,6 +187,7 @@ __global__ __launch_bounds__(256) void gauss_yx_kernel(const float *__restrict__
     }
     __syncthreads();
     float *oplane = out + (int64_t)z * Y * X;
+    uint32_t mlo = 0xFFFFFFFFu, mhi = 0u;
     for (int i = threadIdx.x; i < TY * TX; i += 256) {
         const int r = i / TX, c = i % TX;
         const int y = y0 + r, x = x0 + c;
@@ -130,13 +199,22 @@ __global__ __launch_bounds__(256) void gauss_yx_kernel(const float *__restrict__
             const double p2 = s2 * w[k];
             tmp = tmp + p2;
         }
-        if (y < Y && x < X) oplane[(int64_t)y * X + x] = (float)tmp;
+        if (y < Y && x < X) {
+            oplane[(int64_t)y * X + x] = (float)tmp;
+            const uint32_t u = ford((float)tmp);
+            mlo = u < mlo ? u : mlo;
+            mhi = u > mhi ? u : mhi;
+        }
     }
+    if (mm) mm_fold(mlo, mhi, mm);                     // (otsu_impl's min / max of the smoothed image, without its own pass)
 }
 
+// mm (optional, device, initialised to {0xFFFFFFFF, 0}): receives the ordered-uint min / max of `out` when the last pass is the
+// fused y+x kernel; *mm_done says whether it did
 static int gaussian_impl(isx_ctx *ctx, const float *img, float *out, const int64_t shape[3],
-                         const int32_t sigma[3], float *tmpbuf)
+                         const int32_t sigma[3], float *tmpbuf, uint32_t *mm = nullptr, bool *mm_done = nullptr)
 {
+    if (mm_done) *mm_done = false;
     int64_t n = shape[0] * shape[1] * shape[2];
     int npass = 0;
     for (int a = 0; a < 3; ++a) {
@@ -159,13 +237,20 @@ static int gaussian_impl(isx_ctx *ctx, const float *img, float *out, const int64
             const int nty = (int)((shape[1] + 15) / 16), ntx = (int)((shape[2] + 63) / 64);
             const unsigned grid = (unsigned)(shape[0] * nty * ntx);
             float *dst = out;                          // the fused pass is the last one
-            if (sigma[a] == 2) gauss_yx_kernel<8><<<grid, 256, 0, ctx->stream>>>(src, dst, (int)shape[0], (int)shape[1], (int)shape[2], nty, ntx);
-            else gauss_yx_kernel<4><<<grid, 256, 0, ctx->stream>>>(src, dst, (int)shape[0], (int)shape[1], (int)shape[2], nty, ntx);
+            if (sigma[a] == 2) gauss_yx_kernel<8><<<grid, 256, 0, ctx->stream>>>(src, dst, (int)shape[0], (int)shape[1], (int)shape[2], nty, ntx, mm);
+            else gauss_yx_kernel<4><<<grid, 256, 0, ctx->stream>>>(src, dst, (int)shape[0], (int)shape[1], (int)shape[2], nty, ntx, mm);
+            if (mm && mm_done) *mm_done = true;
             ISX_CHECK_LAUNCH();
             break;
         }
         int remaining = npass - done - 1;
         float *dst = (remaining % 2 == 0) ? out : tmpbuf;
+        const int64_t nxb = (shape[2] + 255) / 256, zseg = 64, nseg = (shape[0] + zseg - 1) / zseg;
+        if (a == 0 && ctx->ftune.gauss_fused && shape[0] < (1 << 24) && shape[1] < (1 << 24) && shape[2] < (1 << 24) &&
+            nxb * shape[1] * nseg < (int64_t)0x7FFFFFFF) {
+            if (sigma[a] == 2) gauss_z_kernel<8><<<(unsigned)(nxb * shape[1] * nseg), 256, 0, ctx->stream>>>(src, dst, (int)shape[0], (int)shape[1], (int)shape[2], (int)zseg, (int)nxb);
+            else gauss_z_kernel<4><<<(unsigned)(nxb * shape[1] * nseg), 256, 0, ctx->stream>>>(src, dst, (int)shape[0], (int)shape[1], (int)shape[2], (int)zseg, (int)nxb);
+        } else
         if (sigma[a] == 2)
             gauss_pass_kernel<8><<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(src, dst, shape[0], shape[1], shape[2], a);
         else
@@ -204,42 +289,57 @@ __global__ void minmax_kernel(const float *__restrict__ a, int64_t n, uint32_t *
         lo = u < lo ? u : lo;
         hi = u > hi ? u : hi;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t l2 = __shfl_down(lo, o), h2 = __shfl_down(hi, o);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&mm[0], lo);
-        atomicMax(&mm[1], hi);
-    }
+    mm_fold(lo, hi, mm);          // (one atomic pair per block, and only when it improves: the per-wave pairs -- 16 k of them on one cache
+                                  //  line -- were a third of this kernel's time)
 }
 
 // strided channel max for W0 (3 channels at once): cm[c] = ordered max of fm[c*n ...]
+// (cm[c] = max, cm[4 + c] = min: the minimum costs nothing in the same pass, and with both the value range of the padded, normalised
+//  affinities follows without reading them again -- aff_range_kernel)
 __global__ void chanmax_kernel(const float *__restrict__ fm, int64_t n, uint32_t *cm)
 {
     int c = blockIdx.y;
     const float *a = fm + (int64_t)c * n;
-    uint32_t hi = 0u;
+    uint32_t hi = 0u, lo = 0xFFFFFFFFu;
     const int64_t head = (int64_t)((16 - ((uintptr_t)a & 15)) & 15) / 4;          // (as minmax_kernel: 16-byte loads)
     const int64_t h = head < n ? head : n, n4 = (n - h) / 4;
     const float4 *a4 = (const float4 *)(a + h);
     const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = tid0; i < n4; i += stride) {
-        const float4 v = a4[i];
+    // (two 16-byte loads in flight per lane: with the minimum beside the maximum one load per iteration ran at 2.4 TB/s)
+    for (int64_t i = tid0; i < n4; i += 2 * stride) {
+        const float4 v = a4[i], w = a4[i + stride < n4 ? i + stride : i];
         const uint32_t u0 = ford(v.x), u1 = ford(v.y), u2 = ford(v.z), u3 = ford(v.w);
-        const uint32_t h01 = u0 > u1 ? u0 : u1, h23 = u2 > u3 ? u2 : u3, h4 = h01 > h23 ? h01 : h23;
-        hi = h4 > hi ? h4 : hi;
+        const uint32_t u4 = ford(w.x), u5 = ford(w.y), u6 = ford(w.z), u7 = ford(w.w);
+        const uint32_t h01 = u0 > u1 ? u0 : u1, h23 = u2 > u3 ? u2 : u3, h45 = u4 > u5 ? u4 : u5, h67 = u6 > u7 ? u6 : u7;
+        const uint32_t l01 = u0 < u1 ? u0 : u1, l23 = u2 < u3 ? u2 : u3, l45 = u4 < u5 ? u4 : u5, l67 = u6 < u7 ? u6 : u7;
+        const uint32_t h4 = h01 > h23 ? h01 : h23, h8 = h45 > h67 ? h45 : h67, l4 = l01 < l23 ? l01 : l23, l8 = l45 < l67 ? l45 : l67;
+        const uint32_t hh = h4 > h8 ? h4 : h8, ll = l4 < l8 ? l4 : l8;
+        hi = hh > hi ? hh : hi;
+        lo = ll < lo ? ll : lo;
     }
     for (int64_t i = tid0; i < h + (n - h - 4 * n4); i += stride) {
         const uint32_t u = ford(a[i < h ? i : 4 * n4 + i]);
         hi = u > hi ? u : hi;
+        lo = u < lo ? u : lo;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t h2 = __shfl_down(hi, o);
-        hi = h2 > hi ? h2 : hi;
+    mm_fold2(lo, hi, &cm[4 + c], &cm[c]);
+}
+
+// Value range of what aff_pad_kernel writes, from the channel extrema alone: x -> x / mx is monotone for mx > 0 (correctly rounded
+// division), so min / max of a channel's quotients are the quotients of its min / max, and the padding adds 0.  amm = {ordered min,
+// ordered max, valid}; not valid (a channel maximum that is not a positive finite number): the flood measures the range itself.
+__global__ void aff_range_kernel(const uint32_t *cm, uint32_t *amm)
+{
+    float lo = 0.0f, hi = 0.0f;
+    bool ok = true;
+    for (int c = 0; c < 3; ++c) {
+        const float mx = funord(cm[c]), mn = funord(cm[4 + c]);
+        ok = ok && mx > 0.0f && mx < __builtin_inff() && mn == mn;
+        const float ql = mn / mx, qh = mx / mx;
+        lo = ql < lo ? ql : lo;
+        hi = qh > hi ? qh : hi;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(&cm[c], hi);
+    amm[0] = ford(lo); amm[1] = ford(hi); amm[2] = ok ? 1u : 0u;
 }
 
 __global__ void otsu_edges_kernel(const uint32_t *mm, float *edges)
@@ -318,27 +418,45 @@ __global__ void otsu_final_kernel(const unsigned long long *counts, const float 
     *thresh = s / 2.0f;
 }
 
-static int otsu_impl(isx_ctx *ctx, const float *img, int64_t n, float *thresh_dev)
+// mm_ready: the ordered-uint min / max of img, already on the device (gaussian_impl's fused last pass), else nullptr
+static int otsu_impl(isx_ctx *ctx, const float *img, int64_t n, float *thresh_dev, uint32_t *mm_ready = nullptr)
 {
-    Scratch<uint32_t> mm(ctx, 2);
+    Scratch<uint32_t> mm_own(ctx, 2);
     Scratch<float> edges(ctx, 257);
     Scratch<unsigned long long> counts(ctx, 256);
-    if (!mm.ok() || !edges.ok() || !counts.ok()) return ISX_ERR_NOMEM;
-    const uint32_t init[2] = {0xFFFFFFFFu, 0u};
-    ISX_HIP(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    if (!mm_own.ok() || !edges.ok() || !counts.ok()) return ISX_ERR_NOMEM;
+    uint32_t *mm = mm_ready ? mm_ready : mm_own.p;
     ISX_HIP(hipMemsetAsync(counts.p, 0, 256 * sizeof(unsigned long long), ctx->stream));
     unsigned grid = cdiv(n, (int64_t)TPB * 8);
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    minmax_kernel<<<grid, TPB, 0, ctx->stream>>>(img, n, mm.p);
+    if (!mm_ready) {
+        const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+        ISX_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        minmax_kernel<<<grid, TPB, 0, ctx->stream>>>(img, n, mm);
+        ISX_CHECK_LAUNCH();
+    }
+    otsu_edges_kernel<<<1, 320, 0, ctx->stream>>>(mm, edges.p);
     ISX_CHECK_LAUNCH();
-    otsu_edges_kernel<<<1, 320, 0, ctx->stream>>>(mm.p, edges.p);
+    hist_kernel<<<grid, TPB, 0, ctx->stream>>>(img, n, mm, edges.p, counts.p);
     ISX_CHECK_LAUNCH();
-    hist_kernel<<<grid, TPB, 0, ctx->stream>>>(img, n, mm.p, edges.p, counts.p);
-    ISX_CHECK_LAUNCH();
-    otsu_final_kernel<<<1, 64, 0, ctx->stream>>>(counts.p, edges.p, mm.p, img, thresh_dev);
+    otsu_final_kernel<<<1, 64, 0, ctx->stream>>>(counts.p, edges.p, mm, img, thresh_dev);
     ISX_CHECK_LAUNCH();
     return ISX_OK;
+}
+
+// _get_mask's threshold (watershed.py:226-233): Otsu of the sigma-2 Gaussian of img; the Gaussian's last pass hands the min / max over
+static int smooth_otsu(isx_ctx *ctx, const float *img, const int64_t shape[3], float *sm, float *tmp, float *thresh_dev)
+{
+    const int64_t n = shape[0] * shape[1] * shape[2];
+    const int32_t sig[3] = {2, 2, 2};
+    Scratch<uint32_t> mm(ctx, 2);
+    if (!mm.ok()) return ISX_ERR_NOMEM;
+    const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+    ISX_HIP(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    bool mm_done = false;
+    ISX_TRY(gaussian_impl(ctx, img, sm, shape, sig, tmp, mm.p, &mm_done));
+    return otsu_impl(ctx, sm, n, thresh_dev, mm_done ? mm.p : nullptr);
 }
 
 // mask (optionally zero-padded by `pad` voxels per side) = img > *thresh
@@ -426,7 +544,7 @@ __global__ __launch_bounds__(256) void peak_kernel(const float *__restrict__ g, 
     if (tid == 0) {
         uint32_t run = 0;
         for (int i = 0; i < 32; ++i) { const uint32_t c2 = wcnt[i]; wcnt[i] = run; run += c2; }
-        wcnt[32] = run ? atomicAdd(count, run) : 0u;
+        wcnt[32] = run ? atomicAdd(count, run) : 0u;          // (spread over 64 cache lines as a timing probe: 1.76 -> 1.65 ms for the whole seed stage -- not the bound)
     }
     __syncthreads();
     const uint32_t gbase = wcnt[32];
@@ -515,8 +633,11 @@ __global__ void ccl_flatten_kernel(uint32_t *parent, int64_t N)
 // the run (when it is the bigger one so far) or is added directly.  A giant, porous component thus costs
 // about one same-address atomic per 2048 voxels (same-address atomics serialise in L2: the first version
 // flushed at every hole and spent 350 ms on a 512^3 frame).
+// FLATTEN: the pass that makes every voxel point at its root is this same walk (the root a lane counts is the root it has just found
+// and stored): one read of the pointers instead of two and one launch less (ccl_flatten_kernel 0.77 + this kernel 0.83 ms at 512^3).
 static constexpr int CCL_RUN = 32;
-__global__ void ccl_sizes_kernel(const uint32_t *__restrict__ parent, uint32_t *sizes, int64_t N)
+template <bool FLATTEN>
+__global__ void ccl_sizes_kernel(uint32_t *parent, uint32_t *sizes, int64_t N)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -525,7 +646,15 @@ __global__ void ccl_sizes_kernel(const uint32_t *__restrict__ parent, uint32_t *
     uint32_t run_root = NO_PARENT, run_cnt = 0;                  // wave-uniform
     for (int k = 0; k < CCL_RUN; ++k) {
         const int64_t i = base + (int64_t)k * 64 + lane;
-        const uint32_t p = (i < N) ? parent[i] : NO_PARENT;
+        uint32_t p = NO_PARENT;
+        if (i < N) {
+            if constexpr (FLATTEN) {
+                if (uf_ld(parent + i) != NO_PARENT) {
+                    p = uf_find(parent, (uint32_t)i);
+                    atomicMin(&parent[i], p);
+                }
+            } else p = parent[i];
+        }
         bool todo = p != NO_PARENT;
         if (run_root != NO_PARENT) {
             run_cnt += (uint32_t)__popcll(__ballot(todo && p == run_root));
@@ -548,19 +677,28 @@ __global__ void ccl_sizes_kernel(const uint32_t *__restrict__ parent, uint32_t *
     if (lane == 0 && run_root != NO_PARENT && run_cnt) atomicAdd(&sizes[run_root], run_cnt);
 }
 
+// (four voxels per thread: one 16-byte read of the roots, one 4-byte write of the mask)
 __global__ void ccl_apply_kernel(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ sizes,
                                  uint32_t min_area, uint32_t max_area, uint8_t *__restrict__ mask_out,
-                                 int64_t N)
+                                 int64_t N, int vec)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    uint32_t r = parent[i];
-    uint8_t keep = 0;
-    if (r != NO_PARENT) {
-        uint32_t s = sizes[r];
-        keep = (s >= min_area && s < max_area);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto keep = [&](uint32_t r) __attribute__((always_inline)) -> uint32_t {
+        if (r == NO_PARENT) return 0u;
+        const uint32_t sz = sizes[r];
+        return (sz >= min_area && sz < max_area) ? 1u : 0u;
+    };
+    if (!vec) {
+        if (t < N) mask_out[t] = (uint8_t)keep(parent[t]);
+        return;
     }
-    mask_out[i] = keep;
+    const int64_t n4 = N >> 2;
+    if (t < n4) {
+        const uint4 r = ((const uint4 *)parent)[t];
+        ((uint32_t *)mask_out)[t] = keep(r.x) | (keep(r.y) << 8) | (keep(r.z) << 16) | (keep(r.w) << 24);
+    } else if (t == n4) {
+        for (int64_t i = 4 * n4; i < N; ++i) mask_out[i] = (uint8_t)keep(parent[i]);
+    }
 }
 
 // Two-level labelling: a block first resolves its own 8 x 16 x 32 tile with a union-find in LDS (no global traffic
@@ -627,16 +765,42 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t *__restrict
 }
 
 // cross-tile links: voxels on the low x / y / z face of their tile
-__global__ void ccl_seam_kernel(const uint8_t *__restrict__ mask, uint32_t *parent, int64_t PZ, int64_t PY, int64_t PX)
+__device__ __forceinline__ void ccl_seam_one(const uint8_t *__restrict__ mask, uint32_t *parent, uint32_t i, uint32_t x, uint32_t y, uint32_t z,
+                                             uint32_t px, uint32_t py)
 {
-    // (32-bit index arithmetic: the launcher guarantees N < 2^32, and three 64-bit divisions per masked voxel were most of this kernel)
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t px = (uint32_t)PX, py = (uint32_t)PY, N = (uint32_t)(PZ * PY * PX);
-    if (i >= N || !mask[i]) return;
-    const uint32_t x = i % px, r = i / px, y = r % py, z = r / py;
     if (x > 0 && x % CT_X == 0 && mask[i - 1]) uf_union(parent, i, i - 1);
     if (y > 0 && y % CT_Y == 0 && mask[i - px]) uf_union(parent, i, i - px);
     if (z > 0 && z % CT_Z == 0 && mask[i - px * py]) uf_union(parent, i, i - px * py);
+}
+
+// (32-bit index arithmetic: the launcher guarantees N < 2^32.)  A thread takes 16 consecutive voxels with ONE 16-byte mask load and
+// two divisions, then walks the coordinates: a thread per voxel -- 135 M threads at 512^3, most of which read one byte and leave --
+// was 1 ms, a quarter of the stage.  `vec` = the mask pointer is 16-byte aligned and rows are at least 16 voxels long.
+__global__ void ccl_seam_kernel(const uint8_t *__restrict__ mask, uint32_t *parent, int64_t PZ, int64_t PY, int64_t PX, int vec)
+{
+    const uint32_t px = (uint32_t)PX, py = (uint32_t)PY, N = (uint32_t)(PZ * PY * PX);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!vec) {
+        const uint32_t i = t;
+        if (i >= N || !mask[i]) return;
+        const uint32_t x = i % px, r = i / px, y = r % py, z = r / py;
+        ccl_seam_one(mask, parent, i, x, y, z, px, py);
+        return;
+    }
+    const uint32_t n16 = N >> 4;
+    if (t > n16) return;
+    const uint32_t base = t << 4;
+    uint32_t m[4] = {0u, 0u, 0u, 0u};
+    int cntv = 16;
+    if (t < n16) { const uint4 v = ((const uint4 *)mask)[t]; m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w; }
+    else { cntv = (int)(N - base); for (int j = 0; j < cntv; ++j) m[j >> 2] |= (uint32_t)(mask[base + j] != 0) << (8 * (j & 3)); }
+    if (!(m[0] | m[1] | m[2] | m[3])) return;
+    uint32_t x = base % px, r = base / px, y = r % py, z = r / py;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < cntv && ((m[j >> 2] >> (8 * (j & 3))) & 0xFFu)) ccl_seam_one(mask, parent, base + j, x, y, z, px, py);
+        if (++x == px) { x = 0; if (++y == py) { y = 0; ++z; } }
+    }
 }
 
 static int ccl_impl(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], uint32_t *parent,
@@ -649,13 +813,23 @@ static int ccl_impl(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], 
               ntx = (int)((pshape[2] + CT_X - 1) / CT_X);
     ccl_tile_kernel<<<(unsigned)(ntz * nty * ntx), 256, 0, ctx->stream>>>(mask, parent, pshape[0], pshape[1], pshape[2], ntx, nty);
     ISX_CHECK_LAUNCH();
-    ccl_seam_kernel<<<grid, TPB, 0, ctx->stream>>>(mask, parent, pshape[0], pshape[1], pshape[2]);
+    const int vec = ((uintptr_t)mask & 15) == 0 && pshape[2] >= 16;
+    ccl_seam_kernel<<<vec ? cdiv((N >> 4) + 1, TPB) : grid, TPB, 0, ctx->stream>>>(mask, parent, pshape[0], pshape[1], pshape[2], vec);
     ISX_CHECK_LAUNCH();
+    // (tried in round 5 and dropped: four voxels per thread in the flatten pass -- 1.13 instead of 0.77 ms, its time is the pointer
+    //  chases, not the launch -- and per-tile counts from the tile kernel folded into the roots by the flatten pass instead of
+    //  ccl_sizes_kernel: the tile kernel 0.86 -> 1.8 ms, the flatten pass 11 ms)
+    if (sizes && ctx->ftune.ccl_fused) {
+        ISX_HIP(hipMemsetAsync(sizes, 0, N * sizeof(uint32_t), ctx->stream));
+        ccl_sizes_kernel<true><<<cdiv(cdiv(N, (int64_t)64 * CCL_RUN) * 64, TPB), TPB, 0, ctx->stream>>>(parent, sizes, N);
+        ISX_CHECK_LAUNCH();
+        return ISX_OK;
+    }
     ccl_flatten_kernel<<<grid, TPB, 0, ctx->stream>>>(parent, N);
     ISX_CHECK_LAUNCH();
     if (sizes) {
         ISX_HIP(hipMemsetAsync(sizes, 0, N * sizeof(uint32_t), ctx->stream));
-        ccl_sizes_kernel<<<cdiv(cdiv(N, (int64_t)64 * CCL_RUN) * 64, TPB), TPB, 0, ctx->stream>>>(parent, sizes, N);
+        ccl_sizes_kernel<false><<<cdiv(cdiv(N, (int64_t)64 * CCL_RUN) * 64, TPB), TPB, 0, ctx->stream>>>(parent, sizes, N);
         ISX_CHECK_LAUNCH();
     }
     return ISX_OK;
@@ -1568,8 +1742,9 @@ __global__ void comp_order_key_kernel(const unsigned long long *comp_off, uint32
 // parent/sizes: CCL of `mask` if the caller already has it, else nullptr.
 static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint32_t n_seeds,
                       const uint8_t *mask, uint32_t *out, const int64_t pshape[3],
-                      const uint32_t *parent_in, const uint32_t *sizes_in, const float *scale)
+                      const uint32_t *parent_in, const uint32_t *sizes_in, const float *scale, const uint32_t *aff_mm = nullptr)
 {
+    // aff_mm: ordered-uint {min, max, valid} of aff on the device when the caller can derive them (aff_range_kernel), else nullptr
     if (n_seeds == 0) {
         set_error("zero seeds: the reference raises here (np.apply_along_axis, watershed.py:50)");
         return ISX_ERR_NO_SEEDS;
@@ -1672,13 +1847,22 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
     {
         Scratch<uint32_t> mm(ctx, 2);
         if (!mm.ok()) return ISX_ERR_NOMEM;
-        const uint32_t init[2] = {0xFFFFFFFFu, 0u};
-        ISX_HIP(hipMemcpyAsync(mm.p, init, 8, hipMemcpyHostToDevice, ctx->stream));
-        minmax_kernel<<<1024, TPB, 0, ctx->stream>>>(aff, 3 * PN, mm.p);
-        ISX_CHECK_LAUNCH();
-        uint32_t hmm[2];
-        ISX_HIP(hipMemcpyAsync(hmm, mm.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-        ISX_HIP(hipStreamSynchronize(ctx->stream));
+        uint32_t hmm[3] = {0u, 0u, 0u};
+        if (aff_mm) {
+            ISX_HIP(hipMemcpyAsync(hmm, aff_mm, 12, hipMemcpyDeviceToHost, ctx->stream));
+            ISX_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        const bool derived = hmm[2] != 0;
+        const uint32_t d0 = hmm[0], d1 = hmm[1];
+        if (!derived || ctx->ftune.ws_check) {
+            const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+            ISX_HIP(hipMemcpyAsync(mm.p, init, 8, hipMemcpyHostToDevice, ctx->stream));
+            minmax_kernel<<<1024, TPB, 0, ctx->stream>>>(aff, 3 * PN, mm.p);
+            ISX_CHECK_LAUNCH();
+            ISX_HIP(hipMemcpyAsync(hmm, mm.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+            ISX_HIP(hipStreamSynchronize(ctx->stream));
+            ISX_REQUIRE(!derived || (hmm[0] == d0 && hmm[1] == d1), "internal: derived affinity range %08x..%08x, measured %08x..%08x", d0, d1, hmm[0], hmm[1]);
+        }
         auto unord = [](uint32_t u) { uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &b, 4); return f; };
         const float rlo = unord(hmm[0]), rhi = unord(hmm[1]);
         const float smin = std::min(s[0], std::min(s[1], s[2])), smax = std::max(s[0], std::max(s[1], s[2]));
@@ -1909,9 +2093,7 @@ int isx_ws_mask(isx_ctx *ctx, const float *img, const int64_t shape[3], uint8_t 
     int64_t n = shape[0] * shape[1] * shape[2];
     Scratch<float> sm(ctx, n), tmp(ctx, n), t(ctx, 1);
     if (!sm.ok() || !tmp.ok() || !t.ok()) return ISX_ERR_NOMEM;
-    const int32_t sig[3] = {2, 2, 2};
-    ISX_TRY(gaussian_impl(ctx, img, sm.p, shape, sig, tmp.p));
-    ISX_TRY(otsu_impl(ctx, sm.p, n, t.p));
+    ISX_TRY(smooth_otsu(ctx, img, shape, sm.p, tmp.p, t.p));
     mask_kernel<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(img, t.p, shape[0], shape[1], shape[2], 0, mask);
     ISX_CHECK_LAUNCH();
     if (thresh) {
@@ -1955,7 +2137,8 @@ int isx_ws_filter(isx_ctx *ctx, const uint8_t *mask, const int64_t pshape[3], in
     ISX_TRY(ccl_impl(ctx, mask, pshape, parent.p, sizes.p));
     uint32_t lo = (uint32_t)(min_area < 0 ? 0 : (min_area > 0xFFFFFFFFll ? 0xFFFFFFFFll : min_area));
     uint32_t hi = (uint32_t)(max_area < 0 ? 0 : (max_area > 0xFFFFFFFFll ? 0xFFFFFFFFll : max_area));
-    ccl_apply_kernel<<<cdiv(N, TPB), TPB, 0, ctx->stream>>>(parent.p, sizes.p, lo, hi, mask_out, N);
+    { const int vec = ((uintptr_t)mask_out & 3) == 0;
+      ccl_apply_kernel<<<vec ? cdiv((N >> 2) + 1, TPB) : cdiv(N, TPB), TPB, 0, ctx->stream>>>(parent.p, sizes.p, lo, hi, mask_out, N, vec); }
     ISX_CHECK_LAUNCH();
     if (n_out) *n_out = 0;
     if (n_seeds > 0) {
@@ -2067,9 +2250,7 @@ int isx_segment_output_image_scaled(isx_ctx *ctx, const float *fm, const int64_t
         } else {
             Scratch<float> sm(ctx, n), tmp(ctx, n);
             if (!sm.ok() || !tmp.ok()) return ISX_ERR_NOMEM;
-            const int32_t sig[3] = {2, 2, 2};
-            ISX_TRY(gaussian_impl(ctx, fm + 3 * n, sm.p, shape, sig, tmp.p));
-            ISX_TRY(otsu_impl(ctx, sm.p, n, thr.p));
+            ISX_TRY(smooth_otsu(ctx, fm + 3 * n, shape, sm.p, tmp.p, thr.p));
         }
         mask_kernel<<<cdiv(PN, TPB), TPB, 0, ctx->stream>>>(fm + 3 * n, thr.p, Z, Y, X, 1, mask_p.p);
         ISX_CHECK_LAUNCH();
@@ -2089,7 +2270,8 @@ int isx_segment_output_image_scaled(isx_ctx *ctx, const float *fm, const int64_t
         ISX_TRY(ccl_impl(ctx, mask_p.p, pshape, parent.p, sizes.p));
         uint32_t lo = (uint32_t)(min_area < 0 ? 0 : (min_area > 0xFFFFFFFFll ? 0xFFFFFFFFll : min_area));
         uint32_t hi = (uint32_t)(max_area < 0 ? 0 : (max_area > 0xFFFFFFFFll ? 0xFFFFFFFFll : max_area));
-        ccl_apply_kernel<<<cdiv(PN, TPB), TPB, 0, ctx->stream>>>(parent.p, sizes.p, lo, hi, mask_f, PN);
+        { const int vec = ((uintptr_t)mask_f & 3) == 0;
+          ccl_apply_kernel<<<vec ? cdiv((PN >> 2) + 1, TPB) : cdiv(PN, TPB), TPB, 0, ctx->stream>>>(parent.p, sizes.p, lo, hi, mask_f, PN, vec); }
         ISX_CHECK_LAUNCH();
         if (n_raw > 0) {
             Scratch<int64_t> coords(ctx, (size_t)n_raw * 3), coords_keep(ctx, (size_t)n_raw * 3);
@@ -2131,11 +2313,12 @@ int isx_segment_output_image_scaled(isx_ctx *ctx, const float *fm, const int64_t
 
     // ---- W0 affinities + W4 flood -----------------------------------------------------
     Scratch<float> aff(ctx, (size_t)3 * PN);
-    Scratch<uint32_t> cm(ctx, 4);
-    if (!aff.ok() || !cm.ok()) return ISX_ERR_NOMEM;
+    Scratch<uint32_t> cm(ctx, 8), amm(ctx, 4);
+    if (!aff.ok() || !cm.ok() || !amm.ok()) return ISX_ERR_NOMEM;
     {
         ProfScope ps(ctx, ISX_PROF_WS_FILTERS);
         ISX_HIP(hipMemsetAsync(cm.p, 0, 16, ctx->stream));
+        ISX_HIP(hipMemsetAsync(cm.p + 4, 0xFF, 16, ctx->stream));
         unsigned g = cdiv(n, (int64_t)TPB * 8);
         if (g > 2048) g = 2048;
         chanmax_kernel<<<dim3(g, 3), TPB, 0, ctx->stream>>>(fm, n, cm.p);
@@ -2143,9 +2326,11 @@ int isx_segment_output_image_scaled(isx_ctx *ctx, const float *fm, const int64_t
         ISX_REQUIRE(3 * (Z + 2) * (Y + 2) < (int64_t)0x7FFFFFFF, "volume too large for the padding kernel's grid");
         aff_pad_kernel<<<(unsigned)(3 * (Z + 2) * (Y + 2)), 256, 0, ctx->stream>>>(fm, cm.p, Z, Y, X, aff.p);
         ISX_CHECK_LAUNCH();
+        aff_range_kernel<<<1, 1, 0, ctx->stream>>>(cm.p, amm.p);
+        ISX_CHECK_LAUNCH();
     }
     // the filtered mask's components are a subset of the raw mask's: reuse roots and sizes
-    ISX_TRY(flood_impl(ctx, aff.p, ridx_keep.p, n_keep, mask_f, labels, pshape, parent.p, sizes.p, scale));
+    ISX_TRY(flood_impl(ctx, aff.p, ridx_keep.p, n_keep, mask_f, labels, pshape, parent.p, sizes.p, scale, amm.p));
     return ISX_OK;
 }
 

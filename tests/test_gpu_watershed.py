@@ -269,6 +269,36 @@ def test_connected_components_helper(ws):
         assert (roots.ravel()[idx] == idx.min()).all() and sizes.ravel()[idx.min()] == idx.size
 
 
+@pytest.mark.parametrize("shape", [(12, 40, 44), (20, 37, 70), (9, 18, 15)])
+def test_component_pass_variants_agree(ws, flood_knobs, shape):
+    """The labelling's passes in their other forms: flatten + sizes as two kernels (ISX_CCL_FUSED=0; default: one walk finds, stores and
+    counts), and the seam pass's 16-voxel form against its voxel-per-thread form (taken for a mask that is not 16-byte aligned or has
+    rows shorter than 16 voxels) -- roots and sizes identical, and ndi.label's."""
+    import torch
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(11)
+    mask = ndi.gaussian_filter(rng.random(shape), 1.2) > 0.5
+    n = int(np.prod(shape))
+    buf = torch.zeros(n + 1, dtype=torch.uint8, device="cuda")
+    buf[1:] = torch.from_numpy(mask.ravel().view(np.uint8)).cuda()
+    unaligned = buf[1:].view(shape)
+    assert unaligned.data_ptr() % 16 != 0
+    res = []
+    for env in ({"ISX_CCL_FUSED": "1"}, {"ISX_CCL_FUSED": "0"}):
+        flood_knobs(env)
+        for m in (mask, unaligned):
+            r, s = ws.connected_components(m)
+            res.append((np.asarray(r.cpu() if hasattr(r, "cpu") else r).view(np.uint32), np.asarray(s.cpu() if hasattr(s, "cpu") else s).view(np.uint32)))
+    for r, s in res[1:]:
+        assert np.array_equal(r, res[0][0]) and np.array_equal(s, res[0][1])
+    lab, ncomp = ndi.label(mask)
+    roots, sizes = res[0]
+    assert len(np.unique(roots[mask])) == ncomp and (roots[~mask] == 0xFFFFFFFF).all()
+    for c in range(1, min(ncomp, 30) + 1):
+        idx = np.flatnonzero(lab.ravel() == c)
+        assert (roots.ravel()[idx] == idx.min()).all() and sizes.ravel()[idx.min()] == idx.size
+
+
 @pytest.mark.parametrize("scale,abs_thresh", [((2.0, -1.0, 0.5), None), (0.25, 0.5)])
 def test_segment_output_image_scale_and_absolute_thresh(ws, scale, abs_thresh):
     """segment_output_image's general form (watershed.py:165-223 with `scale=` / `absolute_thresh=`): one library call
@@ -289,6 +319,21 @@ def test_segment_output_image_scale_and_absolute_thresh(ws, scale, abs_thresh):
     assert np.asarray(seg).max() > 0
 
 
+@pytest.mark.parametrize("shift", [0.0, -0.3, -2.0])
+def test_derived_affinity_range_is_the_measured_one(ws, flood_knobs, shift):
+    """The flood's bucket map takes the value range of the padded, normalised affinities from the channel extrema
+    (`aff_range_kernel`: x -> x / max is monotone) instead of reading all of them again.  ISX_WS_CHECK=1 makes the library measure the
+    range as well and fail on any difference; with a channel whose maximum is not positive (shift -2) the derivation declares itself
+    invalid and the measured range is used.  Labels as without the check."""
+    from tests.synth import smooth_feature_map
+    fm = smooth_feature_map((12, 40, 36), 23)
+    fm[:3] += np.float32(shift)
+    a = ws.segment_output_image(fm, (0, 1, 2), 4, 3)
+    flood_knobs({"ISX_WS_CHECK": "1"})
+    b = ws.segment_output_image(fm, (0, 1, 2), 4, 3)
+    assert np.array_equal(np.asarray(a[0]), np.asarray(b[0]))
+
+
 def test_gaussian_refuses_to_run_in_place(ws):
     """A Gaussian pass reads neighbours that other work-groups of the same pass write: isx_ws_gaussian with img == out is an
     argument error (include/itersegx.h), not a silent race."""
@@ -305,14 +350,15 @@ def test_gaussian_refuses_to_run_in_place(ws):
 
 @pytest.mark.parametrize("sigma", [2, (0, 1, 1), (0, 2, 2), 1])
 def test_fused_gaussian_is_the_two_pass_one_bit_for_bit(ws, flood_knobs, sigma):
-    """ISX_GAUSS_FUSED (default 1): the y and the x pass of a plane in one kernel with a float32 intermediate in LDS
+    """ISX_GAUSS_FUSED (default 1): the z pass as a march over a register ring of planes (`gauss_z_kernel`, several z segments
+    on the tall shapes) and the y and the x pass of a plane in one kernel with a float32 intermediate in LDS
     (`gauss_yx_kernel`) against one kernel per axis -- scipy's axis order and per-pass float32 storage either way; shapes with
     partial tiles, single rows / columns and planes narrower than the filter (everything clamps, mode 'nearest'), and
     scipy itself on a small one."""
     from scipy import ndimage as ndi
     rng = np.random.default_rng(5)
     sig = (sigma,) * 3 if np.isscalar(sigma) else sigma
-    for shape in [(9, 70, 130), (3, 16, 64), (5, 17, 65), (4, 5, 3), (2, 1, 200), (6, 33, 1)]:
+    for shape in [(9, 70, 130), (3, 16, 64), (5, 17, 65), (4, 5, 3), (2, 1, 200), (6, 33, 1), (150, 9, 300), (65, 3, 20)]:
         x = rng.random(shape, dtype=np.float32)
         flood_knobs({"ISX_GAUSS_FUSED": "1"})
         a = ws.gaussian(x, sig)
