@@ -61,6 +61,7 @@ struct UNetState;   // unet.hip
 // Development knobs (environment, read ONCE per context at isx_ctx_create): the library keeps no process-global mutable
 // state -- everything lives in the handle, so contexts can be driven from different host threads.
 struct isx_tune {
+    int bn_run_fused = 1;           // ISX_BN_RUN_FUSED: 0 = the running statistics by a launch per layer (rounds 1-4) instead of one per forward pass
     int h2_mt2 = 1;                 // ISX_H2_MT2: 0 never, 1 big launches, 2 always -- two row tiles per wave in conv_h2
     int h2_force_bn64 = 0;          // ISX_H2_FORCE_BN64
     int xcd_remap = 1;              // ISX_CONV_XCD_REMAP

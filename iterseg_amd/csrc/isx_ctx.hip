@@ -142,6 +142,7 @@ static void read_knobs(isx_ctx *c)
 {
     isx_tune t;
     if (const char *e = getenv("ISX_H2_MT2")) t.h2_mt2 = atoi(e);
+    if (const char *e = getenv("ISX_BN_RUN_FUSED")) t.bn_run_fused = atoi(e);
     if (const char *e = getenv("ISX_H2_FORCE_BN64")) t.h2_force_bn64 = atoi(e);
     if (const char *e = getenv("ISX_CONV_XCD_REMAP")) t.xcd_remap = atoi(e);
     if (const char *e = getenv("ISX_H2_NJ2")) t.h2_nj2 = atoi(e);

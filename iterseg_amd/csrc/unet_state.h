@@ -81,6 +81,7 @@ struct UNetState {
     int last_n = 0;
     bool up_folded[ISX_MAX_UPS] = {false};     // last forward: ups[i] was NOT materialised (the tail kernel up-sampled it on read)
     bool pool_planar[4] = {false}, ups_planar[ISX_MAX_UPS] = {false};      // last forward: pool[i] / ups[i] are stored planar
+    std::vector<int> bn_pending;      // layers of the forward pass in progress whose running statistics are updated at its end (bn_running_all_kernel)
     bool pool_presplit[4] = {false};  // last forward: pool[i] holds its values already split for the split-f16 kernels ([8 hi halves][8 residual halves] per voxel and plane)
     bool planar[ISX_MAX_LAYERS] = {false};   // last forward: raw[li] is stored planar (first convolution of a module whose only reader is the second)
     int arith[ISX_MAX_LAYERS] = {0};  // how each convolution ran in the last forward (ISX_ARITH_*, isx_unet_precision_report)

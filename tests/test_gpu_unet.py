@@ -60,6 +60,35 @@ def test_running_statistics_side_effect(golden):
     assert list(sd.keys()) == list(weights.unet_schema().keys())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("out", [5, (3, 2)])
+def test_running_statistics_in_one_launch_per_pass(monkeypatch, out):
+    """ISX_BN_RUN_FUSED (default 1): the running statistics of all layers are updated by one kernel at the end of a multi-chunk forward
+    pass (chunk after chunk per channel, the reference's order) instead of one launch per layer in the middle of it: every running
+    mean / variance and counter of the state dict identical bit for bit after two passes over several chunks, and within rounding of a
+    chunk-by-chunk run (batch 1, where bn_finalize_kernel updates them itself)."""
+    import numpy as np
+    from iterseg_amd import weights
+    from iterseg_amd.unet import UNet
+    import torch
+    sd = weights.generate_state_dict(21, out_channels=out)
+    vol = torch.from_numpy(np.random.default_rng(22).random((12, 80, 64), dtype=np.float32)).cuda()
+    chunk, margin = (6, 48, 32), (1, 8, 8)
+    res, n_chunks = [], None
+    for fused, batch in (("1", 8), ("0", 8), ("1", 1)):
+        monkeypatch.setenv("ISX_BN_RUN_FUSED", fused)
+        u = UNet(1, out, batch=batch)
+        u.load_state_dict(sd)
+        for _ in range(2):
+            u.predict_volume(vol, chunk, margin)
+        res.append({k: np.asarray(v) for k, v in u.state_dict().items() if "running" in k or "tracked" in k})
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+        # (one chunk per launch takes other tile forms: its batch statistics differ in their last bits, so do the running ones)
+        assert np.allclose(res[0][k], res[2][k], rtol=1e-5, atol=1e-6), k
+    assert int(res[0]["c0.batch0.num_batches_tracked"]) >= 2 * 8
+
+
 @pytest.mark.parametrize("tag", ["10x48x48", "9x40x56"])
 def test_chunked_predict_matches_reference(net, golden, tag):
     from iterseg_amd import predict
