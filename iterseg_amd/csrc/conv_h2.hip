@@ -617,7 +617,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvArgs &a)
         if (tid < BN && !a.no_stats) {
             float s = 0.f, q = 0.f;
             for (int wv = 0; wv < NW; ++wv) { s += red[(wv * BN + tid) * 2]; q += red[(wv * BN + tid) * 2 + 1]; }
-            int64_t o = ((int64_t)b * a.tiles_per_chunk + tile) * a.Cout + ntile_j * BN + tid;
+            // [chunk][channel][tile] (tile fastest): bn_finalize_kernel's lanes walk a channel's tiles -- with the channels fastest
+            // every lane of it touched its own 128-byte line (57 us for c0.conv1's 2 560 tiles x 64 chunks)
+            int64_t o = ((int64_t)b * a.Cout + ntile_j * BN + tid) * a.tiles_per_chunk + tile;
             a.psum[o] = s;
             a.psq[o] = q;
         }

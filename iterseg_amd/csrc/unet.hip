@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict
     if (threadIdx.x < 32) {
         float ss = 0.f, qq = 0.f;
         for (int wv = 0; wv < 4; ++wv) { ss += red[wv][threadIdx.x][0]; qq += red[wv][threadIdx.x][1]; }
-        int64_t o = ((int64_t)b * blocks_per_chunk + blk) * 32 + threadIdx.x;
+        int64_t o = ((int64_t)b * 32 + threadIdx.x) * blocks_per_chunk + blk;          // [chunk][channel][tile]: see bn_finalize_kernel
         psum[o] = ss;
         psq[o] = qq;
     }
@@ -426,13 +426,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
                                                           const float *__restrict__ beta, float *__restrict__ scale,
                                                           float *__restrict__ shift, float *__restrict__ bmean,
                                                           float *__restrict__ bvar, float *__restrict__ invstd_out,
-                                                          float *__restrict__ rmean, float *__restrict__ rvar)
+                                                          float *__restrict__ rmean, float *__restrict__ rvar, int tile_fastest)
 {
+    // tile_fastest: the partial sums are [chunk][channel][tile] (conv_first_kernel, the conv_h2 kernels: consecutive lanes read
+    // consecutive floats) instead of [chunk][tile][channel]; same lanes, same order, same sums
     __shared__ double rs[256], rq[256];
     const int c = blockIdx.x, b = blockIdx.y;
     double s = 0.0, q = 0.0;
     for (int t = threadIdx.x; t < tiles; t += 256) {
-        int64_t o = ((int64_t)b * tiles + t) * C + c;
+        int64_t o = tile_fastest ? ((int64_t)b * C + c) * tiles + t : ((int64_t)b * tiles + t) * C + c;
         s += (double)psum[o];
         q += (double)psq[o];
     }
@@ -1284,6 +1286,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
     ConvBN &L = u->cv[li];
     const int cin = sa.C + sb.C;
     int stat_tiles = L.tiles;                 // tiles per chunk in the partial-sum layout the conv kernel wrote
+    int stat_tile_fastest = 0;                // ... which is [chunk][channel][tile] for conv_first_kernel and the conv_h2 kernels
     ISX_REQUIRE(cin == L.cin, "internal: layer %s fed %d channels, expects %d", L.conv.c_str(), cin, L.cin);
     u->planar[li] = false;
     if (use_mfma(L.cin, L.cout)) {
@@ -1304,6 +1307,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
             const int out_planar = (want_planar && L.cout % 8 == 0) ? 1 : 0;
             u->planar[li] = out_planar != 0;
             ISX_TRY(launch_conv_h2(ctx, l, B, sa, sb, wh, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0, ctx->tune.xcd_remap, &stat_tiles, pm, out_planar, ex));
+            stat_tile_fastest = 1;
         } else {
             ISX_REQUIRE(!ex, "internal: up-sampling on read needs the reduced-precision convolution");
             ISX_TRY(launch_conv_mfma(ctx, l, B, sa, sb, L.w, L.bias, L.cout, u->raw[li], L.psum, L.psq, 0));
@@ -1365,6 +1369,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         conv_first_kernel<<<(unsigned)(B * L.tiles), 256, 0, ctx->stream>>>(sa.p, L.w, L.bias, l.D, l.H, l.W, u->raw[li],
                                                                            L.psum, L.psq, L.tiles, ctx->tune.conv_first_nt, want_planar ? 1 : 0);
         ISX_CHECK_LAUNCH();
+        stat_tile_fastest = 1;
     } else {
         ProfScope ps(ctx, ISX_PROF_CONV_DIRECT);
         if (L.cin == 5 && L.cout == 5 && sa.C == 5 && sb.C == 0 && sa.scale) {
@@ -1387,7 +1392,7 @@ static int run_conv(isx_ctx *ctx, int li, const Level &l, int B, Src sa, Src sb,
         ProfScope ps(ctx, ISX_PROF_ELEMENTWISE);
         bn_finalize_kernel<<<dim3((unsigned)L.cout, (unsigned)B), 256, 0, ctx->stream>>>(
             L.psum, L.psq, stat_tiles, L.cout, (double)l.M, L.gamma, L.beta, L.scale, L.shift, L.bmean, L.bvar, L.invstd,
-            B == 1 ? L.rmean : nullptr, B == 1 ? L.rvar : nullptr);
+            B == 1 ? L.rmean : nullptr, B == 1 ? L.rvar : nullptr, stat_tile_fastest);
         ISX_CHECK_LAUNCH();
         if (B > 1) {
             if (ctx->tune.bn_run_fused) u->bn_pending.push_back(li);           // forward_batch updates them all at its end
