@@ -1911,13 +1911,10 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
         bk_lo = vlo;
         bk_inv = (vhi > vlo && std::isfinite(vhi - vlo)) ? (float)nbuckets / (vhi - vlo) : 0.0f;
     }
-    // small components: one lane each; large ones: one wave each (both launched over all components,
-    // each picks its own by size -- no host round trip to split the list)
-    flood_kernel<<<cdiv(n_comp, 64), 64, 0, ctx->stream>>>(aff, mask, out, keys_sorted.p, n_seeds,
-                                                          comp_first.p, comp_off.p, n_comp, pool.p,
-                                                          pshape[1], pshape[2], PN, s[0], s[1], s[2], coop_min,
-                                                          ctx->ws_shard_rank, ctx->ws_shard_world);
-    ISX_CHECK_LAUNCH();
+    // small components: one lane each; large ones: one wave or one work-group each (every kernel is launched over all components and
+    // picks its own by size -- no host round trip to split the list).  Components are disjoint, so the kernels are independent: the
+    // one-lane kernel runs on the main stream beside the side streams' tiers (in front of them it was 4.4 ms of a structured 512^3
+    // volume's 56, on the critical path for nothing)
     {
         flood_state_init_kernel<<<cdiv(PN, TPB), TPB, 0, ctx->stream>>>(mask, out, vstate.p, PN);
         ISX_CHECK_LAUNCH();
@@ -1957,6 +1954,11 @@ static int flood_impl(isx_ctx *ctx, const float *aff, const uint32_t *ridx, uint
             order.p, aff, mask, out, vstate.p, keys_sorted.p, n_seeds, comp_first.p, comp_off.p, n_comp, pool.p, arena_off.p, arena.p, pshape[1],
             pshape[2], PN, s[0], s[1], s[2], small_max, run_limit, drain_n, wcap, tcap, max_bursts, bk_lo, bk_inv, stats.p, ctx->ws_shard_rank,
             ctx->ws_shard_world, trace_p, group_min);
+        ISX_CHECK_LAUNCH();
+        flood_kernel<<<cdiv(n_comp, 64), 64, 0, ctx->stream>>>(aff, mask, out, keys_sorted.p, n_seeds,
+                                                              comp_first.p, comp_off.p, n_comp, pool.p,
+                                                              pshape[1], pshape[2], PN, s[0], s[1], s[2], coop_min,
+                                                              ctx->ws_shard_rank, ctx->ws_shard_world);
         ISX_CHECK_LAUNCH();
         if (small_max > coop_min) {
             const int s_wcap = wcap < WIN_SW ? wcap : WIN_SW, s_tcap = tcap < WIN_ST ? tcap : WIN_ST;
