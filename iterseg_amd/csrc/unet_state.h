@@ -30,7 +30,7 @@ struct ConvBN {                 // one Conv3d followed by its BatchNorm3d
     float *scale = nullptr, *shift = nullptr;       // [B][cout], valid after bn_finalize
     float *bmean = nullptr, *bvar = nullptr;        // [B][cout] batch mean / unbiased var
     float *invstd = nullptr;                        // [B][cout] 1/sqrt(biased var + eps) (backward)
-    float *psum = nullptr, *psq = nullptr;          // [B][tiles][cout] partial sums
+    float *psum = nullptr, *psq = nullptr;          // partial sums: [B][cout][tiles] from conv_first_kernel and the conv_h2 kernels (tile fastest: bn_finalize_kernel reads them coalesced), [B][tiles][cout] from the others
     int tiles = 0;
     float gmax = 0.f, bmax = 0.f;                   // max |gamma|, max |beta|: |BN output| <= gmax * sqrt(M - 1) + bmax
 };
@@ -105,7 +105,7 @@ struct ConvArgs {
     const float *w;        // packed [Cout/BN][Cin/4][taps][4][BN]
     const float *bias;     // [Cout]
     float *out;            // [B][M][store_cols] raw conv output (+bias)
-    float *psum, *psq;     // [B][tiles][Cout]
+    float *psum, *psq;     // [B][Cout][tiles] (conv_h2 kernels: tile fastest) / [B][tiles][Cout] (conv_mfma_kernel)
     int D, H, W, Cout;
     int mode;              // 0: 2x8x(8 MT) voxel tiles; 1: 2 planes x 64 MT row-wrapped positions; 2: 1 plane x 128 MT
     int tiles_per_chunk, nty, ntx, ntp;
